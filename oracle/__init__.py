@@ -1,0 +1,199 @@
+"""ctypes doorway to the CPU oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+``oracle/liboracle.so`` holds the C restatements of the reference algorithms
+(harris_oracle.c, fast9_oracle.c, canny_oracle.c, ...); ``oracle/_ref/*.so``
+hold the reference's own sources compiled in place (only buildable where
+/root/reference exists; the built files travel to the GPU box).
+
+Only tests/, ``__graft_entry__.smoke()`` and bench.py's ``cpu_baseline`` leg may
+import this package.  ``image_amd`` never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+
+
+def build(ref: bool = True) -> None:
+    """Compile liboracle.so and, when /root/reference is present, oracle/_ref/*.so."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+    if ref and os.path.isdir("/root/reference"):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build(ref=False)
+        _lib = C.CDLL(path)
+    return _lib
+
+
+def ref_path(name: str) -> str:
+    return os.path.join(_HERE, "_ref", f"libref_{name}.so")
+
+
+def have_ref(name: str) -> bool:
+    return os.path.exists(ref_path(name))
+
+
+_refs: dict = {}
+
+
+def ref(name: str) -> C.CDLL:
+    if name not in _refs:
+        _refs[name] = C.CDLL(ref_path(name))
+    return _refs[name]
+
+
+# --------------------------------------------------------------------- Harris
+HARRIS_DEFAULTS = dict(k=0.06, sigma_d=1.0, sigma_i=2.5, threshold=130.0, gaussian=0, gradient=0,
+                       strategy=0, Nselect=1, measure=0, Nscales=1, precision=0, cells=10)
+
+
+def _harris_args(img, kw):
+    p = dict(HARRIS_DEFAULTS); p.update(kw)
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    ny, nx = img.shape
+    return img, nx, ny, p
+
+
+def harris(img, planes: bool = False, **kw):
+    """Restated harris_scale().  img: (ny, nx) array.  Returns (xyR[n,3] float32[, planes dict])."""
+    img, nx, ny, p = _harris_args(img, kw)
+    fn = lib().orc_harris
+    fn.restype = C.c_long
+    cap = nx * ny // 4 + 16
+    out = np.zeros((cap, 3), np.float32)
+    pl = np.zeros((6, ny, nx), np.float32) if planes else None
+    n = fn(img.ctypes.data_as(C.c_void_p), nx, ny, C.c_float(p["k"]), C.c_float(p["sigma_d"]),
+           C.c_float(p["sigma_i"]), C.c_float(p["threshold"]), p["gaussian"], p["gradient"],
+           p["strategy"], p["Nselect"], p["measure"], p["Nscales"], p["precision"], p["cells"],
+           out.ctypes.data_as(C.c_void_p), C.c_long(cap),
+           pl.ctypes.data_as(C.c_void_p) if planes else None)
+    res = out[:n].copy()
+    if planes:
+        return res, dict(zip(("Ix", "Iy", "A", "B", "C", "R"), pl))
+    return res
+
+
+def ref_harris(img, threads: int | None = None, **kw):
+    """The reference's own harris_scale() (oracle/_ref/libref_harris.so)."""
+    img, nx, ny, p = _harris_args(img, kw)
+    L = ref("harris")
+    if threads is not None:
+        L.ref_set_threads(int(threads))
+    fn = L.ref_harris
+    fn.restype = C.c_long
+    cap = nx * ny // 4 + 16
+    out = np.zeros((cap, 3), np.float32)
+    n = fn(img.ctypes.data_as(C.c_void_p), nx, ny, C.c_float(p["k"]), C.c_float(p["sigma_d"]),
+           C.c_float(p["sigma_i"]), C.c_float(p["threshold"]), p["gaussian"], p["gradient"],
+           p["strategy"], p["Nselect"], p["measure"], p["Nscales"], p["precision"], p["cells"],
+           out.ctypes.data_as(C.c_void_p), C.c_long(cap))
+    return out[:n].copy()
+
+
+def harris_stage(which: str, *arrays, use_ref: bool = False, **kw):
+    """Single reference stages for plane-level parity: 'gaussian', 'gradient',
+    'autocorrelation', 'response', 'nms'."""
+    L = ref("harris") if use_ref else lib()
+    pre = "ref_" if use_ref else "orc_"
+    a = [np.ascontiguousarray(x, dtype=np.float32) for x in arrays]
+    ny, nx = a[0].shape
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    if which == "gaussian":
+        out = np.empty_like(a[0])
+        getattr(L, pre + "gaussian")(vp(a[0]), vp(out), nx, ny, C.c_float(kw["sigma"]), kw.get("type", 0))
+        return out
+    if which == "gradient":
+        ix, iy = np.zeros_like(a[0]), np.zeros_like(a[0])
+        getattr(L, pre + "gradient")(vp(a[0]), vp(ix), vp(iy), nx, ny, kw.get("type", 0))
+        return ix, iy
+    if which == "autocorrelation":
+        A, B, Cc = (np.empty_like(a[0]) for _ in range(3))
+        getattr(L, pre + "autocorrelation")(vp(a[0]), vp(a[1]), vp(A), vp(B), vp(Cc),
+                                            C.c_float(kw["sigma"]), nx, ny, kw.get("gauss", 0))
+        return A, B, Cc
+    if which == "response":
+        R = np.empty_like(a[0])
+        getattr(L, pre + "response")(vp(a[0]), vp(a[1]), vp(a[2]), vp(R), kw.get("measure", 0), nx, ny,
+                                     C.c_float(kw.get("k", 0.06)))
+        return R
+    if which == "nms":
+        fn = getattr(L, pre + "nms"); fn.restype = C.c_long
+        cap = nx * ny // 4 + 16
+        out = np.zeros((cap, 3), np.float32)
+        n = fn(vp(a[0]), nx, ny, C.c_float(kw["Th"]), int(kw["radius"]), vp(out), C.c_long(cap))
+        return out[:n].copy()
+    raise ValueError(which)
+
+
+# --------------------------------------------------------------------- FAST-9
+def fast9(img, threshold: int, suppress_non_max: bool = False, stride: int | None = None,
+          width: int | None = None):
+    """Restated F9::detectCorners.  img: (h, stride) uint8.  Returns int32 (n,2) of (x,y)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, s = img.shape
+    w = s if width is None else width
+    fn = lib().orc_fast9; fn.restype = C.c_long
+    cap = w * h // 2 + 16
+    out = np.zeros((cap, 2), np.int32)
+    n = fn(img.ctypes.data_as(C.c_void_p), w, h, s if stride is None else stride,
+           int(threshold) & 0xFF, int(bool(suppress_non_max)), out.ctypes.data_as(C.c_void_p),
+           C.c_long(cap), None)
+    return out[:n].copy()
+
+
+def ref_fast9(img, threshold: int, suppress_non_max: bool = False, width: int | None = None):
+    """The reference's own C API f9_detect_corners (f9.h:77-86)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, s = img.shape
+    w = s if width is None else width
+    L = ref("f9")
+    L.f9_alloc.restype = C.c_void_p
+    L.f9_detect_corners.restype = C.c_void_p
+    ctx = C.c_void_p(L.f9_alloc())
+    n = C.c_int(0)
+    p = L.f9_detect_corners(ctx, img.ctypes.data_as(C.c_void_p), w, h, s, C.c_ubyte(int(threshold) & 0xFF),
+                            C.c_bool(bool(suppress_non_max)), C.byref(n))
+    if n.value:
+        out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int)), shape=(n.value, 2)).copy()
+    else:
+        out = np.zeros((0, 2), np.int32)
+    L.f9_dealloc(ctx)
+    return out.astype(np.int32)
+
+
+# ---------------------------------------------------------------------- Canny
+def canny(img, s: float = 2.0, low_thr: float = 3.0, high_thr: float = 10.0, accGrad: bool = True,
+          debug: bool = False):
+    """Restated canny_edge_detector().  img: (ny, nx) uint8 with C index x + nx*y.
+    Returns (edges uint8 (ny,nx) of 0/255, pixels_nonzero[, dict(blur, grad, nms)])."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    ny, nx = img.shape
+    edges = np.zeros((ny, nx), np.uint8)
+    fn = lib().orc_canny; fn.restype = C.c_long
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    if debug:
+        blur = np.zeros((ny, nx)); grad = np.zeros((ny, nx)); nms = np.zeros((ny, nx), np.uint8)
+        n = fn(vp(img), nx, ny, C.c_double(s), C.c_double(low_thr), C.c_double(high_thr),
+               int(bool(accGrad)), vp(edges), vp(blur), vp(grad), vp(nms))
+        return edges, int(n), dict(blur=blur, grad=grad, nms=nms)
+    n = fn(vp(img), nx, ny, C.c_double(s), C.c_double(low_thr), C.c_double(high_thr),
+           int(bool(accGrad)), vp(edges), None, None, None)
+    return edges, int(n)

@@ -1,0 +1,85 @@
+"""Generate tests/golden/*.npz from the reference's own code (oracle/_ref, built by
+`make -C oracle ref` from /root/reference) on the reference's own example images
+and on seeded synthetic frames.  Run in the build container only:
+
+    python scripts/make_golden.py
+
+The .npz files carry the input image (so the GPU box, which has no
+/root/reference, can replay them) and the expected outputs.  Canny has no
+compilable reference (FFTW3 absent): its vectors come from the restatement in
+oracle/canny_oracle.c and are labelled ``unpinned``.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+import fixtures  # noqa: E402
+import oracle  # noqa: E402
+from image_amd import pnm, synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+REF = fixtures.REF
+
+HARRIS_CASES = {
+    "default": dict(),
+    "rcpp_default": dict(gaussian=1, precision=1),
+    "no_gaussian": dict(gaussian=2),
+    "sobel": dict(gradient=1),
+    "shi_tomasi": dict(measure=1, threshold=1.0),
+    "harmonic": dict(measure=2, threshold=1.0),
+    "quartic": dict(precision=2),
+    "sorted": dict(strategy=1),
+    "n_corners": dict(strategy=2, Nselect=50),
+    "distributed": dict(strategy=3, Nselect=100),
+    "two_scales": dict(gaussian=1, Nscales=2),
+    "three_scales": dict(Nscales=3),
+}
+
+
+def harris_golden(name, img):
+    out = {"image": img.astype(np.uint8)}
+    for case, kw in HARRIS_CASES.items():
+        out["xyR_" + case] = oracle.ref_harris(img, **kw)
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, {k: v.shape for k, v in out.items()})
+
+
+def fast9_golden(name, img, thresholds):
+    out = {"image": img.astype(np.uint8)}
+    for thr in thresholds:
+        for nms in (0, 1):
+            out[f"xy_t{thr}_n{nms}"] = oracle.ref_fast9(img, thr, bool(nms))
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, {k: v.shape for k, v in out.items()})
+
+
+def canny_golden(name, img):
+    out = {"image": img.astype(np.uint8), "pinned": np.array(0)}
+    for acc in (0, 1):
+        edges, n = oracle.canny(img, accGrad=bool(acc))
+        out[f"edges_bits_a{acc}"] = np.packbits(edges > 0)
+        out[f"nonzero_a{acc}"] = np.array(n)
+    np.savez_compressed(os.path.join(OUT, name), **out)
+    print(name, {k: (v.shape, int(v) if v.ndim == 0 else None) for k, v in out.items()})
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    building = fixtures.read_rds_int_matrix(
+        f"{REF}/image.CornerDetectionHarris/inst/extdata/building.rds")
+    chairs = pnm.read_pgm(f"{REF}/image.CornerDetectionF9/inst/extdata/chairs.pgm")
+    harris_golden("harris_building", building)
+    harris_golden("harris_synth_640x480_seed1", synth.frame(1, 640, 480))
+    fast9_golden("fast9_chairs", chairs, (20, 80, 100))
+    fast9_golden("fast9_synth_640x480_seed1", synth.frame(1, 640, 480), (10, 20, 50))
+    # R hands Canny the column-major memory of grey[row, col], i.e. the transposed raster
+    canny_golden("canny_chairs", np.ascontiguousarray(chairs.T))
+
+
+if __name__ == "__main__":
+    main()
