@@ -1,0 +1,97 @@
+"""ctypes signatures for the C ABI declared in include/imgfd.h.
+
+``bind(cdll)`` attaches argtypes/restypes to a loaded library.  The product loads
+``image_amd/libimgfd.so`` through :mod:`image_amd._lib`; the CPU-only kernel-logic tests bind the
+same signatures onto the host-emulator build of the same sources (tests/hipemu).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+c_void_pp = C.POINTER(C.c_void_p)
+
+
+class Corner(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("R", C.c_float)]
+
+
+class Corners(C.Structure):
+    _fields_ = [("corners", C.POINTER(Corner)), ("n", C.c_int64), ("stage_seconds", C.c_double * 7)]
+
+
+class Point(C.Structure):
+    _fields_ = [("x", C.c_int), ("y", C.c_int)]
+
+
+class Points(C.Structure):
+    _fields_ = [("points", C.POINTER(Point)), ("n", C.c_int64)]
+
+
+class Frames(C.Structure):
+    _fields_ = [("d_frames", C.c_void_p), ("n_frames", C.c_int), ("nx", C.c_int), ("ny", C.c_int),
+                ("frame_stride_bytes", C.c_size_t), ("row_stride_bytes", C.c_int), ("dtype", C.c_int)]
+
+
+# every symbol include/imgfd.h declares: (restype, argtypes)
+SIGNATURES = {
+    "imgfd_version": (C.c_int, []),
+    "imgfd_ctx_create": (C.c_int, [C.c_int, c_void_pp]),
+    "imgfd_ctx_create_on_stream": (C.c_int, [C.c_int, C.c_void_p, c_void_pp]),
+    "imgfd_ctx_destroy": (None, [C.c_void_p]),
+    "imgfd_last_error": (C.c_char_p, [C.c_void_p]),
+    "imgfd_ctx_stream": (C.c_void_p, [C.c_void_p]),
+    "imgfd_ctx_sync": (C.c_int, [C.c_void_p]),
+    "imgfd_free": (None, [C.c_void_p]),
+    "imgfd_set_fir_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "imgfd_harris": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
+                               C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_int, C.c_int, C.POINTER(Corners)]),
+    "imgfd_fast9": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint8, C.c_int,
+                              C.POINTER(Points)]),
+    "imgfd_canny": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                              C.c_int, C.c_void_p, C.POINTER(C.c_int64)]),
+    "imgfd_harris_dev": (C.c_int, [C.c_void_p, C.POINTER(Frames), C.c_float, C.c_float, C.c_float, C.c_float,
+                                   C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "imgfd_fast9_dev": (C.c_int, [C.c_void_p, C.POINTER(Frames), C.c_uint8, C.c_int, C.c_void_p, C.c_int64,
+                                  C.c_void_p]),
+    "imgfd_canny_dev": (C.c_int, [C.c_void_p, C.POINTER(Frames), C.c_double, C.c_double, C.c_double, C.c_int,
+                                  C.c_void_p, C.c_void_p]),
+    "imgfd_k_gaussian": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int]),
+    "imgfd_k_gradient": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "imgfd_k_structure_tensor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int, C.c_int, C.c_float, C.c_int]),
+    "imgfd_k_response": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_int, C.c_float]),
+    "imgfd_k_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int64,
+                              C.c_void_p]),
+    "imgfd_time_structure_tensor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
+                                              C.POINTER(C.c_double)]),
+    "imgfd_synth_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_uint32,
+                                     C.c_void_p, C.c_int]),
+}
+
+
+def bind(lib: C.CDLL, strict: bool = True) -> C.CDLL:
+    missing = []
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    if missing and strict:
+        raise ImportError(f"{lib._name} does not export: {', '.join(missing)}")
+    return lib
+
+
+class ImgfdError(RuntimeError):
+    pass
+
+
+def check(lib: C.CDLL, ctx, status: int, what: str) -> None:
+    if status != 0:
+        msg = lib.imgfd_last_error(ctx) if ctx else b""
+        raise ImgfdError(f"{what} failed with imgfd_status {status}: {(msg or b'').decode(errors='replace')}")

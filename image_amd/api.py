@@ -1,0 +1,185 @@
+"""Python mirror of the reference's R-level functions for the hot path.
+
+R is not available in the build image, so the host side above the C ABI is written in Python with the
+same names, arguments, defaults, argument handling and return structure as the R wrappers:
+
+  image_harris()               image.CornerDetectionHarris/R/pkg.R:56-106
+  detect_corners()             image.CornerDetectionHarris/R/RcppExports.R:4-6 (numeric enum codes)
+  image_detect_corners()       image.CornerDetectionF9/R/image_detect_corners.R:48-60
+  image_canny_edge_detector()  image.CannyEdges/R/canny_edges_detector.R:63-67
+
+An R matrix ``x`` is mirrored by a 2-D numpy array with the same ``[row, col]`` indexing.  R hands the
+matrix's column-major memory to C, so the C image (index ``i + nrow*j``) is ``x.T`` in numpy terms.
+Every function calls libimgfd.so through ctypes; nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _binding, _lib
+
+_GAUSSIAN = ("fast Gaussian", "precise Gaussian", "no Gaussian")
+_GRADIENT = ("central differences", "Sobel operator")
+_STRATEGY = ("all corners", "sort all corners", "N corners", "distributed N corners")
+_MEASURE = ("Harris", "Shi-Tomasi", "Harmonic Mean")
+_PRECISION = ("quadratic approximation", "quartic interpolation", "no subpixel")
+
+
+class RList(dict):
+    """An R list with a class attribute: dict access plus ``.r_class``."""
+
+    r_class: str = ""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:  # pragma: no cover
+            raise AttributeError(k) from e
+
+
+def _match_arg(arg, choices, name):
+    """R's match.arg(arg) for a formal whose default is the choices vector."""
+    if isinstance(arg, (tuple, list)):
+        if tuple(arg) == tuple(choices):
+            return choices[0]
+        if len(arg) != 1:
+            raise ValueError(f"'{name}' must be of length 1")
+        arg = arg[0]
+    hits = [c for c in choices if c.startswith(arg)]
+    if arg in choices:
+        hits = [arg]
+    if len(hits) != 1:
+        raise ValueError(f"'{name}' should be one of " + ", ".join(f"'{c}'" for c in choices))
+    return hits[0]
+
+
+def _r_option_code(arg, choices, name):
+    """``which(arg %in% match.arg(arg)) - 1L`` exactly as pkg.R:70-74 evaluates it.
+
+    For the untouched default (the whole choices vector) and for any exact single string this is 0;
+    a partially matched string gives integer(0), which Rcpp rejects."""
+    matched = _match_arg(arg, choices, name)
+    vec = list(arg) if isinstance(arg, (tuple, list)) else [arg]
+    which = [i + 1 for i, v in enumerate(vec) if v == matched]
+    if len(which) != 1:
+        raise ValueError("Expecting a single value: [extent=%d]." % len(which))
+    return which[0] - 1
+
+
+def _ctx(ctx):
+    return ctx if ctx is not None else _lib.default_context()
+
+
+def detect_corners(x, nx, ny, k=0.060000, sigma_d=1.000000, sigma_i=2.500000, threshold=130, gaussian=1,
+                   gradient=0, strategy=0, Nselect=1, measure=0, Nscales=1, precision=1, cells=10, verbose=1,
+                   ctx=None):
+    """Rcpp-level detect_corners(): rcpp_harris.cpp:19-60 (numeric enum codes, Rcpp defaults).
+
+    ``x`` is the NumericVector: any array with nx*ny elements in C-image order (x fastest)."""
+    ctx = _ctx(ctx)
+    img = np.ascontiguousarray(np.asarray(x, dtype=np.float64).ravel(order="K")).astype(np.float32)
+    if img.size != int(nx) * int(ny):
+        raise ValueError("x must hold nx*ny values")
+    out = _binding.Corners()
+    st = ctx.lib.imgfd_harris(ctx.handle, img.ctypes.data_as(C.c_void_p), int(nx), int(ny), float(k),
+                              float(sigma_d), float(sigma_i), float(threshold), int(gaussian), int(gradient),
+                              int(strategy), int(Nselect), int(measure), int(Nscales), int(precision),
+                              int(cells), int(bool(verbose)), C.byref(out))
+    ctx.check(st, "imgfd_harris")
+    n = out.n
+    if n:
+        arr = np.ctypeslib.as_array(C.cast(out.corners, C.POINTER(C.c_float)), shape=(n, 3)).copy()
+        ctx.lib.imgfd_free(out.corners)
+    else:
+        arr = np.zeros((0, 3), np.float32)
+    if verbose:
+        names = (" 1.Smoothing the image: \t \t", " 2.Computing the gradient: \t \t",
+                 " 3.Computing the autocorrelation: \t", " 4.Computing corner strength function: \t",
+                 " 5.Non-maximum suppression:  \t\t", " 6.Selecting output corners:  \t\t",
+                 " 7.Calculating subpixel accuracy: \t")
+        print("\nHarris corner detection:")
+        print("[nx=%d, ny=%d, sigma_i=%f]" % (nx, ny, sigma_i))
+        for i, nm in enumerate(names):
+            if i == 6 and precision not in (1, 2):
+                continue
+            print("%sTime: %fs" % (nm, out.stage_seconds[i]))
+        print(" * Number of corners detected: %d" % n)
+    res = RList(x=arr[:, 0].astype(np.float64), y=arr[:, 1].astype(np.float64),
+                strength=arr[:, 2].astype(np.float64))
+    return res
+
+
+def image_harris(x, k=0.060000, sigma_d=1.000000, sigma_i=2.500000, threshold=130,
+                 gaussian=_GAUSSIAN, gradient=_GRADIENT, strategy=_STRATEGY, Nselect=1, measure=_MEASURE,
+                 Nscales=1, precision=_PRECISION, cells=10, verbose=False, ctx=None):
+    """image_harris(): pkg.R:56-106.  ``x``: matrix (W x H, like the R call) of grey values."""
+    gaussian = _r_option_code(gaussian, _GAUSSIAN, "gaussian")
+    gradient = _r_option_code(gradient, _GRADIENT, "gradient")
+    strategy = _r_option_code(strategy, _STRATEGY, "strategy")
+    measure = _r_option_code(measure, _MEASURE, "measure")
+    precision = _r_option_code(precision, _PRECISION, "precision")
+    x = np.asarray(x)
+    if x.ndim != 2:
+        raise ValueError("x is not a matrix nor a magick-image")
+    w, h = x.shape  # w <- nrow(x); h <- ncol(x), pkg.R:94-95
+    corners = detect_corners(x.T, w, h, k=k, sigma_d=sigma_d, sigma_i=sigma_i, threshold=threshold,
+                             gaussian=gaussian, gradient=gradient, strategy=strategy, Nselect=Nselect,
+                             measure=measure, Nscales=Nscales, precision=precision, cells=cells,
+                             verbose=verbose, ctx=ctx)
+    corners.r_class = "image.harris"
+    return corners
+
+
+def _as_integer(x):
+    """R's as.integer() on a numeric matrix: truncation toward zero."""
+    x = np.asarray(x)
+    if np.issubdtype(x.dtype, np.integer):
+        return x.astype(np.int64)
+    return np.trunc(x).astype(np.int64)
+
+
+def image_detect_corners(x, threshold=50, suppress_non_max=False, ctx=None):
+    """image_detect_corners(): image_detect_corners.R:48-60 over f9_rcpp.cpp:8-35."""
+    x = np.asarray(x)
+    if x.ndim != 2:
+        raise ValueError("is.matrix(x) is not TRUE")
+    ctx = _ctx(ctx)
+    width, height = x.shape  # width = nrow(x), height = ncol(x), bytes_per_row = nrow(x)
+    # (unsigned char) x[i] on the IntegerVector, f9_rcpp.cpp:11; memory is column-major == x.T raster
+    img = np.ascontiguousarray((_as_integer(x).T & 0xFF).astype(np.uint8))
+    out = _binding.Points()
+    st = ctx.lib.imgfd_fast9(ctx.handle, img.ctypes.data_as(C.c_void_p), int(width), int(height), int(width),
+                             int(_as_integer(threshold)) & 0xFF, int(bool(suppress_non_max)), C.byref(out))
+    ctx.check(st, "imgfd_fast9")
+    n = out.n
+    if n:
+        pts = np.ctypeslib.as_array(C.cast(out.points, C.POINTER(C.c_int)), shape=(n, 2)).copy()
+        ctx.lib.imgfd_free(out.points)
+    else:
+        pts = np.zeros((0, 2), np.int32)
+    # corners_x = out.y ; corners_y = width - out.x, f9_rcpp.cpp:29-30
+    res = RList(x=pts[:, 1].astype(np.float64), y=(width - pts[:, 0]).astype(np.float64))
+    res.r_class = "image.corners"
+    return res
+
+
+def image_canny_edge_detector(x, s=2, low_thr=3, high_thr=10, accGrad=True, ctx=None):
+    """image_canny_edge_detector(): canny_edges_detector.R:63-67 over rcpp_canny.cpp:122-244."""
+    x = np.asarray(x)
+    if x.ndim != 2:
+        raise ValueError("x must be a matrix")
+    ctx = _ctx(ctx)
+    nx, ny = x.shape  # X = nrow(x), Y = ncol(x)
+    img = np.ascontiguousarray((_as_integer(x).T & 0xFF).astype(np.uint8))  # rcpp_canny.cpp:135-136
+    edges = np.zeros((ny, nx), np.uint8)
+    nonzero = C.c_int64(0)
+    st = ctx.lib.imgfd_canny(ctx.handle, img.ctypes.data_as(C.c_void_p), int(nx), int(ny), float(s), float(low_thr),
+                             float(high_thr), int(bool(accGrad)), edges.ctypes.data_as(C.c_void_p), C.byref(nonzero))
+    ctx.check(st, "imgfd_canny")
+    res = RList(edges=edges.T.astype(np.float64),  # NumericMatrix(nx, ny), rcpp_canny.cpp:226-233
+                pixels_nonzero=int(nonzero.value), nx=float(nx), ny=float(ny), s=float(s),
+                low_thr=float(low_thr), high_thr=float(high_thr), accGrad=bool(accGrad))
+    res.r_class = "image_canny"
+    return res

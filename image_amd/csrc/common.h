@@ -1,0 +1,108 @@
+// image_amd/csrc/common.h -- shared host-side plumbing of libimgfd (context, workspace, error macros).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/imgfd.h"
+
+#define IMGFD_MAX_TAPS 64 /* FIR half-size (B[0..size-1]) the kernels accept */
+
+struct imgfd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    int fir_mode = 1;  // 1 = fused accumulate, 0 = strict
+    int num_cu = 256;
+    std::string err;
+    // grow-only device workspace arena (bump-allocated per call, reset at call entry)
+    char *ws = nullptr;
+    size_t ws_size = 0;
+    size_t ws_used = 0;
+    std::vector<void *> ws_old;  // superseded arenas, freed at destroy/sync points
+    // pinned host staging
+    char *pin = nullptr;
+    size_t pin_size = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+#define IMGFD_HIP(ctx, call)                                                                       \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            char b_[512];                                                                          \
+            snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (ctx)->err = b_;                                                                       \
+            return IMGFD_ERR_HIP;                                                                  \
+        }                                                                                          \
+    } while (0)
+
+#define IMGFD_TRY(expr)                       \
+    do {                                      \
+        imgfd_status s_ = (expr);             \
+        if (s_ != IMGFD_OK) return s_;        \
+    } while (0)
+
+static inline imgfd_status imgfd_fail(imgfd_ctx *ctx, imgfd_status s, const char *msg)
+{
+    if (ctx) ctx->err = msg;
+    return s;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// workspace: all allocations of one API call are carved from one arena; ws_reserve() guarantees
+// capacity up front so no pointer handed out earlier in the call is invalidated.
+imgfd_status ws_reserve(imgfd_ctx *ctx, size_t bytes);
+void *ws_alloc(imgfd_ctx *ctx, size_t bytes);  // 256-byte aligned; nullptr if the reservation is exceeded
+static inline void ws_reset(imgfd_ctx *ctx) { ctx->ws_used = 0; }
+imgfd_status pin_reserve(imgfd_ctx *ctx, size_t bytes);
+
+// ---- kernel launchers shared between translation units (device pointers, async on ctx->stream)
+struct FrameGeom {
+    int nx, ny;
+    int n_frames;
+};
+
+// fir.hip
+imgfd_status launch_gaussian(imgfd_ctx *ctx, const void *d_in, int in_is_u8, int in_pitch,
+                             size_t in_frame_stride_bytes, float *d_out, int nx, int ny, int n_frames,
+                             float sigma, int type, float *d_tmp);
+imgfd_status launch_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_A,
+                                     float *d_B, float *d_C, int nx, int ny, int n_frames, float sigma,
+                                     int gauss, float *d_tmp);
+size_t gaussian_tmp_bytes(int nx, int ny, int n_frames, float sigma, int type, int planes);
+// harris_stages.hip
+imgfd_status launch_gradient(imgfd_ctx *ctx, const float *d_I, float *d_Ix, float *d_Iy, int nx, int ny,
+                             int n_frames, int type);
+imgfd_status launch_response(imgfd_ctx *ctx, const float *d_A, const float *d_B, const float *d_C,
+                             float *d_R, int nx, int ny, int n_frames, int measure, float k);
+imgfd_status launch_convert_u8_f32(imgfd_ctx *ctx, const uint8_t *d_in, int in_pitch,
+                                   size_t in_frame_stride, float *d_out, int nx, int ny, int n_frames);
+// compact.hip: ordered (raster) stream compaction from a per-pixel bit mask
+struct CompactBuffers {
+    unsigned long long *mask;  // n_frames * ny * words_per_row
+    unsigned *rowcount;        // n_frames * ny   (must be zero before the producer kernel runs)
+    unsigned *rowoff;          // n_frames * ny
+    int words_per_row;
+};
+size_t compact_bytes(int nx, int ny, int n_frames);
+imgfd_status compact_carve(imgfd_ctx *ctx, int nx, int ny, int n_frames, CompactBuffers *cb);
+imgfd_status compact_clear(imgfd_ctx *ctx, const CompactBuffers &cb, int ny, int n_frames);
+// scan row counts, then scatter: kind 0 = imgfd_corner {x,y,R[y*nx+x]}, kind 1 = imgfd_point {x,y}
+imgfd_status compact_emit(imgfd_ctx *ctx, const CompactBuffers &cb, int nx, int ny, int n_frames, int kind,
+                          const float *d_R, void *d_out, int64_t cap, int64_t *d_counts);
+// nms.hip
+imgfd_status launch_harris_nms(imgfd_ctx *ctx, const float *d_R, int nx, int ny, int n_frames, float Th,
+                               int radius, const CompactBuffers &cb);
+// fast9.hip
+imgfd_status launch_fast9(imgfd_ctx *ctx, const uint8_t *d_img, int w, int h, int stride,
+                          size_t frame_stride, int n_frames, int threshold, int nonmax,
+                          uint8_t *d_score, const CompactBuffers &cb);

@@ -1,0 +1,135 @@
+// image_amd/csrc/compact.hip -- raster-ordered stream compaction shared by Harris NMS and FAST-9.
+//
+// Both reference detectors return their features in raster order (Harris: corners_row[] concatenated
+// row by row, harris.cpp:251-252; FAST-9: the y/x double loop of f9.cpp:2959-2960), and that order is
+// part of what the R functions return.  The detector kernels therefore do not append with atomics;
+// they publish one bit per pixel (a 64-bit __ballot word per wave) plus integer per-row counts.  This
+// file turns that into the ordered list:
+//   rows_scan : one workgroup per frame, exclusive scan of the ny row counts -> row offsets + total
+//   scatter   : one wave per row, lane l owns mask word l (+64k): wave-level prefix of popcounts, then
+//               each lane walks its set bits and writes records at rowoff + prefix + k.
+// Integer-only bookkeeping: the output is deterministic and identical to a sequential scan.
+#include "common.h"
+
+#define SCAN_NT 1024
+
+size_t compact_bytes(int nx, int ny, int n_frames)
+{
+    const size_t wpr = (size_t)ceil_div(nx, 64);
+    return align_up(sizeof(unsigned long long) * wpr * ny * n_frames, 256) +
+           2 * align_up(sizeof(unsigned) * (size_t)ny * n_frames, 256);
+}
+
+imgfd_status compact_carve(imgfd_ctx *ctx, int nx, int ny, int n_frames, CompactBuffers *cb)
+{
+    cb->words_per_row = ceil_div(nx, 64);
+    cb->mask = (unsigned long long *)ws_alloc(ctx, sizeof(unsigned long long) * (size_t)cb->words_per_row * ny * n_frames);
+    cb->rowcount = (unsigned *)ws_alloc(ctx, sizeof(unsigned) * (size_t)ny * n_frames);
+    cb->rowoff = (unsigned *)ws_alloc(ctx, sizeof(unsigned) * (size_t)ny * n_frames);
+    if (!cb->mask || !cb->rowcount || !cb->rowoff) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    return IMGFD_OK;
+}
+
+imgfd_status compact_clear(imgfd_ctx *ctx, const CompactBuffers &cb, int ny, int n_frames)
+{
+    IMGFD_HIP(ctx, hipMemsetAsync(cb.rowcount, 0, sizeof(unsigned) * (size_t)ny * n_frames, ctx->stream));
+    return IMGFD_OK;
+}
+
+__global__ void __launch_bounds__(SCAN_NT) rows_scan(const unsigned *__restrict__ rowcount,
+                                                     unsigned *__restrict__ rowoff, int ny,
+                                                     long long *__restrict__ counts)
+{
+    __shared__ unsigned wsum[SCAN_NT / 64];
+    __shared__ unsigned carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned *rc = rowcount + (size_t)blockIdx.x * ny;
+    unsigned *ro = rowoff + (size_t)blockIdx.x * ny;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < ny; base += SCAN_NT) {
+        const int i = base + tid;
+        const unsigned v = i < ny ? rc[i] : 0u;
+        // inclusive scan inside the wave
+        unsigned incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        unsigned wbase = 0;
+        for (int w = 0; w < wv; w++) wbase += wsum[w];
+        const unsigned carry = carry_s;
+        if (i < ny) ro[i] = carry + wbase + incl - v;
+        __syncthreads();
+        if (tid == SCAN_NT - 1) carry_s = carry + wbase + incl;
+        __syncthreads();
+    }
+    if (tid == 0) counts[blockIdx.x] = (long long)carry_s;
+}
+
+// KIND 0: imgfd_corner {x, y, R[y*nx+x]};  KIND 1: imgfd_point {x, y}
+template <int KIND>
+__global__ void __launch_bounds__(256) scatter_rows(const unsigned long long *__restrict__ mask,
+                                                    const unsigned *__restrict__ rowoff, int words_per_row,
+                                                    int nx, int ny, const float *__restrict__ R,
+                                                    void *__restrict__ out, long long cap)
+{
+    const int lane = threadIdx.x & 63;
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per row
+    const int frame = blockIdx.y;
+    const bool row_ok = y < ny;
+    const int yy = row_ok ? y : 0;
+    const unsigned long long *mrow = mask + ((size_t)frame * ny + yy) * words_per_row;
+    unsigned running = row_ok ? rowoff[(size_t)frame * ny + yy] : 0u;
+    for (int w0 = 0; w0 < words_per_row; w0 += 64) {
+        const int w = w0 + lane;
+        unsigned long long m = (row_ok && w < words_per_row) ? mrow[w] : 0ull;
+        const unsigned c = (unsigned)__popcll(m);
+        unsigned incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        const unsigned total = __shfl(incl, 63);
+        unsigned pos = running + incl - c;
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int x = w * 64 + b;
+            if ((long long)pos < cap) {
+                if (KIND == 0) {
+                    imgfd_corner *o = reinterpret_cast<imgfd_corner *>(out) + (size_t)frame * cap + pos;
+                    o->x = (float)x;
+                    o->y = (float)y;
+                    o->R = R[((size_t)frame * ny + y) * nx + x];
+                } else {
+                    imgfd_point *o = reinterpret_cast<imgfd_point *>(out) + (size_t)frame * cap + pos;
+                    o->x = x;
+                    o->y = y;
+                }
+            }
+            pos++;
+        }
+        running += total;
+    }
+}
+
+imgfd_status compact_emit(imgfd_ctx *ctx, const CompactBuffers &cb, int nx, int ny, int n_frames, int kind,
+                          const float *d_R, void *d_out, int64_t cap, int64_t *d_counts)
+{
+    hipLaunchKernelGGL(rows_scan, dim3(n_frames), dim3(SCAN_NT), 0, ctx->stream, cb.rowcount, cb.rowoff, ny,
+                       (long long *)d_counts);
+    dim3 grid(ceil_div(ny, 4), n_frames);
+    if (kind == 0)
+        hipLaunchKernelGGL(scatter_rows<0>, grid, dim3(256), 0, ctx->stream, cb.mask, cb.rowoff,
+                           cb.words_per_row, nx, ny, d_R, d_out, (long long)cap);
+    else
+        hipLaunchKernelGGL(scatter_rows<1>, grid, dim3(256), 0, ctx->stream, cb.mask, cb.rowoff,
+                           cb.words_per_row, nx, ny, d_R, d_out, (long long)cap);
+    IMGFD_HIP(ctx, hipGetLastError());
+    return IMGFD_OK;
+}

@@ -1,0 +1,129 @@
+// image_amd/csrc/ctx.cpp -- context, workspace arena and small utilities of libimgfd.
+#include "common.h"
+
+#include <stdlib.h>
+
+extern "C" {
+
+int imgfd_version(void) { return IMGFD_VERSION; }
+
+static imgfd_status ctx_init(int device, void *stream, bool own, imgfd_ctx **out)
+{
+    if (!out) return IMGFD_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return IMGFD_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return IMGFD_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return IMGFD_ERR_NO_DEVICE;
+    imgfd_ctx *ctx = new imgfd_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        ctx->num_cu = prop.multiProcessorCount;
+    if (own) {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return IMGFD_ERR_HIP;
+        }
+    } else {
+        ctx->stream = (hipStream_t)stream;
+    }
+    ctx->own_stream = own;
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return IMGFD_ERR_HIP;
+    }
+    const char *m = getenv("IMGFD_FIR_MODE");
+    if (m) ctx->fir_mode = atoi(m) ? 1 : 0;
+    *out = ctx;
+    return IMGFD_OK;
+}
+
+imgfd_status imgfd_ctx_create(int device, imgfd_ctx **out) { return ctx_init(device, nullptr, true, out); }
+
+imgfd_status imgfd_ctx_create_on_stream(int device, void *stream, imgfd_ctx **out)
+{
+    return ctx_init(device, stream, false, out);
+}
+
+void imgfd_ctx_destroy(imgfd_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void *p : ctx->ws_old) (void)hipFree(p);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *imgfd_last_error(const imgfd_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+void *imgfd_ctx_stream(imgfd_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+imgfd_status imgfd_ctx_sync(imgfd_ctx *ctx)
+{
+    if (!ctx) return IMGFD_ERR_INVALID;
+    IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (void *p : ctx->ws_old) (void)hipFree(p);
+    ctx->ws_old.clear();
+    return IMGFD_OK;
+}
+
+void imgfd_free(void *p) { free(p); }
+
+imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode)
+{
+    if (!ctx || (mode != 0 && mode != 1)) return IMGFD_ERR_INVALID;
+    ctx->fir_mode = mode;
+    return IMGFD_OK;
+}
+
+}  // extern "C"
+
+imgfd_status ws_reserve(imgfd_ctx *ctx, size_t bytes)
+{
+    ctx->ws_used = 0;
+    if (bytes <= ctx->ws_size) return IMGFD_OK;
+    // kernels of earlier calls may still be using the old arena: retire it, free at the next sync
+    if (ctx->ws) ctx->ws_old.push_back(ctx->ws);
+    ctx->ws = nullptr;
+    ctx->ws_size = 0;
+    bytes = align_up(bytes + bytes / 8, (size_t)1 << 20);
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        ctx->err = "hipMalloc of the device workspace failed";
+        return IMGFD_ERR_OOM;
+    }
+    ctx->ws = (char *)p;
+    ctx->ws_size = bytes;
+    return IMGFD_OK;
+}
+
+void *ws_alloc(imgfd_ctx *ctx, size_t bytes)
+{
+    size_t off = align_up(ctx->ws_used, 256);
+    if (off + bytes > ctx->ws_size) return nullptr;
+    ctx->ws_used = off + bytes;
+    return ctx->ws + off;
+}
+
+imgfd_status pin_reserve(imgfd_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->pin_size) return IMGFD_OK;
+    IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
+    ctx->pin = nullptr;
+    ctx->pin_size = 0;
+    void *p = nullptr;
+    bytes = align_up(bytes, (size_t)1 << 20);
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        ctx->err = "hipHostMalloc of the pinned staging buffer failed";
+        return IMGFD_ERR_OOM;
+    }
+    ctx->pin = (char *)p;
+    ctx->pin_size = bytes;
+    return IMGFD_OK;
+}

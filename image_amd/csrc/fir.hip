@@ -1,0 +1,470 @@
+// image_amd/csrc/fir.hip -- separable double-accumulated Gaussian FIR for gfx950 (K1 and K3).
+//
+// Replaces discrete_gaussian(), image.CornerDetectionHarris/src/gaussian.cpp:289-395, and the pass
+// that dominates the reference's run time, compute_autocorrelation_matrix(), harris.cpp:44-70
+// (products Ix*Ix, Ix*Iy, Iy*Iy in float, then three in-place Gaussians).
+//
+// Numerics contract (SURVEY.md 7 "hard part 1", Appendix A):
+//   - taps B[0..size-1] are computed on the host with the reference's literal expressions (fir_coeffs)
+//   - each 1-D pass widens float -> double, forms  B[0]*R[i] + sum_j B[j]*(R[i-j]+R[i+j])  with j
+//     ascending, pair added first, and rounds to float ONCE per pass (gaussian.cpp:351-359, 382-390)
+//   - borders: left/top logical -k -> k, right/bottom logical n-1+k -> n-k (gaussian.cpp:345-349)
+//   - FMA=false: the reference's exact operation sequence (the library is built -ffp-contract=off);
+//     FMA=true: sum = fma(B[j], pair, sum) in the f64 accumulation only.
+//
+// Kernel shape (fir_march): one 256-thread workgroup owns a TW-column strip of one frame and marches
+// down a segment of rows in chunks of CH rows.  Per chunk: (1) coalesced global loads of CH rows x
+// (TW+2R) columns into LDS (the next chunk is prefetched into registers while this one computes);
+// (2) row pass: a thread owns 8 consecutive pixels of one row, reads its 8+2R window with
+// ds_read_b128 from a bank-swizzled tile, converts once to f64 and slides the window in registers;
+// results (rounded to float) go to an LDS ring of row-filtered rows; (3) column pass: a thread owns
+// one column and 8 consecutive output rows, reads its 8+2R window from the ring (lane <-> column:
+// conflict-free), and stores 256-byte coalesced row segments.  Row-filtered rows are computed once per
+// segment (2R halo rows per segment, not per tile), no intermediate plane ever leaves the CU: HBM
+// traffic is the algorithmic 8 B read + 12 B written per pixel (plus the strip halo, served by L2).
+#include "common.h"
+
+#include <math.h>
+
+#define FIR_NT 256
+#define FIR_PX 8
+
+struct FirParams {
+    const void *in0;
+    const void *in1;
+    float *out0;
+    float *out1;
+    float *out2;
+    int nx, ny;
+    int in_pitch;           // elements per input row
+    long in_frame_stride;   // elements between input frames
+    long out_frame_stride;  // elements between output frames (output pitch is nx)
+    int seg_rows;           // output rows per workgroup segment
+    int xcd_remap;          // 1: remap workgroup ids so an XCD (id % 8) owns a contiguous run of tiles
+    double B[IMGFD_MAX_TAPS];
+};
+
+// left/top: whole-sample reflection (-k -> k); right/bottom: half-sample (n-1+k -> n-k)
+__device__ __forceinline__ int fir_reflect(int i, int n)
+{
+    if (i < 0) i = -i;
+    else if (i >= n) i = 2 * n - 1 - i;
+    return min(max(i, 0), n - 1);
+}
+
+template <int R, bool FMA>
+__device__ __forceinline__ void fir_window8(const double (&d)[FIR_PX + 2 * R], const double *B,
+                                            float (&out)[FIR_PX])
+{
+#pragma unroll
+    for (int o = 0; o < FIR_PX; o++) {
+        double sum = B[0] * d[o + R];
+#pragma unroll
+        for (int j = 1; j <= R; j++) {
+            double pair = d[o + R - j] + d[o + R + j];
+            if (FMA) sum = __builtin_fma(B[j], pair, sum);
+            else sum += B[j] * pair;
+        }
+        out[o] = (float)sum;
+    }
+}
+
+constexpr int fir_ring_size(int need)
+{
+    int r = 1;
+    while (r < need) r *= 2;
+    return r;
+}
+// float4 slots per LDS tile row: W4 data slots, +1 slot of skew per 16 slots, rounded to 16 slots
+// (= 64 dwords) so that 16 lanes x ds_read_b128 at stride 32 B land on 16 distinct 4-bank groups.
+constexpr int fir_rpitch4(int w4) { return ((w4 + ((w4 - 1) >> 4)) + 15) / 16 * 16; }
+__device__ __forceinline__ int fir_swz4(int q) { return q + (q >> 4); }
+
+template <int R, int MODE, int TW, int CH>
+struct FirGeom {
+    static constexpr int NI = MODE == 2 ? 2 : 1;
+    static constexpr int NP = MODE == 2 ? 3 : 1;
+    static constexpr int W = TW + 2 * R;
+    static constexpr int W4 = (W + 3) / 4;
+    static constexpr int RP4 = fir_rpitch4(W4);
+    static constexpr int RPITCH = RP4 * 4;
+    static constexpr int RING = fir_ring_size(CH + 2 * R);
+    static constexpr int NW = FIR_PX + 2 * R;   // window length
+    static constexpr int NW4 = (NW + 3) / 4;    // float4 reads per window
+    static constexpr int NLOAD = (CH * W + FIR_NT - 1) / FIR_NT;
+    static constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)NI * CH * RPITCH + (size_t)NP * RING * TW);
+};
+
+// MODE 0: one f32 plane in -> one plane out;  MODE 1: one u8 plane in;  MODE 2: Ix,Iy in -> A,B,C out
+template <int R, int MODE, int TW, int CH, bool FMA>
+__global__ void __launch_bounds__(FIR_NT) fir_march(FirParams p)
+{
+    using G = FirGeom<R, MODE, TW, CH>;
+    constexpr int NI = G::NI, NP = G::NP, W = G::W, RPITCH = G::RPITCH, RING = G::RING;
+    constexpr int NW = G::NW, NW4 = G::NW4, NLOAD = G::NLOAD;
+    constexpr int STRIPS = TW / FIR_PX;
+
+    HIP_DYNAMIC_SHARED(float4, smem4)
+    float *raw = reinterpret_cast<float *>(smem4);  // [NI][CH][RPITCH], columns swizzled per float4
+    float *ring = raw + NI * CH * RPITCH;           // [NP][RING][TW]
+
+    const int tid = threadIdx.x;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcd_remap) {
+        const int total = gridDim.x * gridDim.y;
+        const int id = bx + gridDim.x * by;
+        const int q = total >> 3, rem = total & 7;
+        const int xcd = id & 7, local = id >> 3;
+        const int nid = xcd * q + min(xcd, rem) + local;
+        bx = nid % (int)gridDim.x;
+        by = nid / (int)gridDim.x;
+    }
+    const int frame = blockIdx.z;
+    const int x0 = bx * TW;
+    const int y0 = by * p.seg_rows;
+    const int y1 = min(p.ny, y0 + p.seg_rows);
+    const int nrows = y1 - y0;
+    const int nchunks = (nrows + 2 * R + CH - 1) / CH;
+    const int ybase = y0 - R;
+
+    const float *in0f = reinterpret_cast<const float *>(p.in0) + (size_t)frame * p.in_frame_stride;
+    const float *in1f = reinterpret_cast<const float *>(p.in1) + (size_t)frame * p.in_frame_stride;
+    const unsigned char *in0b = reinterpret_cast<const unsigned char *>(p.in0) + (size_t)frame * p.in_frame_stride;
+    float *outp[3] = {p.out0 + (size_t)frame * p.out_frame_stride,
+                      NP == 3 ? p.out1 + (size_t)frame * p.out_frame_stride : nullptr,
+                      NP == 3 ? p.out2 + (size_t)frame * p.out_frame_stride : nullptr};
+
+    float pre0[NLOAD], pre1[NLOAD];
+
+    // ---- issue the global loads of one chunk into registers
+    auto prefetch = [&](int chunk) {
+#pragma unroll
+        for (int l = 0; l < NLOAD; l++) {
+            const int i = tid + l * FIR_NT;
+            pre0[l] = 0.f;
+            pre1[l] = 0.f;
+            if (i < CH * W) {
+                const int r = i / W, c = i - r * W;
+                const int gy = fir_reflect(ybase + chunk * CH + r, p.ny);
+                const int gx = fir_reflect(x0 - R + c, p.nx);
+                const size_t off = (size_t)gy * p.in_pitch + gx;
+                if (MODE == 1) pre0[l] = (float)in0b[off];
+                else pre0[l] = in0f[off];
+                if (MODE == 2) pre1[l] = in1f[off];
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int l = 0; l < NLOAD; l++) {
+            const int i = tid + l * FIR_NT;
+            if (i < CH * W) {
+                const int r = i / W, c = i - r * W;
+                const int cs = c + 4 * (c >> 6);  // == 4*fir_swz4(c>>2) + (c&3)
+                raw[(0 * CH + r) * RPITCH + cs] = pre0[l];
+                if (MODE == 2) raw[(1 * CH + r) * RPITCH + cs] = pre1[l];
+            }
+        }
+    };
+
+    prefetch(0);
+    for (int chunk = 0; chunk < nchunks; chunk++) {
+        commit();
+        __syncthreads();
+        if (chunk + 1 < nchunks) prefetch(chunk + 1);
+
+        // ---- row pass: raw tile -> ring of row-filtered rows
+        for (int item = tid; item < CH * STRIPS; item += FIR_NT) {
+            const int r = item / STRIPS, s = item - r * STRIPS;
+            float wx[NW4 * 4], wy[NW4 * 4];
+            const float4 *rx = reinterpret_cast<const float4 *>(raw + (0 * CH + r) * RPITCH);
+            const float4 *ry = reinterpret_cast<const float4 *>(raw + (1 * CH + r) * RPITCH);
+#pragma unroll
+            for (int q = 0; q < NW4; q++) {
+                const float4 v = rx[fir_swz4(2 * s + q)];
+                wx[4 * q] = v.x; wx[4 * q + 1] = v.y; wx[4 * q + 2] = v.z; wx[4 * q + 3] = v.w;
+                if (MODE == 2) {
+                    const float4 u = ry[fir_swz4(2 * s + q)];
+                    wy[4 * q] = u.x; wy[4 * q + 1] = u.y; wy[4 * q + 2] = u.z; wy[4 * q + 3] = u.w;
+                }
+            }
+            const int slot = (chunk * CH + r) & (RING - 1);
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++) {
+                double d[NW];
+#pragma unroll
+                for (int k = 0; k < NW; k++) {
+                    float v;
+                    if (MODE != 2) v = wx[k];
+                    else if (pl == 0) v = wx[k] * wx[k];  // harris.cpp:59
+                    else if (pl == 1) v = wx[k] * wy[k];  // harris.cpp:60
+                    else v = wy[k] * wy[k];               // harris.cpp:61
+                    d[k] = (double)v;
+                }
+                float o[FIR_PX];
+                fir_window8<R, FMA>(d, p.B, o);
+                float4 *dst = reinterpret_cast<float4 *>(ring + (pl * RING + slot) * TW + FIR_PX * s);
+                dst[0] = make_float4(o[0], o[1], o[2], o[3]);
+                dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+            }
+        }
+        __syncthreads();
+
+        // ---- column pass: ring -> global
+        for (int item = tid; item < TW * (CH / FIR_PX); item += FIR_NT) {
+            const int g = item / TW, col = item - g * TW;
+            const int oi0 = chunk * CH - 2 * R + FIR_PX * g;
+            const int gx = x0 + col;
+            if (oi0 + FIR_PX <= 0 || oi0 >= nrows) continue;
+#pragma unroll
+            for (int pl = 0; pl < NP; pl++) {
+                double d[NW];
+#pragma unroll
+                for (int k = 0; k < NW; k++)
+                    d[k] = (double)ring[(pl * RING + ((oi0 + k) & (RING - 1))) * TW + col];
+                float o[FIR_PX];
+                fir_window8<R, FMA>(d, p.B, o);
+                if (gx < p.nx) {
+#pragma unroll
+                    for (int k = 0; k < FIR_PX; k++) {
+                        const int oi = oi0 + k;
+                        if (oi >= 0 && oi < nrows) outp[pl][(size_t)(y0 + oi) * p.nx + gx] = o[k];
+                    }
+                }
+            }
+        }
+        // the next commit() writes `raw` (last read before the barrier above); the next row pass
+        // writes ring slots only after the barrier that follows commit(), by which time every thread
+        // has left this column pass.
+    }
+}
+
+// ------------------------------------------------------------------ generic fallback (any radius)
+// One thread per output pixel, taps from kernarg memory; used for sigmas whose radius has no
+// specialised instantiation.  Same operation order, same borders.
+struct FirGenericParams {
+    const float *in;
+    float *out;
+    int nx, ny, size;  // size = taps B[0..size-1]
+    int horizontal;
+    int fma;
+    long frame_stride;
+    double B[IMGFD_MAX_TAPS];
+};
+
+__global__ void __launch_bounds__(256) fir_generic_pass(FirGenericParams p)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= p.nx) return;
+    const float *in = p.in + (size_t)blockIdx.z * p.frame_stride;
+    float *out = p.out + (size_t)blockIdx.z * p.frame_stride;
+    const int n = p.horizontal ? p.nx : p.ny;
+    const int c = p.horizontal ? x : y;
+    auto at = [&](int i) -> double {
+        const int r = fir_reflect(i, n);
+        return (double)(p.horizontal ? in[(size_t)y * p.nx + r] : in[(size_t)r * p.nx + x]);
+    };
+    double sum = p.B[0] * at(c);
+    for (int j = 1; j < p.size; j++) {
+        const double pair = at(c - j) + at(c + j);
+        if (p.fma) sum = __builtin_fma(p.B[j], pair, sum);
+        else sum += p.B[j] * pair;
+    }
+    out[(size_t)y * p.nx + x] = (float)sum;
+}
+
+__global__ void __launch_bounds__(256) tensor_products(const float *Ix, const float *Iy, float *A, float *B,
+                                                       float *C, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float ix = Ix[i], iy = Iy[i];
+    A[i] = ix * ix;
+    B[i] = ix * iy;
+    C[i] = iy * iy;
+}
+
+__global__ void __launch_bounds__(256) plane_copy(const void *in, int in_is_u8, int in_pitch,
+                                                  size_t in_frame_stride, float *out, int nx, int ny)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= nx) return;
+    const size_t src = (size_t)blockIdx.z * in_frame_stride + (size_t)y * in_pitch + x;
+    const float v = in_is_u8 ? (float)reinterpret_cast<const unsigned char *>(in)[src]
+                             : reinterpret_cast<const float *>(in)[src];
+    out[((size_t)blockIdx.z * ny + y) * nx + x] = v;
+}
+
+// ------------------------------------------------------------------ host side
+// taps exactly as gaussian.cpp:307-330 (den in float, integer -i*i, pi = 3.1415926)
+static int fir_coeffs(float sigma, int precision, double *B)
+{
+    double den = 2 * sigma * sigma;
+    int size = (int)(precision * sigma) + 1;
+    if (size > IMGFD_MAX_TAPS) return -1;
+    for (int i = 0; i < size; i++) B[i] = 1 / (sigma * sqrt(2.0 * 3.1415926)) * exp(-i * i / den);
+    double norm = 0;
+    for (int i = 0; i < size; i++) norm += B[i];
+    norm *= 2;
+    norm -= B[0];
+    for (int i = 0; i < size; i++) B[i] /= norm;
+    return size;
+}
+
+template <int R, int MODE, int TW, int CH>
+static imgfd_status launch_march(imgfd_ctx *ctx, FirParams &p, int n_frames)
+{
+    using G = FirGeom<R, MODE, TW, CH>;
+    const int strips = ceil_div(p.nx, TW);
+    // segments: enough workgroups for >= 2 per CU, segment length 16m+2 so that (rows+2R) fills whole chunks
+    int want = ceil_div(2 * ctx->num_cu, strips * n_frames);
+    int seg = ceil_div(p.ny, want < 1 ? 1 : want);
+    int m = ceil_div(seg + 2 * R, CH);
+    if (m < 2) m = 2;
+    seg = m * CH - 2 * R;
+    p.seg_rows = seg;
+    dim3 grid(strips, ceil_div(p.ny, seg), n_frames);
+    static const char *env = getenv("IMGFD_XCD_REMAP");
+    p.xcd_remap = env ? atoi(env) : 1;
+    const size_t lds = G::LDS_BYTES;
+    if (ctx->fir_mode) {
+        IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)fir_march<R, MODE, TW, CH, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((fir_march<R, MODE, TW, CH, true>), grid, dim3(FIR_NT), lds, ctx->stream, p);
+    } else {
+        IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)fir_march<R, MODE, TW, CH, false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((fir_march<R, MODE, TW, CH, false>), grid, dim3(FIR_NT), lds, ctx->stream, p);
+    }
+    IMGFD_HIP(ctx, hipGetLastError());
+    return IMGFD_OK;
+}
+
+static imgfd_status launch_generic(imgfd_ctx *ctx, const float *in, float *tmp, float *out, int nx, int ny,
+                                   int n_frames, int size, const double *B)
+{
+    FirGenericParams g;
+    memset(&g, 0, sizeof g);
+    g.nx = nx; g.ny = ny; g.size = size; g.fma = ctx->fir_mode; g.frame_stride = (long)nx * ny;
+    memcpy(g.B, B, sizeof(double) * size);
+    dim3 grid(ceil_div(nx, 256), ny, n_frames);
+    g.in = in; g.out = tmp; g.horizontal = 1;
+    hipLaunchKernelGGL(fir_generic_pass, grid, dim3(256), 0, ctx->stream, g);
+    g.in = tmp; g.out = out; g.horizontal = 0;
+    hipLaunchKernelGGL(fir_generic_pass, grid, dim3(256), 0, ctx->stream, g);
+    IMGFD_HIP(ctx, hipGetLastError());
+    return IMGFD_OK;
+}
+
+static bool fir_has_fast_path(int R, int mode)
+{
+    if (mode == 2) return R == 7 || R == 3 || R == 1;
+    return R == 3;
+}
+
+size_t gaussian_tmp_bytes(int nx, int ny, int n_frames, float sigma, int type, int planes)
+{
+    (void)planes;
+    if (type == 1) return sizeof(float) * (size_t)nx * ny * n_frames;  // SII scratch
+    if (type != 0 || sigma <= 0) return 0;
+    int size = (int)(3 * sigma) + 1;
+    return sizeof(float) * (size_t)nx * ny * n_frames;  // generic two-pass scratch (unused on fast paths)
+    (void)size;
+}
+
+imgfd_status launch_sii_gaussian(imgfd_ctx *ctx, const float *d_in, float *d_out, int nx, int ny,
+                                 int n_frames, float sigma);
+
+// gaussian(): gaussian.cpp:403-430.  d_in may be u8 or f32 with its own pitch; d_out is a packed
+// f32 plane; d_tmp (nx*ny*n_frames floats) is needed for the generic/SII paths only.
+imgfd_status launch_gaussian(imgfd_ctx *ctx, const void *d_in, int in_is_u8, int in_pitch,
+                             size_t in_frame_stride, float *d_out, int nx, int ny, int n_frames,
+                             float sigma, int type, float *d_tmp)
+{
+    dim3 cgrid(ceil_div(nx, 256), ny, n_frames);
+    auto copy = [&]() -> imgfd_status {
+        if (d_in == (const void *)d_out) return IMGFD_OK;
+        hipLaunchKernelGGL(plane_copy, cgrid, dim3(256), 0, ctx->stream, d_in, in_is_u8, in_pitch,
+                           in_frame_stride, d_out, nx, ny);
+        IMGFD_HIP(ctx, hipGetLastError());
+        return IMGFD_OK;
+    };
+    if (type == 1) {
+        if (in_is_u8 || in_pitch != nx || d_in == (const void *)d_out) {
+            if (!d_tmp) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "SII gaussian needs a scratch plane");
+            hipLaunchKernelGGL(plane_copy, cgrid, dim3(256), 0, ctx->stream, d_in, in_is_u8, in_pitch,
+                               in_frame_stride, d_tmp, nx, ny);
+            return launch_sii_gaussian(ctx, d_tmp, d_out, nx, ny, n_frames, sigma);
+        }
+        return launch_sii_gaussian(ctx, (const float *)d_in, d_out, nx, ny, n_frames, sigma);
+    }
+    if (type != 0 || sigma <= 0) return copy();  // NO_GAUSSIAN / sigma<=0: gaussian.cpp:299-305, 424-429
+    FirParams p;
+    memset(&p, 0, sizeof p);
+    int size = fir_coeffs(sigma, 3, p.B);
+    if (size < 0) return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "gaussian sigma too large (more than 64 taps)");
+    if (size > nx) return copy();  // gaussian.cpp:312: output untouched == input (the reference works in place)
+    const int R = size - 1;
+    p.in0 = d_in; p.in1 = nullptr; p.out0 = d_out; p.nx = nx; p.ny = ny; p.in_pitch = in_pitch;
+    p.in_frame_stride = (long)in_frame_stride; p.out_frame_stride = (long)nx * ny;
+    if (R == 3 && !(d_in == (const void *)d_out)) {
+        if (in_is_u8) return launch_march<3, 1, 128, 16>(ctx, p, n_frames);
+        return launch_march<3, 0, 128, 16>(ctx, p, n_frames);
+    }
+    if (!d_tmp) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "generic gaussian needs a scratch plane");
+    const float *src = (const float *)d_in;
+    if (in_is_u8 || in_pitch != nx || in_frame_stride != (size_t)nx * ny) {
+        hipLaunchKernelGGL(plane_copy, cgrid, dim3(256), 0, ctx->stream, d_in, in_is_u8, in_pitch,
+                           in_frame_stride, d_out, nx, ny);
+        src = d_out;
+    }
+    return launch_generic(ctx, src, d_tmp, d_out, nx, ny, n_frames, size, p.B);
+}
+
+// compute_autocorrelation_matrix(): harris.cpp:44-70
+imgfd_status launch_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_A,
+                                     float *d_B, float *d_C, int nx, int ny, int n_frames, float sigma,
+                                     int gauss, float *d_tmp)
+{
+    if (gauss == 2) gauss = 1;  // harris.cpp:64-65
+    const size_t n = (size_t)nx * ny * n_frames;
+    auto products = [&]() -> imgfd_status {
+        hipLaunchKernelGGL(tensor_products, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           d_Ix, d_Iy, d_A, d_B, d_C, n);
+        IMGFD_HIP(ctx, hipGetLastError());
+        return IMGFD_OK;
+    };
+    if (gauss == 1) {
+        if (!d_tmp) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "SII structure tensor needs a scratch plane");
+        IMGFD_TRY(products());
+        float *pl[3] = {d_A, d_B, d_C};
+        for (int i = 0; i < 3; i++) {
+            IMGFD_HIP(ctx, hipMemcpyAsync(d_tmp, pl[i], n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+            IMGFD_TRY(launch_sii_gaussian(ctx, d_tmp, pl[i], nx, ny, n_frames, sigma));
+        }
+        return IMGFD_OK;
+    }
+    if (sigma <= 0) return products();
+    FirParams p;
+    memset(&p, 0, sizeof p);
+    int size = fir_coeffs(sigma, 3, p.B);
+    if (size < 0) return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "gaussian sigma too large (more than 64 taps)");
+    if (size > nx) return products();
+    const int R = size - 1;
+    p.in0 = d_Ix; p.in1 = d_Iy; p.out0 = d_A; p.out1 = d_B; p.out2 = d_C; p.nx = nx; p.ny = ny;
+    p.in_pitch = nx; p.in_frame_stride = (long)nx * ny; p.out_frame_stride = (long)nx * ny;
+    if (fir_has_fast_path(R, 2)) {
+        switch (R) {
+            case 7: return launch_march<7, 2, 128, 16>(ctx, p, n_frames);
+            case 3: return launch_march<3, 2, 128, 16>(ctx, p, n_frames);
+            case 1: return launch_march<1, 2, 128, 16>(ctx, p, n_frames);
+        }
+    }
+    if (!d_tmp) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "generic structure tensor needs a scratch plane");
+    IMGFD_TRY(products());
+    float *pl[3] = {d_A, d_B, d_C};
+    for (int i = 0; i < 3; i++) IMGFD_TRY(launch_generic(ctx, pl[i], d_tmp, pl[i], nx, ny, n_frames, size, p.B));
+    return IMGFD_OK;
+}

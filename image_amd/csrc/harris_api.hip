@@ -1,0 +1,445 @@
+// image_amd/csrc/harris_api.hip -- host orchestration of the Harris path behind the C ABI.
+//
+// Mirrors detect_corners() (image.CornerDetectionHarris/src/rcpp_harris.cpp:19-60), harris_scale()
+// (harris.cpp:554-608) and harris() (:473-546): the per-pixel stages run on the device (fir.hip,
+// harris_stages.hip, nms.hip, compact.hip); the per-corner stages that the reference runs on a few
+// thousand items -- select_output_corners (:263-332), compute_subpixel_precision (:340-381 with
+// interpolation.cpp), select_corners (:443-465) -- run on the host over the compacted list, in the
+// reference's own arithmetic (float variables, double-promoted constants, std::sort with the same
+// comparator).
+#include "common.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <chrono>
+#include <vector>
+
+// zoom_out(): zoom.cpp:121-139.  bicubic_interpolation_at() is evaluated at integer coordinates only
+// (uu-x == 0), where cubic_interpolation() returns v[1] exactly: a 2x decimation.
+__global__ void __launch_bounds__(256) zoom_out_kernel(const float *__restrict__ I, float *__restrict__ Iz, int nx,
+                                                       int nxx, int nyy)
+{
+    const int j1 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i1 = blockIdx.y;
+    if (j1 < nxx && i1 < nyy) Iz[(size_t)i1 * nxx + j1] = I[(size_t)(2 * i1) * nx + 2 * j1];
+}
+
+// 3x3 neighbourhood of R around each corner (harris.cpp:353-370), for the host-side sub-pixel step
+__global__ void __launch_bounds__(256) gather3x3_kernel(const float *__restrict__ R, int nx,
+                                                        const imgfd_corner *__restrict__ c, long long n,
+                                                        float *__restrict__ M)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)c[i].x, y = (int)c[i].y;
+    const float *p = R + (size_t)y * nx + x;
+    float *m = M + 9 * i;
+    m[0] = p[-nx - 1]; m[1] = p[-nx]; m[2] = p[-nx + 1];
+    m[3] = p[-1];      m[4] = p[0];   m[5] = p[1];
+    m[6] = p[nx - 1];  m[7] = p[nx];  m[8] = p[nx + 1];
+}
+
+namespace {
+
+struct HCorner {
+    float x, y, R;
+    float M[9];
+};
+// inverse sort, harris.cpp:29-36
+inline bool operator<(const HCorner &a, const HCorner &b) { return a.R > b.R; }
+
+// quadratic_approximation, interpolation.cpp:27-54
+bool quadratic_approximation(const float *M, float &x, float &y, float &Mo)
+{
+    float fx = 0.5 * (M[5] - M[3]);
+    float fy = 0.5 * (M[7] - M[1]);
+    float fxx = (M[5] - 2 * M[4] + M[3]);
+    float fyy = (M[7] - 2 * M[4] + M[1]);
+    float fxy = 0.25 * (M[0] - M[2] - M[6] + M[8]);
+    float det = fxx * fyy - fxy * fxy;
+    if (det * det < 1E-6) return false;
+    float dx = (fyy * fx - fxy * fy) / det;
+    float dy = (fxx * fy - fxy * fx) / det;
+    x -= dx;
+    y -= dy;
+    Mo = M[4] + fx * dx + fy * dy + 0.5 * (fxx * dx * dx + 2 * dx * dy * fxy + fyy * dy * dy);
+    return true;
+}
+
+// quartic_interpolation, interpolation.cpp:171-212 (+ helpers :62-160)
+bool quartic_interpolation(const float *M, float &x, float &y, float &Mo)
+{
+    const float TOL = 1E-10;
+    float D[2], b[2], H[3], a[9];
+    float dx = 0, dy = 0;
+    a[0] = M[4] - 0.5 * (M[1] + M[3] + M[5] + M[7]) + 0.25 * (M[0] + M[2] + M[6] + M[8]);
+    a[1] = 0.5 * (M[1] - M[7]) + 0.25 * (-M[0] - M[2] + M[6] + M[8]);
+    a[2] = 0.5 * (M[3] - M[5]) + 0.25 * (-M[0] + M[2] - M[6] + M[8]);
+    a[3] = 0.5 * (M[3] + M[5]) - M[4];
+    a[4] = 0.5 * (M[1] + M[7]) - M[4];
+    a[5] = 0.25 * (M[0] - M[2] - M[6] + M[8]);
+    a[6] = 0.5 * (M[5] - M[3]);
+    a[7] = 0.5 * (M[7] - M[1]);
+    a[8] = M[4];
+    int i = 0;
+    do {
+        D[0] = 2 * a[0] * dx * dy * dy + 2 * a[1] * dx * dy + 2 * a[2] * dy * dy + 2 * a[3] * dx + a[5] * dy + a[6];
+        D[1] = 2 * a[0] * dx * dx * dy + 2 * a[1] * dx * dx + 2 * a[2] * dx * dy + 2 * a[4] * dy + a[5] * dx + a[7];
+        H[0] = 2 * a[0] * dy * dy + 2 * a[1] * dy + 2 * a[3];
+        H[1] = 4 * a[0] * dx * dy + 2 * a[1] * dx + 2 * a[2] * dy + a[5];
+        H[2] = 2 * a[0] * dx * dx + 2 * a[2] * dx + 2 * a[4];
+        float det = H[0] * H[2] - H[1] * H[1];
+        if (det * det < 1E-10) return false;
+        b[0] = (D[0] * H[2] - D[1] * H[1]) / det;
+        b[1] = (D[1] * H[0] - D[0] * H[1]) / det;
+        dx -= b[0];
+        dy -= b[1];
+        i++;
+    } while (D[0] * D[0] + D[1] * D[1] > TOL && i < 20);
+    if (dx > 1 || dx < -1 || dy > 1 || dy < -1 || std::isnan(dx) || std::isnan(dy)) return false;
+    x += dx;
+    y += dy;
+    Mo = a[0] * dx * dx * dy * dy + a[1] * dx * dx * dy + a[2] * dx * dy * dy + a[3] * dx * dx + a[4] * dy * dy +
+         a[5] * dx * dy + a[6] * dx + a[7] * dy + a[8];
+    return true;
+}
+
+// select_output_corners, harris.cpp:263-332
+void select_output_corners(std::vector<HCorner> &corners, int strategy, int cells, int N, int nx, int ny)
+{
+    switch (strategy) {
+        default:
+        case IMGFD_ALL_CORNERS: break;
+        case IMGFD_ALL_CORNERS_SORTED: std::sort(corners.begin(), corners.end()); break;
+        case IMGFD_N_CORNERS:
+            std::sort(corners.begin(), corners.end());
+            if (N < (int)corners.size()) corners.erase(corners.begin() + (N < 0 ? 0 : N), corners.end());
+            break;
+        case IMGFD_DISTRIBUTED_N_CORNERS: {
+            int cellx = cells, celly = cells;
+            if (cellx > nx) cellx = nx;
+            if (celly > ny) celly = ny;
+            if (cellx < 1) cellx = 1;
+            if (celly < 1) celly = 1;
+            int size = cellx * celly;
+            int Ncell = N / size;
+            if (Ncell < 1) Ncell = 1;
+            std::vector<std::vector<HCorner>> cell_corners(size);
+            float Dx = (float)nx / cellx;
+            float Dy = (float)ny / celly;
+            for (size_t i = 0; i < corners.size(); i++) {
+                int px = (float)corners[i].x / Dx;
+                int py = (float)corners[i].y / Dy;
+                int idx = py * cellx + px;
+                if (idx < 0) idx = 0;
+                if (idx >= size) idx = size - 1;
+                cell_corners[idx].push_back(corners[i]);
+            }
+            for (int i = 0; i < size; i++) std::sort(cell_corners[i].begin(), cell_corners[i].end());
+            corners.resize(0);
+            for (int i = 0; i < size; i++) {
+                if ((int)cell_corners[i].size() > Ncell)
+                    corners.insert(corners.end(), cell_corners[i].begin(), cell_corners[i].begin() + Ncell);
+                else
+                    corners.insert(corners.end(), cell_corners[i].begin(), cell_corners[i].end());
+            }
+            std::sort(corners.begin(), corners.end());
+            if (N < (int)corners.size()) corners.erase(corners.begin() + (N < 0 ? 0 : N), corners.end());
+            break;
+        }
+    }
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct HarrisArgs {
+    float k, sigma_d, sigma_i, Th;
+    int gauss, grad, measure, strategy, cells, N, precision, verbose;
+};
+
+size_t harris_ws_bytes(int nx, int ny, int n_frames, int64_t cap)
+{
+    const size_t plane = align_up(sizeof(float) * (size_t)nx * ny * n_frames, 256);
+    return 8 * plane + compact_bytes(nx, ny, n_frames) + align_up(sizeof(imgfd_corner) * (size_t)cap * n_frames, 256) +
+           align_up(sizeof(float) * 9 * (size_t)cap * n_frames, 256) + align_up(sizeof(int64_t) * n_frames, 256) + 4096;
+}
+
+struct HarrisPlanes {
+    float *Is, *Ix, *Iy, *A, *B, *C, *R, *tmp;
+    CompactBuffers cb;
+};
+
+imgfd_status carve_planes(imgfd_ctx *ctx, int nx, int ny, int n_frames, HarrisPlanes *hp)
+{
+    const size_t bytes = sizeof(float) * (size_t)nx * ny * n_frames;
+    float **pl[8] = {&hp->Is, &hp->Ix, &hp->Iy, &hp->A, &hp->B, &hp->C, &hp->R, &hp->tmp};
+    for (auto p : pl) {
+        *p = (float *)ws_alloc(ctx, bytes);
+        if (!*p) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    }
+    return compact_carve(ctx, nx, ny, n_frames, &hp->cb);
+}
+
+// the device part of harris(): harris.cpp:510-523.  Input may be u8 or f32 with its own pitch.
+imgfd_status harris_device_stages(imgfd_ctx *ctx, const void *d_in, int in_is_u8, int in_pitch,
+                                  size_t in_frame_stride, int nx, int ny, int n_frames, const HarrisArgs &a,
+                                  const HarrisPlanes &hp, imgfd_corner *d_corners, int64_t cap, int64_t *d_counts,
+                                  double *stage_seconds)
+{
+    double t0 = 0;
+    auto tick = [&](int stage) -> imgfd_status {
+        if (!stage_seconds) return IMGFD_OK;
+        IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const double t = now_s();
+        if (stage >= 0) stage_seconds[stage] = t - t0;
+        t0 = t;
+        return IMGFD_OK;
+    };
+    IMGFD_TRY(tick(-1));
+    IMGFD_TRY(compact_clear(ctx, hp.cb, ny, n_frames));
+    IMGFD_TRY(launch_gaussian(ctx, d_in, in_is_u8, in_pitch, in_frame_stride, hp.Is, nx, ny, n_frames, a.sigma_d,
+                              a.gauss, hp.tmp));
+    IMGFD_TRY(tick(0));
+    IMGFD_TRY(launch_gradient(ctx, hp.Is, hp.Ix, hp.Iy, nx, ny, n_frames, a.grad));
+    IMGFD_TRY(tick(1));
+    IMGFD_TRY(launch_structure_tensor(ctx, hp.Ix, hp.Iy, hp.A, hp.B, hp.C, nx, ny, n_frames, a.sigma_i, a.gauss,
+                                      hp.tmp));
+    IMGFD_TRY(tick(2));
+    IMGFD_TRY(launch_response(ctx, hp.A, hp.B, hp.C, hp.R, nx, ny, n_frames, a.measure, a.k));
+    IMGFD_TRY(tick(3));
+    const int radius = (int)(2 * a.sigma_i + 0.5);  // harris.cpp:523, double -> int truncation
+    IMGFD_TRY(launch_harris_nms(ctx, hp.R, nx, ny, n_frames, a.Th, radius, hp.cb));
+    IMGFD_TRY(compact_emit(ctx, hp.cb, nx, ny, n_frames, 0, hp.R, d_corners, cap, d_counts));
+    IMGFD_TRY(tick(4));
+    return IMGFD_OK;
+}
+
+// harris(): one scale, device stages + host stages; d_I is an f32 device plane
+imgfd_status harris_one(imgfd_ctx *ctx, const float *d_I, int nx, int ny, const HarrisArgs &a,
+                        std::vector<HCorner> &corners, double *stage_seconds)
+{
+    corners.clear();
+    if (nx < 3 || ny < 3) return IMGFD_OK;  // harris.cpp:493
+    // the window rule admits at most one corner per 2x2 block (radius >= 1)
+    const int64_t cap = (int64_t)nx * ny / 4 + 16;
+    {
+        // d_I lives in the caller's arena slice; planes are carved after the current watermark
+        const size_t mark = ctx->ws_used;
+        HarrisPlanes hp;
+        IMGFD_TRY(carve_planes(ctx, nx, ny, 1, &hp));
+        imgfd_corner *d_corners = (imgfd_corner *)ws_alloc(ctx, sizeof(imgfd_corner) * (size_t)cap);
+        float *d_M = (float *)ws_alloc(ctx, sizeof(float) * 9 * (size_t)cap);
+        int64_t *d_count = (int64_t *)ws_alloc(ctx, sizeof(int64_t));
+        if (!d_corners || !d_M || !d_count) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+        IMGFD_TRY(harris_device_stages(ctx, d_I, 0, nx, (size_t)nx * ny, nx, ny, 1, a, hp, d_corners, cap, d_count,
+                                       stage_seconds));
+        int64_t n = 0;
+        IMGFD_HIP(ctx, hipMemcpyAsync(&n, d_count, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
+        IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (n > cap) n = cap;
+        std::vector<imgfd_corner> host((size_t)n);
+        std::vector<float> M;
+        const bool sub = a.precision == IMGFD_QUADRATIC_APPROXIMATION || a.precision == IMGFD_QUARTIC_INTERPOLATION;
+        if (n) {
+            if (sub) {
+                hipLaunchKernelGGL(gather3x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   hp.R, nx, d_corners, (long long)n, d_M);
+                M.resize(9 * (size_t)n);
+                IMGFD_HIP(ctx, hipMemcpyAsync(M.data(), d_M, sizeof(float) * 9 * n, hipMemcpyDeviceToHost, ctx->stream));
+            }
+            IMGFD_HIP(ctx, hipMemcpyAsync(host.data(), d_corners, sizeof(imgfd_corner) * n, hipMemcpyDeviceToHost,
+                                          ctx->stream));
+            IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        corners.resize((size_t)n);
+        for (int64_t i = 0; i < n; i++) {
+            corners[i].x = host[i].x; corners[i].y = host[i].y; corners[i].R = host[i].R;
+            if (sub) memcpy(corners[i].M, &M[9 * i], sizeof(float) * 9);
+        }
+        double t = now_s();
+        select_output_corners(corners, a.strategy, a.cells, a.N, nx, ny);
+        if (stage_seconds) { stage_seconds[5] = now_s() - t; t = now_s(); }
+        if (sub) {
+            for (auto &c : corners) {
+                if (a.precision == IMGFD_QUADRATIC_APPROXIMATION) quadratic_approximation(c.M, c.x, c.y, c.R);
+                else quartic_interpolation(c.M, c.x, c.y, c.R);
+            }
+            if (stage_seconds) stage_seconds[6] = now_s() - t;
+        }
+        ctx->ws_used = mark;
+        return IMGFD_OK;
+    }
+}
+
+// harris_scale(): harris.cpp:554-608
+imgfd_status harris_scale(imgfd_ctx *ctx, const float *d_I, int nx, int ny, int Nscales, HarrisArgs a,
+                          std::vector<HCorner> &corners, double *stage_seconds)
+{
+    if (Nscales <= 1 || nx <= 64 || ny <= 64) return harris_one(ctx, d_I, nx, ny, a, corners, stage_seconds);
+    const int nxx = nx / 2, nyy = ny / 2;
+    const size_t mark = ctx->ws_used;
+    float *d_Iz = (float *)ws_alloc(ctx, sizeof(float) * (size_t)nxx * nyy);
+    if (!d_Iz) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    hipLaunchKernelGGL(zoom_out_kernel, dim3(ceil_div(nxx, 256), nyy), dim3(256), 0, ctx->stream, d_I, d_Iz, nx, nxx,
+                       nyy);
+    std::vector<HCorner> corners_z;
+    HarrisArgs az = a;
+    az.sigma_i = a.sigma_i / 2;
+    IMGFD_TRY(harris_scale(ctx, d_Iz, nxx, nyy, Nscales - 1, az, corners_z, nullptr));
+    ctx->ws_used = mark;
+    IMGFD_TRY(harris_one(ctx, d_I, nx, ny, a, corners, stage_seconds));
+    // select_corners / distance2, harris.cpp:425-465
+    std::vector<HCorner> kept;
+    for (size_t i = 0; i < corners.size(); i++) {
+        size_t j = 0;
+        for (; j < corners_z.size(); j++) {
+            float dx = (corners_z[j].x - corners[i].x / 2.);
+            float dy = (corners_z[j].y - corners[i].y / 2.);
+            if (!(dx * dx + dy * dy > a.sigma_i * a.sigma_i)) break;
+        }
+        if (j < corners_z.size()) kept.push_back(corners[i]);
+    }
+    corners.swap(kept);
+    return IMGFD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+imgfd_status imgfd_harris(imgfd_ctx *ctx, const float *img, int nx, int ny, float k, float sigma_d,
+                          float sigma_i, float threshold, int gaussian, int gradient, int strategy,
+                          int Nselect, int measure, int Nscales, int precision, int cells, int verbose,
+                          imgfd_corners *out)
+{
+    if (!ctx || !out) return IMGFD_ERR_INVALID;
+    out->corners = nullptr;
+    out->n = 0;
+    memset(out->stage_seconds, 0, sizeof out->stage_seconds);
+    if (!img || nx < 0 || ny < 0) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_harris: bad image");
+    if (nx < 3 || ny < 3) return IMGFD_OK;  // harris.cpp:493 (harris_scale falls through to harris for small images)
+    IMGFD_HIP(ctx, hipSetDevice(ctx->device));
+    // arena: the input plane, a half-size pyramid for the scale check, and one set of stage planes
+    const size_t plane = align_up(sizeof(float) * (size_t)nx * ny, 256);
+    size_t need = plane + harris_ws_bytes(nx, ny, 1, (int64_t)nx * ny / 4 + 16);
+    if (Nscales > 1) need += plane;  // sum of the decimated copies is < plane/3; keep it simple
+    IMGFD_TRY(ws_reserve(ctx, need));
+    float *d_I = (float *)ws_alloc(ctx, sizeof(float) * (size_t)nx * ny);
+    if (!d_I) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    IMGFD_HIP(ctx, hipMemcpyAsync(d_I, img, sizeof(float) * (size_t)nx * ny, hipMemcpyHostToDevice, ctx->stream));
+    HarrisArgs a{k, sigma_d, sigma_i, threshold, gaussian, gradient, measure, strategy, cells, Nselect, precision, verbose};
+    std::vector<HCorner> corners;
+    IMGFD_TRY(harris_scale(ctx, d_I, nx, ny, Nscales, a, corners, verbose ? out->stage_seconds : nullptr));
+    out->n = (int64_t)corners.size();
+    if (out->n) {
+        out->corners = (imgfd_corner *)malloc(sizeof(imgfd_corner) * corners.size());
+        if (!out->corners) return imgfd_fail(ctx, IMGFD_ERR_OOM, "malloc of the corner list failed");
+        for (size_t i = 0; i < corners.size(); i++) {
+            out->corners[i].x = corners[i].x; out->corners[i].y = corners[i].y; out->corners[i].R = corners[i].R;
+        }
+    }
+    return IMGFD_OK;
+}
+
+imgfd_status imgfd_harris_dev(imgfd_ctx *ctx, const imgfd_frames *fr, float k, float sigma_d,
+                              float sigma_i, float threshold, int gaussian, int gradient, int measure,
+                              imgfd_corner *d_corners, int64_t cap, int64_t *d_counts)
+{
+    if (!ctx || !fr || !fr->d_frames || !d_corners || !d_counts || cap < 0 || fr->n_frames < 0)
+        return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_harris_dev: bad argument");
+    const int nx = fr->nx, ny = fr->ny;
+    if (fr->n_frames == 0) return IMGFD_OK;
+    IMGFD_HIP(ctx, hipSetDevice(ctx->device));
+    if (nx < 3 || ny < 3) {
+        IMGFD_HIP(ctx, hipMemsetAsync(d_counts, 0, sizeof(int64_t) * fr->n_frames, ctx->stream));
+        return IMGFD_OK;
+    }
+    const int esz = fr->dtype == 0 ? 1 : 4;
+    if (fr->row_stride_bytes % esz || fr->frame_stride_bytes % esz)
+        return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_harris_dev: strides must be multiples of the element size");
+    // sub-batches bounded by ~3 GiB of stage planes
+    const size_t per_frame = 8 * sizeof(float) * (size_t)nx * ny;
+    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)fr->n_frames, ((size_t)3 << 30) / per_frame));
+    IMGFD_TRY(ws_reserve(ctx, harris_ws_bytes(nx, ny, chunk, 0)));
+    HarrisPlanes hp;
+    IMGFD_TRY(carve_planes(ctx, nx, ny, chunk, &hp));
+    HarrisArgs a{k, sigma_d, sigma_i, threshold, gaussian, gradient, measure, 0, 0, 0, 0, 0};
+    for (int f0 = 0; f0 < fr->n_frames; f0 += chunk) {
+        const int nf = std::min(chunk, fr->n_frames - f0);
+        const char *base = (const char *)fr->d_frames + (size_t)f0 * fr->frame_stride_bytes;
+        IMGFD_TRY(harris_device_stages(ctx, base, fr->dtype == 0, fr->row_stride_bytes / esz,
+                                       fr->frame_stride_bytes / esz, nx, ny, nf, a, hp, d_corners + (size_t)f0 * cap,
+                                       cap, d_counts + f0, nullptr));
+    }
+    return IMGFD_OK;
+}
+
+// ---- stage doorways -------------------------------------------------------------------------
+imgfd_status imgfd_k_gaussian(imgfd_ctx *ctx, const float *d_in, float *d_out, int nx, int ny, float sigma, int type)
+{
+    if (!ctx || !d_in || !d_out || nx < 1 || ny < 1) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_k_gaussian: bad argument");
+    IMGFD_TRY(ws_reserve(ctx, sizeof(float) * (size_t)nx * ny + 4096));
+    float *tmp = (float *)ws_alloc(ctx, sizeof(float) * (size_t)nx * ny);
+    return launch_gaussian(ctx, d_in, 0, nx, (size_t)nx * ny, d_out, nx, ny, 1, sigma, type, tmp);
+}
+
+imgfd_status imgfd_k_gradient(imgfd_ctx *ctx, const float *d_I, float *d_Ix, float *d_Iy, int nx, int ny, int type)
+{
+    if (!ctx || !d_I || !d_Ix || !d_Iy || nx < 3 || ny < 3) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_k_gradient: bad argument");
+    return launch_gradient(ctx, d_I, d_Ix, d_Iy, nx, ny, 1, type);
+}
+
+imgfd_status imgfd_k_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_A,
+                                      float *d_B, float *d_C, int nx, int ny, float sigma, int gauss)
+{
+    if (!ctx || !d_Ix || !d_Iy || !d_A || !d_B || !d_C || nx < 1 || ny < 1)
+        return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_k_structure_tensor: bad argument");
+    IMGFD_TRY(ws_reserve(ctx, sizeof(float) * (size_t)nx * ny + 4096));
+    float *tmp = (float *)ws_alloc(ctx, sizeof(float) * (size_t)nx * ny);
+    return launch_structure_tensor(ctx, d_Ix, d_Iy, d_A, d_B, d_C, nx, ny, 1, sigma, gauss, tmp);
+}
+
+imgfd_status imgfd_k_response(imgfd_ctx *ctx, const float *d_A, const float *d_B, const float *d_C,
+                              float *d_R, int nx, int ny, int measure, float k)
+{
+    if (!ctx || !d_A || !d_B || !d_C || !d_R || nx < 1 || ny < 1)
+        return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_k_response: bad argument");
+    return launch_response(ctx, d_A, d_B, d_C, d_R, nx, ny, 1, measure, k);
+}
+
+imgfd_status imgfd_k_nms(imgfd_ctx *ctx, const float *d_R, int nx, int ny, float Th, int radius,
+                         imgfd_corner *d_corners, int64_t cap, int64_t *d_count)
+{
+    if (!ctx || !d_R || !d_corners || !d_count || nx < 1 || ny < 1 || cap < 0)
+        return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_k_nms: bad argument");
+    IMGFD_TRY(ws_reserve(ctx, compact_bytes(nx, ny, 1) + 4096));
+    CompactBuffers cb;
+    IMGFD_TRY(compact_carve(ctx, nx, ny, 1, &cb));
+    IMGFD_TRY(compact_clear(ctx, cb, ny, 1));
+    IMGFD_TRY(launch_harris_nms(ctx, d_R, nx, ny, 1, Th, radius, cb));
+    return compact_emit(ctx, cb, nx, ny, 1, 0, d_R, d_corners, cap, d_count);
+}
+
+imgfd_status imgfd_time_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy,
+                                         float *d_A, float *d_B, float *d_C, int nx, int ny,
+                                         float sigma, int gauss, int warmup, int iters, double *avg_us)
+{
+    if (!ctx || !avg_us || iters < 1) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_time_structure_tensor: bad argument");
+    IMGFD_TRY(ws_reserve(ctx, sizeof(float) * (size_t)nx * ny + 4096));
+    float *tmp = (float *)ws_alloc(ctx, sizeof(float) * (size_t)nx * ny);
+    for (int i = 0; i < warmup; i++)
+        IMGFD_TRY(launch_structure_tensor(ctx, d_Ix, d_Iy, d_A, d_B, d_C, nx, ny, 1, sigma, gauss, tmp));
+    IMGFD_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < iters; i++)
+        IMGFD_TRY(launch_structure_tensor(ctx, d_Ix, d_Iy, d_A, d_B, d_C, nx, ny, 1, sigma, gauss, tmp));
+    IMGFD_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    IMGFD_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    IMGFD_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *avg_us = 1e3 * (double)ms / iters;
+    return IMGFD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,190 @@
+/*
+ * imgfd.h -- C ABI of libimgfd.so, the MI355X (gfx950) feature-detection backend that replaces the
+ * bundled CPU C/C++ behind five R functions of bnosac/image.  Plain pointers and sizes only.
+ *
+ * Reference interfaces replaced (paths relative to the bnosac/image repository):
+ *   imgfd_harris   <- detect_corners(), image.CornerDetectionHarris/src/rcpp_harris.cpp:19-60, the body
+ *                     of .Call symbol _image_CornerDetectionHarris_detect_corners (src/RcppExports.cpp:9-33)
+ *   imgfd_fast9    <- detect_corners(), image.CornerDetectionF9/src/f9_rcpp.cpp:8-35
+ *                     (_image_CornerDetectionF9_detect_corners, src/RcppExports.cpp:9-23); same argument
+ *                     meaning as the library's own C API f9_detect_corners(), src/f9.h:77-86
+ *   imgfd_canny    <- canny_edge_detector(), image.CannyEdges/src/rcpp_canny.cpp:122-244
+ *                     (_image_CannyEdges_canny_edge_detector, src/RcppExports.cpp:9-24)
+ *   imgfd_fhog     <- dlib_fhog(), image.dlib/src/rcpp_fhog.cpp:10-46 (_image_dlib_dlib_fhog)
+ *   imgfd_surf     <- dlib_surf_points(), image.dlib/src/rcpp_surf.cpp:10-53 (_image_dlib_dlib_surf_points)
+ * INTEGRATION.md shows the .Call glue that binds these from the unchanged R wrappers.
+ *
+ * Conventions
+ *   - every function returns an imgfd_status (0 = ok); nothing throws or longjmps across this boundary;
+ *     imgfd_last_error(ctx) gives the message of the last failure on that context.
+ *   - a context owns one HIP stream, a grow-only device workspace and pinned staging buffers; it is
+ *     thread-compatible (one thread at a time per context), like R's single-threaded .Call.
+ *   - "host" entry points take host pointers (the drop-in path: the R glue hands over R-owned vectors);
+ *     "_dev" entry points take DEVICE pointers to frames already resident in HBM and leave their results
+ *     in device memory -- the batch/stream path the reference has no equivalent of.
+ *   - images are row-major, index = x + nx*y (x fastest), exactly the buffers the reference's glue
+ *     builds from the R vectors.
+ */
+#ifndef IMGFD_H
+#define IMGFD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMGFD_VERSION 1
+
+#if defined(IMGFD_BUILD)
+#define IMGFD_API __attribute__((visibility("default")))
+#else
+#define IMGFD_API
+#endif
+
+typedef enum {
+    IMGFD_OK = 0,
+    IMGFD_ERR_INVALID = 1,   /* bad argument */
+    IMGFD_ERR_NO_DEVICE = 2, /* no usable gfx950 device / HIP runtime failure at init */
+    IMGFD_ERR_HIP = 3,       /* a HIP call failed; see imgfd_last_error */
+    IMGFD_ERR_OOM = 4,
+    IMGFD_ERR_UNSUPPORTED = 5
+} imgfd_status;
+
+typedef struct imgfd_ctx imgfd_ctx;
+
+/* enum codes of the reference, passed through unchanged */
+/* gaussian.h:14-16 */  enum { IMGFD_STD_GAUSSIAN = 0, IMGFD_FAST_GAUSSIAN = 1, IMGFD_NO_GAUSSIAN = 2 };
+/* gradient.h:14-15 */  enum { IMGFD_CENTRAL_DIFFERENCES = 0, IMGFD_SOBEL_OPERATOR = 1 };
+/* harris.h:17-19 */    enum { IMGFD_HARRIS_MEASURE = 0, IMGFD_SHI_TOMASI_MEASURE = 1, IMGFD_HARMONIC_MEAN_MEASURE = 2 };
+/* harris.h:22-25 */    enum { IMGFD_ALL_CORNERS = 0, IMGFD_ALL_CORNERS_SORTED = 1, IMGFD_N_CORNERS = 2, IMGFD_DISTRIBUTED_N_CORNERS = 3 };
+/* interpolation.h:13-15 */ enum { IMGFD_NO_INTERPOLATION = 0, IMGFD_QUADRATIC_APPROXIMATION = 1, IMGFD_QUARTIC_INTERPOLATION = 2 };
+
+/* ------------------------------------------------------------------ context */
+IMGFD_API imgfd_status imgfd_ctx_create(int device, imgfd_ctx **out);
+/* same, but launch on an existing HIP stream (e.g. the caller's torch stream); stream is a hipStream_t */
+IMGFD_API imgfd_status imgfd_ctx_create_on_stream(int device, void *stream, imgfd_ctx **out);
+IMGFD_API void imgfd_ctx_destroy(imgfd_ctx *ctx);
+IMGFD_API const char *imgfd_last_error(const imgfd_ctx *ctx);
+/* hipStream_t of the context */
+IMGFD_API void *imgfd_ctx_stream(imgfd_ctx *ctx);
+IMGFD_API imgfd_status imgfd_ctx_sync(imgfd_ctx *ctx);
+/* free a buffer returned through an out-parameter of this library */
+IMGFD_API void imgfd_free(void *p);
+IMGFD_API int imgfd_version(void);
+/* arithmetic mode of the double-accumulated FIR (Harris Gaussians):
+ *   0 = strict: the reference's operation sequence, no FMA anywhere (bit-exact planes)
+ *   1 = fused-accumulate (default): sum = fma(B[j], pair, sum) inside the f64 accumulation only; the
+ *       f32 stages (products, response) never contract.  Results differ from strict only when the
+ *       f64 sum sits within ~1e-16 relative of a float rounding boundary. */
+IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
+
+/* ------------------------------------------------------------------ Harris */
+typedef struct {
+    float x, y; /* corner position (harris.h:33-46) */
+    float R;    /* corner strength */
+} imgfd_corner;
+
+typedef struct {
+    imgfd_corner *corners; /* library-allocated (imgfd_free), NULL when n == 0 */
+    int64_t n;
+    /* stage wall times in seconds, filled when verbose != 0: smooth, gradient, autocorrelation,
+     * response, nms, select, subpixel (the seven lines harris.cpp:510-538 prints) */
+    double stage_seconds[7];
+} imgfd_corners;
+
+/* Arguments exactly as rcpp_harris.cpp:19-32 after the NumericVector -> float narrowing
+ * (rcpp_harris.cpp:34-35, which the glue performs): img holds nx*ny floats.  Silent-empty cases of the
+ * reference are reproduced (nx<3 || ny<3: harris.cpp:493; image <= 2r+1: harris.cpp:151). */
+IMGFD_API imgfd_status imgfd_harris(imgfd_ctx *ctx, const float *img, int nx, int ny, float k, float sigma_d,
+                          float sigma_i, float threshold, int gaussian, int gradient, int strategy,
+                          int Nselect, int measure, int Nscales, int precision, int cells, int verbose,
+                          imgfd_corners *out);
+
+/* ------------------------------------------------------------------ FAST-9 */
+typedef struct { int x, y; } imgfd_point; /* F9_CORNER, f9.h:40-43 */
+
+typedef struct {
+    imgfd_point *points; /* library-allocated (imgfd_free); raster order like f9.cpp:2959-2960 */
+    int64_t n;
+} imgfd_points;
+
+/* f9_detect_corners(ctx, image_data, width, height, bytes_per_row, threshold, suppress_non_max, &n),
+ * f9.h:77-86.  Coordinates are the library's (x,y); the R-facing remap x<-y, y<-width-x of
+ * f9_rcpp.cpp:29-30 belongs to the glue. */
+IMGFD_API imgfd_status imgfd_fast9(imgfd_ctx *ctx, const uint8_t *img, int width, int height, int bytes_per_row,
+                         uint8_t threshold, int suppress_non_max, imgfd_points *out);
+
+/* ------------------------------------------------------------------ Canny */
+/* canny_edge_detector(image, X, Y, s, low_thr, high_thr, accGrad), rcpp_canny.cpp:122-127, after the
+ * IntegerVector -> unsigned char narrowing (:135-136).  edges: caller-allocated nx*ny bytes, 0 or 255
+ * (:210-215); *pixels_nonzero as :226-233. */
+IMGFD_API imgfd_status imgfd_canny(imgfd_ctx *ctx, const uint8_t *img, int nx, int ny, double s, double low_thr,
+                         double high_thr, int accGrad, uint8_t *edges, int64_t *pixels_nonzero);
+
+/* ------------------------------------------------------------------ device-resident batch path
+ * Frames live in HBM: frame f starts at (char*)d_frames + f*frame_stride_bytes, rows are row_stride
+ * bytes apart.  Results stay on the device in caller-provided buffers so that a stream of frames can
+ * be processed without host synchronisation; counts are int64 per frame.  All launches go to the
+ * context's stream and return immediately. */
+typedef struct {
+    const void *d_frames;
+    int n_frames;
+    int nx, ny;
+    size_t frame_stride_bytes;
+    int row_stride_bytes;
+    int dtype; /* 0 = u8, 1 = f32 (Harris only) */
+} imgfd_frames;
+
+/* Harris, reference default path and every enum code that runs on the device (gaussian 0/1/2,
+ * gradient 0/1, measure 0/1/2); strategy "all corners", no sub-pixel, one scale: exactly what every
+ * public image_harris() call executes.  d_corners: n_frames*cap records, raster order;
+ * d_counts[f] = number of corners found in frame f (may exceed cap; only cap are stored). */
+IMGFD_API imgfd_status imgfd_harris_dev(imgfd_ctx *ctx, const imgfd_frames *fr, float k, float sigma_d,
+                              float sigma_i, float threshold, int gaussian, int gradient, int measure,
+                              imgfd_corner *d_corners, int64_t cap, int64_t *d_counts);
+
+IMGFD_API imgfd_status imgfd_fast9_dev(imgfd_ctx *ctx, const imgfd_frames *fr, uint8_t threshold,
+                             int suppress_non_max, imgfd_point *d_points, int64_t cap,
+                             int64_t *d_counts);
+
+/* d_edges: n_frames * nx*ny bytes (0/255); d_counts[f] = pixels_nonzero of frame f */
+IMGFD_API imgfd_status imgfd_canny_dev(imgfd_ctx *ctx, const imgfd_frames *fr, double s, double low_thr,
+                             double high_thr, int accGrad, uint8_t *d_edges, int64_t *d_counts);
+
+/* ------------------------------------------------------------------ stage doorways (parity + roofline)
+ * Device pointers, one frame, planes of nx*ny floats.  These run the individual kernels of the Harris
+ * path so tests can compare plane by plane and bench.py can time the structure-tensor pass alone. */
+/* K1: discrete_gaussian / SII / copy, gaussian.cpp:403-430 (type as the reference codes) */
+IMGFD_API imgfd_status imgfd_k_gaussian(imgfd_ctx *ctx, const float *d_in, float *d_out, int nx, int ny,
+                              float sigma, int type);
+/* K2: central differences / Sobel, gradient.cpp:115-128 */
+IMGFD_API imgfd_status imgfd_k_gradient(imgfd_ctx *ctx, const float *d_I, float *d_Ix, float *d_Iy, int nx,
+                              int ny, int type);
+/* K3: the structure-tensor pass, compute_autocorrelation_matrix harris.cpp:44-70:
+ * reads Ix,Iy (8 B/px), writes the smoothed A,B,C (12 B/px) */
+IMGFD_API imgfd_status imgfd_k_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_A,
+                                      float *d_B, float *d_C, int nx, int ny, float sigma, int gauss);
+/* K4: compute_corner_response harris.cpp:78-133 */
+IMGFD_API imgfd_status imgfd_k_response(imgfd_ctx *ctx, const float *d_A, const float *d_B, const float *d_C,
+                              float *d_R, int nx, int ny, int measure, float k);
+/* K5: non_maximum_suppression harris.cpp:141-255 + raster-ordered compaction */
+IMGFD_API imgfd_status imgfd_k_nms(imgfd_ctx *ctx, const float *d_R, int nx, int ny, float Th, int radius,
+                         imgfd_corner *d_corners, int64_t cap, int64_t *d_count);
+
+/* Time `iters` back-to-back launches of the structure-tensor kernel with HIP events on the context's
+ * stream (after `warmup` untimed launches); *avg_us = mean microseconds per launch. */
+IMGFD_API imgfd_status imgfd_time_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy,
+                                         float *d_A, float *d_B, float *d_C, int nx, int ny,
+                                         float sigma, int gauss, int warmup, int iters, double *avg_us);
+
+/* Fill n_frames synthetic u8 frames G(seed0+f) directly in HBM (image_amd/synth.py is the host twin). */
+IMGFD_API imgfd_status imgfd_synth_frames(imgfd_ctx *ctx, uint8_t *d_frames, int n_frames, int nx, int ny,
+                                size_t frame_stride_bytes, uint32_t seed0, const int32_t *d_rects,
+                                int n_rect);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMGFD_H */

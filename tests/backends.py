@@ -1,0 +1,203 @@
+"""Two ways to drive the C ABI in tests.
+
+GpuBackend  -- the product: image_amd/libimgfd.so on a real device, buffers are torch CUDA tensors.
+EmuBackend  -- TEST ONLY: the same kernel sources compiled for the host against tests/hipemu (a fiber
+               based HIP emulator); "device" buffers are numpy arrays.  It checks kernel logic on the
+               GPU-less build machine and is never reachable from image_amd.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from image_amd import _binding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _Base:
+    name = "?"
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.ctx = C.c_void_p()
+        st = lib.imgfd_ctx_create(0, C.byref(self.ctx))
+        assert st == 0, f"imgfd_ctx_create -> {st}"
+
+    def check(self, st, what=""):
+        _binding.check(self.lib, self.ctx, st, what)
+
+    def set_fir_mode(self, mode):
+        self.check(self.lib.imgfd_set_fir_mode(self.ctx, mode))
+
+    def frames(self, dev, n, nx, ny, dtype):
+        esz = 1 if dtype == 0 else 4
+        return _binding.Frames(self.ptr(dev), n, nx, ny, nx * ny * esz, nx * esz, dtype)
+
+    # ---- stage doorways on host arrays -----------------------------------------------------
+    def k_gaussian(self, img, sigma, type=0):
+        ny, nx = img.shape
+        d_in = self.to_dev(np.ascontiguousarray(img, np.float32)); d_out = self.empty((ny, nx), np.float32)
+        self.check(self.lib.imgfd_k_gaussian(self.ctx, self.ptr(d_in), self.ptr(d_out), nx, ny, sigma, type), "k_gaussian")
+        return self.to_host(d_out)
+
+    def k_gradient(self, img, type=0):
+        ny, nx = img.shape
+        d_in = self.to_dev(np.ascontiguousarray(img, np.float32))
+        ix = self.empty((ny, nx), np.float32); iy = self.empty((ny, nx), np.float32)
+        self.check(self.lib.imgfd_k_gradient(self.ctx, self.ptr(d_in), self.ptr(ix), self.ptr(iy), nx, ny, type), "k_gradient")
+        return self.to_host(ix), self.to_host(iy)
+
+    def k_structure_tensor(self, ix, iy, sigma, gauss=0):
+        ny, nx = ix.shape
+        dx = self.to_dev(np.ascontiguousarray(ix, np.float32)); dy = self.to_dev(np.ascontiguousarray(iy, np.float32))
+        A, B, Cc = (self.empty((ny, nx), np.float32) for _ in range(3))
+        self.check(self.lib.imgfd_k_structure_tensor(self.ctx, self.ptr(dx), self.ptr(dy), self.ptr(A), self.ptr(B),
+                                                     self.ptr(Cc), nx, ny, sigma, gauss), "k_structure_tensor")
+        return self.to_host(A), self.to_host(B), self.to_host(Cc)
+
+    def k_response(self, A, B, Cc, measure=0, k=0.06):
+        ny, nx = A.shape
+        d = [self.to_dev(np.ascontiguousarray(p, np.float32)) for p in (A, B, Cc)]
+        R = self.empty((ny, nx), np.float32)
+        self.check(self.lib.imgfd_k_response(self.ctx, self.ptr(d[0]), self.ptr(d[1]), self.ptr(d[2]), self.ptr(R),
+                                             nx, ny, measure, k), "k_response")
+        return self.to_host(R)
+
+    def k_nms(self, R, Th, radius):
+        ny, nx = R.shape
+        d = self.to_dev(np.ascontiguousarray(R, np.float32))
+        cap = nx * ny // 4 + 16
+        out = self.empty((cap, 3), np.float32); cnt = self.empty((1,), np.int64)
+        self.check(self.lib.imgfd_k_nms(self.ctx, self.ptr(d), nx, ny, Th, radius, self.ptr(out), cap, self.ptr(cnt)), "k_nms")
+        n = int(self.to_host(cnt)[0])
+        return self.to_host(out)[:n]
+
+    # ---- host-pointer API -------------------------------------------------------------------
+    def harris(self, img, **kw):
+        p = dict(k=0.06, sigma_d=1.0, sigma_i=2.5, threshold=130.0, gaussian=0, gradient=0, strategy=0,
+                 Nselect=1, measure=0, Nscales=1, precision=0, cells=10, verbose=0)
+        p.update(kw)
+        img = np.ascontiguousarray(img, np.float32)
+        ny, nx = img.shape
+        out = _binding.Corners()
+        self.check(self.lib.imgfd_harris(self.ctx, img.ctypes.data_as(C.c_void_p), nx, ny, p["k"], p["sigma_d"],
+                                         p["sigma_i"], p["threshold"], p["gaussian"], p["gradient"], p["strategy"],
+                                         p["Nselect"], p["measure"], p["Nscales"], p["precision"], p["cells"],
+                                         p["verbose"], C.byref(out)), "imgfd_harris")
+        if not out.n:
+            return np.zeros((0, 3), np.float32)
+        arr = np.ctypeslib.as_array(C.cast(out.corners, C.POINTER(C.c_float)), shape=(out.n, 3)).copy()
+        self.lib.imgfd_free(out.corners)
+        return arr
+
+    def fast9(self, img, threshold, nonmax=False, width=None):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, stride = img.shape
+        w = stride if width is None else width
+        out = _binding.Points()
+        self.check(self.lib.imgfd_fast9(self.ctx, img.ctypes.data_as(C.c_void_p), w, h, stride, threshold & 0xFF,
+                                        int(nonmax), C.byref(out)), "imgfd_fast9")
+        if not out.n:
+            return np.zeros((0, 2), np.int32)
+        arr = np.ctypeslib.as_array(C.cast(out.points, C.POINTER(C.c_int)), shape=(out.n, 2)).copy()
+        self.lib.imgfd_free(out.points)
+        return arr
+
+    def canny(self, img, s=2.0, low_thr=3.0, high_thr=10.0, accGrad=True):
+        img = np.ascontiguousarray(img, np.uint8)
+        ny, nx = img.shape
+        edges = np.zeros((ny, nx), np.uint8)
+        n = C.c_int64(0)
+        self.check(self.lib.imgfd_canny(self.ctx, img.ctypes.data_as(C.c_void_p), nx, ny, s, low_thr, high_thr,
+                                        int(accGrad), edges.ctypes.data_as(C.c_void_p), C.byref(n)), "imgfd_canny")
+        return edges, int(n.value)
+
+    # ---- device-resident batch API --------------------------------------------------------------
+    def harris_dev(self, frames, cap=None, **kw):
+        p = dict(k=0.06, sigma_d=1.0, sigma_i=2.5, threshold=130.0, gaussian=0, gradient=0, measure=0)
+        p.update(kw)
+        n, ny, nx = frames.shape
+        dtype = 0 if frames.dtype == np.uint8 else 1
+        d = self.to_dev(np.ascontiguousarray(frames))
+        cap = cap or nx * ny // 4 + 16
+        out = self.empty((n, cap, 3), np.float32); cnt = self.empty((n,), np.int64)
+        fr = self.frames(d, n, nx, ny, dtype)
+        self.check(self.lib.imgfd_harris_dev(self.ctx, C.byref(fr), p["k"], p["sigma_d"], p["sigma_i"], p["threshold"],
+                                             p["gaussian"], p["gradient"], p["measure"], self.ptr(out), cap,
+                                             self.ptr(cnt)), "imgfd_harris_dev")
+        self.sync()
+        cnt = self.to_host(cnt); out = self.to_host(out)
+        return [out[f, :min(int(cnt[f]), cap)] for f in range(n)], cnt
+
+    def fast9_dev(self, frames, threshold, nonmax=False, cap=None):
+        n, ny, nx = frames.shape
+        d = self.to_dev(np.ascontiguousarray(frames, np.uint8))
+        cap = cap or (nx * ny // 2 + 16)
+        out = self.empty((n, cap, 2), np.int32); cnt = self.empty((n,), np.int64)
+        fr = self.frames(d, n, nx, ny, 0)
+        self.check(self.lib.imgfd_fast9_dev(self.ctx, C.byref(fr), threshold & 0xFF, int(nonmax), self.ptr(out), cap,
+                                            self.ptr(cnt)), "imgfd_fast9_dev")
+        self.sync()
+        cnt = self.to_host(cnt); out = self.to_host(out)
+        return [out[f, :min(int(cnt[f]), cap)] for f in range(n)], cnt
+
+    def canny_dev(self, frames, s=2.0, low_thr=3.0, high_thr=10.0, accGrad=True):
+        n, ny, nx = frames.shape
+        d = self.to_dev(np.ascontiguousarray(frames, np.uint8))
+        edges = self.empty((n, ny, nx), np.uint8); cnt = self.empty((n,), np.int64)
+        fr = self.frames(d, n, nx, ny, 0)
+        self.check(self.lib.imgfd_canny_dev(self.ctx, C.byref(fr), s, low_thr, high_thr, int(accGrad),
+                                            self.ptr(edges), self.ptr(cnt)), "imgfd_canny_dev")
+        self.sync()
+        return self.to_host(edges), self.to_host(cnt)
+
+    def sync(self):
+        self.check(self.lib.imgfd_ctx_sync(self.ctx), "sync")
+
+
+class EmuBackend(_Base):
+    name = "emu"
+
+    def __init__(self):
+        path = os.path.join(ROOT, "tests", "hipemu", "libimgfd_emu.so")
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "image_amd", "csrc"), "emu"])
+        super().__init__(_binding.bind(C.CDLL(path), strict=False))
+
+    def to_dev(self, a):
+        return np.ascontiguousarray(a).copy()
+
+    def empty(self, shape, dtype):
+        return np.zeros(shape, dtype)
+
+    def ptr(self, a):
+        return a.ctypes.data_as(C.c_void_p)
+
+    def to_host(self, a):
+        return a
+
+
+class GpuBackend(_Base):
+    name = "gpu"
+
+    def __init__(self):
+        import torch
+        assert torch.cuda.is_available(), "GPU tests need a device"
+        from image_amd import _lib
+        self.torch = torch
+        super().__init__(_lib.load())
+
+    def to_dev(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+    def empty(self, shape, dtype):
+        return self.torch.zeros(shape, dtype=getattr(self.torch, np.dtype(dtype).name), device="cuda:0")
+
+    def ptr(self, t):
+        self.torch.cuda.synchronize()
+        return C.c_void_p(t.data_ptr())
+
+    def to_host(self, t):
+        self.sync()
+        return t.cpu().numpy()

@@ -1,0 +1,366 @@
+// tests/hipemu/hip/hip_runtime.h -- TEST INFRASTRUCTURE ONLY.
+//
+// A tiny single-threaded HIP *emulator* for g++: it lets the unmodified kernel sources of
+// image_amd/csrc/*.hip be compiled for the host (g++ -x c++ -Itests/hipemu) so that kernel LOGIC
+// (tiling, halos, border rules, ordered compaction) can be parity-checked against the oracle in
+// the GPU-less build container (`pytest -m "not gpu"`).  It is never used by the product:
+// image_amd loads only libimgfd.so (hipcc, gfx950) and fails loudly without it.
+//
+// Model: blocks run one after another; the threads of a block are ucontext fibers scheduled
+// round-robin; __syncthreads() and the wave64 cross-lane intrinsics are rendezvous points that
+// yield until every (live) participant has arrived.  Wave intrinsics must be executed by all 64
+// lanes of a wave (convergent code), which is also what the kernels need on real hardware.
+#pragma once
+#include <time.h>
+#include <ucontext.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __constant__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ __attribute__((noinline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define HIP_DYNAMIC_SHARED(type, var) type *var = reinterpret_cast<type *>(hipemu::dyn_smem());
+#define HIPEMU 1
+
+struct dim3 {
+    unsigned x, y, z;
+    constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3_ { unsigned x, y, z; };
+
+// ------------------------------------------------------------------ vector types
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct double2 { double x, y; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+struct uchar4 { unsigned char x, y, z, w; };
+struct uchar2 { unsigned char x, y; };
+struct ushort4 { unsigned short x, y, z, w; };
+static inline float2 make_float2(float x, float y) { return {x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+static inline double2 make_double2(double x, double y) { return {x, y}; }
+static inline int2 make_int2(int x, int y) { return {x, y}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return {x, y, z, w}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return {x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return {x, y, z, w}; }
+static inline uchar4 make_uchar4(unsigned char x, unsigned char y, unsigned char z, unsigned char w) { return {x, y, z, w}; }
+
+// ------------------------------------------------------------------ runtime state
+namespace hipemu {
+
+struct Fiber {
+    ucontext_t ctx;
+    char *stack = nullptr;
+    bool done = true;
+    uint3_ tid{};
+    unsigned linear = 0;
+    unsigned long wave_ops = 0;   // number of wave rendezvous this lane has completed
+    unsigned long block_ops = 0;  // number of block barriers this thread has completed
+};
+
+struct Wave {
+    unsigned long arrived = 0;    // monotonic count of lane arrivals at wave rendezvous
+    unsigned nlanes = 0;
+    unsigned long long slots[2][64];
+};
+
+struct State {
+    ucontext_t sched;
+    std::vector<Fiber> fibers;
+    std::vector<Wave> waves;
+    Fiber *cur = nullptr;
+    unsigned nthreads = 0;
+    unsigned long block_arrived = 0;
+    unsigned long progress = 0;
+    std::function<void()> body;
+    std::vector<char> dyn;
+    dim3 grid, block;
+    uint3_ bid{};
+};
+
+inline State &S() { static State s; return s; }
+inline void *dyn_smem() { return S().dyn.data(); }
+
+static const size_t kStack = 256 * 1024;
+
+inline void yield() { State &s = S(); swapcontext(&s.cur->ctx, &s.sched); }
+
+inline void trampoline() {
+    State &s = S();
+    s.body();
+    s.cur->done = true;
+    s.progress++;
+    swapcontext(&s.cur->ctx, &s.sched);
+}
+
+inline void run_block() {
+    State &s = S();
+    unsigned n = s.nthreads;
+    if (s.fibers.size() < n) s.fibers.resize(n);
+    unsigned nw = (n + 63) / 64;
+    s.waves.assign(nw, Wave());
+    for (unsigned w = 0; w < nw; w++) s.waves[w].nlanes = std::min(64u, n - 64 * w);
+    s.block_arrived = 0;
+    for (unsigned t = 0; t < n; t++) {
+        Fiber &f = s.fibers[t];
+        if (!f.stack) f.stack = (char *)malloc(kStack);
+        f.done = false; f.linear = t; f.wave_ops = 0; f.block_ops = 0;
+        f.tid.x = t % s.block.x; f.tid.y = (t / s.block.x) % s.block.y; f.tid.z = t / (s.block.x * s.block.y);
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = kStack; f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())trampoline, 0);
+    }
+    unsigned live = n;
+    while (live) {
+        unsigned long before = s.progress;
+        live = 0;
+        for (unsigned t = 0; t < n; t++) {
+            Fiber &f = s.fibers[t];
+            if (f.done) continue;
+            s.cur = &f;
+            swapcontext(&s.sched, &f.ctx);
+            if (!f.done) live++;
+        }
+        if (live && s.progress == before) {
+            fprintf(stderr, "hipemu: deadlock in block (%u,%u,%u): %u threads wait at a barrier or wave "
+                            "intrinsic the others never reach (divergent __syncthreads/__ballot/__shfl?)\n",
+                    s.bid.x, s.bid.y, s.bid.z, live);
+            abort();
+        }
+    }
+}
+
+inline void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> body) {
+    State &s = S();
+    s.grid = grid; s.block = block; s.body = std::move(body);
+    s.nthreads = block.x * block.y * block.z;
+    if (s.dyn.size() < shmem + 16) s.dyn.resize(shmem + 16);
+    for (unsigned z = 0; z < grid.z; z++)
+        for (unsigned y = 0; y < grid.y; y++)
+            for (unsigned x = 0; x < grid.x; x++) {
+                s.bid = {x, y, z};
+                run_block();
+            }
+}
+
+// block barrier: wait until every thread of the block has arrived (exited threads never do: the
+// kernels keep barriers outside divergent exits, as HIP requires)
+inline void block_barrier() {
+    State &s = S();
+    Fiber *f = s.cur;
+    s.block_arrived++;
+    s.progress++;
+    unsigned long need = (f->block_ops + 1) * (unsigned long)s.nthreads;
+    while (s.block_arrived < need) yield();
+    f->block_ops++;
+}
+
+// wave rendezvous with a 64-bit payload per lane; returns pointer to the 64 slots of this op
+inline const unsigned long long *wave_exchange(unsigned long long v) {
+    State &s = S();
+    Fiber *f = s.cur;
+    Wave &w = s.waves[f->linear / 64];
+    unsigned par = f->wave_ops & 1;
+    w.slots[par][f->linear % 64] = v;
+    w.arrived++;
+    s.progress++;
+    unsigned long need = (f->wave_ops + 1) * (unsigned long)w.nlanes;
+    while (w.arrived < need) yield();
+    f->wave_ops++;
+    return w.slots[par];
+}
+inline unsigned wave_nlanes() { State &s = S(); return s.waves[s.cur->linear / 64].nlanes; }
+
+struct IdxProxyX { operator unsigned() const; };
+}  // namespace hipemu
+
+// threadIdx/blockIdx/blockDim/gridDim as objects whose members read the current fiber
+struct hipemu_tid_t {
+    struct X { operator unsigned() const { return hipemu::S().cur->tid.x; } } x;
+    struct Y { operator unsigned() const { return hipemu::S().cur->tid.y; } } y;
+    struct Z { operator unsigned() const { return hipemu::S().cur->tid.z; } } z;
+};
+struct hipemu_bid_t {
+    struct X { operator unsigned() const { return hipemu::S().bid.x; } } x;
+    struct Y { operator unsigned() const { return hipemu::S().bid.y; } } y;
+    struct Z { operator unsigned() const { return hipemu::S().bid.z; } } z;
+};
+struct hipemu_bdim_t {
+    struct X { operator unsigned() const { return hipemu::S().block.x; } } x;
+    struct Y { operator unsigned() const { return hipemu::S().block.y; } } y;
+    struct Z { operator unsigned() const { return hipemu::S().block.z; } } z;
+};
+struct hipemu_gdim_t {
+    struct X { operator unsigned() const { return hipemu::S().grid.x; } } x;
+    struct Y { operator unsigned() const { return hipemu::S().grid.y; } } y;
+    struct Z { operator unsigned() const { return hipemu::S().grid.z; } } z;
+};
+static hipemu_tid_t threadIdx;
+static hipemu_bid_t blockIdx;
+static hipemu_bdim_t blockDim;
+static hipemu_gdim_t gridDim;
+static const int warpSize = 64;
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hipemu::launch(dim3(grid), dim3(block), (shmem), [&]() { kernel(__VA_ARGS__); })
+
+// ------------------------------------------------------------------ device intrinsics
+static inline void __syncthreads() { hipemu::block_barrier(); }
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
+static inline unsigned __lane_id() { return hipemu::S().cur->linear % 64; }
+
+static inline unsigned long long __ballot(int pred) {
+    const unsigned long long *s = hipemu::wave_exchange(pred ? 1ull : 0ull);
+    unsigned long long m = 0;
+    unsigned n = hipemu::wave_nlanes();
+    for (unsigned i = 0; i < n; i++) m |= (s[i] & 1ull) << i;
+    return m;
+}
+static inline int __any(int pred) { return __ballot(pred) != 0; }
+static inline int __all(int pred) {
+    unsigned n = hipemu::wave_nlanes();
+    unsigned long long full = n == 64 ? ~0ull : ((1ull << n) - 1);
+    return __ballot(pred) == full;
+}
+template <typename T> static inline T hipemu_shfl_idx(T v, int src) {
+    static_assert(sizeof(T) <= 8, "shfl payload");
+    unsigned long long raw = 0;
+    memcpy(&raw, &v, sizeof(T));
+    const unsigned long long *s = hipemu::wave_exchange(raw);
+    T out;
+    memcpy(&out, &s[src & 63], sizeof(T));
+    return out;
+}
+template <typename T> static inline T __shfl(T v, int src, int width = 64) {
+    int lane = (int)__lane_id();
+    int base = lane & ~(width - 1);
+    return hipemu_shfl_idx(v, base + (src & (width - 1)));
+}
+template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64) {
+    int lane = (int)__lane_id();
+    int base = lane & ~(width - 1);
+    int src = lane - (int)d;
+    return hipemu_shfl_idx(v, src < base ? lane : src);
+}
+template <typename T> static inline T __shfl_down(T v, unsigned d, int width = 64) {
+    int lane = (int)__lane_id();
+    int base = lane & ~(width - 1);
+    int src = lane + (int)d;
+    return hipemu_shfl_idx(v, src >= base + width ? lane : src);
+}
+template <typename T> static inline T __shfl_xor(T v, int m, int width = 64) {
+    int lane = (int)__lane_id();
+    int base = lane & ~(width - 1);
+    int src = lane ^ m;
+    return hipemu_shfl_idx(v, src >= base + width ? lane : src);
+}
+static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __ffs(int x) { return __builtin_ffs(x); }
+static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
+static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
+static inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
+static inline unsigned __brev(unsigned x) {
+    unsigned r = 0;
+    for (int i = 0; i < 32; i++) r |= ((x >> i) & 1u) << (31 - i);
+    return r;
+}
+
+template <typename T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
+template <typename T> static inline T atomicSub(T *p, T v) { T o = *p; *p = o - v; return o; }
+template <typename T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <typename T> static inline T atomicMin(T *p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <typename T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
+template <typename T> static inline T atomicAnd(T *p, T v) { T o = *p; *p = o & v; return o; }
+template <typename T> static inline T atomicExch(T *p, T v) { T o = *p; *p = v; return o; }
+template <typename T> static inline T atomicCAS(T *p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
+
+// HIP device code sees min/max overloads for scalars
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+static inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
+static inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
+static inline long min(long a, long b) { return a < b ? a : b; }
+static inline long max(long a, long b) { return a > b ? a : b; }
+static inline long long min(long long a, long long b) { return a < b ? a : b; }
+static inline long long max(long long a, long long b) { return a > b ? a : b; }
+static inline unsigned long min(unsigned long a, unsigned long b) { return a < b ? a : b; }
+static inline unsigned long max(unsigned long a, unsigned long b) { return a > b ? a : b; }
+static inline float min(float a, float b) { return fminf(a, b); }
+static inline float max(float a, float b) { return fmaxf(a, b); }
+static inline double min(double a, double b) { return fmin(a, b); }
+static inline double max(double a, double b) { return fmax(a, b); }
+
+// ------------------------------------------------------------------ host API
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100 };
+typedef struct hipemu_stream *hipStream_t;
+typedef struct hipemu_event { double t; } *hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+struct hipDeviceProp_t {
+    char name[256]; char gcnArchName[256]; int multiProcessorCount; size_t totalGlobalMem; int warpSize;
+    size_t sharedMemPerBlock; int maxThreadsPerBlock; int clockRate;
+};
+#define hipHostMallocDefault 0
+#define hipStreamNonBlocking 1
+#define hipEventDefault 0
+
+static inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
+    memset(p, 0, sizeof(*p));
+    strcpy(p->name, "hipemu (host)"); strcpy(p->gcnArchName, "hipemu");
+    p->multiProcessorCount = 256; p->totalGlobalMem = 1ull << 34; p->warpSize = 64;
+    p->sharedMemPerBlock = 160 * 1024; p->maxThreadsPerBlock = 1024; p->clockRate = 2400000;
+    return hipSuccess;
+}
+static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <typename T> static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
+static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+template <typename T> static inline hipError_t hipHostMalloc(T **p, size_t n, unsigned f = 0) { return hipMalloc((void **)p, n); }
+static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t = 0) { return hipMemcpy(d, s, n, k); }
+static inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t = 0) {
+    for (size_t r = 0; r < h; r++) memmove((char *)d + r * dp, (const char *)s + r * sp, w);
+    return hipSuccess;
+}
+static inline hipError_t hipMemset(void *d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = 0) { return hipMemset(d, v, n); }
+static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline double hipemu_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new hipemu_event{0}; return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = 0) { e->t = hipemu_now(); return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
+static inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = 1ull << 33; *t = 1ull << 34; return hipSuccess; }

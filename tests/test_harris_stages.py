@@ -1,0 +1,120 @@
+"""Plane-by-plane parity of the Harris device stages against the oracle (bit-exact in strict mode)."""
+import numpy as np
+import pytest
+
+import oracle
+from image_amd import synth
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def assert_bits_equal(a, b, what):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    assert a.shape == b.shape, what
+    bad = bits(a) != bits(b)
+    assert not bad.any(), f"{what}: {bad.sum()} of {bad.size} values differ, first at {np.argwhere(bad)[0]}, " \
+                          f"max rel {np.max(np.abs(a - b) / np.maximum(1e-30, np.abs(b)))}"
+
+
+SIZES = [(64, 48), (200, 150), (331, 257), (640, 480)]
+
+
+@pytest.mark.parametrize("nx,ny", SIZES)
+def test_smoothing_sigma1_bit_exact(be, nx, ny):
+    img = synth.frame(11, nx, ny).astype(np.float32)
+    be.set_fir_mode(0)
+    got = be.k_gaussian(img, 1.0, 0)
+    assert_bits_equal(got, oracle.harris_stage("gaussian", img, sigma=1.0, type=0), "discrete_gaussian sigma 1")
+
+
+@pytest.mark.parametrize("sigma", [0.5, 1.25, 2.0, 2.5, 4.0])
+def test_gaussian_other_sigmas_bit_exact(be, sigma):
+    img = synth.frame(12, 150, 97).astype(np.float32)
+    be.set_fir_mode(0)
+    got = be.k_gaussian(img, sigma, 0)
+    assert_bits_equal(got, oracle.harris_stage("gaussian", img, sigma=sigma, type=0), f"discrete_gaussian {sigma}")
+
+
+def test_gaussian_copy_cases(be):
+    img = synth.frame(13, 40, 30).astype(np.float32)
+    assert_bits_equal(be.k_gaussian(img, 1.0, 2), img, "NO_GAUSSIAN is a copy")
+    assert_bits_equal(be.k_gaussian(img, 0.0, 0), img, "sigma<=0 is a copy")
+    tiny = synth.frame(13, 5, 30).astype(np.float32)
+    assert_bits_equal(be.k_gaussian(tiny, 2.5, 0), tiny, "size>xdim leaves the image untouched")
+
+
+@pytest.mark.parametrize("type", [0, 1])
+@pytest.mark.parametrize("nx,ny", [(3, 3), (64, 48), (201, 77)])
+def test_gradient_bit_exact(be, nx, ny, type):
+    img = oracle.harris_stage("gaussian", synth.frame(14, nx, ny).astype(np.float32), sigma=1.0, type=0)
+    ix, iy = be.k_gradient(img, type)
+    rx, ry = oracle.harris_stage("gradient", img, type=type)
+    assert_bits_equal(ix, rx, "Ix")
+    assert_bits_equal(iy, ry, "Iy")
+
+
+def _gradients(seed, nx, ny):
+    img = oracle.harris_stage("gaussian", synth.frame(seed, nx, ny).astype(np.float32), sigma=1.0, type=0)
+    return oracle.harris_stage("gradient", img, type=0)
+
+
+@pytest.mark.parametrize("nx,ny", SIZES)
+def test_structure_tensor_strict_bit_exact(be, nx, ny):
+    ix, iy = _gradients(15, nx, ny)
+    be.set_fir_mode(0)
+    got = be.k_structure_tensor(ix, iy, 2.5, 0)
+    ref = oracle.harris_stage("autocorrelation", ix, iy, sigma=2.5, gauss=0)
+    for g, r, nm in zip(got, ref, "ABC"):
+        assert_bits_equal(g, r, f"structure tensor {nm} (strict)")
+
+
+@pytest.mark.parametrize("sigma", [0.625, 1.25, 3.0])
+def test_structure_tensor_other_sigmas(be, sigma):
+    ix, iy = _gradients(16, 160, 120)
+    be.set_fir_mode(0)
+    got = be.k_structure_tensor(ix, iy, sigma, 0)
+    ref = oracle.harris_stage("autocorrelation", ix, iy, sigma=sigma, gauss=0)
+    for g, r, nm in zip(got, ref, "ABC"):
+        assert_bits_equal(g, r, f"structure tensor {nm} sigma {sigma}")
+
+
+def test_structure_tensor_fused_accumulate_within_tolerance(be):
+    """fir_mode 1 (fma inside the f64 accumulation): north_star tolerance is 1e-4 relative; the
+    planes differ from strict by at most 1 float ulp and almost nowhere."""
+    ix, iy = _gradients(17, 640, 480)
+    be.set_fir_mode(1)
+    got = be.k_structure_tensor(ix, iy, 2.5, 0)
+    ref = oracle.harris_stage("autocorrelation", ix, iy, sigma=2.5, gauss=0)
+    be.set_fir_mode(0)
+    total_bad = 0
+    for g, r in zip(got, ref):
+        rel = np.abs(g - r) / np.maximum(np.abs(r), 1e-30)
+        assert rel.max() <= 1.2e-7, rel.max()          # <= 1 ulp
+        total_bad += int((bits(g) != bits(r)).sum())
+    assert total_bad <= 5, total_bad                      # expected ~0.1 per frame of this size
+
+
+@pytest.mark.parametrize("measure", [0, 1, 2])
+def test_response_bit_exact(be, measure):
+    ix, iy = _gradients(18, 200, 150)
+    A, B, Cc = oracle.harris_stage("autocorrelation", ix, iy, sigma=2.5, gauss=0)
+    got = be.k_response(A, B, Cc, measure, 0.06)
+    assert_bits_equal(got, oracle.harris_stage("response", A, B, Cc, measure=measure, k=0.06), f"response {measure}")
+
+
+@pytest.mark.parametrize("radius,Th", [(5, 130.0), (1, 10.0), (3, 1000.0), (8, 0.5)])
+def test_nms_window_rule_matches_scanline(be, radius, Th):
+    ix, iy = _gradients(19, 320, 240)
+    A, B, Cc = oracle.harris_stage("autocorrelation", ix, iy, sigma=2.5, gauss=0)
+    R = oracle.harris_stage("response", A, B, Cc, measure=0, k=0.06)
+    got = be.k_nms(R, Th, radius)
+    ref = oracle.harris_stage("nms", R, Th=Th, radius=radius)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert np.array_equal(bits(got), bits(ref))
+
+
+def test_nms_small_image_is_empty(be):
+    R = np.random.default_rng(0).random((11, 40)).astype(np.float32) * 1000
+    assert be.k_nms(R, 0.0, 5).shape[0] == 0
