@@ -67,6 +67,8 @@ SIGNATURES = {
     "imgfd_time_structure_tensor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
                                               C.POINTER(C.c_double)]),
+    "imgfd_profile_k3": (C.c_int, [C.c_void_p, C.c_int]),
+    "imgfd_profile_k3_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "imgfd_synth_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_uint32,
                                      C.c_void_p, C.c_int]),
 }

@@ -30,6 +30,10 @@ struct imgfd_ctx {
     char *pin = nullptr;
     size_t pin_size = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // in-pipeline K3 timing (imgfd_profile_k3)
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;  // pairs
+    size_t prof_used = 0;
 };
 
 #define IMGFD_HIP(ctx, call)                                                                       \
@@ -64,6 +68,8 @@ imgfd_status ws_reserve(imgfd_ctx *ctx, size_t bytes);
 void *ws_alloc(imgfd_ctx *ctx, size_t bytes);  // 256-byte aligned; nullptr if the reservation is exceeded
 static inline void ws_reset(imgfd_ctx *ctx) { ctx->ws_used = 0; }
 imgfd_status pin_reserve(imgfd_ctx *ctx, size_t bytes);
+// records a profiling event on the stream when K3 profiling is on (no-op otherwise)
+imgfd_status prof_mark(imgfd_ctx *ctx);
 
 // ---- kernel launchers shared between translation units (device pointers, async on ctx->stream)
 struct FrameGeom {

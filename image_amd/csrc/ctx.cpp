@@ -54,6 +54,7 @@ void imgfd_ctx_destroy(imgfd_ctx *ctx)
     for (void *p : ctx->ws_old) (void)hipFree(p);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
+    for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -81,7 +82,44 @@ imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode)
     return IMGFD_OK;
 }
 
+imgfd_status imgfd_profile_k3(imgfd_ctx *ctx, int enable)
+{
+    if (!ctx) return IMGFD_ERR_INVALID;
+    ctx->prof_on = enable != 0;
+    ctx->prof_used = 0;
+    return IMGFD_OK;
+}
+
+imgfd_status imgfd_profile_k3_read(imgfd_ctx *ctx, double *total_us, int *launches)
+{
+    if (!ctx || !total_us || !launches) return IMGFD_ERR_INVALID;
+    IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double tot = 0;
+    const size_t pairs = ctx->prof_used / 2;
+    for (size_t i = 0; i < pairs; i++) {
+        float ms = 0;
+        IMGFD_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
+        tot += 1e3 * (double)ms;
+    }
+    *total_us = tot;
+    *launches = (int)pairs;
+    ctx->prof_used = 0;
+    return IMGFD_OK;
+}
+
 }  // extern "C"
+
+imgfd_status prof_mark(imgfd_ctx *ctx)
+{
+    if (!ctx->prof_on) return IMGFD_OK;
+    if (ctx->prof_used == ctx->prof_ev.size()) {
+        hipEvent_t e;
+        IMGFD_HIP(ctx, hipEventCreate(&e));
+        ctx->prof_ev.push_back(e);
+    }
+    IMGFD_HIP(ctx, hipEventRecord(ctx->prof_ev[ctx->prof_used++], ctx->stream));
+    return IMGFD_OK;
+}
 
 imgfd_status ws_reserve(imgfd_ctx *ctx, size_t bytes)
 {

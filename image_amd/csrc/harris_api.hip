@@ -204,8 +204,10 @@ imgfd_status harris_device_stages(imgfd_ctx *ctx, const void *d_in, int in_is_u8
     IMGFD_TRY(tick(0));
     IMGFD_TRY(launch_gradient(ctx, hp.Is, hp.Ix, hp.Iy, nx, ny, n_frames, a.grad));
     IMGFD_TRY(tick(1));
+    IMGFD_TRY(prof_mark(ctx));
     IMGFD_TRY(launch_structure_tensor(ctx, hp.Ix, hp.Iy, hp.A, hp.B, hp.C, nx, ny, n_frames, a.sigma_i, a.gauss,
                                       hp.tmp));
+    IMGFD_TRY(prof_mark(ctx));
     IMGFD_TRY(tick(2));
     IMGFD_TRY(launch_response(ctx, hp.A, hp.B, hp.C, hp.R, nx, ny, n_frames, a.measure, a.k));
     IMGFD_TRY(tick(3));

@@ -1,0 +1,98 @@
+"""Device-resident batch path: torch CUDA tensors in, torch CUDA tensors out, no host copies.
+
+torch is plumbing here (device memory, the current stream, torch.distributed in stream.py); every
+computation is a kernel of libimgfd.so launched through the ``*_dev`` entry points of the C ABI on
+torch's current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _binding, _lib, synth
+
+
+class DeviceDetector:
+    """One imgfd context bound to ``torch.cuda.current_stream(device)``."""
+
+    def __init__(self, device: int | None = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("image_amd.device needs a HIP device (no CPU fallback)")
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.stream = torch.cuda.current_stream(self.device)
+        self.ctx = _lib.Context(self.device, stream=self.stream.cuda_stream)
+        self.lib = self.ctx.lib
+
+    # ------------------------------------------------------------------ helpers
+    def _frames(self, t: torch.Tensor) -> _binding.Frames:
+        if t.dim() == 2:
+            t = t[None]
+        assert t.is_cuda and t.dim() == 3 and t.stride(2) == 1, "frames must be [n, ny, nx] CUDA tensors, x contiguous"
+        dtype = {torch.uint8: 0, torch.float32: 1}[t.dtype]
+        esz = t.element_size()
+        n, ny, nx = t.shape
+        return _binding.Frames(t.data_ptr(), n, nx, ny, t.stride(0) * esz if n > 1 else nx * ny * esz,
+                               t.stride(1) * esz, dtype)
+
+    def synth_frames(self, n: int, nx: int, ny: int, seed0: int, n_rect: int | None = None) -> torch.Tensor:
+        """n frames G(seed0+f) generated on the device (host twin: image_amd.synth.frame)."""
+        if n_rect is None:
+            n_rect = synth.default_rects(nx, ny)
+        rects = np.stack([synth.rectangles(seed0 + f, nx, ny, n_rect) for f in range(n)]).astype(np.int32)
+        d_rects = torch.from_numpy(rects).to(f"cuda:{self.device}")
+        out = torch.empty((n, ny, nx), dtype=torch.uint8, device=f"cuda:{self.device}")
+        self.ctx.check(self.lib.imgfd_synth_frames(self.ctx.handle, out.data_ptr(), n, nx, ny, nx * ny, seed0 & 0xFFFFFFFF,
+                                                   d_rects.data_ptr(), n_rect), "imgfd_synth_frames")
+        self._keep = d_rects  # keep alive until the stream has consumed it
+        return out
+
+    # ------------------------------------------------------------------ detectors
+    def harris(self, frames: torch.Tensor, cap: int = 65536, k=0.06, sigma_d=1.0, sigma_i=2.5, threshold=130.0,
+               gaussian=0, gradient=0, measure=0, out=None):
+        fr = self._frames(frames)
+        dev = frames.device
+        if out is None:
+            out = (torch.empty((fr.n_frames, cap, 3), dtype=torch.float32, device=dev),
+                   torch.empty((fr.n_frames,), dtype=torch.int64, device=dev))
+        corners, counts = out
+        self.ctx.check(self.lib.imgfd_harris_dev(self.ctx.handle, C.byref(fr), k, sigma_d, sigma_i, threshold, gaussian,
+                                                 gradient, measure, corners.data_ptr(), corners.shape[1],
+                                                 counts.data_ptr()), "imgfd_harris_dev")
+        return corners, counts
+
+    def fast9(self, frames: torch.Tensor, threshold: int = 50, suppress_non_max: bool = False, cap: int = 262144,
+              out=None):
+        fr = self._frames(frames)
+        dev = frames.device
+        if out is None:
+            out = (torch.empty((fr.n_frames, cap, 2), dtype=torch.int32, device=dev),
+                   torch.empty((fr.n_frames,), dtype=torch.int64, device=dev))
+        points, counts = out
+        self.ctx.check(self.lib.imgfd_fast9_dev(self.ctx.handle, C.byref(fr), int(threshold) & 0xFF,
+                                                int(bool(suppress_non_max)), points.data_ptr(), points.shape[1],
+                                                counts.data_ptr()), "imgfd_fast9_dev")
+        return points, counts
+
+    def canny(self, frames: torch.Tensor, s=2.0, low_thr=3.0, high_thr=10.0, accGrad=True, out=None):
+        fr = self._frames(frames)
+        dev = frames.device
+        if out is None:
+            out = (torch.empty((fr.n_frames, fr.ny, fr.nx), dtype=torch.uint8, device=dev),
+                   torch.empty((fr.n_frames,), dtype=torch.int64, device=dev))
+        edges, counts = out
+        self.ctx.check(self.lib.imgfd_canny_dev(self.ctx.handle, C.byref(fr), float(s), float(low_thr), float(high_thr),
+                                                int(bool(accGrad)), edges.data_ptr(), counts.data_ptr()),
+                       "imgfd_canny_dev")
+        return edges, counts
+
+    def time_structure_tensor(self, ix: torch.Tensor, iy: torch.Tensor, sigma=2.5, gauss=0, warmup=5, iters=50):
+        """Mean microseconds per launch of the structure-tensor kernel (HIP events on the ctx stream)."""
+        ny, nx = ix.shape[-2:]
+        A, B, Cc = (torch.empty_like(ix) for _ in range(3))
+        us = C.c_double(0)
+        self.ctx.check(self.lib.imgfd_time_structure_tensor(self.ctx.handle, ix.data_ptr(), iy.data_ptr(), A.data_ptr(),
+                                                            B.data_ptr(), Cc.data_ptr(), nx, ny, sigma, gauss, warmup,
+                                                            iters, C.byref(us)), "imgfd_time_structure_tensor")
+        return us.value

@@ -179,6 +179,13 @@ IMGFD_API imgfd_status imgfd_time_structure_tensor(imgfd_ctx *ctx, const float *
                                          float *d_A, float *d_B, float *d_C, int nx, int ny,
                                          float sigma, int gauss, int warmup, int iters, double *avg_us);
 
+/* In-pipeline timing of the structure-tensor pass: while enabled, every launch of that kernel made by
+ * imgfd_harris / imgfd_harris_dev on this context is bracketed by HIP events on the context's stream.
+ * imgfd_profile_k3_read synchronises, returns the summed device time and the number of launches since
+ * the last read, and resets the counters. */
+IMGFD_API imgfd_status imgfd_profile_k3(imgfd_ctx *ctx, int enable);
+IMGFD_API imgfd_status imgfd_profile_k3_read(imgfd_ctx *ctx, double *total_us, int *launches);
+
 /* Fill n_frames synthetic u8 frames G(seed0+f) directly in HBM (image_amd/synth.py is the host twin). */
 IMGFD_API imgfd_status imgfd_synth_frames(imgfd_ctx *ctx, uint8_t *d_frames, int n_frames, int nx, int ny,
                                 size_t frame_stride_bytes, uint32_t seed0, const int32_t *d_rects,
