@@ -15,10 +15,14 @@
 //                atan2 -> cos/sin; we use the unit vector (h,v)/|g| directly (differs by ~1e-16, only
 //                exact ties can flip).  Thresholds are int-truncated (:88,:180).
 //  K12 hysteresis     rcpp_canny.cpp:184-215 + adsf.c: a pixel survives iff its 8-connected component of
-//                marked pixels contains a strong one.  Monotone label propagation (weak -> strong when a
-//                strong 8-neighbour exists): each workgroup iterates its 64x64 tile to a local fixpoint in
-//                LDS; launches repeat until no tile changed.  The fixpoint is unique, so the result does
-//                not depend on scheduling.
+//                marked pixels contains a strong one.  The NMS kernel publishes two bit planes per frame
+//                (S = strong, W = marked; one 64-bit __ballot word per 64 pixels of a row).  Propagation
+//                S |= W & dilate3x3(S) is monotone with a unique fixpoint, so scheduling cannot change the
+//                result.  One WAVE owns a 256x64 tile: lane = row, 4 words per lane; the 3x3 dilation is
+//                shifts + two lane shuffles, and runs of W inside a word are flooded in O(1) with the
+//                carry-propagation trick (m & ~(m+p)).  Tiles iterate to a local fixpoint in registers;
+//                launches repeat until a whole sweep changes nothing (later sweeps of a round exit at
+//                once when the previous one was idle, so one host read-back covers a round).
 #include "common.h"
 
 #include <math.h>
@@ -70,29 +74,189 @@ __global__ void __launch_bounds__(256) canny_blur_cols(const double *__restrict_
     out[((size_t)blockIdx.z * ny + y) * nx + x] = (float)acc;
 }
 
-#define GN_T 32  // tile edge
 
-__global__ void __launch_bounds__(256) canny_grad_nms(const float *__restrict__ blur, unsigned char *__restrict__ out,
-                                                      int nx, int ny, int accGrad, int low_thr, int high_thr)
+// ------------------------------------------------------------------ K9 fast path: fused separable blur
+// One 256-thread workgroup owns a 64-column strip and marches down a segment of rows in chunks of 32:
+//   load   : u8 rows (64 + 2*HL columns, wrap-around addressing) -> LDS, next chunk prefetched in registers
+//   rows   : a thread owns 8 consecutive pixels of one row; pair sums of the u8 taps are exact integers,
+//            one v_cvt_f64_u32 + one f64 FMA per pair; results stay f64 (tools.c multiplies spectra: there
+//            is no rounding between the two passes) in an LDS ring of row-filtered rows
+//   columns: a thread owns one column and 8 consecutive output rows, streams the 8+2R ring rows once
+//            (lane <-> column: conflict-free ds_read_b64), 8 accumulators; the single float rounding
+//            (crealf, tools.c:129) happens at the 256-byte coalesced store.
+// HBM traffic is the algorithmic 1 B read + 4 B written per pixel (+ halo, served by L2).
+#define BM_TW 64
+#define BM_CH 32
+#define BM_NT 256
+#define BM_PX 8
+
+struct BlurMarchParams {
+    const unsigned char *in;
+    float *out;
+    int nx, ny;
+    int row_stride;       // bytes between input rows
+    long frame_stride;    // bytes between input frames
+    int seg_rows;
+    int aligned4;         // base, strides and nx are multiples of 4: dword tile loads
+    double wx[33];        // wx[j], j = 0..R: normalised taps along x (zero padded up to the template radius)
+    double wy[33];
+};
+
+__device__ __forceinline__ int wrap_idx(int i, int n)
 {
-    __shared__ float sb[GN_T + 4][GN_T + 4 + 1];
-    __shared__ double sg[GN_T + 2][GN_T + 2 + 1];
-    __shared__ double sh[GN_T][GN_T + 1];
-    __shared__ double sv[GN_T][GN_T + 1];
+    i %= n;
+    return i < 0 ? i + n : i;
+}
+
+template <int R>
+struct BlurGeom {
+    static constexpr int HL = (R + 3) / 4 * 4;          // halo columns each side, whole dwords
+    static constexpr int WT = BM_TW + 2 * HL;           // tile width in bytes
+    static constexpr int WD = WT / 4;                   // ... in dwords
+    static constexpr int PITCH = WD + 1 - (WD & 1);     // odd dword pitch: two rows cover all 32 banks
+    static constexpr int NQ = (HL - R + BM_PX + 2 * R + 3) / 4;  // dwords of one thread's byte window
+    static constexpr int RING = (BM_CH + 2 * R) <= 64 ? 64 : 128;
+    static constexpr int NLD = (BM_CH * WD + BM_NT - 1) / BM_NT;
+    static constexpr size_t LDS_BYTES = sizeof(unsigned) * BM_CH * PITCH + sizeof(double) * RING * BM_TW;
+};
+
+template <int R>
+__global__ void __launch_bounds__(BM_NT) canny_blur_march(BlurMarchParams p)
+{
+    using G = BlurGeom<R>;
+    constexpr int HL = G::HL, WD = G::WD, PITCH = G::PITCH, NQ = G::NQ, RING = G::RING, NLD = G::NLD;
+    HIP_DYNAMIC_SHARED(double, smem_d)
+    double *ring = smem_d;                                               // [RING][BM_TW]
+    unsigned *raw = reinterpret_cast<unsigned *>(smem_d + RING * BM_TW);  // [BM_CH][PITCH]
+
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * GN_T, y0 = blockIdx.y * GN_T;
+    const int x0 = blockIdx.x * BM_TW;
+    const int y0 = blockIdx.y * p.seg_rows;
+    const int nrows = min(p.ny, y0 + p.seg_rows) - y0;
+    const int nchunks = (nrows + 2 * R + BM_CH - 1) / BM_CH;
+    const int ybase = y0 - R;
+    const unsigned char *in = p.in + (size_t)blockIdx.z * p.frame_stride;
+    float *out = p.out + (size_t)blockIdx.z * p.nx * p.ny;
+
+    unsigned pre[NLD];
+    auto prefetch = [&](int chunk) {
+#pragma unroll
+        for (int l = 0; l < NLD; l++) {
+            const int i = tid + l * BM_NT;
+            pre[l] = 0;
+            if (i < BM_CH * WD) {
+                const int r = i / WD, q = i - r * WD;
+                const int gy = wrap_idx(ybase + chunk * BM_CH + r, p.ny);
+                const int gx = x0 - HL + 4 * q;
+                const unsigned char *row = in + (size_t)gy * p.row_stride;
+                if (p.aligned4) {
+                    pre[l] = *reinterpret_cast<const unsigned *>(row + wrap_idx(gx, p.nx));
+                } else {
+                    unsigned v = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) v |= (unsigned)row[wrap_idx(gx + b, p.nx)] << (8 * b);
+                    pre[l] = v;
+                }
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int l = 0; l < NLD; l++) {
+            const int i = tid + l * BM_NT;
+            if (i < BM_CH * WD) {
+                const int r = i / WD, q = i - r * WD;
+                raw[r * PITCH + q] = pre[l];
+            }
+        }
+    };
+
+    prefetch(0);
+    for (int chunk = 0; chunk < nchunks; chunk++) {
+        commit();
+        __syncthreads();
+        if (chunk + 1 < nchunks) prefetch(chunk + 1);
+
+        // ---- row pass: thread = (row r, 8-pixel strip s)
+        {
+            const int r = tid >> 3, s = tid & 7;
+            unsigned dw[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) dw[q] = raw[r * PITCH + 2 * s + q];
+            // byte k of the window = column x0 - HL + 8s + k; output o is centred on byte HL + o
+            double *dst = ring + ((chunk * BM_CH + r) & (RING - 1)) * BM_TW + BM_PX * s;
+#pragma unroll
+            for (int o = 0; o < BM_PX; o++) {
+                const int c = HL + o;
+                double acc = p.wx[0] * (double)((dw[c >> 2] >> (8 * (c & 3))) & 0xffu);
+#pragma unroll
+                for (int j = 1; j <= R; j++) {
+                    const int a = c - j, b = c + j;
+                    const unsigned pair = ((dw[a >> 2] >> (8 * (a & 3))) & 0xffu) + ((dw[b >> 2] >> (8 * (b & 3))) & 0xffu);
+                    acc = __builtin_fma(p.wx[j], (double)pair, acc);
+                }
+                dst[o] = acc;
+            }
+        }
+        __syncthreads();
+
+        // ---- column pass: thread = (8-row group g, column col)
+        {
+            const int g = tid >> 6, col = tid & 63;
+            const int oi0 = chunk * BM_CH - 2 * R + BM_PX * g;  // first output row of the group, relative to y0
+            if (oi0 + BM_PX > 0 && oi0 < nrows) {
+                double acc[BM_PX];
+#pragma unroll
+                for (int o = 0; o < BM_PX; o++) acc[o] = 0.0;
+#pragma unroll
+                for (int k = 0; k < BM_PX + 2 * R; k++) {
+                    const double v = ring[((oi0 + k) & (RING - 1)) * BM_TW + col];
+#pragma unroll
+                    for (int o = 0; o < BM_PX; o++) {
+                        const int j = k - R - o;
+                        if (j >= -R && j <= R) acc[o] = __builtin_fma(p.wy[j < 0 ? -j : j], v, acc[o]);
+                    }
+                }
+                const int gx = x0 + col;
+                if (gx < p.nx) {
+#pragma unroll
+                    for (int o = 0; o < BM_PX; o++) {
+                        const int oi = oi0 + o;
+                        if (oi >= 0 && oi < nrows) out[(size_t)(y0 + oi) * p.nx + gx] = (float)acc[o];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K10+K11
+#define GN_TX 64  // tile width = one __ballot word
+#define GN_TY 16
+
+// strong / marked bit planes: word (y, bx) covers pixels x = 64*bx .. 64*bx+63 of row y
+__global__ void __launch_bounds__(256) canny_grad_nms(const float *__restrict__ blur, unsigned long long *__restrict__ S,
+                                                      unsigned long long *__restrict__ Wm, int nx, int ny,
+                                                      int words_per_row, int accGrad, int low_thr, int high_thr)
+{
+    __shared__ float sb[GN_TY + 4][GN_TX + 4 + 1];
+    __shared__ double sg[GN_TY + 2][GN_TX + 2 + 1];
+    __shared__ double sh[GN_TY][GN_TX + 1];
+    __shared__ double sv[GN_TY][GN_TX + 1];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * GN_TX, y0 = blockIdx.y * GN_TY;
     const float *pl = blur + (size_t)blockIdx.z * nx * ny;
     // blurred tile with a 2-pixel halo, clamp-to-edge (extend(), rcpp_canny.cpp:38-55)
-    for (int i = tid; i < (GN_T + 4) * (GN_T + 4); i += 256) {
-        const int r = i / (GN_T + 4), c = i - r * (GN_T + 4);
+    for (int i = tid; i < (GN_TY + 4) * (GN_TX + 4); i += 256) {
+        const int r = i / (GN_TX + 4), c = i - r * (GN_TX + 4);
         const int gx = min(max(x0 + c - 2, 0), nx - 1), gy = min(max(y0 + r - 2, 0), ny - 1);
         sb[r][c] = pl[(size_t)gy * nx + gx];
     }
     __syncthreads();
     // gradient magnitude for the tile + 1 halo.  A halo position outside the image stands for the
     // clamped pixel (value()), whose own neighbourhood is again clamped: evaluate at clamped coords.
-    for (int i = tid; i < (GN_T + 2) * (GN_T + 2); i += 256) {
-        const int r = i / (GN_T + 2), c = i - r * (GN_T + 2);
+    for (int i = tid; i < (GN_TY + 2) * (GN_TX + 2); i += 256) {
+        const int r = i / (GN_TX + 2), c = i - r * (GN_TX + 2);
         const int gx = min(max(x0 + c - 1, 0), nx - 1), gy = min(max(y0 + r - 1, 0), ny - 1);
         // neighbour coordinates clamped to the image, then mapped into the LDS tile
         const int xm = max(gx - 1, 0) - x0 + 2, xp = min(gx + 1, nx - 1) - x0 + 2, xc = gx - x0 + 2;
@@ -108,111 +272,185 @@ __global__ void __launch_bounds__(256) canny_grad_nms(const float *__restrict__ 
             v = (double)sb[yp][xc] - (double)sb[ym][xc];
         }
         sg[r][c] = hypot(h, v);
-        if (r >= 1 && r <= GN_T && c >= 1 && c <= GN_T) { sh[r - 1][c - 1] = h; sv[r - 1][c - 1] = v; }
+        if (r >= 1 && r <= GN_TY && c >= 1 && c <= GN_TX) { sh[r - 1][c - 1] = h; sv[r - 1][c - 1] = v; }
     }
     __syncthreads();
-    for (int i = tid; i < GN_T * GN_T; i += 256) {
-        const int r = i / GN_T, c = i - r * GN_T;
+    const int c = tid & 63;
+    for (int r = tid >> 6; r < GN_TY; r += 4) {  // one wave per tile row: the ballot is the mask word
         const int gx = x0 + c, gy = y0 + r;
-        if (gx >= nx || gy >= ny) continue;
-        const double now = sg[r + 1][c + 1];
-        // unit direction (cos t, sin t) with t = atan2(v,h); atan2(0,0) = 0 -> (1,0)
-        double ux = 1.0, uy = 0.0;
-        if (now > 0) { ux = sh[r][c] / now; uy = sv[r][c] / now; }
-        double val[2];
+        int o = 0;
+        if (gx < nx && gy < ny) {
+            const double now = sg[r + 1][c + 1];
+            // unit direction (cos t, sin t) with t = atan2(v,h); atan2(0,0) = 0 -> (1,0)
+            double ux = 1.0, uy = 0.0;
+            if (now > 0) { ux = sh[r][c] / now; uy = sv[r][c] / now; }
+            double val[2];
 #pragma unroll
-        for (int d = 0; d < 2; d++) {
-            const double xt = d ? ux : -ux, yt = d ? uy : -uy;
-            // floor() is -1, 0 or (only when the component is exactly 1) 1; in that last case the far
-            // tap has weight 0, so evaluating with x1 = 0 gives the same sum from the 3x3 neighbourhood
-            const double x1 = fmin(floor(xt), 0.0), y1 = fmin(floor(yt), 0.0);
-            const double x2 = x1 + 1, y2 = y1 + 1;
-            const int cx = c + 1 + (int)x1, cy = r + 1 + (int)y1;
-            const double gx1 = (x2 - xt) * sg[cy][cx] + (xt - x1) * sg[cy][cx + 1];
-            const double gx2 = (x2 - xt) * sg[cy + 1][cx] + (xt - x1) * sg[cy + 1][cx + 1];
-            val[d] = (y2 - yt) * gx1 + (yt - y1) * gx2;
+            for (int d = 0; d < 2; d++) {
+                const double xt = d ? ux : -ux, yt = d ? uy : -uy;
+                // floor() is -1, 0 or (only when the component is exactly 1) 1; in that last case the far
+                // tap has weight 0, so evaluating with x1 = 0 gives the same sum from the 3x3 neighbourhood
+                const double x1 = fmin(floor(xt), 0.0), y1 = fmin(floor(yt), 0.0);
+                const double x2 = x1 + 1, y2 = y1 + 1;
+                const int cx = c + 1 + (int)x1, cy = r + 1 + (int)y1;
+                const double gx1 = (x2 - xt) * sg[cy][cx] + (xt - x1) * sg[cy][cx + 1];
+                const double gx2 = (x2 - xt) * sg[cy + 1][cx] + (xt - x1) * sg[cy + 1][cx + 1];
+                val[d] = (y2 - yt) * gx1 + (yt - y1) * gx2;
+            }
+            const double prev = val[0], next = val[1];
+            if ((now <= prev) || (now <= next) || (now <= (double)low_thr)) o = 0;
+            else if (now >= (double)high_thr) o = 2;
+            else o = 1;
         }
-        const double prev = val[0], next = val[1];
-        unsigned char o;
-        if ((now <= prev) || (now <= next) || (now <= (double)low_thr)) o = 0;
-        else if (now >= (double)high_thr) o = 2;
-        else o = 1;
-        out[((size_t)blockIdx.z * ny + gy) * nx + gx] = o;
+        const unsigned long long strong = __ballot(o == 2), marked = __ballot(o >= 1);
+        if (c == 0 && gy < ny) {
+            const size_t w = ((size_t)blockIdx.z * ny + gy) * words_per_row + blockIdx.x;
+            S[w] = strong;
+            Wm[w] = marked;
+        }
     }
 }
 
-#define HY_T 64
-
-// one propagation sweep: tile-local fixpoint in LDS; *changed is set when any pixel of the tile flipped
-__global__ void __launch_bounds__(256) canny_hyst_sweep(unsigned char *__restrict__ st, int nx, int ny,
-                                                        unsigned *__restrict__ changed)
+// ------------------------------------------------------------------ K12
+__device__ __forceinline__ unsigned long long brev64(unsigned long long x)
 {
-    __shared__ unsigned char s[HY_T + 2][HY_T + 2 + 2];
-    __shared__ int flag[2];
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * HY_T, y0 = blockIdx.y * HY_T;
-    unsigned char *pl = st + (size_t)blockIdx.z * nx * ny;
-    for (int i = tid; i < (HY_T + 2) * (HY_T + 2); i += 256) {
-        const int r = i / (HY_T + 2), c = i - r * (HY_T + 2);
-        const int gx = x0 + c - 1, gy = y0 + r - 1;
-        s[r][c] = (gx >= 0 && gx < nx && gy >= 0 && gy < ny) ? pl[(size_t)gy * nx + gx] : 0;
+    return ((unsigned long long)__brev((unsigned)x) << 32) | (unsigned long long)__brev((unsigned)(x >> 32));
+}
+// all bits of m reachable from the seeds p (a subset of m) through runs of consecutive ones in m
+__device__ __forceinline__ unsigned long long flood_runs(unsigned long long m, unsigned long long p)
+{
+    const unsigned long long up = m & ~(m + p);
+    const unsigned long long rm = brev64(m), rp = brev64(p);
+    const unsigned long long dn = brev64(rm & ~(rm + rp));
+    return up | dn | p;
+}
+__device__ __forceinline__ unsigned long long dilate_h(unsigned long long s, unsigned long long left, unsigned long long right)
+{
+    return s | (s << 1) | (s >> 1) | (left >> 63) | (right << 63);
+}
+
+#define HY_WORDS 4  // tile = 256 columns x 64 rows per wave
+
+// One sweep.  flags[sweep] is raised when any tile changed; a sweep whose predecessor (same round) was
+// idle returns at once, so the host may queue a whole round of sweeps behind one read-back.
+__global__ void __launch_bounds__(256) canny_hyst_bits(unsigned long long *__restrict__ S,
+                                                       const unsigned long long *__restrict__ Wm, int wpr, int ny,
+                                                       int tiles_x, int tiles_y, unsigned *__restrict__ flags, int sweep)
+{
+    if (sweep > 0 && flags[sweep - 1] == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= tiles_x * tiles_y) return;  // whole wave leaves together
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int y = ty * 64 + lane;
+    const bool rowok = y < ny;
+    const int w0 = tx * HY_WORDS;
+    unsigned long long *Sf = S + (size_t)blockIdx.y * ny * wpr;
+    const unsigned long long *Wf = Wm + (size_t)blockIdx.y * ny * wpr;
+    unsigned long long s[HY_WORDS + 2], w[HY_WORDS];  // s[0] / s[HY_WORDS+1]: halo words left / right
+    const size_t rowbase = (size_t)(rowok ? y : 0) * wpr;
+#pragma unroll
+    for (int q = 0; q < HY_WORDS + 2; q++) {
+        const int wi = w0 - 1 + q;
+        s[q] = (rowok && wi >= 0 && wi < wpr) ? Sf[rowbase + wi] : 0ull;
     }
-    if (tid == 0) { flag[0] = 0; flag[1] = 0; }
-    __syncthreads();
-    // thread owns a 4x4 patch of the 64x64 tile
-    const int pr = (tid >> 4) * 4 + 1, pc = (tid & 15) * 4 + 1;
+    bool todo = false;
+#pragma unroll
+    for (int q = 0; q < HY_WORDS; q++) {
+        const int wi = w0 + q;
+        w[q] = (rowok && wi < wpr) ? Wf[rowbase + wi] : 0ull;
+        todo = todo || (w[q] & ~s[q + 1]) != 0ull;
+    }
+    if (!__any(todo)) return;  // no marked-but-not-strong pixel in the tile
+    // halo rows above / below: lanes 0..5 fetch the six words, then everybody gets them by shuffle
+    unsigned long long trow = 0ull, brow = 0ull;
+    {
+        const int wi = w0 - 1 + lane;
+        const int yt = ty * 64 - 1, yb = ty * 64 + 64;
+        if (lane < HY_WORDS + 2 && wi >= 0 && wi < wpr) {
+            if (yt >= 0) trow = Sf[(size_t)yt * wpr + wi];
+            if (yb < ny) brow = Sf[(size_t)yb * wpr + wi];
+        }
+    }
+    unsigned long long top_d[HY_WORDS], bot_d[HY_WORDS];
+    {
+        unsigned long long t[HY_WORDS + 2], b[HY_WORDS + 2];
+#pragma unroll
+        for (int q = 0; q < HY_WORDS + 2; q++) { t[q] = __shfl(trow, q); b[q] = __shfl(brow, q); }
+#pragma unroll
+        for (int q = 0; q < HY_WORDS; q++) {
+            top_d[q] = dilate_h(t[q + 1], t[q], t[q + 2]);
+            bot_d[q] = dilate_h(b[q + 1], b[q], b[q + 2]);
+        }
+    }
     bool any = false;
-    for (int it = 0;; it++) {
+    for (;;) {
         bool ch = false;
+        unsigned long long d[HY_WORDS];
 #pragma unroll
-        for (int r = 0; r < 4; r++)
+        for (int q = 0; q < HY_WORDS; q++) d[q] = dilate_h(s[q + 1], s[q], s[q + 2]);
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int rr = pr + r, cc = pc + c;
-                if (s[rr][cc] == 1) {
-                    const bool strong = s[rr - 1][cc - 1] == 2 || s[rr - 1][cc] == 2 || s[rr - 1][cc + 1] == 2 ||
-                                        s[rr][cc - 1] == 2 || s[rr][cc + 1] == 2 || s[rr + 1][cc - 1] == 2 ||
-                                        s[rr + 1][cc] == 2 || s[rr + 1][cc + 1] == 2;
-                    if (strong) { s[rr][cc] = 2; ch = true; }
-                }
+        for (int q = 0; q < HY_WORDS; q++) {
+            unsigned long long up = __shfl_up(d[q], 1), dn = __shfl_down(d[q], 1);
+            if (lane == 0) up = top_d[q];
+            if (lane == 63) dn = bot_d[q];
+            const unsigned long long cand = w[q] & ~s[q + 1] & (d[q] | up | dn);
+            if (cand) {
+                s[q + 1] |= flood_runs(w[q], cand);
+                ch = true;
             }
-        if (ch) { flag[it & 1] = 1; any = true; }
-        __syncthreads();
-        const int f = flag[it & 1];
-        __syncthreads();
-        if (tid == 0) flag[it & 1] = 0;  // reused two iterations later, after the next barrier pair
-        if (!f) break;
+        }
+        if (!__any(ch)) break;
+        any = true;
     }
     if (any) {
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int gx = x0 + pc + c - 1, gy = y0 + pr + r - 1;
-                if (gx < nx && gy < ny && s[pr + r][pc + c] == 2) pl[(size_t)gy * nx + gx] = 2;
-            }
-        atomicOr(changed, 1u);
+        for (int q = 0; q < HY_WORDS; q++) {
+            const int wi = w0 + q;
+            if (rowok && wi < wpr) Sf[rowbase + wi] = s[q + 1];
+        }
+        if (lane == 0) atomicOr(&flags[sweep], 1u);
     }
 }
 
-// edges = 255 where strong, else 0 (rcpp_canny.cpp:210-215); per-frame count of 255s (:226-233)
-__global__ void __launch_bounds__(256) canny_finalize(const unsigned char *__restrict__ st, unsigned char *__restrict__ edges,
-                                                      size_t n_per_frame, unsigned long long *__restrict__ counts)
+// edges = 255 where strong, else 0 (rcpp_canny.cpp:210-215); thread = 16 pixels
+__global__ void __launch_bounds__(256) canny_expand_bits(const unsigned long long *__restrict__ S, int wpr,
+                                                         unsigned char *__restrict__ edges, int nx, int ny)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;  // 16-pixel group along x
+    const int y = blockIdx.y;
+    const int x = 16 * g;
+    if (x >= nx) return;
+    const unsigned long long word = S[((size_t)blockIdx.z * ny + y) * wpr + (x >> 6)];
+    const unsigned bits = (unsigned)(word >> (x & 63)) & 0xffffu;
+    unsigned v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = ((((bits >> (4 * k)) & 0xfu) * 0x00204081u) & 0x01010101u) * 0xffu;
+    unsigned char *dst = edges + ((size_t)blockIdx.z * ny + y) * nx + x;
+    if ((nx & 15) == 0 && (reinterpret_cast<size_t>(edges) & 15) == 0) {
+        *reinterpret_cast<uint4 *>(dst) = make_uint4(v[0], v[1], v[2], v[3]);
+    } else {
+        for (int k = 0; k < 16 && x + k < nx; k++) dst[k] = (unsigned char)(v[k >> 2] >> (8 * (k & 3)));
+    }
+}
+
+// per-frame count of edge pixels (rcpp_canny.cpp:226-233): popcount of the strong plane
+#define CNT_BLOCKS 16
+__global__ void __launch_bounds__(256) canny_count_bits(const unsigned long long *__restrict__ S, size_t words_per_frame,
+                                                        unsigned long long *__restrict__ counts)
 {
     __shared__ unsigned wsum[4];
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int f = blockIdx.y;
-    bool on = false;
-    if (i < n_per_frame) {
-        on = st[(size_t)f * n_per_frame + i] == 2;
-        edges[(size_t)f * n_per_frame + i] = on ? 255 : 0;
-    }
-    const unsigned c = (unsigned)__popcll(__ballot(on));
+    const unsigned long long *Sf = S + (size_t)blockIdx.y * words_per_frame;
+    unsigned c = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words_per_frame; i += (size_t)CNT_BLOCKS * 256)
+        c += (unsigned)__popcll(Sf[i]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (t) atomicAdd(&counts[f], (unsigned long long)t);
+        if (t) atomicAdd(&counts[blockIdx.y], (unsigned long long)t);
     }
 }
 
@@ -242,50 +480,111 @@ imgfd_status make_taps(imgfd_ctx *ctx, int n, double s, BlurTaps *t)
     return IMGFD_OK;
 }
 
+// radius of the taps make_taps keeps, when they form the symmetric set {0, 1..R, n-R..n-1} (n > 2R+1);
+// -1 when the kernel wraps onto itself (tiny images) and only the generic kernels apply
+int symmetric_radius(const BlurTaps &t, int n)
+{
+    if ((t.n & 1) == 0) return -1;
+    const int R = t.n / 2;
+    if (n < 2 * R + 2) return -1;
+    for (int j = 0; j <= R; j++)
+        if (t.off[j] != j) return -1;
+    for (int j = 1; j <= R; j++)
+        if (t.off[t.n - j] != n - j || t.w[t.n - j] != t.w[j]) return -1;
+    return R;
+}
+
+template <int R>
+imgfd_status launch_blur_march(imgfd_ctx *ctx, BlurMarchParams &p, int nf)
+{
+    using G = BlurGeom<R>;
+    const int strips = ceil_div(p.nx, BM_TW);
+    int want = ceil_div(6 * ctx->num_cu, strips * nf);
+    if (want < 1) want = 1;
+    int seg = ceil_div(p.ny, want);
+    int m = ceil_div(seg + 2 * R, BM_CH);
+    if (m < 2) m = 2;
+    seg = m * BM_CH - 2 * R;  // (rows + 2R) fills whole chunks
+    p.seg_rows = seg;
+    dim3 grid(strips, ceil_div(p.ny, seg), nf);
+    IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)canny_blur_march<R>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)G::LDS_BYTES));
+    hipLaunchKernelGGL((canny_blur_march<R>), grid, dim3(BM_NT), G::LDS_BYTES, ctx->stream, p);
+    IMGFD_HIP(ctx, hipGetLastError());
+    return IMGFD_OK;
+}
+
 size_t canny_ws_bytes(int nx, int ny, int nf)
 {
     const size_t n = (size_t)nx * ny * nf;
-    return align_up(n * sizeof(double), 256) + align_up(n * sizeof(float), 256) + align_up(n, 256) + 4096;
+    const size_t words = (size_t)ceil_div(nx, 64) * ny * nf;
+    return align_up(n * sizeof(double), 256) + align_up(n * sizeof(float), 256) + 2 * align_up(words * 8, 256) + 4096;
 }
+
+#define HY_ROUND 12  // sweeps queued per host read-back
 
 // all device work for nf frames; d_edges / d_counts are device buffers
 imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, size_t frame_stride, int nx, int ny,
                           int nf, double s, double low_thr, double high_thr, int accGrad, uint8_t *d_edges,
                           int64_t *d_counts)
 {
-    const size_t n = (size_t)nx * ny * nf;
-    double *tmp = (double *)ws_alloc(ctx, n * sizeof(double));
-    float *blur = (float *)ws_alloc(ctx, n * sizeof(float));
-    unsigned char *st = (unsigned char *)ws_alloc(ctx, n);
-    unsigned *changed = (unsigned *)ws_alloc(ctx, 256);
-    if (!tmp || !blur || !st || !changed) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
     if (!(s > 0)) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "canny: s must be positive");
+    const size_t n = (size_t)nx * ny * nf;
+    const int wpr = ceil_div(nx, 64);
+    const size_t words = (size_t)wpr * ny * nf;
     BlurTaps tx, ty;
     IMGFD_TRY(make_taps(ctx, nx, s, &tx));
     IMGFD_TRY(make_taps(ctx, ny, s, &ty));
-    dim3 g1(ceil_div(nx, 256), ny, nf);
-    hipLaunchKernelGGL(canny_blur_rows, g1, dim3(256), 0, ctx->stream, d_in, row_stride, frame_stride, tmp, nx, ny, tx);
-    hipLaunchKernelGGL(canny_blur_cols, g1, dim3(256), 0, ctx->stream, tmp, blur, nx, ny, ty);
-    dim3 g2(ceil_div(nx, GN_T), ceil_div(ny, GN_T), nf);
-    hipLaunchKernelGGL(canny_grad_nms, g2, dim3(256), 0, ctx->stream, blur, st, nx, ny, accGrad, (int)low_thr,
+    const int Rx = symmetric_radius(tx, nx), Ry = symmetric_radius(ty, ny);
+    const int R = std::max(Rx, Ry);
+    const bool fast = Rx >= 0 && Ry >= 0 && R <= 32;
+    double *tmp = fast ? nullptr : (double *)ws_alloc(ctx, n * sizeof(double));
+    float *blur = (float *)ws_alloc(ctx, n * sizeof(float));
+    unsigned long long *S = (unsigned long long *)ws_alloc(ctx, words * 8);
+    unsigned long long *Wm = (unsigned long long *)ws_alloc(ctx, words * 8);
+    unsigned *flags = (unsigned *)ws_alloc(ctx, 256);
+    if ((!fast && !tmp) || !blur || !S || !Wm || !flags) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    if (fast) {
+        BlurMarchParams p;
+        memset(&p, 0, sizeof p);
+        p.in = d_in; p.out = blur; p.nx = nx; p.ny = ny; p.row_stride = row_stride; p.frame_stride = (long)frame_stride;
+        p.aligned4 = (nx % 4 == 0) && (row_stride % 4 == 0) && (frame_stride % 4 == 0) && ((size_t)d_in % 4 == 0);
+        for (int j = 0; j <= Rx; j++) p.wx[j] = tx.w[j];
+        for (int j = 0; j <= Ry; j++) p.wy[j] = ty.w[j];
+        // zero taps up to the template radius add +0.0 to the sums: exact
+        if (R <= 4) IMGFD_TRY(launch_blur_march<4>(ctx, p, nf));
+        else if (R <= 7) IMGFD_TRY(launch_blur_march<7>(ctx, p, nf));
+        else if (R <= 10) IMGFD_TRY(launch_blur_march<10>(ctx, p, nf));
+        else if (R <= 14) IMGFD_TRY(launch_blur_march<14>(ctx, p, nf));
+        else if (R <= 18) IMGFD_TRY(launch_blur_march<18>(ctx, p, nf));
+        else if (R <= 24) IMGFD_TRY(launch_blur_march<24>(ctx, p, nf));
+        else IMGFD_TRY(launch_blur_march<32>(ctx, p, nf));
+    } else {
+        dim3 g1(ceil_div(nx, 256), ny, nf);
+        hipLaunchKernelGGL(canny_blur_rows, g1, dim3(256), 0, ctx->stream, d_in, row_stride, frame_stride, tmp, nx, ny, tx);
+        hipLaunchKernelGGL(canny_blur_cols, g1, dim3(256), 0, ctx->stream, tmp, blur, nx, ny, ty);
+    }
+    dim3 g2(wpr, ceil_div(ny, GN_TY), nf);
+    hipLaunchKernelGGL(canny_grad_nms, g2, dim3(256), 0, ctx->stream, blur, S, Wm, nx, ny, wpr, accGrad, (int)low_thr,
                        (int)high_thr);
     IMGFD_HIP(ctx, hipGetLastError());
-    // hysteresis: sweeps until a whole sweep changes nothing; the flag is read back every 2 sweeps
-    dim3 g3(ceil_div(nx, HY_T), ceil_div(ny, HY_T), nf);
+    // hysteresis: rounds of HY_ROUND sweeps; converged when the last sweep of a round was idle
+    const int tiles_x = ceil_div(wpr, HY_WORDS), tiles_y = ceil_div(ny, 64);
+    dim3 g3(ceil_div(tiles_x * tiles_y, 4), nf);
     for (int round = 0; round < 100000; round++) {
-        IMGFD_HIP(ctx, hipMemsetAsync(changed, 0, sizeof(unsigned), ctx->stream));
-        hipLaunchKernelGGL(canny_hyst_sweep, g3, dim3(256), 0, ctx->stream, st, nx, ny, changed);
-        unsigned h = 0;
-        if (round & 1) {
-            IMGFD_HIP(ctx, hipMemcpyAsync(&h, changed, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-            IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (!h) break;
-        }
+        IMGFD_HIP(ctx, hipMemsetAsync(flags, 0, sizeof(unsigned) * HY_ROUND, ctx->stream));
+        for (int i = 0; i < HY_ROUND; i++)
+            hipLaunchKernelGGL(canny_hyst_bits, g3, dim3(256), 0, ctx->stream, S, Wm, wpr, ny, tiles_x, tiles_y, flags, i);
+        unsigned last = 0;
+        IMGFD_HIP(ctx, hipMemcpyAsync(&last, flags + HY_ROUND - 1, sizeof last, hipMemcpyDeviceToHost, ctx->stream));
+        IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (!last) break;
     }
     IMGFD_HIP(ctx, hipMemsetAsync(d_counts, 0, sizeof(int64_t) * nf, ctx->stream));
-    const size_t npf = (size_t)nx * ny;
-    hipLaunchKernelGGL(canny_finalize, dim3((unsigned)((npf + 255) / 256), nf), dim3(256), 0, ctx->stream, st, d_edges,
-                       npf, (unsigned long long *)d_counts);
+    hipLaunchKernelGGL(canny_expand_bits, dim3(ceil_div(ceil_div(nx, 16), 256), ny, nf), dim3(256), 0, ctx->stream, S, wpr,
+                       d_edges, nx, ny);
+    hipLaunchKernelGGL(canny_count_bits, dim3(CNT_BLOCKS, nf), dim3(256), 0, ctx->stream, S, (size_t)wpr * ny,
+                       (unsigned long long *)d_counts);
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }
