@@ -26,8 +26,31 @@
 
 #include <math.h>
 
-#define FIR_NT 256
-#define FIR_PX 8
+
+#ifdef FIR_PROFILE
+// experiment build only (make EXTRA=-DFIR_PROFILE): per-phase shader-clock sums over all waves of fir_march
+__device__ unsigned long long g_fir_prof[8];
+#define FIR_T(i)                                                   \
+    do {                                                           \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        if ((threadIdx.x & 63) == 0) prof[i] += t_ - tlast;        \
+        tlast = t_;                                                \
+    } while (0)
+extern "C" __attribute__((visibility("default"))) int imgfd_debug_fir_profile(unsigned long long *out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fir_prof), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_fir_prof), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#else
+#define FIR_T(i)
+#endif
+
+// native 16-byte vector (gcc and clang): unlike HIP's float4 struct it is always promoted to registers
+typedef float fir_v4f __attribute__((vector_size(16)));
 
 struct FirParams {
     const void *in0;
@@ -41,21 +64,43 @@ struct FirParams {
     long out_frame_stride;  // elements between output frames (output pitch is nx)
     int seg_rows;           // output rows per workgroup segment
     int xcd_remap;          // 1: remap workgroup ids so an XCD (id % 8) owns a contiguous run of tiles
+    int vec4;               // 1: input planes, pitch and frame stride are 16-byte aligned (float4 tile loads)
     double B[IMGFD_MAX_TAPS];
 };
 
 // left/top: whole-sample reflection (-k -> k); right/bottom: half-sample (n-1+k -> n-k)
 __device__ __forceinline__ int fir_reflect(int i, int n)
 {
-    if (i < 0) i = -i;
-    else if (i >= n) i = 2 * n - 1 - i;
+    const int lo = -i, hi = 2 * n - 1 - i;
+    i = i < 0 ? lo : (i >= n ? hi : i);
     return min(max(i, 0), n - 1);
 }
 
-template <int R, bool FMA>
+// The FIR_PX output chains advance in lock-step (tap index outer, output inner): a chain's own operation
+// order is the reference's, while consecutive instructions belong to independent chains, so the f64
+// pipeline never waits on the previous result.
+template <int R, bool FMA, int FIR_PX>
 __device__ __forceinline__ void fir_window8(const double (&d)[FIR_PX + 2 * R], const double *B,
                                             float (&out)[FIR_PX])
 {
+#ifdef FIR_INTERLEAVE_CHAINS
+    double sum[FIR_PX];
+#pragma unroll
+    for (int o = 0; o < FIR_PX; o++) sum[o] = B[0] * d[o + R];
+#pragma unroll
+    for (int j = 1; j <= R; j++) {
+        double pair[FIR_PX];
+#pragma unroll
+        for (int o = 0; o < FIR_PX; o++) pair[o] = d[o + R - j] + d[o + R + j];
+#pragma unroll
+        for (int o = 0; o < FIR_PX; o++) {
+            if (FMA) sum[o] = __builtin_fma(B[j], pair[o], sum[o]);
+            else sum[o] += B[j] * pair[o];
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < FIR_PX; o++) out[o] = (float)sum[o];
+#else
 #pragma unroll
     for (int o = 0; o < FIR_PX; o++) {
         double sum = B[0] * d[o + R];
@@ -67,6 +112,7 @@ __device__ __forceinline__ void fir_window8(const double (&d)[FIR_PX + 2 * R], c
         }
         out[o] = (float)sum;
     }
+#endif
 }
 
 constexpr int fir_ring_size(int need)
@@ -80,33 +126,44 @@ constexpr int fir_ring_size(int need)
 constexpr int fir_rpitch4(int w4) { return ((w4 + ((w4 - 1) >> 4)) + 15) / 16 * 16; }
 __device__ __forceinline__ int fir_swz4(int q) { return q + (q >> 4); }
 
-template <int R, int MODE, int TW, int CH>
+// PX = consecutive outputs per thread and pass (4 or 8), NT = threads per workgroup (CH * TW / PX)
+template <int R, int MODE, int TW, int CH, int FIR_PX = 8, int FIR_NT = 256>
 struct FirGeom {
     static constexpr int NI = MODE == 2 ? 2 : 1;
     static constexpr int NP = MODE == 2 ? 3 : 1;
-    static constexpr int W = TW + 2 * R;
-    static constexpr int W4 = (W + 3) / 4;
+    static constexpr int HALO = (R + 3) / 4 * 4;  // tile halo in whole float4 slots: x0-HALO is 16-byte aligned
+    static constexpr int W = TW + 2 * HALO;
+    static constexpr int W4 = W / 4;
     static constexpr int RP4 = fir_rpitch4(W4);
     static constexpr int RPITCH = RP4 * 4;
     static constexpr int RING = fir_ring_size(CH + 2 * R);
-    static constexpr int NW = FIR_PX + 2 * R;   // window length
-    static constexpr int NW4 = (NW + 3) / 4;    // float4 reads per window
-    static constexpr int NLOAD = (CH * W + FIR_NT - 1) / FIR_NT;
+    static constexpr int NW = FIR_PX + 2 * R;            // window length
+    static constexpr int S0 = (HALO - R) / 4;            // first float4 slot of strip 0's window
+    static constexpr int OFF = (HALO - R) % 4;           // window start inside that slot
+    static constexpr int NW4 = (OFF + NW + 3) / 4;       // float4 reads per window
+    static constexpr int NL4 = (CH * W4 + FIR_NT - 1) / FIR_NT;  // float4 tile slots per thread per chunk
     static constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)NI * CH * RPITCH + (size_t)NP * RING * TW);
 };
 
 // MODE 0: one f32 plane in -> one plane out;  MODE 1: one u8 plane in;  MODE 2: Ix,Iy in -> A,B,C out
-template <int R, int MODE, int TW, int CH, bool FMA>
-__global__ void __launch_bounds__(FIR_NT) fir_march(FirParams p)
+template <int R, int MODE, int TW, int CH, bool FMA, int FIR_PX, int FIR_NT, bool VEC>
+#ifdef HIPEMU
+#define FIR_WAVES_PER_EU(n)
+#else
+// LDS (not registers) fixes the residency of this kernel at two workgroups per CU: tell the register allocator so,
+// or it trades VGPRs for an occupancy the LDS footprint can never reach (and spills)
+#define FIR_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#endif
+__global__ void __launch_bounds__(FIR_NT) FIR_WAVES_PER_EU(FIR_NT / 128) fir_march(FirParams p)
 {
-    using G = FirGeom<R, MODE, TW, CH>;
-    constexpr int NI = G::NI, NP = G::NP, W = G::W, RPITCH = G::RPITCH, RING = G::RING;
-    constexpr int NW = G::NW, NW4 = G::NW4, NLOAD = G::NLOAD;
+    using G = FirGeom<R, MODE, TW, CH, FIR_PX, FIR_NT>;
+    constexpr int NI = G::NI, NP = G::NP, W4 = G::W4, RPITCH = G::RPITCH, RING = G::RING, HALO = G::HALO;
+    constexpr int NW = G::NW, NW4 = G::NW4, NL4 = G::NL4, S0 = G::S0, OFF = G::OFF;
     constexpr int STRIPS = TW / FIR_PX;
 
     HIP_DYNAMIC_SHARED(float4, smem4)
-    float *raw = reinterpret_cast<float *>(smem4);  // [NI][CH][RPITCH], columns swizzled per float4
-    float *ring = raw + NI * CH * RPITCH;           // [NP][RING][TW]
+    float4 *raw4 = smem4;                                                   // [NI][CH][RP4], slots swizzled
+    float *ring = reinterpret_cast<float *>(smem4) + NI * CH * RPITCH;      // [NP][RING][TW]
 
     const int tid = threadIdx.x;
     int bx = blockIdx.x, by = blockIdx.y;
@@ -134,57 +191,102 @@ __global__ void __launch_bounds__(FIR_NT) fir_march(FirParams p)
                       NP == 3 ? p.out1 + (size_t)frame * p.out_frame_stride : nullptr,
                       NP == 3 ? p.out2 + (size_t)frame * p.out_frame_stride : nullptr};
 
-    float pre0[NLOAD], pre1[NLOAD];
-
-    // ---- issue the global loads of one chunk into registers
-    auto prefetch = [&](int chunk) {
+    // tile slot owned by this thread in load round l: row tr[l], float4 slot tq[l] (constant over chunks)
+    int tr[NL4], tq[NL4];
+    unsigned xoff[NL4];
 #pragma unroll
-        for (int l = 0; l < NLOAD; l++) {
-            const int i = tid + l * FIR_NT;
-            pre0[l] = 0.f;
-            pre1[l] = 0.f;
-            if (i < CH * W) {
-                const int r = i / W, c = i - r * W;
-                const int gy = fir_reflect(ybase + chunk * CH + r, p.ny);
-                const int gx = fir_reflect(x0 - R + c, p.nx);
-                const size_t off = (size_t)gy * p.in_pitch + gx;
-                if (MODE == 1) pre0[l] = (float)in0b[off];
-                else pre0[l] = in0f[off];
-                if (MODE == 2) pre1[l] = in1f[off];
+    for (int l = 0; l < NL4; l++) {
+        const int i = tid + l * FIR_NT;
+        tr[l] = i / W4;
+        tq[l] = i - tr[l] * W4;
+        // VEC: every slot is fetched as one aligned float4 from an in-range address; slots that hang over the
+        // left/right image border fetch a neighbouring quad and are rewritten in LDS by patch_borders()
+        xoff[l] = (unsigned)min(max(x0 - HALO + 4 * tq[l], 0), max(p.nx - 4, 0));
+    }
+    const bool x_inside = x0 - HALO >= 0 && x0 - HALO + G::W <= p.nx;
+
+    fir_v4f pre0[NL4], pre1[NL4];
+
+    // ---- issue the global loads of one chunk into registers.  One straight-line sequence of loads: no
+    // control-flow merge may touch pre0/pre1 before commit(), or the loads stop being asynchronous.
+    auto prefetch = [&](int chunk) __attribute__((always_inline)) {
+        const int yc = ybase + chunk * CH;
+#pragma unroll
+        for (int l = 0; l < NL4; l++) {
+            if (l < NL4 - 1 || tid + l * FIR_NT < CH * W4) {
+                const int gy = fir_reflect(yc + tr[l], p.ny);
+                if (VEC) {
+                    const unsigned off = (unsigned)gy * (unsigned)p.in_pitch + xoff[l];
+                    pre0[l] = *reinterpret_cast<const fir_v4f *>(in0f + off);
+                    if (MODE == 2) pre1[l] = *reinterpret_cast<const fir_v4f *>(in1f + off);
+                } else {
+                    float v0[4], v1[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int gx = fir_reflect(x0 - HALO + 4 * tq[l] + e, p.nx);
+                        const size_t off = (size_t)gy * p.in_pitch + gx;
+                        if (MODE == 1) v0[e] = (float)in0b[off];
+                        else v0[e] = in0f[off];
+                        v1[e] = MODE == 2 ? in1f[off] : 0.f;
+                    }
+                    pre0[l] = fir_v4f{v0[0], v0[1], v0[2], v0[3]};
+                    if (MODE == 2) pre1[l] = fir_v4f{v1[0], v1[1], v1[2], v1[3]};
+                }
             }
         }
     };
-    auto commit = [&]() {
+    auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int l = 0; l < NLOAD; l++) {
-            const int i = tid + l * FIR_NT;
-            if (i < CH * W) {
-                const int r = i / W, c = i - r * W;
-                const int cs = c + 4 * (c >> 6);  // == 4*fir_swz4(c>>2) + (c&3)
-                raw[(0 * CH + r) * RPITCH + cs] = pre0[l];
-                if (MODE == 2) raw[(1 * CH + r) * RPITCH + cs] = pre1[l];
+        for (int l = 0; l < NL4; l++) {
+            if (l < NL4 - 1 || tid + l * FIR_NT < CH * W4) {
+                reinterpret_cast<fir_v4f *>(raw4)[(0 * CH + tr[l]) * G::RP4 + fir_swz4(tq[l])] = pre0[l];
+                if (MODE == 2) reinterpret_cast<fir_v4f *>(raw4)[(1 * CH + tr[l]) * G::RP4 + fir_swz4(tq[l])] = pre1[l];
+            }
+        }
+        if (VEC && !x_inside) {
+            // border strips only (workgroup-uniform): rebuild the reflected halo columns from the columns
+            // of the same LDS row.  left: x = -k -> k;  right: x = nx-1+k -> nx-k  (gaussian.cpp:345-349)
+            __syncthreads();
+            float *rawf = reinterpret_cast<float *>(raw4);
+            for (int i = tid; i < NI * CH * 2 * HALO; i += FIR_NT) {
+                const int h = i % (2 * HALO), rr = i / (2 * HALO);  // rr = plane*CH + row
+                int c, x;
+                if (h < HALO) { c = h; x = x0 - HALO + c; if (x >= 0) continue; }
+                else { x = p.nx + (h - HALO); c = x - x0 + HALO; if (c >= G::W) continue; }
+                const int sx = fir_reflect(x, p.nx);
+                const int sc = sx - x0 + HALO;
+                if (sc < 0 || sc >= G::W) continue;
+                rawf[(rr * G::RP4 + fir_swz4(c >> 2)) * 4 + (c & 3)] = rawf[(rr * G::RP4 + fir_swz4(sc >> 2)) * 4 + (sc & 3)];
             }
         }
     };
 
+    // Software pipeline.  The loads of chunk c+1 are issued before the row pass of chunk c and written to LDS
+    // right after it (the raw tile is free once every thread has passed the barrier that ends the row pass),
+    // i.e. BEFORE the column pass issues its stores: s_waitcnt vmcnt counts stores too, so waiting for the
+    // prefetched tile at the top of the next iteration would also wait for the stores just issued.
     prefetch(0);
+    FIR_T(0);
+    commit();
     for (int chunk = 0; chunk < nchunks; chunk++) {
-        commit();
+        FIR_T(1);
         __syncthreads();
-        if (chunk + 1 < nchunks) prefetch(chunk + 1);
+        FIR_T(2);
+        prefetch(chunk + 1);  // unconditional (the tile past the last chunk is fetched from clamped rows and never used):
+        FIR_T(3);             // a branch here would make the waitcnt bookkeeping of the loop conservative
 
         // ---- row pass: raw tile -> ring of row-filtered rows
         for (int item = tid; item < CH * STRIPS; item += FIR_NT) {
             const int r = item / STRIPS, s = item - r * STRIPS;
             float wx[NW4 * 4], wy[NW4 * 4];
-            const float4 *rx = reinterpret_cast<const float4 *>(raw + (0 * CH + r) * RPITCH);
-            const float4 *ry = reinterpret_cast<const float4 *>(raw + (1 * CH + r) * RPITCH);
+            const float4 *rx = raw4 + (0 * CH + r) * G::RP4;
+            const float4 *ry = raw4 + (1 * CH + r) * G::RP4;
 #pragma unroll
             for (int q = 0; q < NW4; q++) {
-                const float4 v = rx[fir_swz4(2 * s + q)];
+                const float4 v = rx[fir_swz4((FIR_PX / 4) * s + S0 + q)];
                 wx[4 * q] = v.x; wx[4 * q + 1] = v.y; wx[4 * q + 2] = v.z; wx[4 * q + 3] = v.w;
                 if (MODE == 2) {
-                    const float4 u = ry[fir_swz4(2 * s + q)];
+                    const float4 u = ry[fir_swz4((FIR_PX / 4) * s + S0 + q)];
                     wy[4 * q] = u.x; wy[4 * q + 1] = u.y; wy[4 * q + 2] = u.z; wy[4 * q + 3] = u.w;
                 }
             }
@@ -195,27 +297,32 @@ __global__ void __launch_bounds__(FIR_NT) fir_march(FirParams p)
 #pragma unroll
                 for (int k = 0; k < NW; k++) {
                     float v;
-                    if (MODE != 2) v = wx[k];
-                    else if (pl == 0) v = wx[k] * wx[k];  // harris.cpp:59
-                    else if (pl == 1) v = wx[k] * wy[k];  // harris.cpp:60
-                    else v = wy[k] * wy[k];               // harris.cpp:61
+                    if (MODE != 2) v = wx[OFF + k];
+                    else if (pl == 0) v = wx[OFF + k] * wx[OFF + k];  // harris.cpp:59
+                    else if (pl == 1) v = wx[OFF + k] * wy[OFF + k];  // harris.cpp:60
+                    else v = wy[OFF + k] * wy[OFF + k];               // harris.cpp:61
                     d[k] = (double)v;
                 }
                 float o[FIR_PX];
-                fir_window8<R, FMA>(d, p.B, o);
+                fir_window8<R, FMA, FIR_PX>(d, p.B, o);
                 float4 *dst = reinterpret_cast<float4 *>(ring + (pl * RING + slot) * TW + FIR_PX * s);
-                dst[0] = make_float4(o[0], o[1], o[2], o[3]);
-                dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+#pragma unroll
+                for (int h = 0; h < FIR_PX / 4; h++) dst[h] = make_float4(o[4 * h], o[4 * h + 1], o[4 * h + 2], o[4 * h + 3]);
             }
         }
+        FIR_T(4);
         __syncthreads();
+        FIR_T(5);
+        commit();
 
         // ---- column pass: ring -> global
         for (int item = tid; item < TW * (CH / FIR_PX); item += FIR_NT) {
             const int g = item / TW, col = item - g * TW;
             const int oi0 = chunk * CH - 2 * R + FIR_PX * g;
             const int gx = x0 + col;
-            if (oi0 + FIR_PX <= 0 || oi0 >= nrows) continue;
+            if (oi0 + FIR_PX <= 0 || oi0 >= nrows || gx >= p.nx) continue;
+            const bool full = oi0 >= 0 && oi0 + FIR_PX <= nrows;
+            const unsigned obase = (unsigned)(y0 + oi0) * (unsigned)p.nx + (unsigned)gx;  // fits: one frame < 2^32 px
 #pragma unroll
             for (int pl = 0; pl < NP; pl++) {
                 double d[NW];
@@ -223,8 +330,11 @@ __global__ void __launch_bounds__(FIR_NT) fir_march(FirParams p)
                 for (int k = 0; k < NW; k++)
                     d[k] = (double)ring[(pl * RING + ((oi0 + k) & (RING - 1))) * TW + col];
                 float o[FIR_PX];
-                fir_window8<R, FMA>(d, p.B, o);
-                if (gx < p.nx) {
+                fir_window8<R, FMA, FIR_PX>(d, p.B, o);
+                if (full) {
+#pragma unroll
+                    for (int k = 0; k < FIR_PX; k++) outp[pl][obase + (unsigned)k * (unsigned)p.nx] = o[k];
+                } else {
 #pragma unroll
                     for (int k = 0; k < FIR_PX; k++) {
                         const int oi = oi0 + k;
@@ -233,10 +343,14 @@ __global__ void __launch_bounds__(FIR_NT) fir_march(FirParams p)
                 }
             }
         }
-        // the next commit() writes `raw` (last read before the barrier above); the next row pass
-        // writes ring slots only after the barrier that follows commit(), by which time every thread
-        // has left this column pass.
+        FIR_T(6);
+        // the next row pass writes ring slots only after the barrier at the top of the loop, by which time
+        // every thread has left this column pass.
     }
+#ifdef FIR_PROFILE
+    if ((threadIdx.x & 63) == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&g_fir_prof[i], prof[i]);
+#endif
 }
 
 // ------------------------------------------------------------------ generic fallback (any radius)
@@ -313,33 +427,53 @@ static int fir_coeffs(float sigma, int precision, double *B)
     return size;
 }
 
-template <int R, int MODE, int TW, int CH>
+template <int R, int MODE, int TW, int CH, int FIR_PX = 8, int FIR_NT = 256>
 static imgfd_status launch_march(imgfd_ctx *ctx, FirParams &p, int n_frames)
 {
-    using G = FirGeom<R, MODE, TW, CH>;
+    using G = FirGeom<R, MODE, TW, CH, FIR_PX, FIR_NT>;
     const int strips = ceil_div(p.nx, TW);
-    // segments: enough workgroups for >= 2 per CU, segment length 16m+2 so that (rows+2R) fills whole chunks
-    int want = ceil_div(2 * ctx->num_cu, strips * n_frames);
-    int seg = ceil_div(p.ny, want < 1 ? 1 : want);
-    int m = ceil_div(seg + 2 * R, CH);
-    if (m < 2) m = 2;
-    seg = m * CH - 2 * R;
+    // Segment length: a workgroup walks (rows + 2R) rows in chunks of CH.  With `slots` workgroups resident on the
+    // chip, the pass takes ceil(workgroups / slots) rounds of (chunks per segment) steps: pick the segment count
+    // that minimises that product (ties: fewer, longer segments = less halo work).
+    static int per_cu = 0;
+    if (!per_cu) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)fir_march<R, MODE, TW, CH, true, FIR_PX, FIR_NT, MODE != 1>, FIR_NT,
+                                                         G::LDS_BYTES) != hipSuccess || n < 1)
+            n = 2;
+        per_cu = n;
+    }
+    const long slots = (long)per_cu * ctx->num_cu;
+    long best_cost = -1;
+    int seg = p.ny;
+    for (int nseg = 1; nseg <= ceil_div(p.ny, CH); nseg++) {
+        int m = ceil_div(ceil_div(p.ny, nseg) + 2 * R, CH);
+        if (m < 2) m = 2;
+        const int sr = m * CH - 2 * R;  // (rows + 2R) fills whole chunks
+        const long wgs = (long)strips * ceil_div(p.ny, sr) * n_frames;
+        const long cost = ((wgs + slots - 1) / slots) * m;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; seg = sr; }
+    }
     p.seg_rows = seg;
     dim3 grid(strips, ceil_div(p.ny, seg), n_frames);
     static const char *env = getenv("IMGFD_XCD_REMAP");
     p.xcd_remap = env ? atoi(env) : 1;
+    // float4 tile loads need 16-byte aligned planes, pitch and frame stride, and whole quads per row
+    p.vec4 = MODE != 1 && ((size_t)p.in0 % 16 == 0) && ((size_t)p.in1 % 16 == 0) && p.in_pitch % 4 == 0 &&
+             p.in_frame_stride % 4 == 0 && p.nx % 4 == 0 && p.nx >= 4;
     const size_t lds = G::LDS_BYTES;
+    auto go = [&](auto kern) -> imgfd_status {
+        IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, grid, dim3(FIR_NT), lds, ctx->stream, p);
+        IMGFD_HIP(ctx, hipGetLastError());
+        return IMGFD_OK;
+    };
     if (ctx->fir_mode) {
-        IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)fir_march<R, MODE, TW, CH, true>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((fir_march<R, MODE, TW, CH, true>), grid, dim3(FIR_NT), lds, ctx->stream, p);
-    } else {
-        IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)fir_march<R, MODE, TW, CH, false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((fir_march<R, MODE, TW, CH, false>), grid, dim3(FIR_NT), lds, ctx->stream, p);
+        if (p.vec4) return go(fir_march<R, MODE, TW, CH, true, FIR_PX, FIR_NT, MODE != 1>);
+        return go(fir_march<R, MODE, TW, CH, true, FIR_PX, FIR_NT, false>);
     }
-    IMGFD_HIP(ctx, hipGetLastError());
-    return IMGFD_OK;
+    if (p.vec4) return go(fir_march<R, MODE, TW, CH, false, FIR_PX, FIR_NT, MODE != 1>);
+    return go(fir_march<R, MODE, TW, CH, false, FIR_PX, FIR_NT, false>);
 }
 
 static imgfd_status launch_generic(imgfd_ctx *ctx, const float *in, float *tmp, float *out, int nx, int ny,
@@ -457,7 +591,11 @@ imgfd_status launch_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const fl
     p.in_pitch = nx; p.in_frame_stride = (long)nx * ny; p.out_frame_stride = (long)nx * ny;
     if (fir_has_fast_path(R, 2)) {
         switch (R) {
-            case 7: return launch_march<7, 2, 128, 16>(ctx, p, n_frames);
+            case 7: {
+                static const char *e = getenv("IMGFD_K3_PX4");
+                if (e && atoi(e)) return launch_march<7, 2, 128, 16, 4, 512>(ctx, p, n_frames);
+                return launch_march<7, 2, 128, 16>(ctx, p, n_frames);
+            }
             case 3: return launch_march<3, 2, 128, 16>(ctx, p, n_frames);
             case 1: return launch_march<1, 2, 128, 16>(ctx, p, n_frames);
         }

@@ -364,3 +364,4 @@ static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
 static inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = 1ull << 33; *t = 1ull << 34; return hipSuccess; }
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *n, const void *, int, size_t) { *n = 2; return hipSuccess; }
