@@ -99,13 +99,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
 
-    from image_amd import synth
+    from image_amd import stream, synth
     from image_amd.device import DeviceDetector
 
     det = DeviceDetector(local)
     det.ctx.set_fir_mode(args.fir_mode)
     B = args.batch
-    frames = det.synth_frames(B, NX, NY, seed0=50000 + rank * B)  # per-rank frame subset
+    first, _ = stream.rank_block(B * world, rank, world)  # weak scaling: B frames per rank, contiguous blocks
+    frames = det.synth_frames(B, NX, NY, seed0=stream.frame_seed(50000, first))
     cap_h, cap_f = 65536, 262144
     h_out = (torch.empty((B, cap_h, 3), dtype=torch.float32, device="cuda"), torch.empty((B,), dtype=torch.int64, device="cuda"))
     f_out = (torch.empty((B, cap_f, 2), dtype=torch.int32, device="cuda"), torch.empty((B,), dtype=torch.int64, device="cuda"))
@@ -144,12 +145,9 @@ def main():
     det.ctx.check(det.lib.imgfd_profile_k3_read(det.ctx.handle, C.byref(k3_us), C.byref(k3_n)), "profile read")
     det.lib.imgfd_profile_k3(det.ctx.handle, 0)
 
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     counts = torch.stack([h_out[1].sum(), f_out[1].sum(), c_out[1].sum() if have_canny else torch.zeros((), dtype=torch.int64, device="cuda")])
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)       # max over ranks
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)  # the path's only collective: feature counts
-    dt = float(t.item())
+    # the path's only collective: feature counts (sum) and the elapsed time (max over ranks)
+    counts, dt = stream.reduce_counts(counts, dt, dist if world > 1 else None)
 
     if rank == 0:
         px_per_step = B * NX * NY * world

@@ -1,0 +1,33 @@
+"""Sharding of a frame stream over the GPUs of one node.
+
+Every frame is an independent unit: rank r of W owns a contiguous block of the stream, keeps its inputs,
+intermediates and feature lists local, and the only collective of the whole path is the reduction of a few
+int64 feature counts (plus the max-over-ranks of the elapsed time for reporting).  No halo, no exchange.
+"""
+from __future__ import annotations
+
+
+def rank_block(n_frames: int, rank: int, world: int) -> tuple[int, int]:
+    """(first frame, number of frames) of rank `rank`: blocks of ceil/floor(n/W), earlier ranks take the remainder."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    q, r = divmod(int(n_frames), world)
+    start = rank * q + min(rank, r)
+    return start, q + (1 if rank < r else 0)
+
+
+def frame_seed(seed0: int, frame: int) -> int:
+    """Seed of global frame index `frame` (config 5: G(seed = 50000 + f))."""
+    return int(seed0) + int(frame)
+
+
+def reduce_counts(counts, elapsed_s: float, dist=None, device=None):
+    """Sum the per-rank feature counts and take the max elapsed time over ranks.
+
+    counts: 1-D int64 torch tensor on the rank's device.  Returns (total_counts tensor, max elapsed float)."""
+    import torch
+    t = torch.tensor([elapsed_s], dtype=torch.float64, device=counts.device if device is None else device)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return counts, float(t.item())

@@ -1,0 +1,145 @@
+"""The oracle itself (CPU, no GPU): the C restatements in oracle/ against
+
+  * the golden vectors in tests/golden/ (outputs of the reference's own code, scripts/make_golden.py);
+  * the reference compiled in place (oracle/_ref), when /root/reference was present at build time
+    (this container; never on the GPU box) -- stage by stage and end to end, bit for bit;
+  * for Canny (reference not compilable: FFTW3 absent -> PARITY UNPINNED) a literal numpy restatement of
+    tools.c:166-185 (fft2 product) and the BASELINE.md anchors.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from image_amd import synth
+from scripts_path import HARRIS_CASES
+
+needs_ref = pytest.mark.skipif(not (oracle.have_ref("harris") and oracle.have_ref("f9")),
+                               reason="oracle/_ref not built (needs /root/reference)")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("fixture", ["harris_building", "harris_synth_640x480_seed1"])
+@pytest.mark.parametrize("case", sorted(HARRIS_CASES))
+def test_harris_restatement_matches_reference_golden(golden, fixture, case):
+    g = golden(fixture)
+    ref = g["xyR_" + case]
+    got = oracle.harris(g["image"].astype(np.float32), **HARRIS_CASES[case])
+    assert got.shape == ref.shape, (case, got.shape, ref.shape)
+    assert np.array_equal(bits(got), bits(ref)), case
+
+
+def test_harris_building_anchor(golden):
+    """SURVEY 8c anchor: building.rds, R-default codes -> 251 corners, first = (6, 85, 30426.795)."""
+    got = oracle.harris(golden("harris_building")["image"].astype(np.float32))
+    assert got.shape[0] == 251
+    assert got[0, 0] == 6 and got[0, 1] == 85 and abs(got[0, 2] - 30426.795) < 0.01
+    assert int(got[:, 0].sum()) == 75383 and int(got[:, 1].sum()) == 50407
+
+
+@pytest.mark.parametrize("fixture,thrs", [("fast9_chairs", (20, 50, 80, 100)), ("fast9_synth_640x480_seed1", (10, 20, 50))])
+def test_fast9_restatement_matches_reference_golden(golden, fixture, thrs):
+    g = golden(fixture)
+    for thr in thrs:
+        for nms in (0, 1):
+            key = f"xy_t{thr}_n{nms}"
+            if key not in g.files:
+                continue
+            assert np.array_equal(oracle.fast9(g["image"], thr, bool(nms)), g[key]), key
+
+
+def test_fast9_chairs_anchor(golden):
+    img = golden("fast9_chairs")["image"]
+    assert oracle.fast9(img, 80, False).shape[0] == 926
+    assert oracle.fast9(img, 80, True).shape[0] == 347
+    assert oracle.fast9(img, 100, False).shape[0] == 411
+
+
+@needs_ref
+@pytest.mark.parametrize("seed,nx,ny", [(31, 97, 64), (32, 320, 200), (33, 641, 479)])
+def test_harris_stages_against_compiled_reference(seed, nx, ny):
+    img = synth.frame(seed, nx, ny).astype(np.float32)
+    for sigma in (1.0, 2.5):
+        a = oracle.harris_stage("gaussian", img, sigma=sigma, type=0)
+        b = oracle.harris_stage("gaussian", img, sigma=sigma, type=0, use_ref=True)
+        assert np.array_equal(bits(a), bits(b)), ("gaussian", sigma)
+    Is = oracle.harris_stage("gaussian", img, sigma=1.0, type=0)
+    for t in (0, 1):
+        a = oracle.harris_stage("gradient", Is, type=t)
+        b = oracle.harris_stage("gradient", Is, type=t, use_ref=True)
+        assert all(np.array_equal(bits(x), bits(y)) for x, y in zip(a, b)), ("gradient", t)
+    ix, iy = oracle.harris_stage("gradient", Is, type=0)
+    a = oracle.harris_stage("autocorrelation", ix, iy, sigma=2.5, gauss=0)
+    b = oracle.harris_stage("autocorrelation", ix, iy, sigma=2.5, gauss=0, use_ref=True)
+    assert all(np.array_equal(bits(x), bits(y)) for x, y in zip(a, b)), "autocorrelation"
+    for m in (0, 1, 2):
+        ra = oracle.harris_stage("response", *a, measure=m, k=0.06)
+        rb = oracle.harris_stage("response", *a, measure=m, k=0.06, use_ref=True)
+        assert np.array_equal(bits(ra), bits(rb)), ("response", m)
+    R = oracle.harris_stage("response", *a, measure=0, k=0.06)
+    na = oracle.harris_stage("nms", R, Th=130.0, radius=5)
+    nb = oracle.harris_stage("nms", R, Th=130.0, radius=5, use_ref=True)
+    assert np.array_equal(bits(na), bits(nb)), "nms"
+
+
+@needs_ref
+@pytest.mark.parametrize("case", sorted(HARRIS_CASES))
+def test_harris_end_to_end_against_compiled_reference(case):
+    img = synth.frame(34, 400, 300).astype(np.float32)
+    a = oracle.harris(img, **HARRIS_CASES[case])
+    b = oracle.ref_harris(img, **HARRIS_CASES[case])
+    assert a.shape == b.shape and np.array_equal(bits(a), bits(b)), case
+
+
+@needs_ref
+def test_fast9_against_compiled_reference():
+    rng = np.random.default_rng(5)
+    for i in range(6):
+        img = (synth.frame(40 + i, 200, 120) if i % 2 else rng.integers(0, 256, (90, 131)).astype(np.uint8))
+        for thr in (0, 7, 20, 50, 119):
+            for nms in (False, True):
+                assert np.array_equal(oracle.fast9(img, thr, nms), oracle.ref_fast9(img, thr, nms)), (i, thr, nms)
+
+
+# ------------------------------------------------------------------ Canny (parity unpinned)
+def _numpy_gblur(img, s):
+    """tools.c:146-185 literally: y = float(ifft2(fft2(x) * fft2(g)) / (w h)) with the wrapped Gaussian."""
+    h, w = img.shape
+    xs = np.where(np.arange(w) < w // 2, np.arange(w), np.arange(w) - w).astype(np.float64)
+    ys = np.where(np.arange(h) < h // 2, np.arange(h), np.arange(h) - h).astype(np.float64)
+    g = np.exp(-(xs[None, :] ** 2 + ys[:, None] ** 2) / (s * s))
+    g /= g.sum()
+    y = np.fft.ifft2(np.fft.fft2(img.astype(np.float64)) * np.fft.fft2(g))
+    return y.real.astype(np.float32)
+
+
+@pytest.mark.parametrize("nx,ny,s", [(64, 48, 2.0), (128, 100, 2.0), (90, 61, 1.0), (75, 40, 3.0)])
+def test_canny_blur_equals_fft_product(nx, ny, s):
+    img = synth.frame(50, nx, ny)
+    _, _, dbg = oracle.canny(img, s=s, debug=True)
+    fft = _numpy_gblur(img, s).astype(np.float64)
+    # an FFT carries ~1e-13 absolute error on 0..255 data: equal up to the last float bit
+    assert np.max(np.abs(dbg["blur"] - fft)) <= 2.0 ** -16
+
+
+def test_canny_anchors(golden):
+    g = golden("canny_chairs")
+    _, n = oracle.canny(g["image"])
+    assert n == 38012 == int(g["nonzero_a1"])
+    _, n0 = oracle.canny(g["image"], accGrad=False)
+    assert n0 == 24621
+
+
+def test_canny_hysteresis_is_connected_components():
+    """edges == marked pixels whose 8-connected component contains a strong pixel (adsf.c semantics)."""
+    from scipy import ndimage
+    img = synth.frame(51, 160, 120)
+    edges, n, dbg = oracle.canny(img, debug=True)
+    lab, k = ndimage.label(dbg["nms"] > 0, structure=np.ones((3, 3)))
+    keep = np.zeros(k + 1, bool)
+    keep[np.unique(lab[dbg["nms"] == 2])] = True
+    keep[0] = False
+    assert np.array_equal(edges > 0, keep[lab])
+    assert n == int(np.count_nonzero(edges))
