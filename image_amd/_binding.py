@@ -33,8 +33,14 @@ class Frames(C.Structure):
 
 
 # every symbol include/imgfd.h declares: (restype, argtypes)
+c_float_pp = C.POINTER(C.POINTER(C.c_float))
+c_int_p = C.POINTER(C.c_int)
+
 SIGNATURES = {
     "imgfd_version": (C.c_int, []),
+    "imgfd_fhog": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_float_pp, c_int_p, c_int_p]),
+    "imgfd_fhog_size": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p]),
+    "imgfd_fhog_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "imgfd_ctx_create": (C.c_int, [C.c_int, c_void_pp]),
     "imgfd_ctx_create_on_stream": (C.c_int, [C.c_int, C.c_void_p, c_void_pp]),
     "imgfd_ctx_destroy": (None, [C.c_void_p]),

@@ -7,6 +7,7 @@ same names, arguments, defaults, argument handling and return structure as the R
   detect_corners()             image.CornerDetectionHarris/R/RcppExports.R:4-6 (numeric enum codes)
   image_detect_corners()       image.CornerDetectionF9/R/image_detect_corners.R:48-60
   image_canny_edge_detector()  image.CannyEdges/R/canny_edges_detector.R:63-67
+  image_fhog()                 image.dlib/R/image_fhog.R:35-48
 
 An R matrix ``x`` is mirrored by a 2-D numpy array with the same ``[row, col]`` indexing.  R hands the
 matrix's column-major memory to C, so the C image (index ``i + nrow*j``) is ``x.T`` in numpy terms.
@@ -182,4 +183,38 @@ def image_canny_edge_detector(x, s=2, low_thr=3, high_thr=10, accGrad=True, ctx=
                 pixels_nonzero=int(nonzero.value), nx=float(nx), ny=float(ny), s=float(s),
                 low_thr=float(low_thr), high_thr=float(high_thr), accGrad=bool(accGrad))
     res.r_class = "image_canny"
+    return res
+
+
+def _rgb_bytes(x):
+    """The glue's std::vector<int> -> rgb_pixel narrowing (rcpp_fhog.cpp:17-24) of an R integer array with
+    dim (3, width, height): element [ch, c, r] sits at ch + 3*c + 3*cols*r, i.e. interlaced RGB rows."""
+    x = np.asarray(x)
+    if x.ndim != 3 or x.shape[0] != 3:
+        raise ValueError("x must be a 3-dimensional array: RGB x width x height")
+    _, width, height = x.shape
+    rgb = np.ascontiguousarray((_as_integer(x) & 0xFF).astype(np.uint8).transpose(2, 1, 0))  # (height, width, 3)
+    return rgb, width, height
+
+
+def image_fhog(x, cell_size=8, filter_rows_padding=1, filter_cols_padding=1, ctx=None):
+    """image_fhog(): image_fhog.R:35-48 over dlib_fhog(), rcpp_fhog.cpp:10-46."""
+    ctx = _ctx(ctx)
+    rgb, width, height = _rgb_bytes(x)
+    hog = C.POINTER(C.c_float)()
+    nr, nc = C.c_int(0), C.c_int(0)
+    st = ctx.lib.imgfd_fhog(ctx.handle, rgb.ctypes.data_as(C.c_void_p), int(height), int(width), int(cell_size),
+                            int(filter_rows_padding), int(filter_cols_padding), C.byref(hog), C.byref(nr), C.byref(nc))
+    ctx.check(st, "imgfd_fhog")
+    n = 31 * nr.value * nc.value
+    if n:
+        flat = np.ctypeslib.as_array(hog, shape=(n,)).astype(np.float64)
+        ctx.lib.imgfd_free(hog)
+    else:
+        flat = np.zeros((0,), np.float64)
+    # out$fhog <- array(out$fhog, dim = c(hog_height, hog_width, 31)): column-major fill
+    res = RList(hog_height=nr.value, hog_width=nc.value,
+                fhog=flat.reshape((nr.value, nc.value, 31), order="F"),
+                hog_cell_size=int(cell_size), filter_rows_padding=int(filter_rows_padding),
+                filter_cols_padding=int(filter_cols_padding))
     return res

@@ -1,0 +1,325 @@
+// image_amd/csrc/fhog.hip -- Felzenszwalb HOG (dlib fHOG) behind imgfd_fhog / imgfd_fhog_dev (K13-K15).
+//
+// Replaces dlib_fhog(), image.dlib/src/rcpp_fhog.cpp:10-46, i.e. dlib's extract_fhog_features
+// (image.dlib/inst/dlib-19.20/dlib/image_transforms/fhog.h:1104-1113 -> impl_extract_fhog_features :702-1046)
+// for interlaced 8-bit RGB input, cell_size > 1.
+//
+// The reference adds every pixel's gradient magnitude into 4 histogram cells with `+=` while it walks the
+// image in raster order (:821-956), so each float bin is a sum in a fixed order.  The device keeps that
+// order without atomics by turning the scatter into a gather:
+//   K13 fhog_grad_orient : one thread per pixel -> packed (squared gradient length : 27 bits | orientation : 5
+//                          bits) of the colour channel with the strongest gradient (:24-59 / :147-275)
+//   K14 fhog_cell_hist   : one thread per histogram cell walks the <= (2*cell+2)^2 pixels that vote into it,
+//                          in raster order, with the reference's own bilinear weights; then the cell energy
+//                          (:959-968).  Deterministic, and bit-identical to the sequential sums.
+//   K15 fhog_features    : one thread per output cell: 4 block norms, 18 + 9 + 4 features (:970-1045) in the
+//                          lane order of dlib's simd4f code (sum = (l0+l2)+(l1+l3), the SSE2 build CRAN ships).
+// The reference handles columns in groups of 8 with float "SIMD" arithmetic and the remainder with a scalar
+// tail whose rounding order and colour tie-break differ (:828-918 vs :920-955); both are reproduced, keyed on
+// the pixel's column (fhog_is_body).  Library build flag -ffp-contract=off keeps a*b+c unfused like x86-64 -O2.
+#include "common.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+#include <algorithm>
+
+struct FhogGeom {
+    int rows, cols, cs;
+    int cells_nr, cells_nc;    // fhog.h:780-781
+    int visible_nr, visible_nc;  // :817-818
+    int body_end;              // columns 1 .. body_end-1 take the 8-wide path, the rest the scalar tail
+    int hog_nr, hog_nc;        // interior cells (:806-807)
+    int out_nr, out_nc;        // with filter padding (init_hog :455)
+    int off_r, off_c;          // :813-814
+};
+
+static bool fhog_geometry(int rows, int cols, int cs, int pad_r, int pad_c, FhogGeom *g)
+{
+    memset(g, 0, sizeof *g);
+    g->rows = rows; g->cols = cols; g->cs = cs;
+    g->cells_nr = (int)((float)rows / (float)cs + 0.5);
+    g->cells_nc = (int)((float)cols / (float)cs + 0.5);
+    if (g->cells_nr == 0 || g->cells_nc == 0) return false;
+    g->hog_nr = std::max(g->cells_nr - 2, 0);
+    g->hog_nc = std::max(g->cells_nc - 2, 0);
+    if (g->hog_nr == 0 || g->hog_nc == 0) return false;
+    g->out_nr = g->hog_nr + pad_r - 1;
+    g->out_nc = g->hog_nc + pad_c - 1;
+    g->off_r = (pad_r - 1) / 2;
+    g->off_c = (pad_c - 1) / 2;
+    g->visible_nr = (int)std::min((long)g->cells_nr * cs, (long)rows) - 1;
+    g->visible_nc = (int)std::min((long)g->cells_nc * cs, (long)cols) - 1;
+    int x = 1;
+    while (x < g->visible_nc - 7) x += 8;  // for (x = 1; x < visible_nc - 7; x += 8), :828
+    g->body_end = x;
+    return true;
+}
+
+__constant__ float FHOG_DIRS[9][2] = {{1.0000f, 0.0000f}, {0.9397f, 0.3420f}, {0.7660f, 0.6428f}, {0.500f, 0.8660f},
+                                      {0.1736f, 0.9848f}, {-0.1736f, 0.9848f}, {-0.5000f, 0.8660f},
+                                      {-0.7660f, 0.6428f}, {-0.9397f, 0.3420f}};
+
+// K13: packed[y*cols + x] = (len << 5) | best_o for 1 <= y < visible_nr, 1 <= x < visible_nc; 0 elsewhere
+// (a zero-length gradient votes +0.0f, which leaves every sum unchanged)
+__global__ void __launch_bounds__(256) fhog_grad_orient(const unsigned char *__restrict__ rgb, size_t frame_stride,
+                                                        unsigned *__restrict__ packed, FhogGeom g)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= g.cols) return;
+    unsigned out = 0;
+    if (y >= 1 && y < g.visible_nr && x >= 1 && x < g.visible_nc) {
+        const unsigned char *img = rgb + (size_t)blockIdx.z * frame_stride;
+        const unsigned char *pc = img + 3 * ((size_t)y * g.cols + x);
+        const int rs = 3 * g.cols;
+        int gx[3], gy[3], len[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            gx[ch] = (int)pc[3 + ch] - (int)pc[-3 + ch];
+            gy[ch] = (int)pc[rs + ch] - (int)pc[-rs + ch];
+            len[ch] = gx[ch] * gx[ch] + gy[ch] * gy[ch];
+        }
+        int tx, ty, tl;
+        if (x < g.body_end) {  // simd8 get_gradient, :265-274: strict > keeps the LATER channel on ties
+            if (len[0] > len[1]) { tx = gx[0]; ty = gy[0]; tl = len[0]; } else { tx = gx[1]; ty = gy[1]; tl = len[1]; }
+            if (!(tl > len[2])) { tx = gx[2]; ty = gy[2]; tl = len[2]; }
+        } else {               // scalar get_gradient, :24-59: strict > keeps the EARLIER channel on ties
+            tx = gx[0]; ty = gy[0]; tl = len[0];
+            if (len[1] > tl) { tl = len[1]; tx = gx[1]; ty = gy[1]; }
+            if (len[2] > tl) { tl = len[2]; tx = gx[2]; ty = gy[2]; }
+        }
+        const float fx = (float)tx, fy = (float)ty;
+        float best_dot = 0;
+        int best_o = 0;
+#pragma unroll
+        for (int o = 0; o < 9; o++) {  // :846-859 and :929-943 decide identically
+            const float dot = fx * FHOG_DIRS[o][0] + fy * FHOG_DIRS[o][1];
+            if (dot > best_dot) { best_dot = dot; best_o = o; }
+            else if (-dot > best_dot) { best_dot = -dot; best_o = o + 9; }
+        }
+        out = ((unsigned)tl << 5) | (unsigned)best_o;
+    }
+    packed[((size_t)blockIdx.z * g.rows + y) * g.cols + x] = out;
+}
+
+// K14: hist[(hr*HC + hc)*18 + o] for 1 <= hr <= cells_nr, 1 <= hc <= cells_nc (HC = cells_nc+2), and the
+// cell energy norm[(hr-1)*cells_nc + hc-1]
+__global__ void __launch_bounds__(64) fhog_cell_hist(const unsigned *__restrict__ packed, float *__restrict__ hist,
+                                                     float *__restrict__ norm, FhogGeom g)
+{
+    __shared__ float bins[64][19];
+    const int hc = blockIdx.x * 8 + (threadIdx.x & 7) + 1;
+    const int hr = blockIdx.y * 8 + (threadIdx.x >> 3) + 1;
+    if (hr > g.cells_nr || hc > g.cells_nc) return;
+    float *b = bins[threadIdx.x];
+#pragma unroll
+    for (int o = 0; o < 18; o++) b[o] = 0.f;
+    const unsigned *pk = packed + (size_t)blockIdx.z * g.rows * g.cols;
+    const int cs = g.cs;
+    // candidate rows / columns: every pixel whose bilinear footprint can touch this cell, widened by one
+    const int y_lo = max(1, cs * (hr - 2) + cs / 2 - 1), y_hi = min(g.visible_nr - 1, cs * hr + cs / 2 + 1);
+    const int x_lo = max(1, cs * (hc - 2) + cs / 2 - 1), x_hi = min(g.visible_nc - 1, cs * hc + cs / 2 + 1);
+    for (int y = y_lo; y <= y_hi; y++) {
+        const float yp = ((float)y + 0.5) / (float)cs - 0.5;  // :823-826 (double arithmetic, float result)
+        const int iyp = (int)floor(yp);
+        const float vy0 = yp - iyp;
+        const float vy1 = 1.0 - vy0;
+        float wy;
+        if (iyp + 1 == hr) wy = vy1;
+        else if (iyp + 2 == hr) wy = vy0;
+        else continue;
+        const unsigned *row = pk + (size_t)y * g.cols;
+        for (int x = x_lo; x <= x_hi; x++) {
+            const unsigned p = row[x];
+            const int o = p & 31;
+            const float v = sqrtf((float)(p >> 5));
+            float w;
+            if (x < g.body_end) {  // :838-841, :863-870: hist column ixp / ixp+1, weights vy*(vx*v)
+                const float xp = ((float)x + 0.5f) / (float)cs + 0.5f;
+                const int ixp = (int)xp;
+                const float vx0 = xp - (float)ixp;
+                const float vx1 = 1.0f - vx0;
+                if (ixp == hc) w = wy * (vx1 * v);
+                else if (ixp + 1 == hc) w = wy * (vx0 * v);
+                else continue;
+            } else {               // :946-954: hist column ixp+1 / ixp+2, weights (vy*vx)*v
+                const float xp = ((double)x + 0.5) / (double)cs - 0.5;
+                const int ixp = (int)floor(xp);
+                const float vx0 = xp - ixp;
+                const float vx1 = 1.0 - vx0;
+                if (ixp + 1 == hc) w = wy * vx1 * v;
+                else if (ixp + 2 == hc) w = wy * vx0 * v;
+                else continue;
+            }
+            b[o] += w;
+        }
+    }
+    const int HC = g.cells_nc + 2;
+    float *dst = hist + (((size_t)blockIdx.z * (g.cells_nr + 2) + hr) * HC + hc) * 18;
+    float e = 0.f;
+#pragma unroll
+    for (int o = 0; o < 18; o++) dst[o] = b[o];
+#pragma unroll
+    for (int o = 0; o < 9; o++) e += (b[o] + b[o + 9]) * (b[o] + b[o + 9]);  // :959-968
+    norm[((size_t)blockIdx.z * g.cells_nr + (hr - 1)) * g.cells_nc + (hc - 1)] = e;
+}
+
+__device__ __forceinline__ float fhog_sum4(const float (&h)[4]) { return (h[0] + h[2]) + (h[1] + h[3]); }
+
+// K15: out[feat][xx][yy] (feature-major, then column, rows fastest: the order rcpp_fhog.cpp:29-38 emits)
+__global__ void __launch_bounds__(256) fhog_features(const float *__restrict__ hist, const float *__restrict__ norm,
+                                                     float *__restrict__ out, FhogGeom g)
+{
+    const int y = blockIdx.x * 64 + (threadIdx.x & 63);  // rows fastest: coalesced stores
+    const int x = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= g.hog_nr || x >= g.hog_nc) return;
+    const float *nm = norm + (size_t)blockIdx.z * g.cells_nr * g.cells_nc;
+    const int NC = g.cells_nc;
+#define NORM(r, c) nm[(size_t)(r) * NC + (c)]
+    const float z1[4] = {NORM(y + 1, x + 1), NORM(y, x + 1), NORM(y + 1, x), NORM(y, x)};
+    const float z2[4] = {NORM(y + 1, x + 2), NORM(y, x + 2), NORM(y + 1, x + 1), NORM(y, x + 1)};
+    const float z3[4] = {NORM(y + 2, x + 1), NORM(y + 1, x + 1), NORM(y + 2, x), NORM(y + 1, x)};
+    const float z4[4] = {NORM(y + 2, x + 2), NORM(y + 1, x + 2), NORM(y + 2, x + 1), NORM(y + 1, x + 1)};
+#undef NORM
+    const float eps = 0.0001;
+    float nn[4], n[4], t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        nn[l] = 0.2f * sqrtf(z1[l] + z2[l] + z3[l] + z4[l] + eps);  // :997
+        n[l] = 0.1f / nn[l];                                        // :998
+    }
+    const float *h = hist + (((size_t)blockIdx.z * (g.cells_nr + 2) + (y + 2)) * (g.cells_nc + 2) + (x + 2)) * 18;
+    float hv[18];
+#pragma unroll
+    for (int o = 0; o < 18; o++) hv[o] = h[o];
+    const size_t plane = (size_t)g.out_nr * g.out_nc;
+    float *dst = out + (size_t)blockIdx.z * plane * 31 + (size_t)(x + g.off_c) * g.out_nr + (y + g.off_r);
+#pragma unroll
+    for (int o = 0; o < 18; o += 3) {  // contrast-sensitive, :1005-1017
+        float h0[4], h1[4], h2[4];
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            h0[l] = fminf(hv[o], nn[l]) * n[l];
+            h1[l] = fminf(hv[o + 1], nn[l]) * n[l];
+            h2[l] = fminf(hv[o + 2], nn[l]) * n[l];
+            t[l] += h0[l] + h1[l] + h2[l];
+        }
+        dst[(size_t)o * plane] = fhog_sum4(h0);
+        dst[(size_t)(o + 1) * plane] = fhog_sum4(h1);
+        dst[(size_t)(o + 2) * plane] = fhog_sum4(h2);
+    }
+#pragma unroll
+    for (int l = 0; l < 4; l++) t[l] *= (float)(2 * 0.2357);  // :1019
+#pragma unroll
+    for (int o = 0; o < 9; o += 3) {   // contrast-insensitive, :1022-1033
+        const float t0 = hv[o] + hv[o + 9], t1 = hv[o + 1] + hv[o + 10], t2 = hv[o + 2] + hv[o + 11];
+        float h0[4], h1[4], h2[4];
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            h0[l] = fminf(t0, nn[l]) * n[l];
+            h1[l] = fminf(t1, nn[l]) * n[l];
+            h2[l] = fminf(t2, nn[l]) * n[l];
+        }
+        dst[(size_t)(o + 18) * plane] = fhog_sum4(h0);
+        dst[(size_t)(o + 19) * plane] = fhog_sum4(h1);
+        dst[(size_t)(o + 20) * plane] = fhog_sum4(h2);
+    }
+#pragma unroll
+    for (int l = 0; l < 4; l++) dst[(size_t)(27 + l) * plane] = t[l];  // texture, :1040-1043
+}
+
+namespace {
+
+size_t fhog_ws_bytes(const FhogGeom &g, int nf)
+{
+    return align_up(sizeof(unsigned) * (size_t)g.rows * g.cols * nf, 256) +
+           align_up(sizeof(float) * (size_t)(g.cells_nr + 2) * (g.cells_nc + 2) * 18 * nf, 256) +
+           align_up(sizeof(float) * (size_t)g.cells_nr * g.cells_nc * nf, 256) + 4096;
+}
+
+// d_rgb: nf interlaced RGB frames; d_out: nf * 31 * out_nc * out_nr floats
+imgfd_status fhog_device(imgfd_ctx *ctx, const uint8_t *d_rgb, size_t frame_stride, const FhogGeom &g, int nf, float *d_out)
+{
+    unsigned *packed = (unsigned *)ws_alloc(ctx, sizeof(unsigned) * (size_t)g.rows * g.cols * nf);
+    float *hist = (float *)ws_alloc(ctx, sizeof(float) * (size_t)(g.cells_nr + 2) * (g.cells_nc + 2) * 18 * nf);
+    float *norm = (float *)ws_alloc(ctx, sizeof(float) * (size_t)g.cells_nr * g.cells_nc * nf);
+    if (!packed || !hist || !norm) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    const size_t out_n = (size_t)31 * g.out_nr * g.out_nc * nf;
+    if (g.out_nr != g.hog_nr || g.out_nc != g.hog_nc)  // init_hog: zero border of the padded output
+        IMGFD_HIP(ctx, hipMemsetAsync(d_out, 0, out_n * sizeof(float), ctx->stream));
+    hipLaunchKernelGGL(fhog_grad_orient, dim3(ceil_div(g.cols, 256), g.rows, nf), dim3(256), 0, ctx->stream, d_rgb,
+                       frame_stride, packed, g);
+    hipLaunchKernelGGL(fhog_cell_hist, dim3(ceil_div(g.cells_nc, 8), ceil_div(g.cells_nr, 8), nf), dim3(64), 0,
+                       ctx->stream, packed, hist, norm, g);
+    hipLaunchKernelGGL(fhog_features, dim3(ceil_div(g.hog_nr, 64), ceil_div(g.hog_nc, 4), nf), dim3(256), 0, ctx->stream,
+                       hist, norm, d_out, g);
+    IMGFD_HIP(ctx, hipGetLastError());
+    return IMGFD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+imgfd_status imgfd_fhog_size(int rows, int cols, int cell_size, int filter_rows_padding, int filter_cols_padding,
+                             int *hog_nr, int *hog_nc)
+{
+    if (!hog_nr || !hog_nc) return IMGFD_ERR_INVALID;
+    *hog_nr = *hog_nc = 0;
+    if (rows < 0 || cols < 0 || cell_size < 1 || filter_rows_padding < 1 || filter_cols_padding < 1) return IMGFD_ERR_INVALID;
+    if (cell_size == 1) return IMGFD_ERR_UNSUPPORTED;
+    FhogGeom g;
+    if (fhog_geometry(rows, cols, cell_size, filter_rows_padding, filter_cols_padding, &g)) { *hog_nr = g.out_nr; *hog_nc = g.out_nc; }
+    return IMGFD_OK;
+}
+
+imgfd_status imgfd_fhog(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, int cell_size, int filter_rows_padding,
+                        int filter_cols_padding, float **hog, int *hog_nr, int *hog_nc)
+{
+    if (!ctx) return IMGFD_ERR_INVALID;
+    if (!rgb || !hog || !hog_nr || !hog_nc || rows < 0 || cols < 0 || cell_size < 1 || filter_rows_padding < 1 || filter_cols_padding < 1)
+        return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_fhog: bad argument (DLIB_ASSERT of fhog.h:712-720)");
+    *hog = nullptr; *hog_nr = 0; *hog_nc = 0;
+    if (cell_size == 1) return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "imgfd_fhog: cell_size 1 (fhog.h:499-694) is not implemented");
+    FhogGeom g;
+    if (!fhog_geometry(rows, cols, cell_size, filter_rows_padding, filter_cols_padding, &g)) return IMGFD_OK;  // hog.clear()
+    IMGFD_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t in_bytes = (size_t)3 * rows * cols, out_n = (size_t)31 * g.out_nr * g.out_nc;
+    IMGFD_TRY(ws_reserve(ctx, fhog_ws_bytes(g, 1) + align_up(in_bytes, 256) + align_up(out_n * sizeof(float), 256)));
+    uint8_t *d_in = (uint8_t *)ws_alloc(ctx, in_bytes);
+    float *d_out = (float *)ws_alloc(ctx, out_n * sizeof(float));
+    if (!d_in || !d_out) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    IMGFD_HIP(ctx, hipMemcpyAsync(d_in, rgb, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    IMGFD_TRY(fhog_device(ctx, d_in, in_bytes, g, 1, d_out));
+    float *h = (float *)malloc(out_n * sizeof(float));
+    if (!h) return imgfd_fail(ctx, IMGFD_ERR_OOM, "malloc of the fhog output failed");
+    IMGFD_HIP(ctx, hipMemcpyAsync(h, d_out, out_n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *hog = h; *hog_nr = g.out_nr; *hog_nc = g.out_nc;
+    return IMGFD_OK;
+}
+
+imgfd_status imgfd_fhog_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, int rows, int cols, size_t frame_stride_bytes,
+                            int cell_size, int filter_rows_padding, int filter_cols_padding, float *d_hog)
+{
+    if (!ctx) return IMGFD_ERR_INVALID;
+    if (!d_rgb || !d_hog || n_frames < 0 || rows < 0 || cols < 0 || cell_size < 1 || filter_rows_padding < 1 || filter_cols_padding < 1)
+        return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_fhog_dev: bad argument");
+    if (cell_size == 1) return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "imgfd_fhog_dev: cell_size 1 is not implemented");
+    FhogGeom g;
+    if (!n_frames || !fhog_geometry(rows, cols, cell_size, filter_rows_padding, filter_cols_padding, &g)) return IMGFD_OK;
+    IMGFD_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t per_frame = fhog_ws_bytes(g, 1);
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_frames, ((size_t)2 << 30) / per_frame));
+    IMGFD_TRY(ws_reserve(ctx, fhog_ws_bytes(g, chunk)));
+    const size_t out_n = (size_t)31 * g.out_nr * g.out_nc;
+    for (int f0 = 0; f0 < n_frames; f0 += chunk) {
+        const int nf = std::min(chunk, n_frames - f0);
+        ctx->ws_used = 0;
+        IMGFD_TRY(fhog_device(ctx, d_rgb + (size_t)f0 * frame_stride_bytes, frame_stride_bytes, g, nf, d_hog + (size_t)f0 * out_n));
+    }
+    return IMGFD_OK;
+}
+
+}  // extern "C"

@@ -123,6 +123,25 @@ IMGFD_API imgfd_status imgfd_fast9(imgfd_ctx *ctx, const uint8_t *img, int width
 IMGFD_API imgfd_status imgfd_canny(imgfd_ctx *ctx, const uint8_t *img, int nx, int ny, double s, double low_thr,
                          double high_thr, int accGrad, uint8_t *edges, int64_t *pixels_nonzero);
 
+/* ------------------------------------------------------------------ fHOG (dlib)
+ * dlib_fhog(x, rows, cols, cell_size, filter_rows_padding, filter_cols_padding), rcpp_fhog.cpp:10-15, after the
+ * std::vector<int> -> rgb_pixel narrowing (:17-24, performed by the glue): rgb holds rows*cols interlaced
+ * (r,g,b) bytes, pixel (r,c) at 3*(c + r*cols).  *hog (library-allocated, imgfd_free) holds
+ * 31 * hog_nc * hog_nr floats in the order the reference glue emits them (rcpp_fhog.cpp:29-38): feature-major, then
+ * column x, then row y fastest -- R reshapes it to [hog_height, hog_width, 31] (image_fhog.R:46).  An image too small
+ * for 3x3 cells gives *hog = NULL, 0 x 0 (hog.clear(), fhog.h:783-812).  cell_size == 1 (fhog.h:499-694) returns
+ * IMGFD_ERR_UNSUPPORTED. */
+IMGFD_API imgfd_status imgfd_fhog(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, int cell_size,
+                        int filter_rows_padding, int filter_cols_padding, float **hog, int *hog_nr, int *hog_nc);
+/* output size of imgfd_fhog / imgfd_fhog_dev for a rows x cols image (no device needed) */
+IMGFD_API imgfd_status imgfd_fhog_size(int rows, int cols, int cell_size, int filter_rows_padding, int filter_cols_padding,
+                             int *hog_nr, int *hog_nc);
+/* batch of n_frames interlaced RGB frames resident in HBM (frame f at d_rgb + f*frame_stride_bytes, rows packed);
+ * d_hog: n_frames * 31*hog_nc*hog_nr floats, each frame in the layout of imgfd_fhog */
+IMGFD_API imgfd_status imgfd_fhog_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, int rows, int cols,
+                            size_t frame_stride_bytes, int cell_size, int filter_rows_padding, int filter_cols_padding,
+                            float *d_hog);
+
 /* ------------------------------------------------------------------ device-resident batch path
  * Frames live in HBM: frame f starts at (char*)d_frames + f*frame_stride_bytes, rows are row_stride
  * bytes apart.  Results stay on the device in caller-provided buffers so that a stream of frames can

@@ -197,3 +197,44 @@ def canny(img, s: float = 2.0, low_thr: float = 3.0, high_thr: float = 10.0, acc
     n = fn(vp(img), nx, ny, C.c_double(s), C.c_double(low_thr), C.c_double(high_thr),
            int(bool(accGrad)), vp(edges), None, None, None)
     return edges, int(n)
+
+
+# ----------------------------------------------------------------------- fHOG
+def _rgb(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    assert img.ndim == 3 and img.shape[2] == 3, "rgb image (rows, cols, 3)"
+    return img
+
+
+def fhog(rgb, cell_size: int = 8, pad_r: int = 1, pad_c: int = 1, debug: bool = False):
+    """Restated extract_fhog_features (oracle/fhog_oracle.c).  rgb: (rows, cols, 3) uint8.
+    Returns hog (hog_nr, hog_nc, 31) float32 in dlib's array2d order [, dict(hist, norm)]."""
+    rgb = _rgb(rgb)
+    rows, cols, _ = rgb.shape
+    nr, nc = C.c_int(), C.c_int()
+    if lib().orc_fhog_dims(rows, cols, cell_size, pad_r, pad_c, C.byref(nr), C.byref(nc)):
+        raise ValueError("fhog oracle: unsupported arguments (cell_size < 2?)")
+    out = np.zeros((nr.value, nc.value, 31), np.float32)
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    cells_nr = int(np.float32(rows) / np.float32(cell_size) + 0.5)
+    cells_nc = int(np.float32(cols) / np.float32(cell_size) + 0.5)
+    hist = np.zeros((cells_nr + 2, cells_nc + 2, 18), np.float32) if debug else None
+    norm = np.zeros((cells_nr, cells_nc), np.float32) if debug else None
+    if out.size:
+        lib().orc_fhog(vp(rgb), rows, cols, cell_size, pad_r, pad_c, vp(out), vp(hist) if debug else None,
+                       vp(norm) if debug else None)
+    return (out, dict(hist=hist, norm=norm)) if debug else out
+
+
+def ref_fhog(rgb, cell_size: int = 8, pad_r: int = 1, pad_c: int = 1):
+    """dlib's own extract_fhog_features (oracle/_ref/libref_dlib.so), array2d order (hog_nr, hog_nc, 31)."""
+    rgb = _rgb(rgb)
+    rows, cols, _ = rgb.shape
+    L = ref("dlib")
+    nr, nc = C.c_int(), C.c_int()
+    L.ref_fhog(rgb.ctypes.data_as(C.c_void_p), rows, cols, cell_size, pad_r, pad_c, None, C.byref(nr), C.byref(nc))
+    out = np.zeros((nr.value, nc.value, 31), np.float32)
+    if out.size:
+        L.ref_fhog(rgb.ctypes.data_as(C.c_void_p), rows, cols, cell_size, pad_r, pad_c,
+                   out.ctypes.data_as(C.c_void_p), C.byref(nr), C.byref(nc))
+    return out

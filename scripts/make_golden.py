@@ -49,6 +49,16 @@ def harris_golden(name, img):
     print(name, {k: v.shape for k, v in out.items()})
 
 
+def fhog_golden():
+    """dlib's own extract_fhog_features on the reference's example image (image.dlib/inst/extdata)."""
+    from PIL import Image
+    img = np.asarray(Image.open(os.path.join(REF, "image.dlib", "inst", "extdata", "cruise_boat.png")).convert("RGB"))
+    out = {"image": img, "hog_c8": oracle.ref_fhog(img, 8, 1, 1), "hog_c4": oracle.ref_fhog(img, 4, 1, 1),
+           "hog_c8_p33": oracle.ref_fhog(img, 8, 3, 3)}
+    np.savez_compressed(os.path.join(OUT, "fhog_cruise_boat"), **out)
+    print("fhog_cruise_boat", {k: v.shape for k, v in out.items()})
+
+
 def fast9_golden(name, img, thresholds):
     out = {"image": img.astype(np.uint8)}
     for thr in thresholds:

@@ -114,6 +114,31 @@ class _Base:
                                         int(accGrad), edges.ctypes.data_as(C.c_void_p), C.byref(n)), "imgfd_canny")
         return edges, int(n.value)
 
+    def fhog(self, rgb, cell_size=8, pad_r=1, pad_c=1):
+        """host-pointer imgfd_fhog; returns dlib's array2d order (hog_nr, hog_nc, 31)"""
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        rows, cols, _ = rgb.shape
+        hog = C.POINTER(C.c_float)(); nr = C.c_int(0); nc = C.c_int(0)
+        self.check(self.lib.imgfd_fhog(self.ctx, rgb.ctypes.data_as(C.c_void_p), rows, cols, cell_size, pad_r, pad_c,
+                                       C.byref(hog), C.byref(nr), C.byref(nc)), "imgfd_fhog")
+        if not nr.value * nc.value:
+            return np.zeros((0, 0, 31), np.float32)
+        flat = np.ctypeslib.as_array(hog, shape=(31, nc.value, nr.value)).copy()
+        self.lib.imgfd_free(hog)
+        return np.ascontiguousarray(flat.transpose(2, 1, 0))
+
+    def fhog_dev(self, frames, cell_size=8, pad_r=1, pad_c=1):
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, rows, cols, _ = frames.shape
+        nr = C.c_int(0); nc = C.c_int(0)
+        self.check(self.lib.imgfd_fhog_size(rows, cols, cell_size, pad_r, pad_c, C.byref(nr), C.byref(nc)), "fhog_size")
+        d = self.to_dev(frames)
+        out = self.empty((n, 31, nc.value, nr.value), np.float32)
+        self.check(self.lib.imgfd_fhog_dev(self.ctx, self.ptr(d), n, rows, cols, rows * cols * 3, cell_size, pad_r, pad_c,
+                                           self.ptr(out)), "imgfd_fhog_dev")
+        self.sync()
+        return np.ascontiguousarray(self.to_host(out).transpose(0, 3, 2, 1))
+
     # ---- device-resident batch API --------------------------------------------------------------
     def harris_dev(self, frames, cap=None, **kw):
         p = dict(k=0.06, sigma_d=1.0, sigma_i=2.5, threshold=130.0, gaussian=0, gradient=0, measure=0)

@@ -1,0 +1,72 @@
+"""fHOG: the device path against the restatement oracle (itself bit-identical to dlib built the way CRAN builds
+it, tests/test_oracle_dlib.py) and against golden vectors made by dlib's own code.  The kernels keep the
+reference's summation order, so the comparison is exact; the acceptance bar is dlib's own 1e-6."""
+import numpy as np
+import pytest
+
+import oracle
+from image_amd import synth
+
+TOL = 1e-6  # dlib/test/fhog.cpp:49,77
+
+
+def check(got, ref):
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    if got.size:
+        assert np.max(np.abs(got - ref)) <= TOL
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "same summation order -> same bits"
+
+
+@pytest.mark.parametrize("w,h,cs,pr,pc", [(200, 150, 8, 1, 1), (203, 149, 8, 1, 1), (331, 257, 8, 3, 2), (120, 90, 6, 1, 1),
+                                          (123, 97, 5, 2, 3), (64, 64, 16, 1, 1), (100, 100, 4, 1, 1), (37, 29, 8, 1, 1),
+                                          (30, 41, 2, 1, 1)])
+def test_matches_oracle(be, w, h, cs, pr, pc):
+    rgb = synth.frame_rgb(61, w, h)
+    check(be.fhog(rgb, cs, pr, pc), oracle.fhog(rgb, cs, pr, pc))
+
+
+def test_gray_replicated_and_flat(be):
+    g = np.stack([synth.frame(62, 160, 120)] * 3, -1)
+    check(be.fhog(g), oracle.fhog(g))
+    flat = np.full((64, 80, 3), 77, np.uint8)
+    got = be.fhog(flat)
+    check(got, oracle.fhog(flat))
+    assert np.all(got[..., :27] == 0)  # no gradient anywhere
+
+
+@pytest.mark.parametrize("w,h", [(8, 8), (16, 23), (23, 16), (3, 3), (1, 1)])
+def test_too_small_is_empty(be, w, h):
+    rgb = synth.frame_rgb(63, max(w, 16), max(h, 16))[:h, :w]
+    assert be.fhog(rgb).size == 0 and oracle.fhog(rgb).size == 0  # hog.clear(), fhog.h:783-812
+
+
+def test_golden_dlib(be, golden):
+    """vectors written by dlib's own extract_fhog_features (scripts/make_golden.py, oracle/_ref)"""
+    g = golden("fhog_cruise_boat")
+    for cs in (8, 4):
+        ref = g[f"hog_c{cs}"]
+        got = be.fhog(g["image"], cs, 1, 1)
+        assert got.shape == ref.shape and np.max(np.abs(got - ref)) <= TOL
+    ref = g["hog_c8_p33"]
+    assert np.max(np.abs(be.fhog(g["image"], 8, 3, 3) - ref)) <= TOL
+
+
+def test_batch_dev(be):
+    frames = np.stack([synth.frame_rgb(70 + f, 96, 80) for f in range(3)])
+    got = be.fhog_dev(frames, 8, 1, 1)
+    for f in range(3):
+        check(got[f], oracle.fhog(frames[f]))
+
+
+def test_r_level_mirror(be):
+    """image_fhog(): x is (3, width, height); $fhog is [hog_height, hog_width, 31] (image_fhog.R:35-48)"""
+    if be.name != "gpu":
+        pytest.skip("image_amd.api binds the product library")
+    from image_amd import api
+    rgb = synth.frame_rgb(64, 120, 88)            # (height, width, 3)
+    x = rgb.transpose(2, 1, 0).astype(np.int32)   # (3, width, height)
+    out = api.image_fhog(x, cell_size=8)
+    ref = oracle.fhog(rgb)
+    assert (out["hog_height"], out["hog_width"]) == ref.shape[:2]
+    assert out["fhog"].shape == ref.shape and np.max(np.abs(out["fhog"] - ref)) <= TOL
+    assert out["hog_cell_size"] == 8 and out["filter_rows_padding"] == 1

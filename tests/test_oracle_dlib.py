@@ -1,0 +1,36 @@
+"""The dlib restatements (oracle/fhog_oracle.c, oracle/surf_oracle.c) against dlib itself compiled in place
+(oracle/_ref/libref_dlib.so; only where /root/reference exists) and against the committed golden vectors."""
+import numpy as np
+import pytest
+
+import oracle
+from image_amd import synth
+
+needs_ref = pytest.mark.skipif(not oracle.have_ref("dlib"), reason="oracle/_ref/libref_dlib.so not built")
+
+
+@needs_ref
+@pytest.mark.parametrize("w,h,cs,pr,pc", [(200, 150, 8, 1, 1), (203, 149, 8, 1, 1), (331, 257, 8, 3, 2), (120, 90, 6, 1, 1),
+                                          (123, 97, 5, 2, 3), (64, 64, 16, 1, 1), (100, 100, 4, 1, 1), (20, 20, 8, 1, 1),
+                                          (37, 29, 8, 1, 1), (511, 300, 8, 1, 1), (30, 41, 2, 1, 1), (90, 70, 3, 1, 1)])
+def test_fhog_restatement_is_bit_identical_to_dlib(w, h, cs, pr, pc):
+    rgb = synth.frame_rgb(7, w, h)
+    a, b = oracle.ref_fhog(rgb, cs, pr, pc), oracle.fhog(rgb, cs, pr, pc)
+    assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@needs_ref
+def test_fhog_colour_ties_and_gray():
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 4, (70, 93, 3)).astype(np.uint8) * 60   # many equal-length channel gradients
+    a, b = oracle.ref_fhog(img), oracle.fhog(img)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    g = np.stack([synth.frame(9, 160, 120)] * 3, -1)
+    assert np.array_equal(oracle.ref_fhog(g).view(np.uint32), oracle.fhog(g).view(np.uint32))
+
+
+def test_fhog_golden(golden):
+    g = golden("fhog_cruise_boat")
+    for key, (cs, pr, pc) in {"hog_c8": (8, 1, 1), "hog_c4": (4, 1, 1), "hog_c8_p33": (8, 3, 3)}.items():
+        got = oracle.fhog(g["image"], cs, pr, pc)
+        assert got.shape == g[key].shape and np.array_equal(got.view(np.uint32), g[key].view(np.uint32)), key
