@@ -27,6 +27,11 @@ class Points(C.Structure):
     _fields_ = [("points", C.POINTER(Point)), ("n", C.c_int64)]
 
 
+class SurfOut(C.Structure):
+    _fields_ = [("n", C.c_int64)] + [(k, C.POINTER(C.c_double)) for k in
+                                     ("x", "y", "angle", "pyramid_scale", "score", "laplacian", "surf", "data")]
+
+
 class Frames(C.Structure):
     _fields_ = [("d_frames", C.c_void_p), ("n_frames", C.c_int), ("nx", C.c_int), ("ny", C.c_int),
                 ("frame_stride_bytes", C.c_size_t), ("row_stride_bytes", C.c_int), ("dtype", C.c_int)]
@@ -38,6 +43,9 @@ c_int_p = C.POINTER(C.c_int)
 
 SIGNATURES = {
     "imgfd_version": (C.c_int, []),
+    "imgfd_surf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_double, C.POINTER(SurfOut)]),
+    "imgfd_surf_interest_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "imgfd_k_surf_integral": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "imgfd_fhog": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_float_pp, c_int_p, c_int_p]),
     "imgfd_fhog_size": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p]),
     "imgfd_fhog_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p]),

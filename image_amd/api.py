@@ -8,6 +8,7 @@ same names, arguments, defaults, argument handling and return structure as the R
   image_detect_corners()       image.CornerDetectionF9/R/image_detect_corners.R:48-60
   image_canny_edge_detector()  image.CannyEdges/R/canny_edges_detector.R:63-67
   image_fhog()                 image.dlib/R/image_fhog.R:35-48
+  image_surf()                 image.dlib/R/image_surf.R:83-90
 
 An R matrix ``x`` is mirrored by a 2-D numpy array with the same ``[row, col]`` indexing.  R hands the
 matrix's column-major memory to C, so the C image (index ``i + nrow*j``) is ``x.T`` in numpy terms.
@@ -217,4 +218,24 @@ def image_fhog(x, cell_size=8, filter_rows_padding=1, filter_cols_padding=1, ctx
                 fhog=flat.reshape((nr.value, nc.value, 31), order="F"),
                 hog_cell_size=int(cell_size), filter_rows_padding=int(filter_rows_padding),
                 filter_cols_padding=int(filter_cols_padding))
+    return res
+
+
+def image_surf(x, max_points=1000, detection_threshold=30, ctx=None):
+    """image_surf(): image_surf.R:83-90 over dlib_surf_points(), rcpp_surf.cpp:10-53."""
+    ctx = _ctx(ctx)
+    rgb, width, height = _rgb_bytes(x)
+    out = _binding.SurfOut()
+    st = ctx.lib.imgfd_surf(ctx.handle, rgb.ctypes.data_as(C.c_void_p), int(height), int(width), int(max_points),
+                            float(detection_threshold), C.byref(out))
+    ctx.check(st, "imgfd_surf")
+    n = int(out.n)
+
+    def vec(p, m):
+        return np.ctypeslib.as_array(p, shape=(m,)).copy() if m else np.zeros((0,), np.float64)
+    res = RList(points=n, x=vec(out.x, n), y=vec(out.y, n), angle=vec(out.angle, n), pyramid_scale=vec(out.pyramid_scale, n),
+                score=vec(out.score, n), laplacian=vec(out.laplacian, n), surf=vec(out.surf, n * 64).reshape(n, 64))
+    if n:
+        ctx.lib.imgfd_free(out.data)
+    res["surf"][np.isnan(res["surf"])] = 0  # out$surf[is.nan(out$surf)] <- 0, image_surf.R:88
     return res

@@ -1,0 +1,385 @@
+// image_amd/csrc/surf.hip -- SURF keypoints (dlib) behind imgfd_surf (K16-K18 on the device, K19 on the host).
+//
+// Replaces dlib_surf_points(), image.dlib/src/rcpp_surf.cpp:10-53, i.e. dlib's get_surf_points
+// (image.dlib/inst/dlib-19.20/dlib/image_keypoint/surf.h:237-288):
+//   K16 integral image   integral_image_generic<int32>::load, dlib/image_transforms/integral_image.h:33-62, with
+//                        gray = (r+g+b)/3 (dlib/pixel.h:775-783).  int32 sums wrap (4096^2 bright tiles overflow);
+//                        wrap-around addition is associative, so a parallel scan gives the reference's bits:
+//                        surf_gray_rowscan (one workgroup per row) + surf_colscan (thread per column).
+//   K17 Hessian pyramid  hessian_pyramid::build_pyramid(img, 4, 6, 2), dlib/image_keypoint/hessian_pyramid.h:87-178:
+//                        24 levels of box-filter determinants in f64, one thread per level pixel, 32 integral-image
+//                        look-ups each (the 67 MB table of a 4096^2 tile lives in the Infinity Cache).
+//   K18 interest points  get_interest_points :453-506: 3x3x3 maximum test (:324-356) + quadratic interpolation with
+//                        the closed-form 3x3 inverse (:411-446, dlib/matrix/matrix_la.h:922-962), in f64 with the
+//                        reference's operation order (no contraction).  Survivors are appended with a sort key
+//                        (octave, interval, row, column); the host orders them by that key = the order in which the
+//                        reference pushes them, then applies surf.h:268's std::sort over reverse iterators.
+//   K19 orientation + 64-d descriptor (surf.h:75-232): per-point libm work (atan2, exp, sin, cos) on <= max_points
+//                        points; done on the host in surf_host.cpp from the integral image (glibc gives the
+//                        reference's bits; moving it to the device is listed as next in SURVEY.md 8f).
+#include "common.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+#define SURF_OCT 4
+#define SURF_INT 6
+
+struct SurfLevel {
+    int step, border_px, lobe, off;  // hessian_pyramid.h:119-128
+    double area_inv;
+    size_t plane;                    // offset (doubles) of the level inside the pyramid buffer
+};
+struct SurfGeom {
+    int rows, cols;
+    int nr[SURF_OCT], nc[SURF_OCT];
+    SurfLevel lev[SURF_OCT * SURF_INT];
+};
+
+static long surf_border_of(long i) { return (long)ceil((3 * (2.0 * (i + 1) + 1)) / 2.0); }  // get_border_size :180-196
+static long surf_step_of(long o) { return 2 * (long)(pow(2.0, (double)o) + 0.5); }          // get_step_size :198-211
+
+static size_t surf_geometry(int rows, int cols, SurfGeom *g)
+{
+    g->rows = rows; g->cols = cols;
+    size_t total = 0;
+    for (int o = 0; o < SURF_OCT; o++) {
+        const long step = surf_step_of(o);
+        g->nr[o] = (int)(rows / step); g->nc[o] = (int)(cols / step);
+        for (int i = 0; i < SURF_INT; i++) {
+            SurfLevel &L = g->lev[o * SURF_INT + i];
+            L.step = (int)step;
+            L.border_px = (int)(surf_border_of(i) * step);
+            L.lobe = (int)((long)(pow(2.0, o + 1.0) + 0.5) * (i + 1) + 1);
+            L.off = L.lobe / 2 + 1;
+            L.area_inv = 1.0 / pow(3.0 * L.lobe, 2.0);
+            L.plane = total;
+            total += (size_t)g->nr[o] * g->nc[o];
+        }
+    }
+    return total;
+}
+
+// ---- K16
+__global__ void __launch_bounds__(256) surf_gray_rowscan(const unsigned char *__restrict__ rgb, unsigned *__restrict__ out,
+                                                         int cols)
+{
+    __shared__ unsigned part[256];
+    const int tid = threadIdx.x;
+    const size_t r = blockIdx.x;
+    const int seg = (cols + 255) / 256;
+    const int c0 = tid * seg, c1 = min(cols, c0 + seg);
+    const unsigned char *p = rgb + 3 * (r * cols);
+    unsigned s = 0;
+    for (int c = c0; c < c1; c++) s += ((unsigned)p[3 * c] + (unsigned)p[3 * c + 1] + (unsigned)p[3 * c + 2]) / 3u;
+    part[tid] = s;
+    __syncthreads();
+    // exclusive prefix of the 256 segment totals (Hillis-Steele in LDS)
+    unsigned incl = s;
+    for (int d = 1; d < 256; d <<= 1) {
+        const unsigned t = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        incl += t;
+        part[tid] = incl;
+        __syncthreads();
+    }
+    unsigned run = incl - s;
+    for (int c = c0; c < c1; c++) {
+        run += ((unsigned)p[3 * c] + (unsigned)p[3 * c + 1] + (unsigned)p[3 * c + 2]) / 3u;
+        out[r * cols + c] = run;
+    }
+}
+
+__global__ void __launch_bounds__(64) surf_colscan(unsigned *__restrict__ I, int rows, int cols)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= cols) return;
+    unsigned acc = 0;
+    int r = 0;
+    for (; r + 8 <= rows; r += 8) {
+        unsigned v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = I[(size_t)(r + k) * cols + c];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { acc += v[k]; I[(size_t)(r + k) * cols + c] = acc; }
+    }
+    for (; r < rows; r++) { acc += I[(size_t)r * cols + c]; I[(size_t)r * cols + c] = acc; }
+}
+
+// get_sum_of_area, integral_image.h:64-96 (uint32 arithmetic = the reference's wrapping int32)
+__device__ __forceinline__ unsigned surf_sum(const unsigned *__restrict__ I, int cols, int l, int t, int r, int b)
+{
+    unsigned tl = 0, tr = 0, bl = 0;
+    const unsigned br = I[(size_t)b * cols + r];
+    if (l - 1 >= 0 && t - 1 >= 0) { tl = I[(size_t)(t - 1) * cols + (l - 1)]; bl = I[(size_t)b * cols + (l - 1)]; tr = I[(size_t)(t - 1) * cols + r]; }
+    else if (l - 1 >= 0) bl = I[(size_t)b * cols + (l - 1)];
+    else if (t - 1 >= 0) tr = I[(size_t)(t - 1) * cols + r];
+    return br - bl - tr + tl;
+}
+// get_sum_of_area(centered_rect(x, y, w, h)), rectangle.h:363-376
+__device__ __forceinline__ int surf_csum(const unsigned *__restrict__ I, int cols, int x, int y, int w, int h)
+{
+    const int l = x - w / 2, t = y - h / 2;
+    return (int)surf_sum(I, cols, l, t, l + w - 1, t + h - 1);
+}
+
+// ---- K17: one launch per octave, blockIdx.z = interval
+__global__ void __launch_bounds__(256) surf_pyramid(const unsigned *__restrict__ I, double *__restrict__ pyr, SurfGeom g, int o)
+{
+    const int lc = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int lr = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const SurfLevel L = g.lev[o * SURF_INT + blockIdx.z];
+    const int r = lr * L.step, c = lc * L.step;
+    if (lr >= g.nr[o] || lc >= g.nc[o]) return;
+    if (r < L.border_px || r >= g.rows - L.border_px || c < L.border_px || c >= g.cols - L.border_px) return;
+    const int lobe = L.lobe, off = L.off, cols = g.cols;
+    double Dxx = surf_csum(I, cols, c, r, lobe * 3, 2 * lobe - 1) - surf_csum(I, cols, c, r, lobe, 2 * lobe - 1) * 3.0;       // :141-142
+    double Dyy = surf_csum(I, cols, c, r, 2 * lobe - 1, lobe * 3) - surf_csum(I, cols, c, r, 2 * lobe - 1, lobe) * 3.0;       // :144-145
+    double Dxy = (int)((unsigned)surf_csum(I, cols, c - off, r + off, lobe, lobe) + (unsigned)surf_csum(I, cols, c + off, r - off, lobe, lobe) -
+                       (unsigned)surf_csum(I, cols, c - off, r - off, lobe, lobe) - (unsigned)surf_csum(I, cols, c + off, r + off, lobe, lobe));  // :147-150
+    Dxx *= L.area_inv; Dyy *= L.area_inv; Dxy *= L.area_inv;
+    double sign = +1;
+    if (Dxx + Dyy < 0) sign = -1;
+    double det = Dxx * Dyy - 0.81 * Dxy * Dxy;
+    if (det < 0) det = 0;
+    pyr[L.plane + (size_t)lr * g.nc[o] + lc] = sign * det;
+}
+
+struct SurfRecord {
+    unsigned long long key;  // ((octave*8 + interval) << 40) | row << 20 | column : the reference's emission order
+    double x, y, scale, score, laplacian;
+};
+
+struct SurfNmsParams {
+    int o;
+    int border_next[SURF_INT];  // get_border_size(i+1) for the interval handled (level coordinates)
+    double thr;
+    double pow2_o1;             // std::pow(2.0, o+1.0)
+    double step;                // get_step_size(o)
+    unsigned long long cap;
+};
+
+// ---- K18: one launch per octave, blockIdx.z + 1 = interval (1..4)
+__global__ void __launch_bounds__(256) surf_nms_interp(const double *__restrict__ pyr, SurfGeom g, SurfNmsParams q,
+                                                       SurfRecord *__restrict__ out, unsigned long long *__restrict__ count)
+{
+    const int o = q.o, i = blockIdx.z + 1;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int nr = g.nr[o], nc = g.nc[o], b = q.border_next[i];
+    if (r < b + 1 || r >= nr - b - 1 || c < b + 1 || c >= nc - b - 1) return;  // :474-476
+    const double *P0 = pyr + g.lev[o * SURF_INT + i - 1].plane;
+    const double *P1 = pyr + g.lev[o * SURF_INT + i].plane;
+    const double *P2 = pyr + g.lev[o * SURF_INT + i + 1].plane;
+#define V(P, rr, cc) fabs((P)[(size_t)(rr) * nc + (cc)])
+    const double raw = P1[(size_t)r * nc + c];
+    const double val = fabs(raw);
+    if (!(val >= q.thr)) return;
+    // is_maximum_in_region :324-356: rejected by any strictly larger value in the 3x3x3 block
+    for (int rr = r - 1; rr <= r + 1; rr++)
+        for (int cc = c - 1; cc <= c + 1; cc++)
+            if (V(P0, rr, cc) > val || V(P1, rr, cc) > val || V(P2, rr, cc) > val) return;
+    // interpolate_point :411-446
+    const double g0 = (V(P1, r, c + 1) - V(P1, r, c - 1)) / 2.0;
+    const double g1 = (V(P1, r + 1, c) - V(P1, r - 1, c)) / 2.0;
+    const double g2 = (V(P2, r, c) - V(P0, r, c)) / 2.0;
+    const double Dxx = (V(P1, r, c + 1) + V(P1, r, c - 1)) - 2 * val;
+    const double Dyy = (V(P1, r + 1, c) + V(P1, r - 1, c)) - 2 * val;
+    const double Dss = (V(P2, r, c) + V(P0, r, c)) - 2 * val;
+    const double Dxy = (V(P1, r + 1, c + 1) + V(P1, r - 1, c - 1) - V(P1, r - 1, c + 1) - V(P1, r + 1, c - 1)) / 4.0;
+    const double Dxs = (V(P2, r, c + 1) + V(P0, r, c - 1) - V(P0, r, c + 1) - V(P2, r, c - 1)) / 4.0;
+    const double Dys = (V(P2, r + 1, c) + V(P0, r - 1, c) - V(P0, r + 1, c) - V(P2, r - 1, c)) / 4.0;
+#undef V
+    // inv() of the symmetric 3x3 [a b c; d e f; g h i], matrix_la.h:922-962 with det :1576-1590
+    const double ma = Dxx, mb = Dxy, mc = Dxs, md = Dxy, me = Dyy, mf = Dys, mg = Dxs, mh = Dys, mi = Dss;
+    double de = ma * (me * mi - mf * mh) - mb * (md * mi - mf * mg) + mc * (md * mh - me * mg);
+    double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
+    if (de != 0) {
+        de = 1.0 / de;
+        v00 = (me * mi - mf * mh) * de; v10 = (mf * mg - md * mi) * de; v20 = (md * mh - me * mg) * de;
+        v01 = (mc * mh - mb * mi) * de; v11 = (ma * mi - mc * mg) * de; v21 = (mb * mg - ma * mh) * de;
+        v02 = (mb * mf - mc * me) * de; v12 = (mc * md - ma * mf) * de; v22 = (ma * me - mb * md) * de;
+    }
+    const double ix = -(v00 * g0 + v01 * g1 + v02 * g2);
+    const double iy = -(v10 * g0 + v11 * g1 + v12 * g2);
+    const double iz = -(v20 * g0 + v21 * g1 + v22 * g2);
+    if (!(fmax(fabs(ix), fmax(fabs(iy), fabs(iz))) < 0.5)) return;
+    SurfRecord rec;
+    rec.key = ((unsigned long long)(o * 8 + i) << 40) | ((unsigned long long)r << 20) | (unsigned long long)c;
+    rec.x = (c + ix) * q.step;
+    rec.y = (r + iy) * q.step;
+    const double lobe = q.pow2_o1 * (i + iz + 1) + 1;
+    rec.scale = 1.2 / 9.0 * (3 * lobe);
+    rec.score = val;
+    rec.laplacian = raw > 0 ? +1.0 : -1.0;  // get_laplacian :294-297
+    const unsigned long long k = atomicAdd(count, 1ull);
+    if (k < q.cap) out[k] = rec;
+}
+
+// surf_host.cpp
+void surf_describe_host(const int32_t *I, int rows, int cols, double x, double y, double scale, double *angle, double *des64);
+
+namespace {
+
+struct SurfDevice {
+    unsigned *integral = nullptr;
+    double *pyr = nullptr;
+    SurfRecord *rec = nullptr;
+    unsigned long long *count = nullptr;
+    unsigned long long cap = 0;
+};
+
+size_t surf_ws_bytes(const SurfGeom &g, size_t pyr_total, unsigned long long cap)
+{
+    const size_t n = (size_t)g.rows * g.cols;
+    return align_up(3 * n, 256) + align_up(4 * n, 256) + align_up(8 * pyr_total, 256) + align_up(sizeof(SurfRecord) * cap, 256) + 4096;
+}
+
+// K16-K18 for one image already in device memory; leaves the records (unordered) + count on the device
+imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const SurfGeom &g, double thr, const SurfDevice &d)
+{
+    hipLaunchKernelGGL(surf_gray_rowscan, dim3(g.rows), dim3(256), 0, ctx->stream, d_rgb, d.integral, g.cols);
+    hipLaunchKernelGGL(surf_colscan, dim3(ceil_div(g.cols, 64)), dim3(64), 0, ctx->stream, d.integral, g.rows, g.cols);
+    IMGFD_HIP(ctx, hipMemsetAsync(d.count, 0, sizeof(unsigned long long), ctx->stream));
+    for (int o = 0; o < SURF_OCT; o++) {
+        if (g.nr[o] < 1 || g.nc[o] < 1) continue;
+        dim3 grid(ceil_div(g.nc[o], 64), ceil_div(g.nr[o], 4), SURF_INT);
+        hipLaunchKernelGGL(surf_pyramid, grid, dim3(256), 0, ctx->stream, d.integral, d.pyr, g, o);
+    }
+    for (int o = 0; o < SURF_OCT; o++) {
+        if (g.nr[o] < 1 || g.nc[o] < 1) continue;
+        SurfNmsParams q;
+        q.o = o; q.thr = thr; q.pow2_o1 = pow(2.0, o + 1.0); q.step = (double)surf_step_of(o); q.cap = d.cap;
+        for (int i = 0; i < SURF_INT; i++) q.border_next[i] = (int)surf_border_of(std::min(i + 1, SURF_INT - 1));
+        dim3 grid(ceil_div(g.nc[o], 64), ceil_div(g.nr[o], 4), SURF_INT - 2);
+        hipLaunchKernelGGL(surf_nms_interp, grid, dim3(256), 0, ctx->stream, d.pyr, g, q, d.rec, d.count);
+    }
+    IMGFD_HIP(ctx, hipGetLastError());
+    return IMGFD_OK;
+}
+
+// uploads the image, runs the device stages, returns the interest points in the reference's emission order
+// (and, if want_integral, the integral image for the host descriptor stage)
+imgfd_status surf_points_host(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, double thr,
+                              std::vector<SurfRecord> &pts, const int32_t **integral)
+{
+    pts.clear();
+    if (rows < 1 || cols < 1) return IMGFD_OK;
+    IMGFD_HIP(ctx, hipSetDevice(ctx->device));
+    SurfGeom g;
+    const size_t total = surf_geometry(rows, cols, &g);
+    const size_t n = (size_t)rows * cols;
+    SurfDevice d;
+    d.cap = 1ull << 16;
+    for (;;) {
+        IMGFD_TRY(ws_reserve(ctx, surf_ws_bytes(g, total, d.cap)));
+        ctx->ws_used = 0;
+        uint8_t *d_rgb = (uint8_t *)ws_alloc(ctx, 3 * n);
+        d.integral = (unsigned *)ws_alloc(ctx, 4 * n);
+        d.pyr = (double *)ws_alloc(ctx, 8 * std::max<size_t>(total, 1));
+        d.rec = (SurfRecord *)ws_alloc(ctx, sizeof(SurfRecord) * d.cap);
+        d.count = (unsigned long long *)ws_alloc(ctx, 256);
+        if (!d_rgb || !d.integral || !d.pyr || !d.rec || !d.count) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+        IMGFD_HIP(ctx, hipMemcpyAsync(d_rgb, rgb, 3 * n, hipMemcpyHostToDevice, ctx->stream));
+        IMGFD_TRY(surf_device_stages(ctx, d_rgb, g, thr, d));
+        unsigned long long cnt = 0;
+        IMGFD_HIP(ctx, hipMemcpyAsync(&cnt, d.count, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+        IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (cnt > d.cap) { d.cap = cnt + 1024; continue; }  // rare: more candidates than the record buffer holds
+        pts.resize((size_t)cnt);
+        if (cnt) IMGFD_HIP(ctx, hipMemcpyAsync(pts.data(), d.rec, sizeof(SurfRecord) * cnt, hipMemcpyDeviceToHost, ctx->stream));
+        if (integral && cnt) {  // the host descriptor stage reads the table from the context's pinned staging buffer
+            IMGFD_TRY(pin_reserve(ctx, 4 * n));
+            IMGFD_HIP(ctx, hipMemcpyAsync(ctx->pin, d.integral, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
+            *integral = reinterpret_cast<const int32_t *>(ctx->pin);
+        }
+        IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        break;
+    }
+    std::sort(pts.begin(), pts.end(), [](const SurfRecord &a, const SurfRecord &b) { return a.key < b.key; });
+    return IMGFD_OK;
+}
+
+// interest_point::operator<, hessian_pyramid.h:31
+struct ScoreLess {
+    bool operator()(const SurfRecord &a, const SurfRecord &b) const { return a.score < b.score; }
+};
+
+}  // namespace
+
+extern "C" {
+
+imgfd_status imgfd_k_surf_integral(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, int32_t *out)
+{
+    if (!ctx) return IMGFD_ERR_INVALID;
+    if (!rgb || !out || rows < 1 || cols < 1) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_k_surf_integral: bad argument");
+    IMGFD_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)rows * cols;
+    IMGFD_TRY(ws_reserve(ctx, align_up(3 * n, 256) + align_up(4 * n, 256) + 512));
+    uint8_t *d_rgb = (uint8_t *)ws_alloc(ctx, 3 * n);
+    unsigned *d_I = (unsigned *)ws_alloc(ctx, 4 * n);
+    if (!d_rgb || !d_I) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    IMGFD_HIP(ctx, hipMemcpyAsync(d_rgb, rgb, 3 * n, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(surf_gray_rowscan, dim3(rows), dim3(256), 0, ctx->stream, d_rgb, d_I, cols);
+    hipLaunchKernelGGL(surf_colscan, dim3(ceil_div(cols, 64)), dim3(64), 0, ctx->stream, d_I, rows, cols);
+    IMGFD_HIP(ctx, hipGetLastError());
+    IMGFD_HIP(ctx, hipMemcpyAsync(out, d_I, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
+    IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IMGFD_OK;
+}
+
+imgfd_status imgfd_surf_interest_points(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, double detection_threshold,
+                                        double *points, int64_t cap, int64_t *n)
+{
+    if (!ctx) return IMGFD_ERR_INVALID;
+    if (!rgb || !n || rows < 0 || cols < 0 || cap < 0 || (cap && !points) || !(detection_threshold >= 0))
+        return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_surf_interest_points: bad argument");
+    std::vector<SurfRecord> pts;
+    IMGFD_TRY(surf_points_host(ctx, rgb, rows, cols, detection_threshold, pts, nullptr));
+    *n = (int64_t)pts.size();
+    for (size_t k = 0; k < pts.size() && (int64_t)k < cap; k++) {
+        double *o = points + 5 * k;
+        o[0] = pts[k].x; o[1] = pts[k].y; o[2] = pts[k].scale; o[3] = pts[k].score; o[4] = pts[k].laplacian;
+    }
+    return IMGFD_OK;
+}
+
+imgfd_status imgfd_surf(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, long max_points, double detection_threshold,
+                        imgfd_surf_out *out)
+{
+    if (!ctx || !out) return IMGFD_ERR_INVALID;
+    memset(out, 0, sizeof *out);
+    if (!rgb || rows < 0 || cols < 0 || !(max_points > 0) || !(detection_threshold >= 0))
+        return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_surf: bad argument (DLIB_ASSERT of surf.h:243-248)");
+    std::vector<SurfRecord> pts;
+    const int32_t *I = nullptr;
+    IMGFD_TRY(surf_points_host(ctx, rgb, rows, cols, detection_threshold, pts, &I));
+    if (pts.empty()) return IMGFD_OK;
+    std::sort(pts.rbegin(), pts.rend(), ScoreLess());  // surf.h:268
+    const size_t lim = std::min((size_t)max_points, pts.size());
+    std::vector<size_t> keep;
+    for (size_t k = 0; k < lim; k++) {  // :271-285: drop points whose 32*scale box leaves the image
+        const unsigned long bs = (unsigned long)(32.0 * pts[k].scale);
+        const long px = (long)floor(pts[k].x + 0.5), py = (long)floor(pts[k].y + 0.5);
+        const long l = px - (long)bs / 2, t = py - (long)bs / 2, r = l + (long)bs - 1, b = t + (long)bs - 1;
+        if (l >= 0 && t >= 0 && r <= cols - 1 && b <= rows - 1) keep.push_back(k);
+    }
+    const size_t m = keep.size();
+    if (!m) return IMGFD_OK;
+    double *data = (double *)malloc(sizeof(double) * m * 70);
+    if (!data) return imgfd_fail(ctx, IMGFD_ERR_OOM, "malloc of the SURF output failed");
+    out->n = (int64_t)m; out->data = data;
+    out->x = data; out->y = data + m; out->angle = data + 2 * m; out->pyramid_scale = data + 3 * m;
+    out->score = data + 4 * m; out->laplacian = data + 5 * m; out->surf = data + 6 * m;
+    for (size_t j = 0; j < m; j++) {
+        const SurfRecord &p = pts[keep[j]];
+        out->x[j] = p.x; out->y[j] = p.y; out->pyramid_scale[j] = p.scale; out->score[j] = p.score; out->laplacian[j] = p.laplacian;
+        surf_describe_host(I, rows, cols, p.x, p.y, p.scale, &out->angle[j], out->surf + 64 * j);
+    }
+    return IMGFD_OK;
+}
+
+}  // extern "C"

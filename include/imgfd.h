@@ -142,6 +142,27 @@ IMGFD_API imgfd_status imgfd_fhog_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int 
                             size_t frame_stride_bytes, int cell_size, int filter_rows_padding, int filter_cols_padding,
                             float *d_hog);
 
+/* ------------------------------------------------------------------ SURF (dlib)
+ * dlib_surf_points(x, rows, cols, max_points, detection_threshold), rcpp_surf.cpp:10-13, after the std::vector<int> ->
+ * rgb_pixel narrowing (:14-21): rgb as for imgfd_fhog.  Output = the vectors the reference glue builds (:23-52):
+ * n points in get_surf_points' order (descending score), surf[i*64 + j] = descriptor j of point i.  One allocation:
+ * release with imgfd_free(out->data).  (R's NaN -> 0 patch of image_surf.R:88 belongs to the R wrapper.) */
+typedef struct {
+    int64_t n;
+    double *x, *y, *angle, *pyramid_scale, *score, *laplacian; /* n each */
+    double *surf;                                              /* n * 64 */
+    double *data;                                              /* the one allocation behind the pointers above */
+} imgfd_surf_out;
+IMGFD_API imgfd_status imgfd_surf(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, long max_points,
+                        double detection_threshold, imgfd_surf_out *out);
+/* device stages only (integral image, Hessian pyramid, 3x3x3 maxima + interpolation), hessian_pyramid.h:453-506:
+ * records of 5 doubles (x, y, scale, score, laplacian) in the order get_interest_points() emits them; *n = number found
+ * (may exceed cap; only cap are stored). */
+IMGFD_API imgfd_status imgfd_surf_interest_points(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols,
+                                        double detection_threshold, double *points, int64_t cap, int64_t *n);
+/* stage doorway: the int32 integral image (integral_image.h:33-62) of the (r+g+b)/3 gray image, rows*cols values */
+IMGFD_API imgfd_status imgfd_k_surf_integral(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, int32_t *out);
+
 /* ------------------------------------------------------------------ device-resident batch path
  * Frames live in HBM: frame f starts at (char*)d_frames + f*frame_stride_bytes, rows are row_stride
  * bytes apart.  Results stay on the device in caller-provided buffers so that a stream of frames can

@@ -238,3 +238,36 @@ def ref_fhog(rgb, cell_size: int = 8, pad_r: int = 1, pad_c: int = 1):
         L.ref_fhog(rgb.ctypes.data_as(C.c_void_p), rows, cols, cell_size, pad_r, pad_c,
                    out.ctypes.data_as(C.c_void_p), C.byref(nr), C.byref(nc))
     return out
+
+
+# ----------------------------------------------------------------------- SURF
+def _surf_call(L, name, rgb, *args, rec, cap=400000):
+    rgb = _rgb(rgb)
+    rows, cols, _ = rgb.shape
+    fn = getattr(L, name); fn.restype = C.c_long
+    out = np.zeros((cap, rec), np.float64)
+    n = fn(rgb.ctypes.data_as(C.c_void_p), rows, cols, *args, out.ctypes.data_as(C.c_void_p), C.c_long(cap))
+    assert n <= cap, "raise cap"
+    return out[:n].copy()
+
+
+def surf_integral(rgb, use_ref: bool = False):
+    rgb = _rgb(rgb)
+    rows, cols, _ = rgb.shape
+    out = np.zeros((rows, cols), np.int32)
+    (ref("dlib").ref_integral if use_ref else lib().orc_surf_integral)(rgb.ctypes.data_as(C.c_void_p), rows, cols,
+                                                                      out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def surf_interest_points(rgb, threshold: float = 30.0, use_ref: bool = False):
+    """(n, 5): x, y, scale, score, laplacian in get_interest_points' emission order."""
+    L, name = (ref("dlib"), "ref_surf_interest_points") if use_ref else (lib(), "orc_surf_interest_points")
+    return _surf_call(L, name, rgb, C.c_double(threshold), rec=6)[:, :5]
+
+
+def surf(rgb, max_points: int = 1000, threshold: float = 30.0, use_ref: bool = False):
+    """dict of x, y, angle, pyramid_scale, score, laplacian (n,) and surf (n, 64), like rcpp_surf.cpp:45-52."""
+    L, name = (ref("dlib"), "ref_surf") if use_ref else (lib(), "orc_surf")
+    r = _surf_call(L, name, rgb, C.c_long(max_points), C.c_double(threshold), rec=71, cap=max(16, min(int(max_points), 400000)))
+    return dict(x=r[:, 0], y=r[:, 1], angle=r[:, 2], pyramid_scale=r[:, 3], score=r[:, 4], laplacian=r[:, 5], surf=r[:, 7:])

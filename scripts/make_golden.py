@@ -59,6 +59,15 @@ def fhog_golden():
     print("fhog_cruise_boat", {k: v.shape for k, v in out.items()})
 
 
+def surf_golden():
+    """dlib's own get_surf_points (max_points 1000, threshold 30: the R defaults) on the reference's example image."""
+    from PIL import Image
+    img = np.asarray(Image.open(os.path.join(REF, "image.dlib", "inst", "extdata", "cruise_boat.png")).convert("RGB"))
+    out = {"image": img, **oracle.surf(img, 1000, 30.0, use_ref=True)}
+    np.savez_compressed(os.path.join(OUT, "surf_cruise_boat"), **out)
+    print("surf_cruise_boat", {k: v.shape for k, v in out.items()})
+
+
 def fast9_golden(name, img, thresholds):
     out = {"image": img.astype(np.uint8)}
     for thr in thresholds:

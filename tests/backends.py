@@ -127,6 +127,37 @@ class _Base:
         self.lib.imgfd_free(hog)
         return np.ascontiguousarray(flat.transpose(2, 1, 0))
 
+    def surf_integral(self, rgb):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        rows, cols, _ = rgb.shape
+        out = np.zeros((rows, cols), np.int32)
+        self.check(self.lib.imgfd_k_surf_integral(self.ctx, rgb.ctypes.data_as(C.c_void_p), rows, cols,
+                                                  out.ctypes.data_as(C.c_void_p)), "imgfd_k_surf_integral")
+        return out
+
+    def surf_interest_points(self, rgb, threshold=30.0, cap=400000):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        rows, cols, _ = rgb.shape
+        out = np.zeros((cap, 5), np.float64); n = C.c_int64(0)
+        self.check(self.lib.imgfd_surf_interest_points(self.ctx, rgb.ctypes.data_as(C.c_void_p), rows, cols, threshold,
+                                                       out.ctypes.data_as(C.c_void_p), cap, C.byref(n)), "imgfd_surf_interest_points")
+        assert n.value <= cap
+        return out[:n.value].copy()
+
+    def surf(self, rgb, max_points=1000, threshold=30.0):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        rows, cols, _ = rgb.shape
+        o = _binding.SurfOut()
+        self.check(self.lib.imgfd_surf(self.ctx, rgb.ctypes.data_as(C.c_void_p), rows, cols, max_points, threshold,
+                                       C.byref(o)), "imgfd_surf")
+        n = int(o.n)
+        vec = lambda p, m: np.ctypeslib.as_array(p, shape=(m,)).copy() if m else np.zeros((0,))
+        res = dict(x=vec(o.x, n), y=vec(o.y, n), angle=vec(o.angle, n), pyramid_scale=vec(o.pyramid_scale, n),
+                   score=vec(o.score, n), laplacian=vec(o.laplacian, n), surf=vec(o.surf, n * 64).reshape(n, 64))
+        if n:
+            self.lib.imgfd_free(o.data)
+        return res
+
     def fhog_dev(self, frames, cell_size=8, pad_r=1, pad_c=1):
         frames = np.ascontiguousarray(frames, np.uint8)
         n, rows, cols, _ = frames.shape

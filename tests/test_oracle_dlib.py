@@ -34,3 +34,30 @@ def test_fhog_golden(golden):
     for key, (cs, pr, pc) in {"hog_c8": (8, 1, 1), "hog_c4": (4, 1, 1), "hog_c8_p33": (8, 3, 3)}.items():
         got = oracle.fhog(g["image"], cs, pr, pc)
         assert got.shape == g[key].shape and np.array_equal(got.view(np.uint32), g[key].view(np.uint32)), key
+
+
+# ----------------------------------------------------------------------------- SURF
+def _blobs(seed, w, h):
+    from test_surf import blobs
+    return blobs(seed, w, h)
+
+
+@needs_ref
+@pytest.mark.parametrize("seed,w,h,thr", [(91, 320, 240, 30.0), (92, 517, 389, 5.0), (93, 700, 500, 30.0)])
+def test_surf_restatement_is_bit_identical_to_dlib(seed, w, h, thr):
+    rgb = _blobs(seed, w, h)
+    assert np.array_equal(oracle.surf_integral(rgb), oracle.surf_integral(rgb, use_ref=True))
+    a, b = oracle.surf_interest_points(rgb, thr), oracle.surf_interest_points(rgb, thr, use_ref=True)
+    assert len(b) > 5 and a.shape == b.shape and np.array_equal(a, b)
+    for mp in (40, 10000):
+        x, y = oracle.surf(rgb, mp, thr), oracle.surf(rgb, mp, thr, use_ref=True)
+        for k in y:
+            assert x[k].shape == y[k].shape and np.array_equal(x[k], y[k]), (k, mp)
+
+
+def test_surf_golden(golden):
+    g = golden("surf_cruise_boat")
+    got = oracle.surf(g["image"], 1000, 30.0)
+    for k in ("x", "y", "angle", "pyramid_scale", "score", "laplacian", "surf"):
+        assert got[k].shape == g[k].shape and np.array_equal(got[k], g[k]), k
+    assert len(g["x"]) > 100

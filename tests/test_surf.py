@@ -1,0 +1,84 @@
+"""SURF: device stages (integral image, Hessian pyramid, maxima + interpolation) and the whole imgfd_surf against the
+restatement oracle (bit-identical to dlib compiled in place, tests/test_oracle_dlib.py; SURF is unpinned upstream: no
+dlib test covers surf.h / hessian_pyramid.h) and against golden vectors written by dlib's own code.
+All arithmetic is int32 / f64 in the reference's operation order, so everything is compared exactly."""
+import numpy as np
+import pytest
+
+import oracle
+from image_amd import synth
+
+
+def blobs(seed, w, h, n=60):
+    """synthetic RGB frame with soft blobs of many sizes (the rectangle frames alone give few Hessian maxima)"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = synth.frame_rgb(seed, w, h).astype(np.float64) * 0.35
+    for _ in range(n):
+        cx, cy, s = rng.uniform(0, w), rng.uniform(0, h), rng.uniform(2.5, 14)
+        amp = rng.uniform(-120, 160, 3)
+        img += amp[None, None, :] * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))[..., None]
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (257, 129), (400, 300), (1031, 517)])
+def test_integral_image_exact(be, w, h):
+    rgb = synth.frame_rgb(81, w, h)
+    assert np.array_equal(be.surf_integral(rgb), oracle.surf_integral(rgb))
+
+
+def test_integral_image_wraps_like_int32(be):
+    if be.name == "emu":
+        pytest.skip("8.6 Mpixel image: too slow on the host emulator (the wrap is integer arithmetic, identical there)")
+    rgb = np.full((2900, 2960, 3), 255, np.uint8)      # 255 * 2900 * 2960 > 2^31: the reference's int32 sums wrap
+    a = be.surf_integral(rgb)
+    assert a.min() < 0
+    assert np.array_equal(a, oracle.surf_integral(rgb))
+
+
+@pytest.mark.parametrize("seed,w,h,thr", [(82, 320, 240, 30.0), (83, 517, 389, 30.0), (84, 400, 300, 5.0), (85, 256, 256, 200.0)])
+def test_interest_points_exact(be, seed, w, h, thr):
+    rgb = blobs(seed, w, h)
+    got, ref = be.surf_interest_points(rgb, thr), oracle.surf_interest_points(rgb, thr)
+    assert len(ref) >= 3
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (9, 9), (30, 30), (65, 40), (100, 90)])
+def test_small_images(be, w, h):
+    rgb = blobs(86, max(w, 16), max(h, 16))[:h, :w]
+    got, ref = be.surf_interest_points(rgb, 1.0), oracle.surf_interest_points(rgb, 1.0)
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+    s = be.surf(rgb, 1000, 1.0)
+    assert len(s["x"]) == len(oracle.surf(rgb, 1000, 1.0)["x"])
+
+
+@pytest.mark.parametrize("max_points,thr", [(1000, 30.0), (50, 30.0), (10000, 5.0)])
+def test_surf_points_and_descriptors_exact(be, max_points, thr):
+    rgb = blobs(87, 480, 360)
+    got, ref = be.surf(rgb, max_points, thr), oracle.surf(rgb, max_points, thr)
+    assert len(ref["x"]) > 3
+    for k in ("x", "y", "pyramid_scale", "score", "laplacian", "angle", "surf"):
+        assert got[k].shape == ref[k].shape, k
+        assert np.array_equal(got[k], ref[k]), k
+
+
+def test_golden_dlib(be, golden):
+    """vectors written by dlib's own get_surf_points on the reference's example image"""
+    g = golden("surf_cruise_boat")
+    got = be.surf(g["image"], 1000, 30.0)
+    for k in ("x", "y", "angle", "pyramid_scale", "score", "laplacian", "surf"):
+        assert got[k].shape == g[k].shape and np.allclose(got[k], g[k], rtol=1e-9, atol=1e-12), k
+        assert np.array_equal(got[k], g[k]), k
+
+
+def test_r_level_mirror(be):
+    if be.name != "gpu":
+        pytest.skip("image_amd.api binds the product library")
+    from image_amd import api
+    rgb = blobs(88, 300, 220)
+    x = rgb.transpose(2, 1, 0).astype(np.int32)   # (3, width, height)
+    out = api.image_surf(x, max_points=200, detection_threshold=30)
+    ref = oracle.surf(rgb, 200, 30.0)
+    assert out["points"] == len(ref["x"]) and out["surf"].shape == (out["points"], 64)
+    assert np.array_equal(out["x"], ref["x"]) and np.array_equal(out["surf"], np.nan_to_num(ref["surf"]))
