@@ -155,6 +155,15 @@ def main():
         k3_bytes = TENSOR_BYTES_PER_PX * NX * NY * B       # algorithmic bytes of one launch (B frames)
         achieved = k3_bytes / (k3_avg_us * 1e-6) / 1e9 if k3_avg_us > 0 else 0.0
         # parity spot-check of frame 0 against the host generator + oracle happens in tests/ (-m gpu)
+        # HBM traffic of one K3 launch from the PMC counters: collected offline in separate rocprofv3 --pmc passes on
+        # this very command (PMC and timing must not share a run) and committed under profiles/
+        traffic = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "k3_traffic.json")))
+            if tr.get("batch") == B:
+                traffic = int(tr["traffic_bytes_per_launch"])
+        except Exception:
+            pass
         res = {
             "metric": "Mpixels/s Harris+FAST9+Canny on 3840x2160 gray",
             "value": round(px_per_step * args.steps / dt / 1e6, 2),
@@ -171,7 +180,7 @@ def main():
                                           "canny_edge_pixels": int(counts[2])}},
             "roofline": {"kernel": "fir_march<7,tensor> (Harris structure-tensor pass)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/k3_traffic.json)",
                          "avg_launch_us": round(k3_avg_us, 2), "launches": k3_n.value,
                          "algorithmic_bytes_per_launch": k3_bytes},
         }

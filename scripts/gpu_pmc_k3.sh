@@ -7,7 +7,7 @@ TAG="${1:-k3}"; KERN="${2:-fir_march<7}"; SCRIPT="${3:-scripts/k3_time.py}"
 cd /tmp
 pmc() {
   name=$1; shift
-  timeout 600 rocprofv3 --pmc "$@" --output-format csv -d "$O/pmc_${TAG}_$name" -o p -- python "$R/$SCRIPT" > "$O/pmc_${TAG}_$name.log" 2>&1
+  timeout 600 rocprofv3 --pmc "$@" --output-format csv -d "$O/pmc_${TAG}_$name" -o p -- python $R/$SCRIPT > "$O/pmc_${TAG}_$name.log" 2>&1
   f=$(find "$O/pmc_${TAG}_$name" -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python - "$f" "$KERN" <<'PY'
 import csv, sys, collections
