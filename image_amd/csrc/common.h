@@ -84,7 +84,12 @@ imgfd_status launch_gaussian(imgfd_ctx *ctx, const void *d_in, int in_is_u8, int
 imgfd_status launch_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_A,
                                      float *d_B, float *d_C, int nx, int ny, int n_frames, float sigma,
                                      int gauss, float *d_tmp);
+// scratch (bytes) launch_gaussian / launch_structure_tensor need in d_tmp for `n_frames` frames
 size_t gaussian_tmp_bytes(int nx, int ny, int n_frames, float sigma, int type, int planes);
+// sii.hip
+size_t sii_scratch_floats(int nx, int ny, float sigma);
+imgfd_status launch_sii_gaussian(imgfd_ctx *ctx, const float *d_in, float *d_out, int nx, int ny, int n_frames, float sigma,
+                                 float *d_cum);
 // harris_stages.hip
 imgfd_status launch_gradient(imgfd_ctx *ctx, const float *d_I, float *d_Ix, float *d_Iy, int nx, int ny,
                              int n_frames, int type);
@@ -105,7 +110,13 @@ imgfd_status compact_clear(imgfd_ctx *ctx, const CompactBuffers &cb, int ny, int
 // scan row counts, then scatter: kind 0 = imgfd_corner {x,y,R[y*nx+x]}, kind 1 = imgfd_point {x,y}
 imgfd_status compact_emit(imgfd_ctx *ctx, const CompactBuffers &cb, int nx, int ny, int n_frames, int kind,
                           const float *d_R, void *d_out, int64_t cap, int64_t *d_counts);
+imgfd_status compact_emit_abc(imgfd_ctx *ctx, const CompactBuffers &cb, int nx, int ny, int n_frames, const float *d_A,
+                              const float *d_B, const float *d_C, int measure, float k, void *d_out, int64_t cap,
+                              int64_t *d_counts);
 // nms.hip
+bool harris_resp_nms_supports(int nx, int ny, int radius);
+imgfd_status launch_harris_resp_nms(imgfd_ctx *ctx, const float *d_A, const float *d_B, const float *d_C, int nx, int ny,
+                                    int n_frames, int measure, float k, float Th, int radius, const CompactBuffers &cb);
 imgfd_status launch_harris_nms(imgfd_ctx *ctx, const float *d_R, int nx, int ny, int n_frames, float Th,
                                int radius, const CompactBuffers &cb);
 // fast9.hip

@@ -10,6 +10,7 @@
 //               each lane walks its set bits and writes records at rowoff + prefix + k.
 // Integer-only bookkeeping: the output is deterministic and identical to a sequential scan.
 #include "common.h"
+#include "harris_device.h"
 
 #define SCAN_NT 1024
 
@@ -70,11 +71,16 @@ __global__ void __launch_bounds__(SCAN_NT) rows_scan(const unsigned *__restrict_
     if (tid == 0) counts[blockIdx.x] = (long long)carry_s;
 }
 
-// KIND 0: imgfd_corner {x, y, R[y*nx+x]};  KIND 1: imgfd_point {x, y}
+struct AbcSource {  // KIND 2..4: strength recomputed from the structure tensor (measure = KIND - 2)
+    const float *A, *B, *C;
+    float k;
+};
+
+// KIND 0: imgfd_corner {x, y, R[y*nx+x]};  KIND 1: imgfd_point {x, y};  KIND 2+m: imgfd_corner with R = response_m(A,B,C)
 template <int KIND>
 __global__ void __launch_bounds__(256) scatter_rows(const unsigned long long *__restrict__ mask,
                                                     const unsigned *__restrict__ rowoff, int words_per_row,
-                                                    int nx, int ny, const float *__restrict__ R,
+                                                    int nx, int ny, const float *__restrict__ R, AbcSource abc,
                                                     void *__restrict__ out, long long cap)
 {
     const int lane = threadIdx.x & 63;
@@ -101,11 +107,13 @@ __global__ void __launch_bounds__(256) scatter_rows(const unsigned long long *__
             m &= m - 1;
             const int x = w * 64 + b;
             if ((long long)pos < cap) {
-                if (KIND == 0) {
+                if (KIND != 1) {
                     imgfd_corner *o = reinterpret_cast<imgfd_corner *>(out) + (size_t)frame * cap + pos;
+                    const size_t p = ((size_t)frame * ny + y) * nx + x;
                     o->x = (float)x;
                     o->y = (float)y;
-                    o->R = R[((size_t)frame * ny + y) * nx + x];
+                    if (KIND == 0) o->R = R[p];
+                    else o->R = harris_response_value<(KIND >= 2 ? KIND - 2 : 0)>(abc.A[p], abc.B[p], abc.C[p], abc.k);
                 } else {
                     imgfd_point *o = reinterpret_cast<imgfd_point *>(out) + (size_t)frame * cap + pos;
                     o->x = x;
@@ -118,18 +126,38 @@ __global__ void __launch_bounds__(256) scatter_rows(const unsigned long long *__
     }
 }
 
-imgfd_status compact_emit(imgfd_ctx *ctx, const CompactBuffers &cb, int nx, int ny, int n_frames, int kind,
-                          const float *d_R, void *d_out, int64_t cap, int64_t *d_counts)
+static imgfd_status compact_emit_impl(imgfd_ctx *ctx, const CompactBuffers &cb, int nx, int ny, int n_frames, int kind,
+                                      const float *d_R, const AbcSource &abc, void *d_out, int64_t cap, int64_t *d_counts)
 {
     hipLaunchKernelGGL(rows_scan, dim3(n_frames), dim3(SCAN_NT), 0, ctx->stream, cb.rowcount, cb.rowoff, ny,
                        (long long *)d_counts);
     dim3 grid(ceil_div(ny, 4), n_frames);
-    if (kind == 0)
-        hipLaunchKernelGGL(scatter_rows<0>, grid, dim3(256), 0, ctx->stream, cb.mask, cb.rowoff,
-                           cb.words_per_row, nx, ny, d_R, d_out, (long long)cap);
-    else
-        hipLaunchKernelGGL(scatter_rows<1>, grid, dim3(256), 0, ctx->stream, cb.mask, cb.rowoff,
-                           cb.words_per_row, nx, ny, d_R, d_out, (long long)cap);
+#define SC_LAUNCH(K) hipLaunchKernelGGL(scatter_rows<K>, grid, dim3(256), 0, ctx->stream, cb.mask, cb.rowoff, cb.words_per_row, nx, ny, d_R, abc, d_out, (long long)cap)
+    switch (kind) {
+        case 0: SC_LAUNCH(0); break;
+        case 1: SC_LAUNCH(1); break;
+        case 2: SC_LAUNCH(2); break;
+        case 3: SC_LAUNCH(3); break;
+        default: SC_LAUNCH(4); break;
+    }
+#undef SC_LAUNCH
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
+}
+
+imgfd_status compact_emit(imgfd_ctx *ctx, const CompactBuffers &cb, int nx, int ny, int n_frames, int kind,
+                          const float *d_R, void *d_out, int64_t cap, int64_t *d_counts)
+{
+    AbcSource none{nullptr, nullptr, nullptr, 0.f};
+    return compact_emit_impl(ctx, cb, nx, ny, n_frames, kind, d_R, none, d_out, cap, d_counts);
+}
+
+// corner records whose strength is recomputed from A, B, C (fused response + NMS path: no R plane exists)
+imgfd_status compact_emit_abc(imgfd_ctx *ctx, const CompactBuffers &cb, int nx, int ny, int n_frames, const float *d_A,
+                              const float *d_B, const float *d_C, int measure, float k, void *d_out, int64_t cap,
+                              int64_t *d_counts)
+{
+    AbcSource abc{d_A, d_B, d_C, k};
+    const int m = measure == IMGFD_SHI_TOMASI_MEASURE ? 1 : (measure == IMGFD_HARMONIC_MEAN_MEASURE ? 2 : 0);
+    return compact_emit_impl(ctx, cb, nx, ny, n_frames, 2 + m, nullptr, abc, d_out, cap, d_counts);
 }

@@ -9,7 +9,8 @@
 //     score = max( max_arcs(min_9 ring) - p - 1 ,  p - min_arcs(max_9 ring) - 1 ).
 // nonMaxSuppression keeps a corner iff none of its 8 neighbours is a corner with score >= its own.
 // All integer arithmetic: results are bit-exact, and compact.hip emits them in the reference's raster
-// order.  One thread per pixel, one wave per 64 pixels of a row (the __ballot word is the mask word).
+// order.  One workgroup per 64x16 tile staged in LDS; a wave covers 64 pixels of a row (the __ballot word is the
+// mask word).
 #include "common.h"
 
 // ring offsets in the order of makeOffsets(): (dx,dy)
@@ -46,25 +47,57 @@ __device__ __forceinline__ int f9_score(const int (&v)[16], int p)
     return max(best_min - p - 1, p - best_max - 1);
 }
 
+#define F9_TX 64   // tile width = one __ballot word
+#define F9_TY 16
+#define F9_HALO 4  // ring radius 3 + 1 (the 3x3 non-max neighbourhood needs the scores of the neighbours)
+
+// One workgroup per 64x16 tile.  The u8 tile (+4 halo) is staged in LDS once (HBM traffic = the algorithmic
+// 1 B/px + halo); the ring test reads LDS; with non-max suppression the scores of the tile (+1 halo) go to a
+// second LDS tile and the 3x3 test runs on it, so neither a score plane nor a second kernel touch HBM.
+// Wave w handles tile rows w, w+4, ...: lane <-> column, so one __ballot is the 64-bit mask word.
 template <int NONMAX>
-__global__ void __launch_bounds__(256) fast9_detect(const unsigned char *__restrict__ img, int w, int h, int stride,
-                                                    size_t frame_stride, int b,
-                                                    unsigned char *__restrict__ score,
-                                                    unsigned long long *__restrict__ mask,
-                                                    unsigned *__restrict__ rowcount, int words_per_row)
+__global__ void __launch_bounds__(256) fast9_tile(const unsigned char *__restrict__ img, int w, int h, int stride,
+                                                  size_t frame_stride, int b, int aligned4,
+                                                  unsigned long long *__restrict__ mask,
+                                                  unsigned *__restrict__ rowcount, int words_per_row)
 {
-    const int lane = threadIdx.x & 63;
-    const int x = blockIdx.x * 64 + lane;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int frame = blockIdx.z;
-    bool corner = false;
-    int sc = 0;
-    if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) {
-        const unsigned char *c = img + (size_t)frame * frame_stride + (size_t)y * stride + x;
+    constexpr int LW = F9_TX + 2 * F9_HALO, LH = F9_TY + 2 * F9_HALO;  // 72 x 24
+    __shared__ unsigned tile32[LH][LW / 4];
+    __shared__ unsigned char sc[F9_TY + 2][F9_TX + 2 + 2];
+    unsigned char(*tile)[LW] = reinterpret_cast<unsigned char(*)[LW]>(tile32);
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * F9_TX, y0 = blockIdx.y * F9_TY;
+    const unsigned char *fr = img + (size_t)blockIdx.z * frame_stride;
+    // ---- stage the tile; out-of-image positions repeat the border pixel (they are never tested, only loaded)
+    for (int i = tid; i < LH * (LW / 4); i += 256) {
+        const int r = i / (LW / 4), q = i - r * (LW / 4);
+        const int gy = min(max(y0 - F9_HALO + r, 0), h - 1);
+        const int gx = x0 - F9_HALO + 4 * q;
+        const unsigned char *row = fr + (size_t)gy * stride;
+        unsigned v;
+        if (aligned4 && gx >= 0 && gx + 3 < w) {
+            v = *reinterpret_cast<const unsigned *>(row + gx);
+        } else {
+            v = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) v |= (unsigned)row[min(max(gx + e, 0), w - 1)] << (8 * e);
+        }
+        tile32[r][q] = v;
+    }
+    __syncthreads();
+    // corner test (+ score) of the pixel at tile position (ty, tx), image position (gx, gy)
+    auto corner_score = [&](int ty, int tx, int gx, int gy) -> int {
+        if (gx < 3 || gx >= w - 3 || gy < 3 || gy >= h - 3) return 0;
+        const unsigned char *c = &tile[ty][tx];
         const int p = *c;
         const int cb = min(255, p + b), c_b = max(0, p - b);
+        // any 9 contiguous ring pixels contain at least two of the four compass points
+        const int n0 = c[3 * LW], n4 = c[3], n8 = c[-3 * LW], n12 = c[-3];
+        const int nb = (n0 > cb) + (n4 > cb) + (n8 > cb) + (n12 > cb);
+        const int nd = (n0 < c_b) + (n4 < c_b) + (n8 < c_b) + (n12 < c_b);
+        if (nb < 2 && nd < 2) return 0;
         int v[16];
-#define F9_LOAD(i, dx, dy) v[i] = c[(dx) + stride * (dy)];
+#define F9_LOAD(i, dx, dy) v[i] = c[(dx) + LW * (dy)];
         F9_RING(F9_LOAD)
 #undef F9_LOAD
         unsigned brighter = 0, darker = 0;
@@ -73,61 +106,49 @@ __global__ void __launch_bounds__(256) fast9_detect(const unsigned char *__restr
             brighter |= (unsigned)(v[i] > cb) << i;
             darker |= (unsigned)(v[i] < c_b) << i;
         }
-        corner = f9_has_arc9(brighter) || f9_has_arc9(darker);
-        if (NONMAX && corner) sc = f9_score(v, p) + 1;  // 1..255; 0 = not a corner
-    }
+        if (!(f9_has_arc9(brighter) || f9_has_arc9(darker))) return 0;
+        return NONMAX ? f9_score(v, p) + 1 : 1;  // score + 1 in 1..255; 0 = not a corner
+    };
+    const int lane = tid & 63, wv = tid >> 6;
     if (NONMAX) {
-        if (x < w && y < h) score[((size_t)frame * h + y) * w + x] = (unsigned char)sc;
-    } else {
-        const unsigned long long word = __ballot(corner);
-        if (lane == 0 && y < h && (int)blockIdx.x < words_per_row) {
-            mask[((size_t)frame * h + y) * words_per_row + blockIdx.x] = word;
-            if (word) atomicAdd(&rowcount[(size_t)frame * h + y], (unsigned)__popcll(word));
+        for (int i = tid; i < (F9_TY + 2) * (F9_TX + 2); i += 256) {
+            const int r = i / (F9_TX + 2), cx = i - r * (F9_TX + 2);
+            sc[r][cx] = (unsigned char)corner_score(r + F9_HALO - 1, cx + F9_HALO - 1, x0 + cx - 1, y0 + r - 1);
+        }
+        __syncthreads();
+    }
+    for (int r = wv; r < F9_TY; r += 4) {
+        const int gy = y0 + r;
+        bool keep;
+        if (NONMAX) {
+            const int s = sc[r + 1][lane + 1];
+            keep = s && sc[r][lane] < s && sc[r][lane + 1] < s && sc[r][lane + 2] < s && sc[r + 1][lane] < s &&
+                   sc[r + 1][lane + 2] < s && sc[r + 2][lane] < s && sc[r + 2][lane + 1] < s && sc[r + 2][lane + 2] < s;
+        } else {
+            keep = corner_score(r + F9_HALO, lane + F9_HALO, x0 + lane, gy) != 0;
+        }
+        const unsigned long long word = __ballot(keep);
+        if (lane == 0 && gy < h) {
+            mask[((size_t)blockIdx.z * h + gy) * words_per_row + blockIdx.x] = word;
+            if (word) atomicAdd(&rowcount[(size_t)blockIdx.z * h + gy], (unsigned)__popcll(word));
         }
     }
 }
 
-__global__ void __launch_bounds__(256) fast9_nms(const unsigned char *__restrict__ score, int w, int h,
-                                                 unsigned long long *__restrict__ mask,
-                                                 unsigned *__restrict__ rowcount, int words_per_row)
-{
-    const int lane = threadIdx.x & 63;
-    const int x = blockIdx.x * 64 + lane;
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int frame = blockIdx.z;
-    bool keep = false;
-    // corners only exist for 3 <= x < w-3, 3 <= y < h-3, so the 3x3 neighbourhood is in range
-    if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3) {
-        const unsigned char *c = score + ((size_t)frame * h + y) * w + x;
-        const int s = *c;
-        if (s) {
-            keep = c[-w - 1] < s && c[-w] < s && c[-w + 1] < s && c[-1] < s && c[1] < s &&
-                   c[w - 1] < s && c[w] < s && c[w + 1] < s;
-        }
-    }
-    const unsigned long long word = __ballot(keep);
-    if (lane == 0 && y < h && (int)blockIdx.x < words_per_row) {
-        mask[((size_t)frame * h + y) * words_per_row + blockIdx.x] = word;
-        if (word) atomicAdd(&rowcount[(size_t)frame * h + y], (unsigned)__popcll(word));
-    }
-}
-
-// d_score: n_frames*w*h bytes of scratch, needed when nonmax != 0
+// d_score is no longer used (kept in the signature for the callers' workspace layout)
 imgfd_status launch_fast9(imgfd_ctx *ctx, const uint8_t *d_img, int w, int h, int stride,
                           size_t frame_stride, int n_frames, int threshold, int nonmax,
                           uint8_t *d_score, const CompactBuffers &cb)
 {
-    dim3 grid(cb.words_per_row, ceil_div(h, 4), n_frames);
-    if (!nonmax) {
-        hipLaunchKernelGGL(fast9_detect<0>, grid, dim3(256), 0, ctx->stream, d_img, w, h, stride, frame_stride,
-                           threshold, (unsigned char *)nullptr, cb.mask, cb.rowcount, cb.words_per_row);
-    } else {
-        if (!d_score) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "fast9 non-max suppression needs a score plane");
-        hipLaunchKernelGGL(fast9_detect<1>, grid, dim3(256), 0, ctx->stream, d_img, w, h, stride, frame_stride,
-                           threshold, d_score, cb.mask, cb.rowcount, cb.words_per_row);
-        hipLaunchKernelGGL(fast9_nms, grid, dim3(256), 0, ctx->stream, d_score, w, h, cb.mask, cb.rowcount,
-                           cb.words_per_row);
-    }
+    (void)d_score;
+    dim3 grid(cb.words_per_row, ceil_div(h, F9_TY), n_frames);
+    const int aligned4 = ((size_t)d_img % 4 == 0) && stride % 4 == 0 && frame_stride % 4 == 0;
+    if (!nonmax)
+        hipLaunchKernelGGL(fast9_tile<0>, grid, dim3(256), 0, ctx->stream, d_img, w, h, stride, frame_stride, threshold,
+                           aligned4, cb.mask, cb.rowcount, cb.words_per_row);
+    else
+        hipLaunchKernelGGL(fast9_tile<1>, grid, dim3(256), 0, ctx->stream, d_img, w, h, stride, frame_stride, threshold,
+                           aligned4, cb.mask, cb.rowcount, cb.words_per_row);
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }

@@ -501,15 +501,10 @@ static bool fir_has_fast_path(int R, int mode)
 size_t gaussian_tmp_bytes(int nx, int ny, int n_frames, float sigma, int type, int planes)
 {
     (void)planes;
-    if (type == 1) return sizeof(float) * (size_t)nx * ny * n_frames;  // SII scratch
-    if (type != 0 || sigma <= 0) return 0;
-    int size = (int)(3 * sigma) + 1;
-    return sizeof(float) * (size_t)nx * ny * n_frames;  // generic two-pass scratch (unused on fast paths)
-    (void)size;
+    if (type == IMGFD_FAST_GAUSSIAN) return sizeof(float) * sii_scratch_floats(nx, ny, sigma) * n_frames;  // cumulative sums
+    if (type != IMGFD_STD_GAUSSIAN || sigma <= 0) return 0;
+    return sizeof(float) * (size_t)nx * ny * n_frames;  // generic two-pass scratch (unused on the marching fast paths)
 }
-
-imgfd_status launch_sii_gaussian(imgfd_ctx *ctx, const float *d_in, float *d_out, int nx, int ny,
-                                 int n_frames, float sigma);
 
 // gaussian(): gaussian.cpp:403-430.  d_in may be u8 or f32 with its own pitch; d_out is a packed
 // f32 plane; d_tmp (nx*ny*n_frames floats) is needed for the generic/SII paths only.
@@ -525,14 +520,15 @@ imgfd_status launch_gaussian(imgfd_ctx *ctx, const void *d_in, int in_is_u8, int
         IMGFD_HIP(ctx, hipGetLastError());
         return IMGFD_OK;
     };
-    if (type == 1) {
-        if (in_is_u8 || in_pitch != nx || d_in == (const void *)d_out) {
-            if (!d_tmp) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "SII gaussian needs a scratch plane");
+    if (type == IMGFD_FAST_GAUSSIAN) {
+        if (!(sigma > 0)) return copy();
+        if (in_is_u8 || in_pitch != nx || in_frame_stride != (size_t)nx * ny) {
+            // widen / repack into the output plane, then filter it in place (the cumulative sums live in d_tmp)
             hipLaunchKernelGGL(plane_copy, cgrid, dim3(256), 0, ctx->stream, d_in, in_is_u8, in_pitch,
-                               in_frame_stride, d_tmp, nx, ny);
-            return launch_sii_gaussian(ctx, d_tmp, d_out, nx, ny, n_frames, sigma);
+                               in_frame_stride, d_out, nx, ny);
+            return launch_sii_gaussian(ctx, d_out, d_out, nx, ny, n_frames, sigma, d_tmp);
         }
-        return launch_sii_gaussian(ctx, (const float *)d_in, d_out, nx, ny, n_frames, sigma);
+        return launch_sii_gaussian(ctx, (const float *)d_in, d_out, nx, ny, n_frames, sigma, d_tmp);
     }
     if (type != 0 || sigma <= 0) return copy();  // NO_GAUSSIAN / sigma<=0: gaussian.cpp:299-305, 424-429
     FirParams p;
@@ -570,14 +566,11 @@ imgfd_status launch_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const fl
         IMGFD_HIP(ctx, hipGetLastError());
         return IMGFD_OK;
     };
-    if (gauss == 1) {
-        if (!d_tmp) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "SII structure tensor needs a scratch plane");
+    if (gauss == IMGFD_FAST_GAUSSIAN) {
         IMGFD_TRY(products());
+        if (!(sigma > 0)) return IMGFD_OK;
         float *pl[3] = {d_A, d_B, d_C};
-        for (int i = 0; i < 3; i++) {
-            IMGFD_HIP(ctx, hipMemcpyAsync(d_tmp, pl[i], n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-            IMGFD_TRY(launch_sii_gaussian(ctx, d_tmp, pl[i], nx, ny, n_frames, sigma));
-        }
+        for (int i = 0; i < 3; i++) IMGFD_TRY(launch_sii_gaussian(ctx, pl[i], pl[i], nx, ny, n_frames, sigma, d_tmp));  // in place, harris.cpp:67-69
         return IMGFD_OK;
     }
     if (sigma <= 0) return products();

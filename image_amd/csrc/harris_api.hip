@@ -159,10 +159,21 @@ struct HarrisArgs {
     int gauss, grad, measure, strategy, cells, N, precision, verbose;
 };
 
-size_t harris_ws_bytes(int nx, int ny, int n_frames, int64_t cap)
+// floats per frame of the scratch plane `tmp`: one image plane, or the padded cumulative-sum plane of the SII Gaussian
+size_t harris_tmp_floats(int nx, int ny, float sigma_d, float sigma_i, int gauss)
+{
+    size_t n = (size_t)nx * ny;
+    if (gauss != IMGFD_STD_GAUSSIAN) {  // code 1: SII everywhere; code 2: SII for the structure tensor (harris.cpp:64-65)
+        n = std::max(n, sii_scratch_floats(nx, ny, sigma_i));
+        if (gauss == IMGFD_FAST_GAUSSIAN) n = std::max(n, sii_scratch_floats(nx, ny, sigma_d));
+    }
+    return n;
+}
+
+size_t harris_ws_bytes(int nx, int ny, int n_frames, int64_t cap, size_t tmp_floats)
 {
     const size_t plane = align_up(sizeof(float) * (size_t)nx * ny * n_frames, 256);
-    return 8 * plane + compact_bytes(nx, ny, n_frames) + align_up(sizeof(imgfd_corner) * (size_t)cap * n_frames, 256) +
+    return 7 * plane + align_up(sizeof(float) * tmp_floats * n_frames, 256) + compact_bytes(nx, ny, n_frames) + align_up(sizeof(imgfd_corner) * (size_t)cap * n_frames, 256) +
            align_up(sizeof(float) * 9 * (size_t)cap * n_frames, 256) + align_up(sizeof(int64_t) * n_frames, 256) + 4096;
 }
 
@@ -171,14 +182,16 @@ struct HarrisPlanes {
     CompactBuffers cb;
 };
 
-imgfd_status carve_planes(imgfd_ctx *ctx, int nx, int ny, int n_frames, HarrisPlanes *hp)
+imgfd_status carve_planes(imgfd_ctx *ctx, int nx, int ny, int n_frames, size_t tmp_floats, HarrisPlanes *hp)
 {
     const size_t bytes = sizeof(float) * (size_t)nx * ny * n_frames;
-    float **pl[8] = {&hp->Is, &hp->Ix, &hp->Iy, &hp->A, &hp->B, &hp->C, &hp->R, &hp->tmp};
+    float **pl[7] = {&hp->Is, &hp->Ix, &hp->Iy, &hp->A, &hp->B, &hp->C, &hp->R};
     for (auto p : pl) {
         *p = (float *)ws_alloc(ctx, bytes);
         if (!*p) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
     }
+    hp->tmp = (float *)ws_alloc(ctx, sizeof(float) * tmp_floats * n_frames);
+    if (!hp->tmp) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
     return compact_carve(ctx, nx, ny, n_frames, &hp->cb);
 }
 
@@ -186,7 +199,7 @@ imgfd_status carve_planes(imgfd_ctx *ctx, int nx, int ny, int n_frames, HarrisPl
 imgfd_status harris_device_stages(imgfd_ctx *ctx, const void *d_in, int in_is_u8, int in_pitch,
                                   size_t in_frame_stride, int nx, int ny, int n_frames, const HarrisArgs &a,
                                   const HarrisPlanes &hp, imgfd_corner *d_corners, int64_t cap, int64_t *d_counts,
-                                  double *stage_seconds)
+                                  double *stage_seconds, bool need_R_plane)
 {
     double t0 = 0;
     auto tick = [&](int stage) -> imgfd_status {
@@ -209,9 +222,16 @@ imgfd_status harris_device_stages(imgfd_ctx *ctx, const void *d_in, int in_is_u8
                                       hp.tmp));
     IMGFD_TRY(prof_mark(ctx));
     IMGFD_TRY(tick(2));
+    const int radius = (int)(2 * a.sigma_i + 0.5);  // harris.cpp:523, double -> int truncation
+    if (!need_R_plane && harris_resp_nms_supports(nx, ny, radius)) {
+        // batch path: response + NMS in one kernel, strengths recomputed for the corner records (no R plane)
+        IMGFD_TRY(launch_harris_resp_nms(ctx, hp.A, hp.B, hp.C, nx, ny, n_frames, a.measure, a.k, a.Th, radius, hp.cb));
+        IMGFD_TRY(compact_emit_abc(ctx, hp.cb, nx, ny, n_frames, hp.A, hp.B, hp.C, a.measure, a.k, d_corners, cap, d_counts));
+        IMGFD_TRY(tick(4));
+        return IMGFD_OK;
+    }
     IMGFD_TRY(launch_response(ctx, hp.A, hp.B, hp.C, hp.R, nx, ny, n_frames, a.measure, a.k));
     IMGFD_TRY(tick(3));
-    const int radius = (int)(2 * a.sigma_i + 0.5);  // harris.cpp:523, double -> int truncation
     IMGFD_TRY(launch_harris_nms(ctx, hp.R, nx, ny, n_frames, a.Th, radius, hp.cb));
     IMGFD_TRY(compact_emit(ctx, hp.cb, nx, ny, n_frames, 0, hp.R, d_corners, cap, d_counts));
     IMGFD_TRY(tick(4));
@@ -230,13 +250,14 @@ imgfd_status harris_one(imgfd_ctx *ctx, const float *d_I, int nx, int ny, const 
         // d_I lives in the caller's arena slice; planes are carved after the current watermark
         const size_t mark = ctx->ws_used;
         HarrisPlanes hp;
-        IMGFD_TRY(carve_planes(ctx, nx, ny, 1, &hp));
+        IMGFD_TRY(carve_planes(ctx, nx, ny, 1, harris_tmp_floats(nx, ny, a.sigma_d, a.sigma_i, a.gauss), &hp));
         imgfd_corner *d_corners = (imgfd_corner *)ws_alloc(ctx, sizeof(imgfd_corner) * (size_t)cap);
         float *d_M = (float *)ws_alloc(ctx, sizeof(float) * 9 * (size_t)cap);
         int64_t *d_count = (int64_t *)ws_alloc(ctx, sizeof(int64_t));
         if (!d_corners || !d_M || !d_count) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+        const bool sub_px = a.precision == IMGFD_QUADRATIC_APPROXIMATION || a.precision == IMGFD_QUARTIC_INTERPOLATION;
         IMGFD_TRY(harris_device_stages(ctx, d_I, 0, nx, (size_t)nx * ny, nx, ny, 1, a, hp, d_corners, cap, d_count,
-                                       stage_seconds));
+                                       stage_seconds, /*need_R_plane=*/sub_px || stage_seconds != nullptr));
         int64_t n = 0;
         IMGFD_HIP(ctx, hipMemcpyAsync(&n, d_count, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
         IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -325,7 +346,9 @@ imgfd_status imgfd_harris(imgfd_ctx *ctx, const float *img, int nx, int ny, floa
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
     // arena: the input plane, a half-size pyramid for the scale check, and one set of stage planes
     const size_t plane = align_up(sizeof(float) * (size_t)nx * ny, 256);
-    size_t need = plane + harris_ws_bytes(nx, ny, 1, (int64_t)nx * ny / 4 + 16);
+    // (the coarser scales use sigma_i/2, /4, ... on smaller images: their scratch is never larger than this one)
+    size_t need = plane + harris_ws_bytes(nx, ny, 1, (int64_t)nx * ny / 4 + 16,
+                                          harris_tmp_floats(nx, ny, sigma_d, sigma_i, gaussian));
     if (Nscales > 1) need += plane;  // sum of the decimated copies is < plane/3; keep it simple
     IMGFD_TRY(ws_reserve(ctx, need));
     float *d_I = (float *)ws_alloc(ctx, sizeof(float) * (size_t)nx * ny);
@@ -364,16 +387,17 @@ imgfd_status imgfd_harris_dev(imgfd_ctx *ctx, const imgfd_frames *fr, float k, f
     // sub-batches bounded by ~3 GiB of stage planes
     const size_t per_frame = 8 * sizeof(float) * (size_t)nx * ny;
     int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)fr->n_frames, ((size_t)3 << 30) / per_frame));
-    IMGFD_TRY(ws_reserve(ctx, harris_ws_bytes(nx, ny, chunk, 0)));
+    const size_t tmp_floats = harris_tmp_floats(nx, ny, sigma_d, sigma_i, gaussian);
+    IMGFD_TRY(ws_reserve(ctx, harris_ws_bytes(nx, ny, chunk, 0, tmp_floats)));
     HarrisPlanes hp;
-    IMGFD_TRY(carve_planes(ctx, nx, ny, chunk, &hp));
+    IMGFD_TRY(carve_planes(ctx, nx, ny, chunk, tmp_floats, &hp));
     HarrisArgs a{k, sigma_d, sigma_i, threshold, gaussian, gradient, measure, 0, 0, 0, 0, 0};
     for (int f0 = 0; f0 < fr->n_frames; f0 += chunk) {
         const int nf = std::min(chunk, fr->n_frames - f0);
         const char *base = (const char *)fr->d_frames + (size_t)f0 * fr->frame_stride_bytes;
         IMGFD_TRY(harris_device_stages(ctx, base, fr->dtype == 0, fr->row_stride_bytes / esz,
                                        fr->frame_stride_bytes / esz, nx, ny, nf, a, hp, d_corners + (size_t)f0 * cap,
-                                       cap, d_counts + f0, nullptr));
+                                       cap, d_counts + f0, nullptr, /*need_R_plane=*/false));
     }
     return IMGFD_OK;
 }
@@ -382,8 +406,9 @@ imgfd_status imgfd_harris_dev(imgfd_ctx *ctx, const imgfd_frames *fr, float k, f
 imgfd_status imgfd_k_gaussian(imgfd_ctx *ctx, const float *d_in, float *d_out, int nx, int ny, float sigma, int type)
 {
     if (!ctx || !d_in || !d_out || nx < 1 || ny < 1) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_k_gaussian: bad argument");
-    IMGFD_TRY(ws_reserve(ctx, sizeof(float) * (size_t)nx * ny + 4096));
-    float *tmp = (float *)ws_alloc(ctx, sizeof(float) * (size_t)nx * ny);
+    const size_t tb = std::max(gaussian_tmp_bytes(nx, ny, 1, sigma, type, 1), sizeof(float) * (size_t)nx * ny);
+    IMGFD_TRY(ws_reserve(ctx, tb + 4096));
+    float *tmp = (float *)ws_alloc(ctx, tb);
     return launch_gaussian(ctx, d_in, 0, nx, (size_t)nx * ny, d_out, nx, ny, 1, sigma, type, tmp);
 }
 
@@ -398,8 +423,10 @@ imgfd_status imgfd_k_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const f
 {
     if (!ctx || !d_Ix || !d_Iy || !d_A || !d_B || !d_C || nx < 1 || ny < 1)
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_k_structure_tensor: bad argument");
-    IMGFD_TRY(ws_reserve(ctx, sizeof(float) * (size_t)nx * ny + 4096));
-    float *tmp = (float *)ws_alloc(ctx, sizeof(float) * (size_t)nx * ny);
+    const size_t tb = std::max(gaussian_tmp_bytes(nx, ny, 1, sigma, gauss == IMGFD_NO_GAUSSIAN ? IMGFD_FAST_GAUSSIAN : gauss, 3),
+                               sizeof(float) * (size_t)nx * ny);
+    IMGFD_TRY(ws_reserve(ctx, tb + 4096));
+    float *tmp = (float *)ws_alloc(ctx, tb);
     return launch_structure_tensor(ctx, d_Ix, d_Iy, d_A, d_B, d_C, nx, ny, 1, sigma, gauss, tmp);
 }
 

@@ -1,0 +1,26 @@
+// image_amd/csrc/harris_device.h -- the corner strength function shared by the kernels that need a value of R:
+// compute_corner_response(), image.CornerDetectionHarris/src/harris.cpp:78-133.  One definition, so the plane
+// written by response_kernel, the values the fused response+NMS kernel compares and the strengths emitted with the
+// corner list are the same bits (library built -ffp-contract=off: rounds where the reference's x86-64 build rounds).
+#pragma once
+#include "common.h"
+
+template <int MEASURE>
+__device__ __forceinline__ float harris_response_value(float a, float b, float c, float k)
+{
+    if (MEASURE == IMGFD_SHI_TOMASI_MEASURE) {
+        // harris.cpp:112-115: float expression, float sqrt, then double arithmetic, float store
+        const float D = sqrtf(a * a - 2 * a * c + 4 * b * b + c * c);
+        return (float)(0.5 * (a + c) - 0.5 * D);
+    } else if (MEASURE == IMGFD_HARMONIC_MEAN_MEASURE) {
+        // harris.cpp:125-128: float det/trace, double divide
+        const float detA = a * c - b * b;
+        const float traceA = a + c;
+        return (float)(2 * detA / (traceA + 0.0001));
+    } else {
+        // harris.cpp:100-103
+        const float detA = a * c - b * b;
+        const float traceA = a + c;
+        return detA - k * traceA * traceA;
+    }
+}

@@ -4,6 +4,7 @@
 // The library is compiled with -ffp-contract=off: every float expression below rounds exactly where
 // the reference's x86-64 build (no FMA) rounds.
 #include "common.h"
+#include "harris_device.h"
 
 // The reference fills the interior, then copies row 1 / ny-2 into rows 0 / ny-1 for columns
 // 1..nx-2 (gradient.cpp:40-46), then copies column 1 / nx-2 into columns 0 / nx-1 for ALL rows
@@ -55,24 +56,7 @@ __global__ void __launch_bounds__(256) response_kernel(const float *__restrict__
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float a = A[i], b = B[i], c = C[i];
-    float r;
-    if (MEASURE == IMGFD_SHI_TOMASI_MEASURE) {
-        // harris.cpp:112-115: float expression, float sqrt, then double arithmetic, float store
-        const float D = sqrtf(a * a - 2 * a * c + 4 * b * b + c * c);
-        r = (float)(0.5 * (a + c) - 0.5 * D);
-    } else if (MEASURE == IMGFD_HARMONIC_MEAN_MEASURE) {
-        // harris.cpp:125-128: float det/trace, double divide
-        const float detA = a * c - b * b;
-        const float traceA = a + c;
-        r = (float)(2 * detA / (traceA + 0.0001));
-    } else {
-        // harris.cpp:100-103
-        const float detA = a * c - b * b;
-        const float traceA = a + c;
-        r = detA - k * traceA * traceA;
-    }
-    R[i] = r;
+    R[i] = harris_response_value<MEASURE>(A[i], B[i], C[i], k);
 }
 
 imgfd_status launch_response(imgfd_ctx *ctx, const float *d_A, const float *d_B, const float *d_C,

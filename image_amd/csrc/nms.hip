@@ -12,6 +12,7 @@
 // with one integer atomic per non-empty word.  A cheap 3x3 pre-test rejects almost every pixel above
 // the threshold before the full window is read (reads hit L1/L2: R is streamed once from HBM).
 #include "common.h"
+#include "harris_device.h"
 
 __global__ void __launch_bounds__(256) harris_nms_kernel(const float *__restrict__ R, int nx, int ny, float Th,
                                                          int radius, unsigned long long *__restrict__ mask,
@@ -62,6 +63,121 @@ imgfd_status launch_harris_nms(imgfd_ctx *ctx, const float *d_R, int nx, int ny,
     dim3 grid(cb.words_per_row, ceil_div(ny, 4), n_frames);
     hipLaunchKernelGGL(harris_nms_kernel, grid, dim3(256), 0, ctx->stream, d_R, nx, ny, Th, radius, cb.mask,
                        cb.rowcount, cb.words_per_row);
+    IMGFD_HIP(ctx, hipGetLastError());
+    return IMGFD_OK;
+}
+
+// ------------------------------------------------------------------ K4 + K5 fused (batch path)
+// The response plane is never materialised.  One workgroup owns a 64x32 tile: (1) R of the tile plus a halo of
+// `radius` (<= RN_HALO) pixels is computed from A, B, C into LDS; (2) every pixel applies the threshold and the 3x3
+// part of the window rule from LDS, survivors go to an LDS candidate list; (3) the waves take candidates in turn and
+// test the full (2r+1)^2 window with all 64 lanes (2 window positions per lane, __any as the verdict): no lane waits
+// for a neighbour's long loop; (4) one __ballot per tile row is the mask word.  HBM traffic: the 12 B/px of A, B, C
+// (halo re-reads are L2 hits).
+#define RN_TX 64
+#define RN_TY 32
+#define RN_HALO 6
+#define RN_MAXC 512  // 3x3 local maxima cannot be denser than one per 2x2 block: 64*32/4
+
+template <int MEASURE>
+__global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                              const float *__restrict__ C, int nx, int ny, float k, float Th,
+                                                              int radius, unsigned long long *__restrict__ mask,
+                                                              unsigned *__restrict__ rowcount, int words_per_row)
+{
+    constexpr int LW = RN_TX + 2 * RN_HALO, LH = RN_TY + 2 * RN_HALO;
+    __shared__ float sR[LH][LW + 1];
+    __shared__ unsigned cand[RN_MAXC];            // (row << 8) | column, tile coordinates
+    __shared__ unsigned char keep[RN_TY][RN_TX];
+    __shared__ unsigned ncand;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int x0 = blockIdx.x * RN_TX, y0 = blockIdx.y * RN_TY;
+    const size_t fo = (size_t)blockIdx.z * nx * ny;
+    const float *Af = A + fo, *Bf = B + fo, *Cf = C + fo;
+    const int H = radius;  // <= RN_HALO (the launcher falls back to the two-kernel path otherwise)
+    if (tid == 0) ncand = 0;
+    for (int i = tid; i < RN_TY * RN_TX; i += 256) keep[i / RN_TX][i % RN_TX] = 0;
+    const int w = RN_TX + 2 * H, hgt = RN_TY + 2 * H;
+    for (int i = tid; i < hgt * w; i += 256) {
+        const int r = i / w, c = i - r * w;
+        const int gx = x0 + c - H, gy = y0 + r - H;
+        float v = 0.f;  // outside the image: never compared (the search domain stays `radius` away from the border)
+        if (gx >= 0 && gx < nx && gy >= 0 && gy < ny) {
+            const size_t p = (size_t)gy * nx + gx;
+            v = harris_response_value<MEASURE>(Af[p], Bf[p], Cf[p], k);
+        }
+        sR[r][c] = v;
+    }
+    __syncthreads();
+    // (2) threshold + 3x3 pre-test with the window rule's own comparisons
+    for (int r = wv; r < RN_TY; r += 4) {
+        const int x = x0 + lane, y = y0 + r;
+        if (y < ny && x >= radius && x < nx - radius && y >= radius && y < ny - radius) {
+            const int rr = r + H, cc = lane + H;
+            const float v = sR[rr][cc];
+            if (!(v < Th)) {  // skip[] = R < Th, harris.cpp:160-162
+                const bool ok = !(sR[rr - 1][cc - 1] >= v) && !(sR[rr - 1][cc] >= v) && !(sR[rr - 1][cc + 1] >= v) &&
+                                !(sR[rr][cc + 1] >= v) && !(sR[rr][cc - 1] > v) && !(sR[rr + 1][cc - 1] > v) &&
+                                !(sR[rr + 1][cc] > v) && !(sR[rr + 1][cc + 1] > v);
+                if (ok) {
+                    const unsigned slot = atomicAdd(&ncand, 1u);
+                    if (slot < RN_MAXC) cand[slot] = ((unsigned)r << 8) | (unsigned)lane;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // (3) full window, one candidate per wave at a time, window positions spread over the lanes
+    const int n = min((int)ncand, RN_MAXC);
+    const int side = 2 * radius + 1, npos = side * side;
+    for (int ci = wv; ci < n; ci += 4) {
+        const int r = cand[ci] >> 8, c = cand[ci] & 255;
+        const float v = sR[r + H][c + H];
+        bool fail = false;
+        for (int pidx = lane; pidx < npos; pidx += 64) {
+            const int dy = pidx / side - radius, dx = pidx % side - radius;
+            if (dy == 0 && dx == 0) continue;
+            const float q = sR[r + H + dy][c + H + dx];
+            const bool strict = dy < 0 || (dy == 0 && dx > 0);  // above, or to the right on the same row: must be <
+            fail = fail || (strict ? (q >= v) : (q > v));
+        }
+        if (!__any(fail) && lane == 0) keep[r][c] = 1;
+    }
+    __syncthreads();
+    // (4) mask words
+    for (int r = wv; r < RN_TY; r += 4) {
+        const int y = y0 + r;
+        const unsigned long long word = __ballot(keep[r][lane] != 0);
+        if (lane == 0 && y < ny) {
+            mask[((size_t)blockIdx.z * ny + y) * words_per_row + blockIdx.x] = word;
+            if (word) atomicAdd(&rowcount[(size_t)blockIdx.z * ny + y], (unsigned)__popcll(word));
+        }
+    }
+}
+
+// false when the fused kernel cannot serve this radius (its LDS halo is RN_HALO): use response + NMS kernels instead
+bool harris_resp_nms_supports(int nx, int ny, int radius)
+{
+    if (ny <= 2 * radius + 1 || nx <= 2 * radius + 1) return true;  // empty search domain: any radius works
+    return (radius < 1 ? 1 : radius) <= RN_HALO;
+}
+
+imgfd_status launch_harris_resp_nms(imgfd_ctx *ctx, const float *d_A, const float *d_B, const float *d_C, int nx, int ny,
+                                    int n_frames, int measure, float k, float Th, int radius, const CompactBuffers &cb)
+{
+    if (ny <= 2 * radius + 1 || nx <= 2 * radius + 1) {
+        // harris.cpp:151-152: nothing is detected on images not larger than the window
+        IMGFD_HIP(ctx, hipMemsetAsync(cb.mask, 0, sizeof(unsigned long long) * (size_t)cb.words_per_row * ny * n_frames, ctx->stream));
+        return IMGFD_OK;
+    }
+    if (radius < 1) radius = 1;
+    if (radius > RN_HALO) return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "fused response+NMS: radius exceeds the LDS halo");
+    dim3 grid(cb.words_per_row, ceil_div(ny, RN_TY), n_frames);
+#define RN_LAUNCH(M) hipLaunchKernelGGL(harris_resp_nms_kernel<M>, grid, dim3(256), 0, ctx->stream, d_A, d_B, d_C, nx, ny, k, Th, radius, cb.mask, cb.rowcount, cb.words_per_row)
+    if (measure == IMGFD_SHI_TOMASI_MEASURE) RN_LAUNCH(1);
+    else if (measure == IMGFD_HARMONIC_MEAN_MEASURE) RN_LAUNCH(2);
+    else RN_LAUNCH(0);
+#undef RN_LAUNCH
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }

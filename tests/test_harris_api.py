@@ -19,8 +19,9 @@ CASES = {
     "distributed": dict(strategy=3, Nselect=100),
     "three_scales": dict(Nscales=3),
 }
-SII_CASES = {"rcpp_default": dict(gaussian=1, precision=1), "no_gaussian": dict(gaussian=2),
-             "two_scales": dict(gaussian=1, Nscales=2)}
+# gaussian codes 1 and 2 run the stacked-integral-images Gaussian (sii.hip): sequential float prefix sums, bit-exact
+CASES.update({"rcpp_default": dict(gaussian=1, precision=1), "no_gaussian": dict(gaussian=2),
+              "two_scales": dict(gaussian=1, Nscales=2)})
 
 
 def bits(a):
@@ -88,3 +89,28 @@ def test_batch_dev_cap_truncates_but_counts_all(be):
     part, counts2 = be.harris_dev(frames, cap=8, threshold=10.0)
     assert counts2[0] == counts[0] and len(part[0]) == 8
     assert np.array_equal(bits(part[0]), bits(full[0][:8]))
+
+
+@pytest.mark.parametrize("kw", [dict(measure=1, threshold=1.0), dict(measure=2, threshold=1.0), dict(sigma_i=4.0),
+                                dict(sigma_i=0.4, threshold=50.0), dict(gradient=1), dict(gaussian=2),
+                                dict(sigma_i=3.0, threshold=5.0)])
+def test_batch_dev_options(be, kw):
+    """the fused response+NMS kernel (window radius <= 6), its two-kernel fallback (sigma_i 4 -> radius 8) and the
+    other measures / gradients give the reference's corner list in the batch path too"""
+    frames = np.stack([synth.frame(120 + f, 180, 131) for f in range(2)])
+    be.set_fir_mode(0)
+    lists, counts = be.harris_dev(frames, **kw)
+    for f in range(2):
+        ref = oracle.harris(frames[f].astype(np.float32), **kw)
+        assert counts[f] == len(ref), kw
+        assert np.array_equal(bits(lists[f]), bits(ref)), kw
+
+
+def test_batch_dev_tile_borders(be):
+    """sizes that straddle the 64x32 tiles of the fused kernel and its candidate list"""
+    be.set_fir_mode(0)
+    for nx, ny in [(64, 32), (65, 33), (127, 63), (130, 97), (13, 40)]:
+        img = synth.frame(9, max(nx, 16), max(ny, 16))[:ny, :nx]
+        lists, counts = be.harris_dev(img[None], threshold=1.0)
+        ref = oracle.harris(img.astype(np.float32), threshold=1.0)
+        assert counts[0] == len(ref) and np.array_equal(bits(lists[0]), bits(ref)), (nx, ny)

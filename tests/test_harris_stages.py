@@ -37,6 +37,24 @@ def test_gaussian_other_sigmas_bit_exact(be, sigma):
     assert_bits_equal(got, oracle.harris_stage("gaussian", img, sigma=sigma, type=0), f"discrete_gaussian {sigma}")
 
 
+@pytest.mark.parametrize("sigma", [1.0, 2.5, 0.3, 6.0])
+@pytest.mark.parametrize("nx,ny", [(64, 48), (201, 77), (70, 130)])
+def test_sii_gaussian_bit_exact(be, nx, ny, sigma):
+    """gaussian code 1: stacked integral images, gaussian.cpp:61-281 (sequential float prefix sums)"""
+    img = synth.frame(20, nx, ny).astype(np.float32)
+    got = be.k_gaussian(img, sigma, 1)
+    assert_bits_equal(got, oracle.harris_stage("gaussian", img, sigma=sigma, type=1), f"SII gaussian {sigma}")
+
+
+@pytest.mark.parametrize("gauss", [1, 2])
+def test_structure_tensor_sii_bit_exact(be, gauss):
+    ix, iy = _gradients(21, 200, 150)
+    got = be.k_structure_tensor(ix, iy, 2.5, gauss)
+    ref = oracle.harris_stage("autocorrelation", ix, iy, sigma=2.5, gauss=gauss)
+    for g, r, nm in zip(got, ref, "ABC"):
+        assert_bits_equal(g, r, f"structure tensor {nm} gauss {gauss}")
+
+
 def test_gaussian_copy_cases(be):
     img = synth.frame(13, 40, 30).astype(np.float32)
     assert_bits_equal(be.k_gaussian(img, 1.0, 2), img, "NO_GAUSSIAN is a copy")
