@@ -234,6 +234,29 @@ __global__ void __launch_bounds__(BM_NT) canny_blur_march(BlurMarchParams p)
 #define GN_TX 64  // tile width = one __ballot word
 #define GN_TY 16
 
+// gradient of the blurred image at (gx, gy), rcpp_canny.cpp:153-170, from the LDS tile `sb` (tile origin x0-2, y0-2).
+// value() clamps coordinates (:38-62), so a neighbour outside the image stands for the border pixel.
+struct CannyGrad { double h, v; };
+__device__ __forceinline__ CannyGrad canny_gradient(const float (*sb)[GN_TX + 4 + 1], int gx, int gy, int x0, int y0, int nx,
+                                                    int ny, int accGrad)
+{
+    const int xm = max(gx - 1, 0) - x0 + 2, xp = min(gx + 1, nx - 1) - x0 + 2, xc = gx - x0 + 2;
+    const int ym = max(gy - 1, 0) - y0 + 2, yp = min(gy + 1, ny - 1) - y0 + 2, yc = gy - y0 + 2;
+    CannyGrad g;
+    if (accGrad) {  // :157-163, evaluation order preserved
+        g.h = 2 * ((double)sb[yc][xp] - (double)sb[yc][xm]) + (double)sb[yp][xp] - (double)sb[yp][xm] +
+              (double)sb[ym][xp] - (double)sb[ym][xm];
+        g.v = 2 * ((double)sb[yp][xc] - (double)sb[ym][xc]) + (double)sb[yp][xp] - (double)sb[ym][xp] +
+              (double)sb[yp][xm] - (double)sb[ym][xm];
+    } else {        // :167-169
+        g.h = (double)sb[yc][xp] - (double)sb[yc][xm];
+        g.v = (double)sb[yp][xc] - (double)sb[ym][xc];
+    }
+    return g;
+}
+// |g|: h and v are exact in f64 (sums of a few floats); sqrt(fma(h,h,v*v)) is within one ulp of hypot(h,v) (:172)
+__device__ __forceinline__ double canny_mag(const CannyGrad &g) { return sqrt(__builtin_fma(g.h, g.h, g.v * g.v)); }
+
 // strong / marked bit planes: word (y, bx) covers pixels x = 64*bx .. 64*bx+63 of row y
 __global__ void __launch_bounds__(256) canny_grad_nms(const float *__restrict__ blur, unsigned long long *__restrict__ S,
                                                       unsigned long long *__restrict__ Wm, int nx, int ny,
@@ -241,8 +264,6 @@ __global__ void __launch_bounds__(256) canny_grad_nms(const float *__restrict__ 
 {
     __shared__ float sb[GN_TY + 4][GN_TX + 4 + 1];
     __shared__ double sg[GN_TY + 2][GN_TX + 2 + 1];
-    __shared__ double sh[GN_TY][GN_TX + 1];
-    __shared__ double sv[GN_TY][GN_TX + 1];
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * GN_TX, y0 = blockIdx.y * GN_TY;
     const float *pl = blur + (size_t)blockIdx.z * nx * ny;
@@ -253,52 +274,53 @@ __global__ void __launch_bounds__(256) canny_grad_nms(const float *__restrict__ 
         sb[r][c] = pl[(size_t)gy * nx + gx];
     }
     __syncthreads();
-    // gradient magnitude for the tile + 1 halo.  A halo position outside the image stands for the
-    // clamped pixel (value()), whose own neighbourhood is again clamped: evaluate at clamped coords.
-    for (int i = tid; i < (GN_TY + 2) * (GN_TX + 2); i += 256) {
-        const int r = i / (GN_TX + 2), c = i - r * (GN_TX + 2);
-        const int gx = min(max(x0 + c - 1, 0), nx - 1), gy = min(max(y0 + r - 1, 0), ny - 1);
-        // neighbour coordinates clamped to the image, then mapped into the LDS tile
-        const int xm = max(gx - 1, 0) - x0 + 2, xp = min(gx + 1, nx - 1) - x0 + 2, xc = gx - x0 + 2;
-        const int ym = max(gy - 1, 0) - y0 + 2, yp = min(gy + 1, ny - 1) - y0 + 2, yc = gy - y0 + 2;
-        double h, v;
-        if (accGrad) {  // rcpp_canny.cpp:157-163, evaluation order preserved
-            h = 2 * ((double)sb[yc][xp] - (double)sb[yc][xm]) + (double)sb[yp][xp] - (double)sb[yp][xm] +
-                (double)sb[ym][xp] - (double)sb[ym][xm];
-            v = 2 * ((double)sb[yp][xc] - (double)sb[ym][xc]) + (double)sb[yp][xp] - (double)sb[ym][xp] +
-                (double)sb[yp][xm] - (double)sb[ym][xm];
-        } else {        // :167-169
-            h = (double)sb[yc][xp] - (double)sb[yc][xm];
-            v = (double)sb[yp][xc] - (double)sb[ym][xc];
-        }
-        sg[r][c] = hypot(h, v);
-        if (r >= 1 && r <= GN_TY && c >= 1 && c <= GN_TX) { sh[r - 1][c - 1] = h; sv[r - 1][c - 1] = v; }
+    // gradient magnitude: the thread's own 4 pixels (lane = column, rows wv, wv+4, ...) keep h, v in registers;
+    // the one-pixel ring around the tile is shared out over the first threads.  A ring position outside the image
+    // stands for the clamped pixel, whose own neighbourhood is clamped again: evaluate at clamped coordinates.
+    const int c = tid & 63, wv = tid >> 6;
+    CannyGrad own[GN_TY / 4];
+#pragma unroll
+    for (int q = 0; q < GN_TY / 4; q++) {
+        const int r = wv + 4 * q;
+        own[q] = canny_gradient(sb, min(x0 + c, nx - 1), min(y0 + r, ny - 1), x0, y0, nx, ny, accGrad);
+        sg[r + 1][c + 1] = canny_mag(own[q]);
+    }
+    constexpr int RING = 2 * (GN_TX + 2) + 2 * GN_TY;
+    if (tid < RING) {
+        int r, cc;
+        if (tid < GN_TX + 2) { r = 0; cc = tid; }
+        else if (tid < 2 * (GN_TX + 2)) { r = GN_TY + 1; cc = tid - (GN_TX + 2); }
+        else { const int k = tid - 2 * (GN_TX + 2); r = 1 + (k >> 1); cc = (k & 1) ? GN_TX + 1 : 0; }
+        const int gx = min(max(x0 + cc - 1, 0), nx - 1), gy = min(max(y0 + r - 1, 0), ny - 1);
+        sg[r][cc] = canny_mag(canny_gradient(sb, gx, gy, x0, y0, nx, ny, accGrad));
     }
     __syncthreads();
-    const int c = tid & 63;
-    for (int r = tid >> 6; r < GN_TY; r += 4) {  // one wave per tile row: the ballot is the mask word
+#pragma unroll
+    for (int q = 0; q < GN_TY / 4; q++) {  // one wave per tile row: the ballot is the mask word
+        const int r = wv + 4 * q;
         const int gx = x0 + c, gy = y0 + r;
         int o = 0;
         if (gx < nx && gy < ny) {
             const double now = sg[r + 1][c + 1];
-            // unit direction (cos t, sin t) with t = atan2(v,h); atan2(0,0) = 0 -> (1,0)
+            // unit direction (cos t, sin t) with t = atan2(v,h) (:69-70,173); atan2(0,0) = 0 -> (1,0)
             double ux = 1.0, uy = 0.0;
-            if (now > 0) { ux = sh[r][c] / now; uy = sv[r][c] / now; }
+            if (now > 0) { ux = own[q].h / now; uy = own[q].v / now; }
+            // bilin(), :65-85, for dir = +1: x1 = floor(ux) is -1, 0 or (only when ux == 1 exactly) 1; in that last
+            // case the far tap has weight 0, so x1 = 0 gives the same sum from the 3x3 neighbourhood.  dir = -1
+            // mirrors the offsets.
             double val[2];
 #pragma unroll
             for (int d = 0; d < 2; d++) {
                 const double xt = d ? ux : -ux, yt = d ? uy : -uy;
-                // floor() is -1, 0 or (only when the component is exactly 1) 1; in that last case the far
-                // tap has weight 0, so evaluating with x1 = 0 gives the same sum from the 3x3 neighbourhood
-                const double x1 = fmin(floor(xt), 0.0), y1 = fmin(floor(yt), 0.0);
-                const double x2 = x1 + 1, y2 = y1 + 1;
-                const int cx = c + 1 + (int)x1, cy = r + 1 + (int)y1;
+                const int ix = xt < 0 ? -1 : 0, iy = yt < 0 ? -1 : 0;
+                const double x1 = (double)ix, y1 = (double)iy, x2 = x1 + 1, y2 = y1 + 1;
+                const int cx = c + 1 + ix, cy = r + 1 + iy;
                 const double gx1 = (x2 - xt) * sg[cy][cx] + (xt - x1) * sg[cy][cx + 1];
                 const double gx2 = (x2 - xt) * sg[cy + 1][cx] + (xt - x1) * sg[cy + 1][cx + 1];
                 val[d] = (y2 - yt) * gx1 + (yt - y1) * gx2;
             }
             const double prev = val[0], next = val[1];
-            if ((now <= prev) || (now <= next) || (now <= (double)low_thr)) o = 0;
+            if ((now <= prev) || (now <= next) || (now <= (double)low_thr)) o = 0;  // maxima(), :88-106
             else if (now >= (double)high_thr) o = 2;
             else o = 1;
         }

@@ -79,12 +79,14 @@ imgfd_status launch_harris_nms(imgfd_ctx *ctx, const float *d_R, int nx, int ny,
 #define RN_HALO 6
 #define RN_MAXC 512  // 3x3 local maxima cannot be denser than one per 2x2 block: 64*32/4
 
-template <int MEASURE>
+// HC > 0: the window radius is the compile-time constant HC (index arithmetic by constants); HC == 0: any radius <= RN_HALO
+template <int MEASURE, int HC>
 __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                               const float *__restrict__ C, int nx, int ny, float k, float Th,
-                                                              int radius, unsigned long long *__restrict__ mask,
+                                                              int radius_rt, unsigned long long *__restrict__ mask,
                                                               unsigned *__restrict__ rowcount, int words_per_row)
 {
+    const int radius = HC > 0 ? HC : radius_rt;
     constexpr int LW = RN_TX + 2 * RN_HALO, LH = RN_TY + 2 * RN_HALO;
     __shared__ float sR[LH][LW + 1];
     __shared__ unsigned cand[RN_MAXC];            // (row << 8) | column, tile coordinates
@@ -173,10 +175,11 @@ imgfd_status launch_harris_resp_nms(imgfd_ctx *ctx, const float *d_A, const floa
     if (radius < 1) radius = 1;
     if (radius > RN_HALO) return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "fused response+NMS: radius exceeds the LDS halo");
     dim3 grid(cb.words_per_row, ceil_div(ny, RN_TY), n_frames);
-#define RN_LAUNCH(M) hipLaunchKernelGGL(harris_resp_nms_kernel<M>, grid, dim3(256), 0, ctx->stream, d_A, d_B, d_C, nx, ny, k, Th, radius, cb.mask, cb.rowcount, cb.words_per_row)
-    if (measure == IMGFD_SHI_TOMASI_MEASURE) RN_LAUNCH(1);
-    else if (measure == IMGFD_HARMONIC_MEAN_MEASURE) RN_LAUNCH(2);
-    else RN_LAUNCH(0);
+#define RN_LAUNCH(M, HC) hipLaunchKernelGGL((harris_resp_nms_kernel<M, HC>), grid, dim3(256), 0, ctx->stream, d_A, d_B, d_C, nx, ny, k, Th, radius, cb.mask, cb.rowcount, cb.words_per_row)
+    if (measure == IMGFD_SHI_TOMASI_MEASURE) RN_LAUNCH(1, 0);
+    else if (measure == IMGFD_HARMONIC_MEAN_MEASURE) RN_LAUNCH(2, 0);
+    else if (radius == 5) RN_LAUNCH(0, 5);  // image_harris() defaults: sigma_i 2.5 -> radius 5
+    else RN_LAUNCH(0, 0);
 #undef RN_LAUNCH
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
