@@ -103,8 +103,85 @@ __global__ void __launch_bounds__(256) fhog_grad_orient(const unsigned char *__r
     packed[((size_t)blockIdx.z * g.rows + y) * g.cols + x] = out;
 }
 
+// packed (len << 5 | orientation) of one pixel from its four neighbours' RGB (little-endian dword soup: byte k of the
+// 12-byte group of 4 pixels is channel k%3 of pixel k/3)
+__device__ __forceinline__ unsigned fhog_pack(const int (&l)[3], const int (&r)[3], const int (&u)[3], const int (&d)[3], bool body)
+{
+    int gx[3], gy[3], len[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        gx[ch] = r[ch] - l[ch];
+        gy[ch] = d[ch] - u[ch];
+        len[ch] = gx[ch] * gx[ch] + gy[ch] * gy[ch];
+    }
+    int tx, ty, tl;
+    if (body) {
+        if (len[0] > len[1]) { tx = gx[0]; ty = gy[0]; tl = len[0]; } else { tx = gx[1]; ty = gy[1]; tl = len[1]; }
+        if (!(tl > len[2])) { tx = gx[2]; ty = gy[2]; tl = len[2]; }
+    } else {
+        tx = gx[0]; ty = gy[0]; tl = len[0];
+        if (len[1] > tl) { tl = len[1]; tx = gx[1]; ty = gy[1]; }
+        if (len[2] > tl) { tl = len[2]; tx = gx[2]; ty = gy[2]; }
+    }
+    const float fx = (float)tx, fy = (float)ty;
+    float best_dot = 0;
+    int best_o = 0;
+#pragma unroll
+    for (int o = 0; o < 9; o++) {
+        const float dot = fx * FHOG_DIRS[o][0] + fy * FHOG_DIRS[o][1];
+        if (dot > best_dot) { best_dot = dot; best_o = o; }
+        else if (-dot > best_dot) { best_dot = -dot; best_o = o + 9; }
+    }
+    return ((unsigned)tl << 5) | (unsigned)best_o;
+}
+
+// K13, fast form: one thread per 4 consecutive pixels (12 bytes = 3 aligned dwords per row when cols % 4 == 0 and the
+// frame is 4-byte aligned): 11 dword loads and one 16-byte store per 4 pixels instead of 12 byte loads per pixel.
+__global__ void __launch_bounds__(256) fhog_grad_orient4(const unsigned char *__restrict__ rgb, size_t frame_stride,
+                                                         unsigned *__restrict__ packed, FhogGeom g)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;  // group of 4 pixels
+    const int y = blockIdx.y;
+    const int x = 4 * q;
+    if (x >= g.cols) return;
+    unsigned out[4] = {0u, 0u, 0u, 0u};
+    if (y >= 1 && y < g.visible_nr) {
+        const unsigned *img = reinterpret_cast<const unsigned *>(rgb + (size_t)blockIdx.z * frame_stride);
+        const int rd = 3 * g.cols / 4;  // dwords per row
+        const unsigned *c = img + (size_t)y * rd + 3 * q;
+        unsigned cen[5], up[3], dn[3];
+        cen[0] = q > 0 ? c[-1] : 0u;
+        cen[1] = c[0]; cen[2] = c[1]; cen[3] = c[2];
+        cen[4] = x + 4 < g.cols ? c[3] : 0u;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { up[k] = c[k - rd]; dn[k] = c[k + rd]; }
+        // byte b (0..19) of the 5-dword centre window; pixel p of the group starts at byte 4 + 3p
+        auto cb = [&](int b) -> int { return (int)((cen[b >> 2] >> (8 * (b & 3))) & 0xffu); };
+        auto ub = [&](int b) -> int { return (int)((up[b >> 2] >> (8 * (b & 3))) & 0xffu); };
+        auto db = [&](int b) -> int { return (int)((dn[b >> 2] >> (8 * (b & 3))) & 0xffu); };
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int xx = x + p;
+            if (xx >= 1 && xx < g.visible_nc) {
+                int l[3], r[3], u[3], d[3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    l[ch] = cb(4 + 3 * (p - 1) + ch);
+                    r[ch] = cb(4 + 3 * (p + 1) + ch);
+                    u[ch] = ub(3 * p + ch);
+                    d[ch] = db(3 * p + ch);
+                }
+                out[p] = fhog_pack(l, r, u, d, xx < g.body_end);
+            }
+        }
+    }
+    *reinterpret_cast<uint4 *>(packed + ((size_t)blockIdx.z * g.rows + y) * g.cols + x) = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
 // K14: hist[(hr*HC + hc)*18 + o] for 1 <= hr <= cells_nr, 1 <= hc <= cells_nc (HC = cells_nc+2), and the
-// cell energy norm[(hr-1)*cells_nc + hc-1]
+// cell energy norm[(hr-1)*cells_nc + hc-1].  The column part of every vote (which of the two bilinear weights this
+// cell receives from column x, :838-841 / :946-949) does not depend on the row: it is tabulated once per thread.
+#define FHOG_MAXW 20  // candidate columns per cell: 2*cs + 3 <= 19 for cs <= 8 (larger cells loop over chunks)
 __global__ void __launch_bounds__(64) fhog_cell_hist(const unsigned *__restrict__ packed, float *__restrict__ hist,
                                                      float *__restrict__ norm, FhogGeom g)
 {
@@ -120,39 +197,89 @@ __global__ void __launch_bounds__(64) fhog_cell_hist(const unsigned *__restrict_
     // candidate rows / columns: every pixel whose bilinear footprint can touch this cell, widened by one
     const int y_lo = max(1, cs * (hr - 2) + cs / 2 - 1), y_hi = min(g.visible_nr - 1, cs * hr + cs / 2 + 1);
     const int x_lo = max(1, cs * (hc - 2) + cs / 2 - 1), x_hi = min(g.visible_nc - 1, cs * hc + cs / 2 + 1);
-    for (int y = y_lo; y <= y_hi; y++) {
-        const float yp = ((float)y + 0.5) / (float)cs - 0.5;  // :823-826 (double arithmetic, float result)
-        const int iyp = (int)floor(yp);
-        const float vy0 = yp - iyp;
-        const float vy1 = 1.0 - vy0;
-        float wy;
-        if (iyp + 1 == hr) wy = vy1;
-        else if (iyp + 2 == hr) wy = vy0;
-        else continue;
-        const unsigned *row = pk + (size_t)y * g.cols;
-        for (int x = x_lo; x <= x_hi; x++) {
-            const unsigned p = row[x];
-            const int o = p & 31;
-            const float v = sqrtf((float)(p >> 5));
-            float w;
-            if (x < g.body_end) {  // :838-841, :863-870: hist column ixp / ixp+1, weights vy*(vx*v)
-                const float xp = ((float)x + 0.5f) / (float)cs + 0.5f;
-                const int ixp = (int)xp;
-                const float vx0 = xp - (float)ixp;
-                const float vx1 = 1.0f - vx0;
-                if (ixp == hc) w = wy * (vx1 * v);
-                else if (ixp + 1 == hc) w = wy * (vx0 * v);
-                else continue;
-            } else {               // :946-954: hist column ixp+1 / ixp+2, weights (vy*vx)*v
-                const float xp = ((double)x + 0.5) / (double)cs - 0.5;
-                const int ixp = (int)floor(xp);
-                const float vx0 = xp - ixp;
-                const float vx1 = 1.0 - vx0;
-                if (ixp + 1 == hc) w = wy * vx1 * v;
-                else if (ixp + 2 == hc) w = wy * vx0 * v;
-                else continue;
+    if (x_hi - x_lo + 1 > FHOG_MAXW) {
+        // large cells: the column table does not fit; evaluate the column weights per vote (same order, same values)
+        for (int y = y_lo; y <= y_hi; y++) {
+            const float yp = ((float)y + 0.5) / (float)cs - 0.5;
+            const int iyp = (int)floor(yp);
+            const float vy0 = yp - iyp;
+            const float vy1 = 1.0 - vy0;
+            float wy;
+            if (iyp + 1 == hr) wy = vy1;
+            else if (iyp + 2 == hr) wy = vy0;
+            else continue;
+            const unsigned *row = pk + (size_t)y * g.cols;
+            for (int x = x_lo; x <= x_hi; x++) {
+                const unsigned p = row[x];
+                const float v = sqrtf((float)(p >> 5));
+                float w;
+                if (x < g.body_end) {
+                    const float xp = ((float)x + 0.5f) / (float)cs + 0.5f;
+                    const int ixp = (int)xp;
+                    const float vx0 = xp - (float)ixp;
+                    const float vx1 = 1.0f - vx0;
+                    if (ixp == hc) w = wy * (vx1 * v);
+                    else if (ixp + 1 == hc) w = wy * (vx0 * v);
+                    else continue;
+                } else {
+                    const float xp = ((double)x + 0.5) / (double)cs - 0.5;
+                    const int ixp = (int)floor(xp);
+                    const float vx0 = xp - ixp;
+                    const float vx1 = 1.0 - vx0;
+                    if (ixp + 1 == hc) w = wy * vx1 * v;
+                    else if (ixp + 2 == hc) w = wy * vx0 * v;
+                    else continue;
+                }
+                b[p & 31] += w;
             }
-            b[o] += w;
+        }
+    } else {
+        const int xc = x_lo;
+        // per column: vx (0 = this column does not vote into the cell) and whether it takes the 8-wide path
+        float vx[FHOG_MAXW];
+        bool body[FHOG_MAXW];
+#pragma unroll
+        for (int k = 0; k < FHOG_MAXW; k++) {
+            const int x = xc + k;
+            vx[k] = -1.f;
+            body[k] = x < g.body_end;
+            if (x <= x_hi) {
+                if (body[k]) {  // :838-841: hist column ixp / ixp+1
+                    const float xp = ((float)x + 0.5f) / (float)cs + 0.5f;
+                    const int ixp = (int)xp;
+                    const float vx0 = xp - (float)ixp;
+                    const float vx1 = 1.0f - vx0;
+                    if (ixp == hc) vx[k] = vx1;
+                    else if (ixp + 1 == hc) vx[k] = vx0;
+                } else {        // :946-949: hist column ixp+1 / ixp+2
+                    const float xp = ((double)x + 0.5) / (double)cs - 0.5;
+                    const int ixp = (int)floor(xp);
+                    const float vx0 = xp - ixp;
+                    const float vx1 = 1.0 - vx0;
+                    if (ixp + 1 == hc) vx[k] = vx1;
+                    else if (ixp + 2 == hc) vx[k] = vx0;
+                }
+            }
+        }
+        for (int y = y_lo; y <= y_hi; y++) {
+            const float yp = ((float)y + 0.5) / (float)cs - 0.5;  // :823-826 (double arithmetic, float result)
+            const int iyp = (int)floor(yp);
+            const float vy0 = yp - iyp;
+            const float vy1 = 1.0 - vy0;
+            float wy;
+            if (iyp + 1 == hr) wy = vy1;
+            else if (iyp + 2 == hr) wy = vy0;
+            else continue;
+            const unsigned *row = pk + (size_t)y * g.cols + xc;
+#pragma unroll
+            for (int k = 0; k < FHOG_MAXW; k++) {
+                if (vx[k] >= 0.f) {  // weights are in [0, 1]; -1 marks "no vote"
+                    const unsigned p = row[k];
+                    const float v = sqrtf((float)(p >> 5));
+                    // :863-870 weights vy*(vx*v)  vs  :951-954 (vy*vx)*v
+                    b[p & 31] += body[k] ? wy * (vx[k] * v) : wy * vx[k] * v;
+                }
+            }
         }
     }
     const int HC = g.cells_nc + 2;
@@ -248,8 +375,12 @@ imgfd_status fhog_device(imgfd_ctx *ctx, const uint8_t *d_rgb, size_t frame_stri
     const size_t out_n = (size_t)31 * g.out_nr * g.out_nc * nf;
     if (g.out_nr != g.hog_nr || g.out_nc != g.hog_nc)  // init_hog: zero border of the padded output
         IMGFD_HIP(ctx, hipMemsetAsync(d_out, 0, out_n * sizeof(float), ctx->stream));
-    hipLaunchKernelGGL(fhog_grad_orient, dim3(ceil_div(g.cols, 256), g.rows, nf), dim3(256), 0, ctx->stream, d_rgb,
-                       frame_stride, packed, g);
+    if (g.cols % 4 == 0 && (size_t)d_rgb % 4 == 0 && frame_stride % 4 == 0 && (size_t)packed % 16 == 0)
+        hipLaunchKernelGGL(fhog_grad_orient4, dim3(ceil_div(g.cols / 4, 256), g.rows, nf), dim3(256), 0, ctx->stream, d_rgb,
+                           frame_stride, packed, g);
+    else
+        hipLaunchKernelGGL(fhog_grad_orient, dim3(ceil_div(g.cols, 256), g.rows, nf), dim3(256), 0, ctx->stream, d_rgb,
+                           frame_stride, packed, g);
     hipLaunchKernelGGL(fhog_cell_hist, dim3(ceil_div(g.cells_nc, 8), ceil_div(g.cells_nr, 8), nf), dim3(64), 0,
                        ctx->stream, packed, hist, norm, g);
     hipLaunchKernelGGL(fhog_features, dim3(ceil_div(g.hog_nr, 64), ceil_div(g.hog_nc, 4), nf), dim3(256), 0, ctx->stream,
