@@ -347,6 +347,33 @@ imgfd_status imgfd_surf_interest_points(imgfd_ctx *ctx, const uint8_t *rgb, int 
     return IMGFD_OK;
 }
 
+imgfd_status imgfd_surf_points_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, int rows, int cols,
+                                   size_t frame_stride_bytes, double detection_threshold, imgfd_surf_point *d_points,
+                                   int64_t cap, int64_t *d_counts)
+{
+    if (!ctx) return IMGFD_ERR_INVALID;
+    if (!d_rgb || !d_points || !d_counts || n_frames < 0 || rows < 1 || cols < 1 || cap < 1 || !(detection_threshold >= 0))
+        return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_surf_points_dev: bad argument");
+    static_assert(sizeof(imgfd_surf_point) == sizeof(SurfRecord), "record layout");
+    if (!n_frames) return IMGFD_OK;
+    IMGFD_HIP(ctx, hipSetDevice(ctx->device));
+    SurfGeom g;
+    const size_t total = surf_geometry(rows, cols, &g);
+    const size_t n = (size_t)rows * cols;
+    IMGFD_TRY(ws_reserve(ctx, align_up(4 * n, 256) + align_up(8 * std::max<size_t>(total, 1), 256) + 4096));
+    SurfDevice d;
+    d.integral = (unsigned *)ws_alloc(ctx, 4 * n);
+    d.pyr = (double *)ws_alloc(ctx, 8 * std::max<size_t>(total, 1));
+    if (!d.integral || !d.pyr) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    d.cap = (unsigned long long)cap;
+    for (int f = 0; f < n_frames; f++) {  // tiles are processed back to back on the context's stream, no host sync
+        d.rec = reinterpret_cast<SurfRecord *>(d_points) + (size_t)f * cap;
+        d.count = reinterpret_cast<unsigned long long *>(d_counts) + f;
+        IMGFD_TRY(surf_device_stages(ctx, d_rgb + (size_t)f * frame_stride_bytes, g, detection_threshold, d));
+    }
+    return IMGFD_OK;
+}
+
 imgfd_status imgfd_surf(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, long max_points, double detection_threshold,
                         imgfd_surf_out *out)
 {

@@ -160,6 +160,17 @@ IMGFD_API imgfd_status imgfd_surf(imgfd_ctx *ctx, const uint8_t *rgb, int rows, 
  * (may exceed cap; only cap are stored). */
 IMGFD_API imgfd_status imgfd_surf_interest_points(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols,
                                         double detection_threshold, double *points, int64_t cap, int64_t *n);
+/* batch of n_frames interlaced RGB tiles resident in HBM: the device stages of imgfd_surf_interest_points per tile.
+ * d_points: n_frames * cap records in NO particular order; sort by `key` (octave, interval, row, column packed in
+ * ascending significance) to get the order the reference emits them in; d_counts[f] = points found in tile f (may
+ * exceed cap; only cap are stored). */
+typedef struct {
+    uint64_t key; /* ((octave*8 + interval) << 40) | (row << 20) | column, in pyramid-level coordinates */
+    double x, y, scale, score, laplacian;
+} imgfd_surf_point;
+IMGFD_API imgfd_status imgfd_surf_points_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, int rows, int cols,
+                                   size_t frame_stride_bytes, double detection_threshold, imgfd_surf_point *d_points,
+                                   int64_t cap, int64_t *d_counts);
 /* stage doorway: the int32 integral image (integral_image.h:33-62) of the (r+g+b)/3 gray image, rows*cols values */
 IMGFD_API imgfd_status imgfd_k_surf_integral(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, int32_t *out);
 

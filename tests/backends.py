@@ -144,6 +144,23 @@ class _Base:
         assert n.value <= cap
         return out[:n.value].copy()
 
+    def surf_points_dev(self, frames, threshold=30.0, cap=4096):
+        """batch device path; returns per tile the (n,5) points sorted into the reference's emission order"""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, rows, cols, _ = frames.shape
+        d = self.to_dev(frames)
+        rec = self.empty((n, cap, 6), np.float64); cnt = self.empty((n,), np.int64)
+        self.check(self.lib.imgfd_surf_points_dev(self.ctx, self.ptr(d), n, rows, cols, rows * cols * 3, threshold,
+                                                  self.ptr(rec), cap, self.ptr(cnt)), "imgfd_surf_points_dev")
+        self.sync()
+        rec = self.to_host(rec); cnt = self.to_host(cnt)
+        out = []
+        for f in range(n):
+            r = rec[f, :min(int(cnt[f]), cap)]
+            keys = np.ascontiguousarray(r[:, 0]).view(np.uint64)
+            out.append(r[np.argsort(keys, kind="stable")][:, 1:])
+        return out, cnt
+
     def surf(self, rgb, max_points=1000, threshold=30.0):
         rgb = np.ascontiguousarray(rgb, np.uint8)
         rows, cols, _ = rgb.shape

@@ -1,0 +1,79 @@
+"""Error behaviour of the C ABI: bad arguments come back as status codes with a message (nothing throws or longjmps
+across the boundary), the reference's silent-empty cases stay silent, and a failed call leaves the context usable."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from image_amd import _binding, synth
+
+OK, INVALID, UNSUPPORTED = 0, 1, 5
+
+
+def msg(be):
+    return (be.lib.imgfd_last_error(be.ctx) or b"").decode()
+
+
+def test_harris_bad_arguments(be):
+    out = _binding.Corners()
+    img = np.zeros((8, 8), np.float32)
+    st = be.lib.imgfd_harris(be.ctx, None, 8, 8, 0.06, 1.0, 2.5, 130.0, 0, 0, 0, 1, 0, 1, 0, 10, 0, C.byref(out))
+    assert st == INVALID and "imgfd_harris" in msg(be)
+    st = be.lib.imgfd_harris(be.ctx, img.ctypes.data_as(C.c_void_p), -1, 8, 0.06, 1.0, 2.5, 130.0, 0, 0, 0, 1, 0, 1, 0, 10, 0, C.byref(out))
+    assert st == INVALID
+    # harris.cpp:493: fewer than 3 rows or columns -> silently no corners
+    st = be.lib.imgfd_harris(be.ctx, img.ctypes.data_as(C.c_void_p), 2, 8, 0.06, 1.0, 2.5, 130.0, 0, 0, 0, 1, 0, 1, 0, 10, 0, C.byref(out))
+    assert st == OK and out.n == 0
+    # the context still works
+    assert len(be.harris(synth.frame(1, 64, 48).astype(np.float32), threshold=1.0)) > 0
+
+
+def test_fast9_bad_arguments(be):
+    out = _binding.Points()
+    img = np.zeros((16, 16), np.uint8)
+    assert be.lib.imgfd_fast9(be.ctx, None, 16, 16, 16, 20, 0, C.byref(out)) == INVALID
+    assert be.lib.imgfd_fast9(be.ctx, img.ctypes.data_as(C.c_void_p), 16, 16, 8, 20, 0, C.byref(out)) == INVALID  # stride < width
+    assert "geometry" in msg(be)
+    assert be.lib.imgfd_fast9(be.ctx, img.ctypes.data_as(C.c_void_p), 6, 6, 16, 20, 0, C.byref(out)) == OK and out.n == 0  # empty domain
+
+
+def test_canny_bad_arguments(be):
+    img = np.zeros((16, 16), np.uint8)
+    edges = np.zeros((16, 16), np.uint8)
+    n = C.c_int64(0)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert be.lib.imgfd_canny(be.ctx, p(img), 16, 16, 0.0, 3.0, 10.0, 1, p(edges), C.byref(n)) == INVALID and "positive" in msg(be)
+    assert be.lib.imgfd_canny(be.ctx, p(img), 0, 16, 2.0, 3.0, 10.0, 1, p(edges), C.byref(n)) == INVALID
+    assert be.lib.imgfd_canny(be.ctx, p(img), 16, 16, 2.0, 3.0, 10.0, 1, None, C.byref(n)) == INVALID
+    e, k = be.canny(synth.frame(2, 40, 30))
+    assert k == np.count_nonzero(e)
+
+
+def test_fhog_bad_arguments(be):
+    rgb = np.zeros((32, 32, 3), np.uint8)
+    hog = C.POINTER(C.c_float)(); nr = C.c_int(0); nc = C.c_int(0)
+    p = rgb.ctypes.data_as(C.c_void_p)
+    assert be.lib.imgfd_fhog(be.ctx, p, 32, 32, 0, 1, 1, C.byref(hog), C.byref(nr), C.byref(nc)) == INVALID
+    assert be.lib.imgfd_fhog(be.ctx, p, 32, 32, 8, 0, 1, C.byref(hog), C.byref(nr), C.byref(nc)) == INVALID
+    assert be.lib.imgfd_fhog(be.ctx, p, 32, 32, 1, 1, 1, C.byref(hog), C.byref(nr), C.byref(nc)) == UNSUPPORTED and "cell_size 1" in msg(be)
+    assert be.lib.imgfd_fhog_size(32, 32, 8, 1, 1, C.byref(nr), C.byref(nc)) == OK and (nr.value, nc.value) == (2, 2)
+    assert be.lib.imgfd_fhog_size(32, 32, 8, 3, 5, C.byref(nr), C.byref(nc)) == OK and (nr.value, nc.value) == (4, 6)
+
+
+def test_surf_bad_arguments(be):
+    rgb = np.zeros((64, 64, 3), np.uint8)
+    o = _binding.SurfOut()
+    p = rgb.ctypes.data_as(C.c_void_p)
+    assert be.lib.imgfd_surf(be.ctx, p, 64, 64, 0, 30.0, C.byref(o)) == INVALID      # max_points > 0 (surf.h:243)
+    assert be.lib.imgfd_surf(be.ctx, p, 64, 64, 10, -1.0, C.byref(o)) == INVALID     # detection_threshold >= 0
+    assert be.lib.imgfd_surf(be.ctx, p, 64, 64, 10, 30.0, C.byref(o)) == OK and o.n == 0  # flat image: no points
+
+
+def test_dev_api_rejects_wrong_dtype(be):
+    frames = synth.frame(3, 64, 48).astype(np.float32)[None]
+    d = be.to_dev(frames)
+    fr = be.frames(d, 1, 64, 48, 1)  # f32 frames are Harris-only
+    pts = be.empty((1, 16, 2), np.int32); cnt = be.empty((1,), np.int64)
+    assert be.lib.imgfd_fast9_dev(be.ctx, C.byref(fr), 20, 0, be.ptr(pts), 16, be.ptr(cnt)) == INVALID
+    edges = be.empty((1, 48, 64), np.uint8)
+    assert be.lib.imgfd_canny_dev(be.ctx, C.byref(fr), 2.0, 3.0, 10.0, 1, be.ptr(edges), be.ptr(cnt)) == INVALID

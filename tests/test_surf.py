@@ -63,6 +63,14 @@ def test_surf_points_and_descriptors_exact(be, max_points, thr):
         assert np.array_equal(got[k], ref[k]), k
 
 
+def test_batch_points_dev(be):
+    frames = np.stack([blobs(95 + f, 256, 192) for f in range(3)])
+    lists, counts = be.surf_points_dev(frames, 10.0)
+    for f in range(3):
+        ref = oracle.surf_interest_points(frames[f], 10.0)
+        assert counts[f] == len(ref) and np.array_equal(lists[f], ref)
+
+
 def test_golden_dlib(be, golden):
     """vectors written by dlib's own get_surf_points on the reference's example image"""
     g = golden("surf_cruise_boat")
