@@ -90,6 +90,13 @@ size_t gaussian_tmp_bytes(int nx, int ny, int n_frames, float sigma, int type, i
 size_t sii_scratch_floats(int nx, int ny, float sigma);
 imgfd_status launch_sii_gaussian(imgfd_ctx *ctx, const float *d_in, float *d_out, int nx, int ny, int n_frames, float sigma,
                                  float *d_cum);
+// taps B[0..size-1] exactly as gaussian.cpp:307-330; returns size (= radius + 1), or -1 if more than IMGFD_MAX_TAPS
+int fir_coeffs(float sigma, int precision, double *B);
+// gauss_grad.hip: discrete Gaussian (radius 3) + gradient in one kernel; returns false when the fused kernel does not
+// apply (other radii, image narrower than the kernel) and the caller runs the two separate stages instead
+bool gauss_grad_fused_supported(int nx, int ny, float sigma, int gauss_type);
+imgfd_status launch_gauss_grad_fused(imgfd_ctx *ctx, const void *d_in, int in_is_u8, int in_pitch, size_t in_frame_stride,
+                                     float *d_Ix, float *d_Iy, int nx, int ny, int n_frames, float sigma, int grad_type);
 // harris_stages.hip
 imgfd_status launch_gradient(imgfd_ctx *ctx, const float *d_I, float *d_Ix, float *d_Iy, int nx, int ny,
                              int n_frames, int type);

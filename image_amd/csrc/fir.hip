@@ -23,6 +23,7 @@
 // segment (2R halo rows per segment, not per tile), no intermediate plane ever leaves the CU: HBM
 // traffic is the algorithmic 8 B read + 12 B written per pixel (plus the strip halo, served by L2).
 #include "common.h"
+#include "fir_device.h"
 
 #include <math.h>
 
@@ -67,53 +68,6 @@ struct FirParams {
     int vec4;               // 1: input planes, pitch and frame stride are 16-byte aligned (float4 tile loads)
     double B[IMGFD_MAX_TAPS];
 };
-
-// left/top: whole-sample reflection (-k -> k); right/bottom: half-sample (n-1+k -> n-k)
-__device__ __forceinline__ int fir_reflect(int i, int n)
-{
-    const int lo = -i, hi = 2 * n - 1 - i;
-    i = i < 0 ? lo : (i >= n ? hi : i);
-    return min(max(i, 0), n - 1);
-}
-
-// The FIR_PX output chains advance in lock-step (tap index outer, output inner): a chain's own operation
-// order is the reference's, while consecutive instructions belong to independent chains, so the f64
-// pipeline never waits on the previous result.
-template <int R, bool FMA, int FIR_PX>
-__device__ __forceinline__ void fir_window8(const double (&d)[FIR_PX + 2 * R], const double *B,
-                                            float (&out)[FIR_PX])
-{
-#ifdef FIR_INTERLEAVE_CHAINS
-    double sum[FIR_PX];
-#pragma unroll
-    for (int o = 0; o < FIR_PX; o++) sum[o] = B[0] * d[o + R];
-#pragma unroll
-    for (int j = 1; j <= R; j++) {
-        double pair[FIR_PX];
-#pragma unroll
-        for (int o = 0; o < FIR_PX; o++) pair[o] = d[o + R - j] + d[o + R + j];
-#pragma unroll
-        for (int o = 0; o < FIR_PX; o++) {
-            if (FMA) sum[o] = __builtin_fma(B[j], pair[o], sum[o]);
-            else sum[o] += B[j] * pair[o];
-        }
-    }
-#pragma unroll
-    for (int o = 0; o < FIR_PX; o++) out[o] = (float)sum[o];
-#else
-#pragma unroll
-    for (int o = 0; o < FIR_PX; o++) {
-        double sum = B[0] * d[o + R];
-#pragma unroll
-        for (int j = 1; j <= R; j++) {
-            double pair = d[o + R - j] + d[o + R + j];
-            if (FMA) sum = __builtin_fma(B[j], pair, sum);
-            else sum += B[j] * pair;
-        }
-        out[o] = (float)sum;
-    }
-#endif
-}
 
 constexpr int fir_ring_size(int need)
 {
@@ -413,7 +367,7 @@ __global__ void __launch_bounds__(256) plane_copy(const void *in, int in_is_u8, 
 
 // ------------------------------------------------------------------ host side
 // taps exactly as gaussian.cpp:307-330 (den in float, integer -i*i, pi = 3.1415926)
-static int fir_coeffs(float sigma, int precision, double *B)
+int fir_coeffs(float sigma, int precision, double *B)
 {
     double den = 2 * sigma * sigma;
     int size = (int)(precision * sigma) + 1;

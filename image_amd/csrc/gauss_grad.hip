@@ -1,0 +1,126 @@
+// image_amd/csrc/gauss_grad.hip -- K1 + K2 fused for the path every image_harris() call takes: the discrete Gaussian
+// of sigma_d (radius 3 for sigma_d = 1) and the gradient of the smoothed image in one kernel.
+//
+// Replaces gaussian(I, I, sigma_d) + gradient(I, Ix, Iy), image.CornerDetectionHarris/src/harris.cpp:511-514, i.e.
+// discrete_gaussian (gaussian.cpp:289-395) followed by central_differences / sobel_operator (gradient.cpp:17-106).
+// The smoothed image never reaches HBM: one workgroup owns a 64x32 tile of Ix, Iy; it stages the (64+3+2R)x(32+3+2R)
+// input pixels in LDS (reflected like the reference's borders), runs the row pass and the column pass with the
+// reference's arithmetic (f64 accumulate, one rounding to float per pass, fir_window8) on the tile plus a one-pixel
+// ring, and differentiates from LDS.  The gradient's border rule -- a border pixel takes the gradient of the nearest
+// interior pixel, gradient.cpp:40-55 -- is applied by clamping the evaluation point to [1, n-2].
+// HBM traffic: 1 B (u8) or 4 B (f32) read + 8 B written per pixel, instead of (1|4)+4 and 4+8 for the two kernels.
+#include "common.h"
+#include "fir_device.h"
+
+#define GG_TX 64
+#define GG_TY 32
+#define GG_PX 4  // outputs per thread and pass (register window of GG_PX + 2R values)
+
+struct GaussGradParams {
+    const void *in;
+    float *Ix, *Iy;
+    int nx, ny, in_pitch;
+    long in_frame_stride;
+    double B[8];
+};
+
+template <int R, int GRAD, bool U8, bool FMA>
+__global__ void __launch_bounds__(256) gauss_grad_tile(GaussGradParams p)
+{
+    // smoothed tile: the 64x32 outputs plus a ring of 2 pixels left/top and 1 right/bottom (a tile that starts on the
+    // last image column/row evaluates its clamped gradient one pixel further inside)
+    constexpr int SW = GG_TX + 3, SH = GG_TY + 3;
+    constexpr int RW = SW + 2 * R, RH = SH + 2 * R;                // raw tile
+    __shared__ float raw[RH][RW + 1];
+    __shared__ float rowf[RH][SW + 1];
+    __shared__ float is[SH][SW + 1];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * GG_TX, y0 = blockIdx.y * GG_TY;
+    const size_t fin = (size_t)blockIdx.z * p.in_frame_stride;
+    // ---- input tile; logical index outside the image -> the reference's reflection (gaussian.cpp:345-349, 376-380)
+    for (int i = tid; i < RH * RW; i += 256) {
+        const int r = i / RW, c = i - r * RW;
+        const int gy = fir_reflect(y0 - 2 - R + r, p.ny), gx = fir_reflect(x0 - 2 - R + c, p.nx);
+        const size_t off = fin + (size_t)gy * p.in_pitch + gx;
+        raw[r][c] = U8 ? (float)reinterpret_cast<const unsigned char *>(p.in)[off] : reinterpret_cast<const float *>(p.in)[off];
+    }
+    __syncthreads();
+    // ---- row pass: rowf[r][c] for r < RH, c < SW; a thread takes GG_PX consecutive columns
+    constexpr int RG = (SW + GG_PX - 1) / GG_PX;
+    for (int i = tid; i < RH * RG; i += 256) {
+        const int r = i / RG, c0 = (i - r * RG) * GG_PX;
+        double d[GG_PX + 2 * R];
+#pragma unroll
+        for (int k = 0; k < GG_PX + 2 * R; k++) d[k] = (double)raw[r][min(c0 + k, RW - 1)];
+        float o[GG_PX];
+        fir_window8<R, FMA, GG_PX>(d, p.B, o);
+#pragma unroll
+        for (int k = 0; k < GG_PX; k++)
+            if (c0 + k < SW) rowf[r][c0 + k] = o[k];
+    }
+    __syncthreads();
+    // ---- column pass: is[r][c] for r < SH, c < SW; a thread takes GG_PX consecutive rows of one column
+    constexpr int CG = (SH + GG_PX - 1) / GG_PX;
+    for (int i = tid; i < CG * SW; i += 256) {
+        const int g = i / SW, c = i - g * SW, r0 = g * GG_PX;
+        double d[GG_PX + 2 * R];
+#pragma unroll
+        for (int k = 0; k < GG_PX + 2 * R; k++) d[k] = (double)rowf[min(r0 + k, RH - 1)][c];
+        float o[GG_PX];
+        fir_window8<R, FMA, GG_PX>(d, p.B, o);
+#pragma unroll
+        for (int k = 0; k < GG_PX; k++)
+            if (r0 + k < SH) is[r0 + k][c] = o[k];
+    }
+    __syncthreads();
+    // ---- gradient: lane = column (coalesced 256-byte row segments)
+    const int lane = tid & 63;
+    float *Ix = p.Ix + (size_t)blockIdx.z * p.nx * p.ny, *Iy = p.Iy + (size_t)blockIdx.z * p.nx * p.ny;
+    for (int r = tid >> 6; r < GG_TY; r += 4) {
+        const int x = x0 + lane, y = y0 + r;
+        if (x >= p.nx || y >= p.ny) continue;
+        // border pixels take the gradient of the nearest interior pixel (gradient.cpp:40-55)
+        const int j = min(max(x, 1), p.nx - 2) - x0 + 2, i = min(max(y, 1), p.ny - 2) - y0 + 2;  // tile coordinates
+        float gx, gy;
+        if (GRAD == IMGFD_SOBEL_OPERATOR) {  // gradient.cpp:80-87: float sums, double constants, double adds, float store
+            gx = (float)(1. / 4. * (is[i][j + 1] - is[i][j - 1]) +
+                         1. / 8. * (is[i - 1][j + 1] + is[i + 1][j + 1] - is[i - 1][j - 1] - is[i + 1][j - 1]));
+            gy = (float)(1. / 4. * (is[i + 1][j] - is[i - 1][j]) +
+                         1. / 8. * (is[i + 1][j + 1] + is[i + 1][j - 1] - is[i - 1][j + 1] - is[i - 1][j - 1]));
+        } else {                             // gradient.cpp:34-35
+            gx = (float)(0.5 * (is[i][j + 1] - is[i][j - 1]));
+            gy = (float)(0.5 * (is[i + 1][j] - is[i - 1][j]));
+        }
+        Ix[(size_t)y * p.nx + x] = gx;
+        Iy[(size_t)y * p.nx + x] = gy;
+    }
+}
+
+bool gauss_grad_fused_supported(int nx, int ny, float sigma, int gauss_type)
+{
+    if (gauss_type != IMGFD_STD_GAUSSIAN || !(sigma > 0) || nx < 3 || ny < 3) return false;
+    const int size = (int)(3 * sigma) + 1;  // gaussian.cpp:310 with the default precision 3
+    return size == 4 && size <= nx;         // radius 3 (sigma_d in [1, 4/3)); gaussian.cpp:312: size > xdim leaves the image untouched
+}
+
+imgfd_status launch_gauss_grad_fused(imgfd_ctx *ctx, const void *d_in, int in_is_u8, int in_pitch, size_t in_frame_stride,
+                                     float *d_Ix, float *d_Iy, int nx, int ny, int n_frames, float sigma, int grad_type)
+{
+    GaussGradParams p;
+    memset(&p, 0, sizeof p);
+    if (fir_coeffs(sigma, 3, p.B) != 4) return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "fused gaussian+gradient: radius is not 3");
+    p.in = d_in; p.Ix = d_Ix; p.Iy = d_Iy; p.nx = nx; p.ny = ny; p.in_pitch = in_pitch; p.in_frame_stride = (long)in_frame_stride;
+    dim3 grid(ceil_div(nx, GG_TX), ceil_div(ny, GG_TY), n_frames);
+    const bool sobel = grad_type == IMGFD_SOBEL_OPERATOR;
+#define GG_LAUNCH(G, U, F) hipLaunchKernelGGL((gauss_grad_tile<3, G, U, F>), grid, dim3(256), 0, ctx->stream, p)
+    if (ctx->fir_mode) {
+        if (in_is_u8) { if (sobel) GG_LAUNCH(1, true, true); else GG_LAUNCH(0, true, true); }
+        else { if (sobel) GG_LAUNCH(1, false, true); else GG_LAUNCH(0, false, true); }
+    } else {
+        if (in_is_u8) { if (sobel) GG_LAUNCH(1, true, false); else GG_LAUNCH(0, true, false); }
+        else { if (sobel) GG_LAUNCH(1, false, false); else GG_LAUNCH(0, false, false); }
+    }
+#undef GG_LAUNCH
+    IMGFD_HIP(ctx, hipGetLastError());
+    return IMGFD_OK;
+}

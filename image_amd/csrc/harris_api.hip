@@ -212,11 +212,17 @@ imgfd_status harris_device_stages(imgfd_ctx *ctx, const void *d_in, int in_is_u8
     };
     IMGFD_TRY(tick(-1));
     IMGFD_TRY(compact_clear(ctx, hp.cb, ny, n_frames));
-    IMGFD_TRY(launch_gaussian(ctx, d_in, in_is_u8, in_pitch, in_frame_stride, hp.Is, nx, ny, n_frames, a.sigma_d,
-                              a.gauss, hp.tmp));
-    IMGFD_TRY(tick(0));
-    IMGFD_TRY(launch_gradient(ctx, hp.Is, hp.Ix, hp.Iy, nx, ny, n_frames, a.grad));
-    IMGFD_TRY(tick(1));
+    if (!stage_seconds && gauss_grad_fused_supported(nx, ny, a.sigma_d, a.gauss)) {
+        // the default path: Gaussian (radius 3) and gradient in one kernel, the smoothed plane stays on chip
+        IMGFD_TRY(launch_gauss_grad_fused(ctx, d_in, in_is_u8, in_pitch, in_frame_stride, hp.Ix, hp.Iy, nx, ny, n_frames,
+                                          a.sigma_d, a.grad));
+    } else {
+        IMGFD_TRY(launch_gaussian(ctx, d_in, in_is_u8, in_pitch, in_frame_stride, hp.Is, nx, ny, n_frames, a.sigma_d,
+                                  a.gauss, hp.tmp));
+        IMGFD_TRY(tick(0));
+        IMGFD_TRY(launch_gradient(ctx, hp.Is, hp.Ix, hp.Iy, nx, ny, n_frames, a.grad));
+        IMGFD_TRY(tick(1));
+    }
     IMGFD_TRY(prof_mark(ctx));
     IMGFD_TRY(launch_structure_tensor(ctx, hp.Ix, hp.Iy, hp.A, hp.B, hp.C, nx, ny, n_frames, a.sigma_i, a.gauss,
                                       hp.tmp));
