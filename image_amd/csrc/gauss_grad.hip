@@ -20,6 +20,7 @@ struct GaussGradParams {
     const void *in;
     float *Ix, *Iy;
     int nx, ny, in_pitch;
+    int vec4;  // input base, pitch and frame stride allow aligned 4-pixel loads
     long in_frame_stride;
     double B[8];
 };
@@ -30,19 +31,38 @@ __global__ void __launch_bounds__(256) gauss_grad_tile(GaussGradParams p)
     // smoothed tile: the 64x32 outputs plus a ring of 2 pixels left/top and 1 right/bottom (a tile that starts on the
     // last image column/row evaluates its clamped gradient one pixel further inside)
     constexpr int SW = GG_TX + 3, SH = GG_TY + 3;
-    constexpr int RW = SW + 2 * R, RH = SH + 2 * R;                // raw tile
-    __shared__ float raw[RH][RW + 1];
+    // raw tile: columns x0-8 .. x0+71 (first column 4-pixel aligned: interior tiles load whole dwords / float4s),
+    // rows y0-2-R .. y0+TY+R
+    constexpr int XO = 8, RW = GG_TX + 2 * XO, RH = SH + 2 * R, OFFX = XO - 2 - R;
+    static_assert(OFFX >= 0 && SW + 2 * R + OFFX <= RW, "raw tile too narrow for this radius");
+    __shared__ __attribute__((aligned(16))) float raw[RH][RW + 4];
     __shared__ float rowf[RH][SW + 1];
     __shared__ float is[SH][SW + 1];
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * GG_TX, y0 = blockIdx.y * GG_TY;
     const size_t fin = (size_t)blockIdx.z * p.in_frame_stride;
     // ---- input tile; logical index outside the image -> the reference's reflection (gaussian.cpp:345-349, 376-380)
-    for (int i = tid; i < RH * RW; i += 256) {
-        const int r = i / RW, c = i - r * RW;
-        const int gy = fir_reflect(y0 - 2 - R + r, p.ny), gx = fir_reflect(x0 - 2 - R + c, p.nx);
-        const size_t off = fin + (size_t)gy * p.in_pitch + gx;
-        raw[r][c] = U8 ? (float)reinterpret_cast<const unsigned char *>(p.in)[off] : reinterpret_cast<const float *>(p.in)[off];
+    if (p.vec4 && x0 - XO >= 0 && x0 - XO + RW <= p.nx) {  // workgroup-uniform: no column reflection in this tile
+        for (int i = tid; i < RH * (RW / 4); i += 256) {
+            const int r = i / (RW / 4), q = i - r * (RW / 4);
+            const int gy = fir_reflect(y0 - 2 - R + r, p.ny);
+            const size_t off = fin + (size_t)gy * p.in_pitch + (x0 - XO + 4 * q);
+            float4 v;
+            if (U8) {
+                const unsigned w = *reinterpret_cast<const unsigned *>(reinterpret_cast<const unsigned char *>(p.in) + off);
+                v = make_float4((float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24));
+            } else {
+                v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(p.in) + off);
+            }
+            *reinterpret_cast<float4 *>(&raw[r][4 * q]) = v;
+        }
+    } else {
+        for (int i = tid; i < RH * RW; i += 256) {
+            const int r = i / RW, c = i - r * RW;
+            const int gy = fir_reflect(y0 - 2 - R + r, p.ny), gx = fir_reflect(x0 - XO + c, p.nx);
+            const size_t off = fin + (size_t)gy * p.in_pitch + gx;
+            raw[r][c] = U8 ? (float)reinterpret_cast<const unsigned char *>(p.in)[off] : reinterpret_cast<const float *>(p.in)[off];
+        }
     }
     __syncthreads();
     // ---- row pass: rowf[r][c] for r < RH, c < SW; a thread takes GG_PX consecutive columns
@@ -51,7 +71,7 @@ __global__ void __launch_bounds__(256) gauss_grad_tile(GaussGradParams p)
         const int r = i / RG, c0 = (i - r * RG) * GG_PX;
         double d[GG_PX + 2 * R];
 #pragma unroll
-        for (int k = 0; k < GG_PX + 2 * R; k++) d[k] = (double)raw[r][min(c0 + k, RW - 1)];
+        for (int k = 0; k < GG_PX + 2 * R; k++) d[k] = (double)raw[r][min(c0 + OFFX + k, RW - 1)];
         float o[GG_PX];
         fir_window8<R, FMA, GG_PX>(d, p.B, o);
 #pragma unroll
@@ -110,6 +130,8 @@ imgfd_status launch_gauss_grad_fused(imgfd_ctx *ctx, const void *d_in, int in_is
     memset(&p, 0, sizeof p);
     if (fir_coeffs(sigma, 3, p.B) != 4) return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "fused gaussian+gradient: radius is not 3");
     p.in = d_in; p.Ix = d_Ix; p.Iy = d_Iy; p.nx = nx; p.ny = ny; p.in_pitch = in_pitch; p.in_frame_stride = (long)in_frame_stride;
+    const size_t esz = in_is_u8 ? 1 : 4;
+    p.vec4 = ((size_t)d_in % (4 * esz) == 0) && in_pitch % 4 == 0 && in_frame_stride % 4 == 0 && nx % 4 == 0;
     dim3 grid(ceil_div(nx, GG_TX), ceil_div(ny, GG_TY), n_frames);
     const bool sobel = grad_type == IMGFD_SOBEL_OPERATOR;
 #define GG_LAUNCH(G, U, F) hipLaunchKernelGGL((gauss_grad_tile<3, G, U, F>), grid, dim3(256), 0, ctx->stream, p)

@@ -83,12 +83,14 @@ imgfd_status launch_harris_nms(imgfd_ctx *ctx, const float *d_R, int nx, int ny,
 template <int MEASURE, int HC>
 __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                               const float *__restrict__ C, int nx, int ny, float k, float Th,
-                                                              int radius_rt, unsigned long long *__restrict__ mask,
+                                                              int radius_rt, int vec4, unsigned long long *__restrict__ mask,
                                                               unsigned *__restrict__ rowcount, int words_per_row)
 {
     const int radius = HC > 0 ? HC : radius_rt;
-    constexpr int LW = RN_TX + 2 * RN_HALO, LH = RN_TY + 2 * RN_HALO;
-    __shared__ float sR[LH][LW + 1];
+    // LDS tile of R: columns x0-8 .. x0+71 (the left offset 8 keeps the tile's first column 16-byte aligned in the
+    // planes, so interior tiles fetch whole float4s), rows y0-radius .. y0+31+radius
+    constexpr int XO = 8, LW = RN_TX + 2 * XO, LH = RN_TY + 2 * RN_HALO, LP = LW + 4;
+    __shared__ __attribute__((aligned(16))) float sR[LH][LP];
     __shared__ unsigned cand[RN_MAXC];            // (row << 8) | column, tile coordinates
     __shared__ unsigned char keep[RN_TY][RN_TX];
     __shared__ unsigned ncand;
@@ -99,23 +101,40 @@ __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__res
     const int H = radius;  // <= RN_HALO (the launcher falls back to the two-kernel path otherwise)
     if (tid == 0) ncand = 0;
     for (int i = tid; i < RN_TY * RN_TX; i += 256) keep[i / RN_TX][i % RN_TX] = 0;
-    const int w = RN_TX + 2 * H, hgt = RN_TY + 2 * H;
-    for (int i = tid; i < hgt * w; i += 256) {
-        const int r = i / w, c = i - r * w;
-        const int gx = x0 + c - H, gy = y0 + r - H;
-        float v = 0.f;  // outside the image: never compared (the search domain stays `radius` away from the border)
-        if (gx >= 0 && gx < nx && gy >= 0 && gy < ny) {
-            const size_t p = (size_t)gy * nx + gx;
-            v = harris_response_value<MEASURE>(Af[p], Bf[p], Cf[p], k);
+    const int hgt = RN_TY + 2 * H;
+    const bool vec = vec4 && x0 - XO >= 0 && x0 - XO + LW <= nx;  // workgroup-uniform
+    if (vec) {
+        for (int i = tid; i < hgt * (LW / 4); i += 256) {
+            const int r = i / (LW / 4), q = i - r * (LW / 4);
+            const int gy = y0 + r - H;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < ny) {
+                const size_t p = (size_t)gy * nx + (x0 - XO + 4 * q);
+                const float4 a = *reinterpret_cast<const float4 *>(Af + p), b = *reinterpret_cast<const float4 *>(Bf + p),
+                             c = *reinterpret_cast<const float4 *>(Cf + p);
+                v = make_float4(harris_response_value<MEASURE>(a.x, b.x, c.x, k), harris_response_value<MEASURE>(a.y, b.y, c.y, k),
+                                harris_response_value<MEASURE>(a.z, b.z, c.z, k), harris_response_value<MEASURE>(a.w, b.w, c.w, k));
+            }
+            *reinterpret_cast<float4 *>(&sR[r][4 * q]) = v;
         }
-        sR[r][c] = v;
+    } else {
+        for (int i = tid; i < hgt * LW; i += 256) {
+            const int r = i / LW, c = i - r * LW;
+            const int gx = x0 + c - XO, gy = y0 + r - H;
+            float v = 0.f;  // outside the image: never compared (the search domain stays `radius` away from the border)
+            if (gx >= 0 && gx < nx && gy >= 0 && gy < ny) {
+                const size_t p = (size_t)gy * nx + gx;
+                v = harris_response_value<MEASURE>(Af[p], Bf[p], Cf[p], k);
+            }
+            sR[r][c] = v;
+        }
     }
     __syncthreads();
     // (2) threshold + 3x3 pre-test with the window rule's own comparisons
     for (int r = wv; r < RN_TY; r += 4) {
         const int x = x0 + lane, y = y0 + r;
         if (y < ny && x >= radius && x < nx - radius && y >= radius && y < ny - radius) {
-            const int rr = r + H, cc = lane + H;
+            const int rr = r + H, cc = lane + XO;
             const float v = sR[rr][cc];
             if (!(v < Th)) {  // skip[] = R < Th, harris.cpp:160-162
                 const bool ok = !(sR[rr - 1][cc - 1] >= v) && !(sR[rr - 1][cc] >= v) && !(sR[rr - 1][cc + 1] >= v) &&
@@ -134,12 +153,12 @@ __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__res
     const int side = 2 * radius + 1, npos = side * side;
     for (int ci = wv; ci < n; ci += 4) {
         const int r = cand[ci] >> 8, c = cand[ci] & 255;
-        const float v = sR[r + H][c + H];
+        const float v = sR[r + H][c + XO];
         bool fail = false;
         for (int pidx = lane; pidx < npos; pidx += 64) {
             const int dy = pidx / side - radius, dx = pidx % side - radius;
             if (dy == 0 && dx == 0) continue;
-            const float q = sR[r + H + dy][c + H + dx];
+            const float q = sR[r + H + dy][c + XO + dx];
             const bool strict = dy < 0 || (dy == 0 && dx > 0);  // above, or to the right on the same row: must be <
             fail = fail || (strict ? (q >= v) : (q > v));
         }
@@ -175,7 +194,9 @@ imgfd_status launch_harris_resp_nms(imgfd_ctx *ctx, const float *d_A, const floa
     if (radius < 1) radius = 1;
     if (radius > RN_HALO) return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "fused response+NMS: radius exceeds the LDS halo");
     dim3 grid(cb.words_per_row, ceil_div(ny, RN_TY), n_frames);
-#define RN_LAUNCH(M, HC) hipLaunchKernelGGL((harris_resp_nms_kernel<M, HC>), grid, dim3(256), 0, ctx->stream, d_A, d_B, d_C, nx, ny, k, Th, radius, cb.mask, cb.rowcount, cb.words_per_row)
+#define RN_LAUNCH(M, HC) hipLaunchKernelGGL((harris_resp_nms_kernel<M, HC>), grid, dim3(256), 0, ctx->stream, d_A, d_B, d_C, nx, ny, k, Th, radius, vec4, cb.mask, cb.rowcount, cb.words_per_row)
+    // float4 tile loads: 16-byte aligned planes and whole quads per row (frames are nx*ny floats apart)
+    const int vec4 = nx % 4 == 0 && (size_t)d_A % 16 == 0 && (size_t)d_B % 16 == 0 && (size_t)d_C % 16 == 0;
     if (measure == IMGFD_SHI_TOMASI_MEASURE) RN_LAUNCH(1, 0);
     else if (measure == IMGFD_HARMONIC_MEAN_MEASURE) RN_LAUNCH(2, 0);
     else if (radius == 5) RN_LAUNCH(0, 5);  // image_harris() defaults: sigma_i 2.5 -> radius 5
