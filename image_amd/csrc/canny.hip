@@ -234,14 +234,24 @@ __global__ void __launch_bounds__(BM_NT) canny_blur_march(BlurMarchParams p)
 #define GN_TX 64  // tile width = one __ballot word
 #define GN_TY 16
 
-// gradient of the blurred image at (gx, gy), rcpp_canny.cpp:153-170, from the LDS tile `sb` (tile origin x0-2, y0-2).
-// value() clamps coordinates (:38-62), so a neighbour outside the image stands for the border pixel.
+#define GN_XO 4  // the LDS tile of the blurred image starts at x0-4 (16-byte aligned in the plane), y0-2
+
+// gradient of the blurred image at (gx, gy), rcpp_canny.cpp:153-170, from the LDS tile `sb`.
+// value() clamps coordinates (:38-62), so a neighbour outside the image stands for the border pixel; INSIDE = the
+// whole tile neighbourhood lies in the image (no clamping needed).
 struct CannyGrad { double h, v; };
-__device__ __forceinline__ CannyGrad canny_gradient(const float (*sb)[GN_TX + 4 + 1], int gx, int gy, int x0, int y0, int nx,
-                                                    int ny, int accGrad)
+template <bool INSIDE>
+__device__ __forceinline__ CannyGrad canny_gradient(const float (*sb)[GN_TX + 2 * GN_XO + 4], int gx, int gy, int x0, int y0,
+                                                    int nx, int ny, int accGrad)
 {
-    const int xm = max(gx - 1, 0) - x0 + 2, xp = min(gx + 1, nx - 1) - x0 + 2, xc = gx - x0 + 2;
-    const int ym = max(gy - 1, 0) - y0 + 2, yp = min(gy + 1, ny - 1) - y0 + 2, yc = gy - y0 + 2;
+    int xm, xp, xc, ym, yp, yc;
+    if (INSIDE) {
+        xc = gx - x0 + GN_XO; xm = xc - 1; xp = xc + 1;
+        yc = gy - y0 + 2; ym = yc - 1; yp = yc + 1;
+    } else {
+        xm = max(gx - 1, 0) - x0 + GN_XO; xp = min(gx + 1, nx - 1) - x0 + GN_XO; xc = gx - x0 + GN_XO;
+        ym = max(gy - 1, 0) - y0 + 2; yp = min(gy + 1, ny - 1) - y0 + 2; yc = gy - y0 + 2;
+    }
     CannyGrad g;
     if (accGrad) {  // :157-163, evaluation order preserved
         g.h = 2 * ((double)sb[yc][xp] - (double)sb[yc][xm]) + (double)sb[yp][xp] - (double)sb[yp][xm] +
@@ -258,20 +268,30 @@ __device__ __forceinline__ CannyGrad canny_gradient(const float (*sb)[GN_TX + 4 
 __device__ __forceinline__ double canny_mag(const CannyGrad &g) { return sqrt(__builtin_fma(g.h, g.h, g.v * g.v)); }
 
 // strong / marked bit planes: word (y, bx) covers pixels x = 64*bx .. 64*bx+63 of row y
-__global__ void __launch_bounds__(256) canny_grad_nms(const float *__restrict__ blur, unsigned long long *__restrict__ S,
-                                                      unsigned long long *__restrict__ Wm, int nx, int ny,
-                                                      int words_per_row, int accGrad, int low_thr, int high_thr)
+template <bool INSIDE>
+__device__ __forceinline__ void canny_grad_nms_tile(float (*sb)[GN_TX + 2 * GN_XO + 4], double (*sg)[GN_TX + 2 + 1],
+                                                    const float *__restrict__ blur, unsigned long long *__restrict__ S,
+                                                    unsigned long long *__restrict__ Wm, int nx, int ny, int words_per_row,
+                                                    int accGrad, int low_thr, int high_thr)
 {
-    __shared__ float sb[GN_TY + 4][GN_TX + 4 + 1];
-    __shared__ double sg[GN_TY + 2][GN_TX + 2 + 1];
+    constexpr int LW = GN_TX + 2 * GN_XO;  // 72 columns: x0-4 .. x0+67
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * GN_TX, y0 = blockIdx.y * GN_TY;
     const float *pl = blur + (size_t)blockIdx.z * nx * ny;
-    // blurred tile with a 2-pixel halo, clamp-to-edge (extend(), rcpp_canny.cpp:38-55)
-    for (int i = tid; i < (GN_TY + 4) * (GN_TX + 4); i += 256) {
-        const int r = i / (GN_TX + 4), c = i - r * (GN_TX + 4);
-        const int gx = min(max(x0 + c - 2, 0), nx - 1), gy = min(max(y0 + r - 2, 0), ny - 1);
-        sb[r][c] = pl[(size_t)gy * nx + gx];
+    // INSIDE tiles see x0-4 >= 0, x0+68 <= nx, y0-2 >= 0, y0+18 <= ny and a 16-byte aligned plane
+    if (INSIDE) {
+        for (int i = tid; i < (GN_TY + 4) * (LW / 4); i += 256) {
+            const int r = i / (LW / 4), q = i - r * (LW / 4);
+            *reinterpret_cast<float4 *>(&sb[r][4 * q]) =
+                *reinterpret_cast<const float4 *>(pl + (size_t)(y0 - 2 + r) * nx + (x0 - GN_XO + 4 * q));
+        }
+    } else {
+        // clamp-to-edge (extend(), rcpp_canny.cpp:38-55)
+        for (int i = tid; i < (GN_TY + 4) * LW; i += 256) {
+            const int r = i / LW, c = i - r * LW;
+            const int gx = min(max(x0 + c - GN_XO, 0), nx - 1), gy = min(max(y0 + r - 2, 0), ny - 1);
+            sb[r][c] = pl[(size_t)gy * nx + gx];
+        }
     }
     __syncthreads();
     // gradient magnitude: the thread's own 4 pixels (lane = column, rows wv, wv+4, ...) keep h, v in registers;
@@ -282,7 +302,8 @@ __global__ void __launch_bounds__(256) canny_grad_nms(const float *__restrict__ 
 #pragma unroll
     for (int q = 0; q < GN_TY / 4; q++) {
         const int r = wv + 4 * q;
-        own[q] = canny_gradient(sb, min(x0 + c, nx - 1), min(y0 + r, ny - 1), x0, y0, nx, ny, accGrad);
+        own[q] = canny_gradient<INSIDE>(sb, INSIDE ? x0 + c : min(x0 + c, nx - 1), INSIDE ? y0 + r : min(y0 + r, ny - 1), x0, y0,
+                                        nx, ny, accGrad);
         sg[r + 1][c + 1] = canny_mag(own[q]);
     }
     constexpr int RING = 2 * (GN_TX + 2) + 2 * GN_TY;
@@ -291,8 +312,8 @@ __global__ void __launch_bounds__(256) canny_grad_nms(const float *__restrict__ 
         if (tid < GN_TX + 2) { r = 0; cc = tid; }
         else if (tid < 2 * (GN_TX + 2)) { r = GN_TY + 1; cc = tid - (GN_TX + 2); }
         else { const int k = tid - 2 * (GN_TX + 2); r = 1 + (k >> 1); cc = (k & 1) ? GN_TX + 1 : 0; }
-        const int gx = min(max(x0 + cc - 1, 0), nx - 1), gy = min(max(y0 + r - 1, 0), ny - 1);
-        sg[r][cc] = canny_mag(canny_gradient(sb, gx, gy, x0, y0, nx, ny, accGrad));
+        const int gx = INSIDE ? x0 + cc - 1 : min(max(x0 + cc - 1, 0), nx - 1), gy = INSIDE ? y0 + r - 1 : min(max(y0 + r - 1, 0), ny - 1);
+        sg[r][cc] = canny_mag(canny_gradient<INSIDE>(sb, gx, gy, x0, y0, nx, ny, accGrad));
     }
     __syncthreads();
 #pragma unroll
@@ -300,11 +321,11 @@ __global__ void __launch_bounds__(256) canny_grad_nms(const float *__restrict__ 
         const int r = wv + 4 * q;
         const int gx = x0 + c, gy = y0 + r;
         int o = 0;
-        if (gx < nx && gy < ny) {
+        if (INSIDE || (gx < nx && gy < ny)) {
             const double now = sg[r + 1][c + 1];
             // unit direction (cos t, sin t) with t = atan2(v,h) (:69-70,173); atan2(0,0) = 0 -> (1,0)
             double ux = 1.0, uy = 0.0;
-            if (now > 0) { ux = own[q].h / now; uy = own[q].v / now; }
+            if (now > 0) { const double rn = 1.0 / now; ux = own[q].h * rn; uy = own[q].v * rn; }
             // bilin(), :65-85, for dir = +1: x1 = floor(ux) is -1, 0 or (only when ux == 1 exactly) 1; in that last
             // case the far tap has weight 0, so x1 = 0 gives the same sum from the 3x3 neighbourhood.  dir = -1
             // mirrors the offsets.
@@ -325,12 +346,25 @@ __global__ void __launch_bounds__(256) canny_grad_nms(const float *__restrict__ 
             else o = 1;
         }
         const unsigned long long strong = __ballot(o == 2), marked = __ballot(o >= 1);
-        if (c == 0 && gy < ny) {
+        if (c == 0 && (INSIDE || gy < ny)) {
             const size_t w = ((size_t)blockIdx.z * ny + gy) * words_per_row + blockIdx.x;
             S[w] = strong;
             Wm[w] = marked;
         }
     }
+}
+
+__global__ void __launch_bounds__(256) canny_grad_nms(const float *__restrict__ blur, unsigned long long *__restrict__ S,
+                                                      unsigned long long *__restrict__ Wm, int nx, int ny,
+                                                      int words_per_row, int accGrad, int low_thr, int high_thr, int vec4)
+{
+    __shared__ __attribute__((aligned(16))) float sb[GN_TY + 4][GN_TX + 2 * GN_XO + 4];
+    __shared__ double sg[GN_TY + 2][GN_TX + 2 + 1];
+    const int x0 = blockIdx.x * GN_TX, y0 = blockIdx.y * GN_TY;
+    // workgroup-uniform: interior tiles skip every clamp and fetch the blurred tile as float4s
+    const bool inside = vec4 && x0 - GN_XO >= 0 && x0 + GN_TX + GN_XO <= nx && y0 - 2 >= 0 && y0 + GN_TY + 2 <= ny;
+    if (inside) canny_grad_nms_tile<true>(sb, sg, blur, S, Wm, nx, ny, words_per_row, accGrad, low_thr, high_thr);
+    else canny_grad_nms_tile<false>(sb, sg, blur, S, Wm, nx, ny, words_per_row, accGrad, low_thr, high_thr);
 }
 
 // ------------------------------------------------------------------ K12
@@ -588,7 +622,7 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
     }
     dim3 g2(wpr, ceil_div(ny, GN_TY), nf);
     hipLaunchKernelGGL(canny_grad_nms, g2, dim3(256), 0, ctx->stream, blur, S, Wm, nx, ny, wpr, accGrad, (int)low_thr,
-                       (int)high_thr);
+                       (int)high_thr, (int)(nx % 4 == 0 && (size_t)blur % 16 == 0));
     IMGFD_HIP(ctx, hipGetLastError());
     // hysteresis: rounds of HY_ROUND sweeps; converged when the last sweep of a round was idle
     const int tiles_x = ceil_div(wpr, HY_WORDS), tiles_y = ceil_div(ny, 64);
