@@ -385,19 +385,59 @@ __device__ __forceinline__ unsigned long long dilate_h(unsigned long long s, uns
     return s | (s << 1) | (s >> 1) | (left >> 63) | (right << 63);
 }
 
+// value of the lane above / below (row y-1 / y+1 of the tile): one DPP wavefront shift per dword on gfx950 (no LDS
+// round trip like ds_bpermute); lanes 0 / 63 receive 0 and are overridden with the halo rows by the caller
+__device__ __forceinline__ unsigned long long lane_above(unsigned long long v)
+{
+#ifdef HIPEMU
+    return __shfl_up(v, 1);
+#else
+    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(v >> 32), 0x138, 0xf, 0xf, false);
+    return ((unsigned long long)hi << 32) | lo;
+#endif
+}
+__device__ __forceinline__ unsigned long long lane_below(unsigned long long v)
+{
+#ifdef HIPEMU
+    return __shfl_down(v, 1);
+#else
+    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(v >> 32), 0x130, 0xf, 0xf, false);
+    return ((unsigned long long)hi << 32) | lo;
+#endif
+}
+
 #define HY_WORDS 4  // tile = 256 columns x 64 rows per wave
 
 // One sweep.  flags[sweep] is raised when any tile changed; a sweep whose predecessor (same round) was
-// idle returns at once, so the host may queue a whole round of sweeps behind one read-back.
+// idle returns at once, so the host may queue a whole round of sweeps behind one read-back.  act[] holds one byte per
+// tile and sweep parity: "this tile changed in that sweep"; a tile can only change if itself or one of its 8
+// neighbours changed in the previous sweep (its inputs are its own words and their halo), so all others leave at once.
 __global__ void __launch_bounds__(256) canny_hyst_bits(unsigned long long *__restrict__ S,
                                                        const unsigned long long *__restrict__ Wm, int wpr, int ny,
-                                                       int tiles_x, int tiles_y, unsigned *__restrict__ flags, int sweep)
+                                                       int tiles_x, int tiles_y, unsigned *__restrict__ flags, int sweep,
+                                                       unsigned char *__restrict__ act, int gsweep)
 {
     if (sweep > 0 && flags[sweep - 1] == 0) return;
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= tiles_x * tiles_y) return;  // whole wave leaves together
+    const int ntiles = tiles_x * tiles_y;
+    if (tile >= ntiles) return;  // whole wave leaves together
     const int tx = tile % tiles_x, ty = tile / tiles_x;
+    unsigned char *act_w = act + ((size_t)(gsweep & 1) * gridDim.y + blockIdx.y) * ntiles;            // written by this sweep
+    const unsigned char *act_r = act + ((size_t)((gsweep + 1) & 1) * gridDim.y + blockIdx.y) * ntiles;  // previous sweep
+    if (gsweep > 0) {
+        bool near = false;
+        if (lane < 9) {
+            const int nx_ = tx + lane % 3 - 1, ny_ = ty + lane / 3 - 1;
+            near = nx_ >= 0 && nx_ < tiles_x && ny_ >= 0 && ny_ < tiles_y && act_r[ny_ * tiles_x + nx_] != 0;
+        }
+        if (!__any(near)) {
+            if (lane == 0) act_w[tile] = 0;
+            return;
+        }
+    }
     const int y = ty * 64 + lane;
     const bool rowok = y < ny;
     const int w0 = tx * HY_WORDS;
@@ -417,7 +457,10 @@ __global__ void __launch_bounds__(256) canny_hyst_bits(unsigned long long *__res
         w[q] = (rowok && wi < wpr) ? Wf[rowbase + wi] : 0ull;
         todo = todo || (w[q] & ~s[q + 1]) != 0ull;
     }
-    if (!__any(todo)) return;  // no marked-but-not-strong pixel in the tile
+    if (!__any(todo)) {  // no marked-but-not-strong pixel in the tile
+        if (lane == 0) act_w[tile] = 0;
+        return;
+    }
     // halo rows above / below: lanes 0..5 fetch the six words, then everybody gets them by shuffle
     unsigned long long trow = 0ull, brow = 0ull;
     {
@@ -447,7 +490,7 @@ __global__ void __launch_bounds__(256) canny_hyst_bits(unsigned long long *__res
         for (int q = 0; q < HY_WORDS; q++) d[q] = dilate_h(s[q + 1], s[q], s[q + 2]);
 #pragma unroll
         for (int q = 0; q < HY_WORDS; q++) {
-            unsigned long long up = __shfl_up(d[q], 1), dn = __shfl_down(d[q], 1);
+            unsigned long long up = lane_above(d[q]), dn = lane_below(d[q]);
             if (lane == 0) up = top_d[q];
             if (lane == 63) dn = bot_d[q];
             const unsigned long long cand = w[q] & ~s[q + 1] & (d[q] | up | dn);
@@ -467,6 +510,7 @@ __global__ void __launch_bounds__(256) canny_hyst_bits(unsigned long long *__res
         }
         if (lane == 0) atomicOr(&flags[sweep], 1u);
     }
+    if (lane == 0) act_w[tile] = any ? 1 : 0;
 }
 
 // edges = 255 where strong, else 0 (rcpp_canny.cpp:210-215); thread = 16 pixels
@@ -574,7 +618,8 @@ size_t canny_ws_bytes(int nx, int ny, int nf)
 {
     const size_t n = (size_t)nx * ny * nf;
     const size_t words = (size_t)ceil_div(nx, 64) * ny * nf;
-    return align_up(n * sizeof(double), 256) + align_up(n * sizeof(float), 256) + 2 * align_up(words * 8, 256) + 4096;
+    return align_up(n * sizeof(double), 256) + align_up(n * sizeof(float), 256) + 2 * align_up(words * 8, 256) +
+           align_up(2 * (size_t)nf * ceil_div(ceil_div(nx, 64), 4) * ceil_div(ny, 64), 256) + 4096;
 }
 
 #define HY_ROUND 12  // sweeps queued per host read-back
@@ -599,7 +644,9 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
     unsigned long long *S = (unsigned long long *)ws_alloc(ctx, words * 8);
     unsigned long long *Wm = (unsigned long long *)ws_alloc(ctx, words * 8);
     unsigned *flags = (unsigned *)ws_alloc(ctx, 256);
-    if ((!fast && !tmp) || !blur || !S || !Wm || !flags) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    const size_t act_bytes = 2 * (size_t)nf * ceil_div(wpr, HY_WORDS) * ceil_div(ny, 64);
+    unsigned char *act = (unsigned char *)ws_alloc(ctx, act_bytes);
+    if ((!fast && !tmp) || !blur || !S || !Wm || !flags || !act) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
     if (fast) {
         BlurMarchParams p;
         memset(&p, 0, sizeof p);
@@ -627,10 +674,12 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
     // hysteresis: rounds of HY_ROUND sweeps; converged when the last sweep of a round was idle
     const int tiles_x = ceil_div(wpr, HY_WORDS), tiles_y = ceil_div(ny, 64);
     dim3 g3(ceil_div(tiles_x * tiles_y, 4), nf);
+    int gsweep = 0;
     for (int round = 0; round < 100000; round++) {
         IMGFD_HIP(ctx, hipMemsetAsync(flags, 0, sizeof(unsigned) * HY_ROUND, ctx->stream));
-        for (int i = 0; i < HY_ROUND; i++)
-            hipLaunchKernelGGL(canny_hyst_bits, g3, dim3(256), 0, ctx->stream, S, Wm, wpr, ny, tiles_x, tiles_y, flags, i);
+        for (int i = 0; i < HY_ROUND; i++, gsweep++)
+            hipLaunchKernelGGL(canny_hyst_bits, g3, dim3(256), 0, ctx->stream, S, Wm, wpr, ny, tiles_x, tiles_y, flags, i,
+                               act, gsweep);
         unsigned last = 0;
         IMGFD_HIP(ctx, hipMemcpyAsync(&last, flags + HY_ROUND - 1, sizeof last, hipMemcpyDeviceToHost, ctx->stream));
         IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
