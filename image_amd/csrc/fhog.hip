@@ -2,7 +2,7 @@
 //
 // Replaces dlib_fhog(), image.dlib/src/rcpp_fhog.cpp:10-46, i.e. dlib's extract_fhog_features
 // (image.dlib/inst/dlib-19.20/dlib/image_transforms/fhog.h:1104-1113 -> impl_extract_fhog_features :702-1046)
-// for interlaced 8-bit RGB input, cell_size > 1.
+// for interlaced 8-bit RGB input; cell_size 1 takes dlib's special case (:499-694, fhog_features_cs1).
 //
 // The reference adds every pixel's gradient magnitude into 4 histogram cells with `+=` while it walks the
 // image in raster order (:821-956), so each float bin is a sum in a fixed order.  The device keeps that
@@ -38,6 +38,18 @@ static bool fhog_geometry(int rows, int cols, int cs, int pad_r, int pad_c, Fhog
 {
     memset(g, 0, sizeof *g);
     g->rows = rows; g->cols = cols; g->cs = cs;
+    if (cs == 1) {  // impl_extract_fhog_features_cell_size_1, fhog.h:536-560: every pixel is a cell
+        if (rows <= 2 || cols <= 2) return false;
+        g->cells_nr = rows; g->cells_nc = cols;
+        g->hog_nr = rows - 2; g->hog_nc = cols - 2;
+        g->out_nr = g->hog_nr + pad_r - 1; g->out_nc = g->hog_nc + pad_c - 1;
+        g->off_r = (pad_r - 1) / 2; g->off_c = (pad_c - 1) / 2;
+        g->visible_nr = rows - 1; g->visible_nc = cols - 1;
+        int x1 = 1;
+        while (x1 < g->visible_nc - 7) x1 += 8;
+        g->body_end = x1;
+        return true;
+    }
     g->cells_nr = (int)((float)rows / (float)cs + 0.5);
     g->cells_nc = (int)((float)cols / (float)cs + 0.5);
     if (g->cells_nr == 0 || g->cells_nc == 0) return false;
@@ -356,10 +368,47 @@ __global__ void __launch_bounds__(256) fhog_features(const float *__restrict__ h
     for (int l = 0; l < 4; l++) dst[(size_t)(27 + l) * plane] = t[l];  // texture, :1040-1043
 }
 
+// cell_size == 1 (fhog.h:499-694): norm = squared gradient length of the pixel (0 on the image border), one
+// contrast-sensitive and one contrast-insensitive feature per pixel (its orientation), texture features from the four
+// 2x2 block norms.  out[feat][xx][yy]; the other 25 planes of a pixel are zero (init_hog_zero_everything).
+__global__ void __launch_bounds__(256) fhog_features_cs1(const unsigned *__restrict__ packed, float *__restrict__ out, FhogGeom g)
+{
+    const int y = blockIdx.x * 64 + (threadIdx.x & 63);  // rows fastest: coalesced stores
+    const int x = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= g.hog_nr || x >= g.hog_nc) return;
+    const unsigned *pk = packed + (size_t)blockIdx.z * g.rows * g.cols;
+#define NORM(r, c) ((float)(pk[(size_t)(r) * g.cols + (c)] >> 5))
+    const float z1[4] = {NORM(y + 1, x + 1), NORM(y, x + 1), NORM(y + 1, x), NORM(y, x)};
+    const float z2[4] = {NORM(y + 1, x + 2), NORM(y, x + 2), NORM(y + 1, x + 1), NORM(y, x + 1)};
+    const float z3[4] = {NORM(y + 2, x + 1), NORM(y + 1, x + 1), NORM(y + 2, x), NORM(y + 1, x)};
+    const float z4[4] = {NORM(y + 2, x + 2), NORM(y + 1, x + 2), NORM(y + 2, x + 1), NORM(y + 1, x + 1)};
+#undef NORM
+    const unsigned centre = pk[(size_t)(y + 1) * g.cols + (x + 1)];
+    const int a = centre & 31;
+    const float temp0 = sqrtf((float)(centre >> 5));  // :651
+    const float eps = 0.0001;
+    float h0[4], t[4];
+#pragma unroll
+    for (int l = 0; l < 4; l++) {
+        const float nn = 0.2f * sqrtf(z1[l] + z2[l] + z3[l] + z4[l] + eps);
+        const float n = 0.1f / nn;
+        h0[l] = fminf(temp0, nn) * n;
+        t[l] = (0.0f + h0[l]) * (float)(2 * 0.2357);
+    }
+    const float vv = fhog_sum4(h0);
+    const size_t plane = (size_t)g.out_nr * g.out_nc;
+    float *dst = out + (size_t)blockIdx.z * plane * 31 + (size_t)(x + g.off_c) * g.out_nr + (y + g.off_r);
+#pragma unroll
+    for (int f = 0; f < 27; f++) dst[(size_t)f * plane] = (f == a || f == a % 9 + 18) ? vv : 0.f;
+#pragma unroll
+    for (int l = 0; l < 4; l++) dst[(size_t)(27 + l) * plane] = t[l];
+}
+
 namespace {
 
 size_t fhog_ws_bytes(const FhogGeom &g, int nf)
 {
+    if (g.cs == 1) return align_up(sizeof(unsigned) * (size_t)g.rows * g.cols * nf, 256) + 4096;  // no histograms
     return align_up(sizeof(unsigned) * (size_t)g.rows * g.cols * nf, 256) +
            align_up(sizeof(float) * (size_t)(g.cells_nr + 2) * (g.cells_nc + 2) * 18 * nf, 256) +
            align_up(sizeof(float) * (size_t)g.cells_nr * g.cells_nc * nf, 256) + 4096;
@@ -369,9 +418,9 @@ size_t fhog_ws_bytes(const FhogGeom &g, int nf)
 imgfd_status fhog_device(imgfd_ctx *ctx, const uint8_t *d_rgb, size_t frame_stride, const FhogGeom &g, int nf, float *d_out)
 {
     unsigned *packed = (unsigned *)ws_alloc(ctx, sizeof(unsigned) * (size_t)g.rows * g.cols * nf);
-    float *hist = (float *)ws_alloc(ctx, sizeof(float) * (size_t)(g.cells_nr + 2) * (g.cells_nc + 2) * 18 * nf);
-    float *norm = (float *)ws_alloc(ctx, sizeof(float) * (size_t)g.cells_nr * g.cells_nc * nf);
-    if (!packed || !hist || !norm) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    float *hist = g.cs == 1 ? nullptr : (float *)ws_alloc(ctx, sizeof(float) * (size_t)(g.cells_nr + 2) * (g.cells_nc + 2) * 18 * nf);
+    float *norm = g.cs == 1 ? nullptr : (float *)ws_alloc(ctx, sizeof(float) * (size_t)g.cells_nr * g.cells_nc * nf);
+    if (!packed || (g.cs != 1 && (!hist || !norm))) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
     const size_t out_n = (size_t)31 * g.out_nr * g.out_nc * nf;
     if (g.out_nr != g.hog_nr || g.out_nc != g.hog_nc)  // init_hog: zero border of the padded output
         IMGFD_HIP(ctx, hipMemsetAsync(d_out, 0, out_n * sizeof(float), ctx->stream));
@@ -381,6 +430,12 @@ imgfd_status fhog_device(imgfd_ctx *ctx, const uint8_t *d_rgb, size_t frame_stri
     else
         hipLaunchKernelGGL(fhog_grad_orient, dim3(ceil_div(g.cols, 256), g.rows, nf), dim3(256), 0, ctx->stream, d_rgb,
                            frame_stride, packed, g);
+    if (g.cs == 1) {
+        hipLaunchKernelGGL(fhog_features_cs1, dim3(ceil_div(g.hog_nr, 64), ceil_div(g.hog_nc, 4), nf), dim3(256), 0, ctx->stream,
+                           packed, d_out, g);
+        IMGFD_HIP(ctx, hipGetLastError());
+        return IMGFD_OK;
+    }
     hipLaunchKernelGGL(fhog_cell_hist, dim3(ceil_div(g.cells_nc, 8), ceil_div(g.cells_nr, 8), nf), dim3(64), 0,
                        ctx->stream, packed, hist, norm, g);
     hipLaunchKernelGGL(fhog_features, dim3(ceil_div(g.hog_nr, 64), ceil_div(g.hog_nc, 4), nf), dim3(256), 0, ctx->stream,
@@ -399,7 +454,6 @@ imgfd_status imgfd_fhog_size(int rows, int cols, int cell_size, int filter_rows_
     if (!hog_nr || !hog_nc) return IMGFD_ERR_INVALID;
     *hog_nr = *hog_nc = 0;
     if (rows < 0 || cols < 0 || cell_size < 1 || filter_rows_padding < 1 || filter_cols_padding < 1) return IMGFD_ERR_INVALID;
-    if (cell_size == 1) return IMGFD_ERR_UNSUPPORTED;
     FhogGeom g;
     if (fhog_geometry(rows, cols, cell_size, filter_rows_padding, filter_cols_padding, &g)) { *hog_nr = g.out_nr; *hog_nc = g.out_nc; }
     return IMGFD_OK;
@@ -412,7 +466,6 @@ imgfd_status imgfd_fhog(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, 
     if (!rgb || !hog || !hog_nr || !hog_nc || rows < 0 || cols < 0 || cell_size < 1 || filter_rows_padding < 1 || filter_cols_padding < 1)
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_fhog: bad argument (DLIB_ASSERT of fhog.h:712-720)");
     *hog = nullptr; *hog_nr = 0; *hog_nc = 0;
-    if (cell_size == 1) return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "imgfd_fhog: cell_size 1 (fhog.h:499-694) is not implemented");
     FhogGeom g;
     if (!fhog_geometry(rows, cols, cell_size, filter_rows_padding, filter_cols_padding, &g)) return IMGFD_OK;  // hog.clear()
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
@@ -437,7 +490,6 @@ imgfd_status imgfd_fhog_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, 
     if (!ctx) return IMGFD_ERR_INVALID;
     if (!d_rgb || !d_hog || n_frames < 0 || rows < 0 || cols < 0 || cell_size < 1 || filter_rows_padding < 1 || filter_cols_padding < 1)
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_fhog_dev: bad argument");
-    if (cell_size == 1) return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "imgfd_fhog_dev: cell_size 1 is not implemented");
     FhogGeom g;
     if (!n_frames || !fhog_geometry(rows, cols, cell_size, filter_rows_padding, filter_cols_padding, &g)) return IMGFD_OK;
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));

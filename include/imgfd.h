@@ -129,8 +129,8 @@ IMGFD_API imgfd_status imgfd_canny(imgfd_ctx *ctx, const uint8_t *img, int nx, i
  * (r,g,b) bytes, pixel (r,c) at 3*(c + r*cols).  *hog (library-allocated, imgfd_free) holds
  * 31 * hog_nc * hog_nr floats in the order the reference glue emits them (rcpp_fhog.cpp:29-38): feature-major, then
  * column x, then row y fastest -- R reshapes it to [hog_height, hog_width, 31] (image_fhog.R:46).  An image too small
- * for 3x3 cells gives *hog = NULL, 0 x 0 (hog.clear(), fhog.h:783-812).  cell_size == 1 (fhog.h:499-694) returns
- * IMGFD_ERR_UNSUPPORTED. */
+ * for 3x3 cells gives *hog = NULL, 0 x 0 (hog.clear(), fhog.h:783-812).  cell_size == 1 takes dlib's special case
+ * (fhog.h:499-694). */
 IMGFD_API imgfd_status imgfd_fhog(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, int cell_size,
                         int filter_rows_padding, int filter_cols_padding, float **hog, int *hog_nr, int *hog_nc);
 /* output size of imgfd_fhog / imgfd_fhog_dev for a rows x cols image (no device needed) */

@@ -55,7 +55,6 @@ def test_fhog_bad_arguments(be):
     p = rgb.ctypes.data_as(C.c_void_p)
     assert be.lib.imgfd_fhog(be.ctx, p, 32, 32, 0, 1, 1, C.byref(hog), C.byref(nr), C.byref(nc)) == INVALID
     assert be.lib.imgfd_fhog(be.ctx, p, 32, 32, 8, 0, 1, C.byref(hog), C.byref(nr), C.byref(nc)) == INVALID
-    assert be.lib.imgfd_fhog(be.ctx, p, 32, 32, 1, 1, 1, C.byref(hog), C.byref(nr), C.byref(nc)) == UNSUPPORTED and "cell_size 1" in msg(be)
     assert be.lib.imgfd_fhog_size(32, 32, 8, 1, 1, C.byref(nr), C.byref(nc)) == OK and (nr.value, nc.value) == (2, 2)
     assert be.lib.imgfd_fhog_size(32, 32, 8, 3, 5, C.byref(nr), C.byref(nc)) == OK and (nr.value, nc.value) == (4, 6)
 

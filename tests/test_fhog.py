@@ -25,6 +25,13 @@ def test_matches_oracle(be, w, h, cs, pr, pc):
     check(be.fhog(rgb, cs, pr, pc), oracle.fhog(rgb, cs, pr, pc))
 
 
+@pytest.mark.parametrize("w,h,pr,pc", [(64, 48, 1, 1), (67, 35, 1, 1), (40, 30, 3, 2), (3, 3, 1, 1), (130, 17, 1, 1)])
+def test_cell_size_1(be, w, h, pr, pc):
+    """dlib's special case impl_extract_fhog_features_cell_size_1 (fhog.h:499-694)"""
+    rgb = synth.frame_rgb(66, max(w, 16), max(h, 16))[:h, :w]
+    check(be.fhog(rgb, 1, pr, pc), oracle.fhog(rgb, 1, pr, pc))
+
+
 def test_gray_replicated_and_flat(be):
     g = np.stack([synth.frame(62, 160, 120)] * 3, -1)
     check(be.fhog(g), oracle.fhog(g))

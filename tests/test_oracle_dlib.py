@@ -20,6 +20,14 @@ def test_fhog_restatement_is_bit_identical_to_dlib(w, h, cs, pr, pc):
 
 
 @needs_ref
+@pytest.mark.parametrize("w,h,pr,pc", [(64, 48, 1, 1), (67, 35, 1, 1), (40, 30, 3, 2), (3, 3, 1, 1), (2, 5, 1, 1), (130, 17, 1, 1)])
+def test_fhog_cell_size_1_restatement_is_bit_identical_to_dlib(w, h, pr, pc):
+    rgb = synth.frame_rgb(4, max(w, 16), max(h, 16))[:h, :w]
+    a, b = oracle.ref_fhog(rgb, 1, pr, pc), oracle.fhog(rgb, 1, pr, pc)
+    assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@needs_ref
 def test_fhog_colour_ties_and_gray():
     rng = np.random.default_rng(3)
     img = rng.integers(0, 4, (70, 93, 3)).astype(np.uint8) * 60   # many equal-length channel gradients
