@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 #define SURF_OCT 4
@@ -404,7 +405,26 @@ imgfd_status imgfd_surf(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, 
     for (size_t j = 0; j < m; j++) {
         const SurfRecord &p = pts[keep[j]];
         out->x[j] = p.x; out->y[j] = p.y; out->pyramid_scale[j] = p.scale; out->score[j] = p.score; out->laplacian[j] = p.laplacian;
-        surf_describe_host(I, rows, cols, p.x, p.y, p.scale, &out->angle[j], out->surf + 64 * j);
+    }
+    // K19 on the host: points are independent (each writes its own angle and descriptor), so they are shared out over
+    // a few threads; every point is computed by exactly the code a single thread would run (same bits)
+    unsigned nthr = std::min<unsigned>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())), (unsigned)(m / 16 + 1));
+    auto work = [&](size_t j0, size_t j1) {
+        for (size_t j = j0; j < j1; j++) {
+            const SurfRecord &p = pts[keep[j]];
+            surf_describe_host(I, rows, cols, p.x, p.y, p.scale, &out->angle[j], out->surf + 64 * j);
+        }
+    };
+    if (nthr <= 1) {
+        work(0, m);
+    } else {
+        std::vector<std::thread> pool;
+        const size_t per = (m + nthr - 1) / nthr;
+        for (unsigned t = 0; t < nthr; t++) {
+            const size_t j0 = std::min(m, t * per), j1 = std::min(m, j0 + per);
+            if (j0 < j1) pool.emplace_back(work, j0, j1);
+        }
+        for (auto &th : pool) th.join();
     }
     return IMGFD_OK;
 }
