@@ -81,15 +81,16 @@ def detect_corners(x, nx, ny, k=0.060000, sigma_d=1.000000, sigma_i=2.500000, th
 
     ``x`` is the NumericVector: any array with nx*ny elements in C-image order (x fastest)."""
     ctx = _ctx(ctx)
-    img = np.ascontiguousarray(np.asarray(x, dtype=np.float64).ravel(order="K")).astype(np.float32)
+    # the NumericVector as R holds it (REAL(x)); the (float) x[i] narrowing of rcpp_harris.cpp:34-35 happens on the device
+    img = np.ascontiguousarray(np.asarray(x, dtype=np.float64).ravel(order="K"))
     if img.size != int(nx) * int(ny):
         raise ValueError("x must hold nx*ny values")
     out = _binding.Corners()
-    st = ctx.lib.imgfd_harris(ctx.handle, img.ctypes.data_as(C.c_void_p), int(nx), int(ny), float(k),
+    st = ctx.lib.imgfd_harris_f64(ctx.handle, img.ctypes.data_as(C.c_void_p), int(nx), int(ny), float(k),
                               float(sigma_d), float(sigma_i), float(threshold), int(gaussian), int(gradient),
                               int(strategy), int(Nselect), int(measure), int(Nscales), int(precision),
                               int(cells), int(bool(verbose)), C.byref(out))
-    ctx.check(st, "imgfd_harris")
+    ctx.check(st, "imgfd_harris_f64")
     n = out.n
     if n:
         arr = np.ctypeslib.as_array(C.cast(out.corners, C.POINTER(C.c_float)), shape=(n, 3)).copy()
@@ -149,12 +150,13 @@ def image_detect_corners(x, threshold=50, suppress_non_max=False, ctx=None):
         raise ValueError("is.matrix(x) is not TRUE")
     ctx = _ctx(ctx)
     width, height = x.shape  # width = nrow(x), height = ncol(x), bytes_per_row = nrow(x)
-    # (unsigned char) x[i] on the IntegerVector, f9_rcpp.cpp:11; memory is column-major == x.T raster
-    img = np.ascontiguousarray((_as_integer(x).T & 0xFF).astype(np.uint8))
+    # as.integer(x): the IntegerVector as R holds it (column-major == x.T raster); (unsigned char) x[i] of
+    # f9_rcpp.cpp:11 happens on the device
+    img = np.ascontiguousarray(_as_integer(x).T.astype(np.int32))
     out = _binding.Points()
-    st = ctx.lib.imgfd_fast9(ctx.handle, img.ctypes.data_as(C.c_void_p), int(width), int(height), int(width),
-                             int(_as_integer(threshold)) & 0xFF, int(bool(suppress_non_max)), C.byref(out))
-    ctx.check(st, "imgfd_fast9")
+    st = ctx.lib.imgfd_fast9_i32(ctx.handle, img.ctypes.data_as(C.c_void_p), int(width), int(height), int(width),
+                                 int(_as_integer(threshold)) & 0xFF, int(bool(suppress_non_max)), C.byref(out))
+    ctx.check(st, "imgfd_fast9_i32")
     n = out.n
     if n:
         pts = np.ctypeslib.as_array(C.cast(out.points, C.POINTER(C.c_int)), shape=(n, 2)).copy()
@@ -174,12 +176,12 @@ def image_canny_edge_detector(x, s=2, low_thr=3, high_thr=10, accGrad=True, ctx=
         raise ValueError("x must be a matrix")
     ctx = _ctx(ctx)
     nx, ny = x.shape  # X = nrow(x), Y = ncol(x)
-    img = np.ascontiguousarray((_as_integer(x).T & 0xFF).astype(np.uint8))  # rcpp_canny.cpp:135-136
+    img = np.ascontiguousarray(_as_integer(x).T.astype(np.int32))  # as.integer(x); rcpp_canny.cpp:135-136 on the device
     edges = np.zeros((ny, nx), np.uint8)
     nonzero = C.c_int64(0)
-    st = ctx.lib.imgfd_canny(ctx.handle, img.ctypes.data_as(C.c_void_p), int(nx), int(ny), float(s), float(low_thr),
+    st = ctx.lib.imgfd_canny_i32(ctx.handle, img.ctypes.data_as(C.c_void_p), int(nx), int(ny), float(s), float(low_thr),
                              float(high_thr), int(bool(accGrad)), edges.ctypes.data_as(C.c_void_p), C.byref(nonzero))
-    ctx.check(st, "imgfd_canny")
+    ctx.check(st, "imgfd_canny_i32")
     res = RList(edges=edges.T.astype(np.float64),  # NumericMatrix(nx, ny), rcpp_canny.cpp:226-233
                 pixels_nonzero=int(nonzero.value), nx=float(nx), ny=float(ny), s=float(s),
                 low_thr=float(low_thr), high_thr=float(high_thr), accGrad=bool(accGrad))
@@ -194,7 +196,9 @@ def _rgb_bytes(x):
     if x.ndim != 3 or x.shape[0] != 3:
         raise ValueError("x must be a 3-dimensional array: RGB x width x height")
     _, width, height = x.shape
-    rgb = np.ascontiguousarray((_as_integer(x) & 0xFF).astype(np.uint8).transpose(2, 1, 0))  # (height, width, 3)
+    # R's column-major (3, W, H) array read as a flat IntegerVector == C-order (H, W, 3); the narrowing to bytes
+    # (rgb_pixel(unsigned char, ..)) happens on the device
+    rgb = np.ascontiguousarray(_as_integer(x).astype(np.int32).transpose(2, 1, 0))  # (height, width, 3) int32
     return rgb, width, height
 
 
@@ -204,9 +208,9 @@ def image_fhog(x, cell_size=8, filter_rows_padding=1, filter_cols_padding=1, ctx
     rgb, width, height = _rgb_bytes(x)
     hog = C.POINTER(C.c_float)()
     nr, nc = C.c_int(0), C.c_int(0)
-    st = ctx.lib.imgfd_fhog(ctx.handle, rgb.ctypes.data_as(C.c_void_p), int(height), int(width), int(cell_size),
-                            int(filter_rows_padding), int(filter_cols_padding), C.byref(hog), C.byref(nr), C.byref(nc))
-    ctx.check(st, "imgfd_fhog")
+    st = ctx.lib.imgfd_fhog_i32(ctx.handle, rgb.ctypes.data_as(C.c_void_p), int(height), int(width), int(cell_size),
+                                int(filter_rows_padding), int(filter_cols_padding), C.byref(hog), C.byref(nr), C.byref(nc))
+    ctx.check(st, "imgfd_fhog_i32")
     n = 31 * nr.value * nc.value
     if n:
         flat = np.ctypeslib.as_array(hog, shape=(n,)).astype(np.float64)
@@ -226,9 +230,9 @@ def image_surf(x, max_points=1000, detection_threshold=30, ctx=None):
     ctx = _ctx(ctx)
     rgb, width, height = _rgb_bytes(x)
     out = _binding.SurfOut()
-    st = ctx.lib.imgfd_surf(ctx.handle, rgb.ctypes.data_as(C.c_void_p), int(height), int(width), int(max_points),
-                            float(detection_threshold), C.byref(out))
-    ctx.check(st, "imgfd_surf")
+    st = ctx.lib.imgfd_surf_i32(ctx.handle, rgb.ctypes.data_as(C.c_void_p), int(height), int(width), int(max_points),
+                                float(detection_threshold), C.byref(out))
+    ctx.check(st, "imgfd_surf_i32")
     n = int(out.n)
 
     def vec(p, m):

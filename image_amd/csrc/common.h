@@ -71,6 +71,11 @@ imgfd_status pin_reserve(imgfd_ctx *ctx, size_t bytes);
 // records a profiling event on the stream when K3 profiling is on (no-op otherwise)
 imgfd_status prof_mark(imgfd_ctx *ctx);
 
+// ingest.hip: element type of a host vector handed to an entry point
+enum { IMGFD_SRC_U8 = 0, IMGFD_SRC_I32 = 1, IMGFD_SRC_F32 = 2, IMGFD_SRC_F64 = 3 };
+size_t upload_stage_bytes(int kind, size_t n);
+imgfd_status upload_image(imgfd_ctx *ctx, const void *host, int kind, size_t n, void *d_dst);
+
 // ---- kernel launchers shared between translation units (device pointers, async on ctx->stream)
 struct FrameGeom {
     int nx, ny;

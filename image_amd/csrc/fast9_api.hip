@@ -7,10 +7,8 @@
 
 #include <algorithm>
 
-extern "C" {
-
-imgfd_status imgfd_fast9(imgfd_ctx *ctx, const uint8_t *img, int width, int height, int bytes_per_row,
-                         uint8_t threshold, int suppress_non_max, imgfd_points *out)
+static imgfd_status fast9_host(imgfd_ctx *ctx, const void *img, int kind, int width, int height, int bytes_per_row,
+                               uint8_t threshold, int suppress_non_max, imgfd_points *out)
 {
     if (!ctx || !out) return IMGFD_ERR_INVALID;
     out->points = nullptr;
@@ -22,7 +20,7 @@ imgfd_status imgfd_fast9(imgfd_ctx *ctx, const uint8_t *img, int width, int heig
     const size_t img_bytes = (size_t)bytes_per_row * height;
     const int64_t cap = (int64_t)(width - 6) * (height - 6);
     const size_t need = align_up(img_bytes, 256) + align_up((size_t)width * height, 256) + compact_bytes(width, height, 1) +
-                        align_up(sizeof(imgfd_point) * (size_t)cap, 256) + 4096;
+                        align_up(sizeof(imgfd_point) * (size_t)cap, 256) + upload_stage_bytes(kind, img_bytes) + 4096;
     IMGFD_TRY(ws_reserve(ctx, need));
     uint8_t *d_img = (uint8_t *)ws_alloc(ctx, img_bytes);
     uint8_t *d_score = (uint8_t *)ws_alloc(ctx, (size_t)width * height);
@@ -31,7 +29,7 @@ imgfd_status imgfd_fast9(imgfd_ctx *ctx, const uint8_t *img, int width, int heig
     imgfd_point *d_points = (imgfd_point *)ws_alloc(ctx, sizeof(imgfd_point) * (size_t)cap);
     int64_t *d_count = (int64_t *)ws_alloc(ctx, sizeof(int64_t));
     if (!d_img || !d_score || !d_points || !d_count) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
-    IMGFD_HIP(ctx, hipMemcpyAsync(d_img, img, img_bytes, hipMemcpyHostToDevice, ctx->stream));
+    IMGFD_TRY(upload_image(ctx, img, kind, img_bytes, d_img));
     IMGFD_TRY(compact_clear(ctx, cb, height, 1));
     IMGFD_TRY(launch_fast9(ctx, d_img, width, height, bytes_per_row, img_bytes, 1, threshold, suppress_non_max, d_score, cb));
     IMGFD_TRY(compact_emit(ctx, cb, width, height, 1, 1, nullptr, d_points, cap, d_count));
@@ -47,6 +45,20 @@ imgfd_status imgfd_fast9(imgfd_ctx *ctx, const uint8_t *img, int width, int heig
         IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return IMGFD_OK;
+}
+
+extern "C" {
+
+imgfd_status imgfd_fast9(imgfd_ctx *ctx, const uint8_t *img, int width, int height, int bytes_per_row,
+                         uint8_t threshold, int suppress_non_max, imgfd_points *out)
+{
+    return fast9_host(ctx, img, IMGFD_SRC_U8, width, height, bytes_per_row, threshold, suppress_non_max, out);
+}
+
+imgfd_status imgfd_fast9_i32(imgfd_ctx *ctx, const int32_t *x, int width, int height, int bytes_per_row,
+                             uint8_t threshold, int suppress_non_max, imgfd_points *out)
+{
+    return fast9_host(ctx, x, IMGFD_SRC_I32, width, height, bytes_per_row, threshold, suppress_non_max, out);
 }
 
 imgfd_status imgfd_fast9_dev(imgfd_ctx *ctx, const imgfd_frames *fr, uint8_t threshold,

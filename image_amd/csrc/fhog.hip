@@ -459,8 +459,8 @@ imgfd_status imgfd_fhog_size(int rows, int cols, int cell_size, int filter_rows_
     return IMGFD_OK;
 }
 
-imgfd_status imgfd_fhog(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, int cell_size, int filter_rows_padding,
-                        int filter_cols_padding, float **hog, int *hog_nr, int *hog_nc)
+static imgfd_status fhog_host(imgfd_ctx *ctx, const void *rgb, int kind, int rows, int cols, int cell_size, int filter_rows_padding,
+                              int filter_cols_padding, float **hog, int *hog_nr, int *hog_nc)
 {
     if (!ctx) return IMGFD_ERR_INVALID;
     if (!rgb || !hog || !hog_nr || !hog_nc || rows < 0 || cols < 0 || cell_size < 1 || filter_rows_padding < 1 || filter_cols_padding < 1)
@@ -470,11 +470,12 @@ imgfd_status imgfd_fhog(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, 
     if (!fhog_geometry(rows, cols, cell_size, filter_rows_padding, filter_cols_padding, &g)) return IMGFD_OK;  // hog.clear()
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
     const size_t in_bytes = (size_t)3 * rows * cols, out_n = (size_t)31 * g.out_nr * g.out_nc;
-    IMGFD_TRY(ws_reserve(ctx, fhog_ws_bytes(g, 1) + align_up(in_bytes, 256) + align_up(out_n * sizeof(float), 256)));
+    IMGFD_TRY(ws_reserve(ctx, fhog_ws_bytes(g, 1) + align_up(in_bytes, 256) + align_up(out_n * sizeof(float), 256) +
+                              upload_stage_bytes(kind, in_bytes)));
     uint8_t *d_in = (uint8_t *)ws_alloc(ctx, in_bytes);
     float *d_out = (float *)ws_alloc(ctx, out_n * sizeof(float));
     if (!d_in || !d_out) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
-    IMGFD_HIP(ctx, hipMemcpyAsync(d_in, rgb, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    IMGFD_TRY(upload_image(ctx, rgb, kind, in_bytes, d_in));
     IMGFD_TRY(fhog_device(ctx, d_in, in_bytes, g, 1, d_out));
     float *h = (float *)malloc(out_n * sizeof(float));
     if (!h) return imgfd_fail(ctx, IMGFD_ERR_OOM, "malloc of the fhog output failed");
@@ -482,6 +483,18 @@ imgfd_status imgfd_fhog(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, 
     IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *hog = h; *hog_nr = g.out_nr; *hog_nc = g.out_nc;
     return IMGFD_OK;
+}
+
+imgfd_status imgfd_fhog(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, int cell_size, int filter_rows_padding,
+                        int filter_cols_padding, float **hog, int *hog_nr, int *hog_nc)
+{
+    return fhog_host(ctx, rgb, IMGFD_SRC_U8, rows, cols, cell_size, filter_rows_padding, filter_cols_padding, hog, hog_nr, hog_nc);
+}
+
+imgfd_status imgfd_fhog_i32(imgfd_ctx *ctx, const int32_t *x, int rows, int cols, int cell_size, int filter_rows_padding,
+                            int filter_cols_padding, float **hog, int *hog_nr, int *hog_nc)
+{
+    return fhog_host(ctx, x, IMGFD_SRC_I32, rows, cols, cell_size, filter_rows_padding, filter_cols_padding, hog, hog_nr, hog_nc);
 }
 
 imgfd_status imgfd_fhog_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, int rows, int cols, size_t frame_stride_bytes,

@@ -338,10 +338,10 @@ imgfd_status harris_scale(imgfd_ctx *ctx, const float *d_I, int nx, int ny, int 
 
 extern "C" {
 
-imgfd_status imgfd_harris(imgfd_ctx *ctx, const float *img, int nx, int ny, float k, float sigma_d,
-                          float sigma_i, float threshold, int gaussian, int gradient, int strategy,
-                          int Nselect, int measure, int Nscales, int precision, int cells, int verbose,
-                          imgfd_corners *out)
+static imgfd_status harris_host(imgfd_ctx *ctx, const void *img, int kind, int nx, int ny, float k, float sigma_d,
+                                float sigma_i, float threshold, int gaussian, int gradient, int strategy,
+                                int Nselect, int measure, int Nscales, int precision, int cells, int verbose,
+                                imgfd_corners *out)
 {
     if (!ctx || !out) return IMGFD_ERR_INVALID;
     out->corners = nullptr;
@@ -356,10 +356,11 @@ imgfd_status imgfd_harris(imgfd_ctx *ctx, const float *img, int nx, int ny, floa
     size_t need = plane + harris_ws_bytes(nx, ny, 1, (int64_t)nx * ny / 4 + 16,
                                           harris_tmp_floats(nx, ny, sigma_d, sigma_i, gaussian));
     if (Nscales > 1) need += plane;  // sum of the decimated copies is < plane/3; keep it simple
+    need += upload_stage_bytes(kind, (size_t)nx * ny);
     IMGFD_TRY(ws_reserve(ctx, need));
     float *d_I = (float *)ws_alloc(ctx, sizeof(float) * (size_t)nx * ny);
     if (!d_I) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
-    IMGFD_HIP(ctx, hipMemcpyAsync(d_I, img, sizeof(float) * (size_t)nx * ny, hipMemcpyHostToDevice, ctx->stream));
+    IMGFD_TRY(upload_image(ctx, img, kind, (size_t)nx * ny, d_I));
     HarrisArgs a{k, sigma_d, sigma_i, threshold, gaussian, gradient, measure, strategy, cells, Nselect, precision, verbose};
     std::vector<HCorner> corners;
     IMGFD_TRY(harris_scale(ctx, d_I, nx, ny, Nscales, a, corners, verbose ? out->stage_seconds : nullptr));
@@ -372,6 +373,24 @@ imgfd_status imgfd_harris(imgfd_ctx *ctx, const float *img, int nx, int ny, floa
         }
     }
     return IMGFD_OK;
+}
+
+imgfd_status imgfd_harris(imgfd_ctx *ctx, const float *img, int nx, int ny, float k, float sigma_d,
+                          float sigma_i, float threshold, int gaussian, int gradient, int strategy,
+                          int Nselect, int measure, int Nscales, int precision, int cells, int verbose,
+                          imgfd_corners *out)
+{
+    return harris_host(ctx, img, IMGFD_SRC_F32, nx, ny, k, sigma_d, sigma_i, threshold, gaussian, gradient, strategy, Nselect,
+                       measure, Nscales, precision, cells, verbose, out);
+}
+
+imgfd_status imgfd_harris_f64(imgfd_ctx *ctx, const double *x, int nx, int ny, float k, float sigma_d,
+                              float sigma_i, float threshold, int gaussian, int gradient, int strategy,
+                              int Nselect, int measure, int Nscales, int precision, int cells, int verbose,
+                              imgfd_corners *out)
+{
+    return harris_host(ctx, x, IMGFD_SRC_F64, nx, ny, k, sigma_d, sigma_i, threshold, gaussian, gradient, strategy, Nselect,
+                       measure, Nscales, precision, cells, verbose, out);
 }
 
 imgfd_status imgfd_harris_dev(imgfd_ctx *ctx, const imgfd_frames *fr, float k, float sigma_d,

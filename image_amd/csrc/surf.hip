@@ -264,7 +264,7 @@ imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const Surf
 
 // uploads the image, runs the device stages, returns the interest points in the reference's emission order
 // (and, if want_integral, the integral image for the host descriptor stage)
-imgfd_status surf_points_host(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, double thr,
+imgfd_status surf_points_host(imgfd_ctx *ctx, const void *rgb, int kind, int rows, int cols, double thr,
                               std::vector<SurfRecord> &pts, const int32_t **integral)
 {
     pts.clear();
@@ -276,7 +276,7 @@ imgfd_status surf_points_host(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int 
     SurfDevice d;
     d.cap = 1ull << 16;
     for (;;) {
-        IMGFD_TRY(ws_reserve(ctx, surf_ws_bytes(g, total, d.cap)));
+        IMGFD_TRY(ws_reserve(ctx, surf_ws_bytes(g, total, d.cap) + upload_stage_bytes(kind, 3 * n)));
         ctx->ws_used = 0;
         uint8_t *d_rgb = (uint8_t *)ws_alloc(ctx, 3 * n);
         d.integral = (unsigned *)ws_alloc(ctx, 4 * n);
@@ -284,7 +284,7 @@ imgfd_status surf_points_host(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int 
         d.rec = (SurfRecord *)ws_alloc(ctx, sizeof(SurfRecord) * d.cap);
         d.count = (unsigned long long *)ws_alloc(ctx, 256);
         if (!d_rgb || !d.integral || !d.pyr || !d.rec || !d.count) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
-        IMGFD_HIP(ctx, hipMemcpyAsync(d_rgb, rgb, 3 * n, hipMemcpyHostToDevice, ctx->stream));
+        IMGFD_TRY(upload_image(ctx, rgb, kind, 3 * n, d_rgb));
         IMGFD_TRY(surf_device_stages(ctx, d_rgb, g, thr, d));
         unsigned long long cnt = 0;
         IMGFD_HIP(ctx, hipMemcpyAsync(&cnt, d.count, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
@@ -339,7 +339,7 @@ imgfd_status imgfd_surf_interest_points(imgfd_ctx *ctx, const uint8_t *rgb, int 
     if (!rgb || !n || rows < 0 || cols < 0 || cap < 0 || (cap && !points) || !(detection_threshold >= 0))
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_surf_interest_points: bad argument");
     std::vector<SurfRecord> pts;
-    IMGFD_TRY(surf_points_host(ctx, rgb, rows, cols, detection_threshold, pts, nullptr));
+    IMGFD_TRY(surf_points_host(ctx, rgb, IMGFD_SRC_U8, rows, cols, detection_threshold, pts, nullptr));
     *n = (int64_t)pts.size();
     for (size_t k = 0; k < pts.size() && (int64_t)k < cap; k++) {
         double *o = points + 5 * k;
@@ -375,8 +375,8 @@ imgfd_status imgfd_surf_points_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_f
     return IMGFD_OK;
 }
 
-imgfd_status imgfd_surf(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, long max_points, double detection_threshold,
-                        imgfd_surf_out *out)
+static imgfd_status surf_host(imgfd_ctx *ctx, const void *rgb, int kind, int rows, int cols, long max_points,
+                              double detection_threshold, imgfd_surf_out *out)
 {
     if (!ctx || !out) return IMGFD_ERR_INVALID;
     memset(out, 0, sizeof *out);
@@ -384,7 +384,7 @@ imgfd_status imgfd_surf(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, 
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_surf: bad argument (DLIB_ASSERT of surf.h:243-248)");
     std::vector<SurfRecord> pts;
     const int32_t *I = nullptr;
-    IMGFD_TRY(surf_points_host(ctx, rgb, rows, cols, detection_threshold, pts, &I));
+    IMGFD_TRY(surf_points_host(ctx, rgb, kind, rows, cols, detection_threshold, pts, &I));
     if (pts.empty()) return IMGFD_OK;
     std::sort(pts.rbegin(), pts.rend(), ScoreLess());  // surf.h:268
     const size_t lim = std::min((size_t)max_points, pts.size());
@@ -427,6 +427,18 @@ imgfd_status imgfd_surf(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, 
         for (auto &th : pool) th.join();
     }
     return IMGFD_OK;
+}
+
+imgfd_status imgfd_surf(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, long max_points, double detection_threshold,
+                        imgfd_surf_out *out)
+{
+    return surf_host(ctx, rgb, IMGFD_SRC_U8, rows, cols, max_points, detection_threshold, out);
+}
+
+imgfd_status imgfd_surf_i32(imgfd_ctx *ctx, const int32_t *x, int rows, int cols, long max_points, double detection_threshold,
+                            imgfd_surf_out *out)
+{
+    return surf_host(ctx, x, IMGFD_SRC_I32, rows, cols, max_points, detection_threshold, out);
 }
 
 }  // extern "C"

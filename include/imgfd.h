@@ -174,6 +174,25 @@ IMGFD_API imgfd_status imgfd_surf_points_dev(imgfd_ctx *ctx, const uint8_t *d_rg
 /* stage doorway: the int32 integral image (integral_image.h:33-62) of the (r+g+b)/3 gray image, rows*cols values */
 IMGFD_API imgfd_status imgfd_k_surf_integral(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, int32_t *out);
 
+/* ------------------------------------------------------------------ R-native vectors
+ * The same entry points for the vectors R actually holds -- what REAL(x) / INTEGER(x) point to -- so the glue needs no
+ * element-by-element narrowing loop on R's single thread: the vector crosses PCIe once and the reference's casts
+ * ((float) x[i], rcpp_harris.cpp:34-35; (unsigned char) x[i], f9_rcpp.cpp:10-11, rcpp_canny.cpp:135-136;
+ * rgb_pixel(x[i], ..), rcpp_fhog.cpp:17-24, rcpp_surf.cpp:14-21) are applied in HBM.  Arguments and results are
+ * otherwise those of the functions above; bytes_per_row / the (3, W, H) interlacing count ELEMENTS here. */
+IMGFD_API imgfd_status imgfd_harris_f64(imgfd_ctx *ctx, const double *x, int nx, int ny, float k, float sigma_d,
+                              float sigma_i, float threshold, int gaussian, int gradient, int strategy,
+                              int Nselect, int measure, int Nscales, int precision, int cells, int verbose,
+                              imgfd_corners *out);
+IMGFD_API imgfd_status imgfd_fast9_i32(imgfd_ctx *ctx, const int32_t *x, int width, int height, int bytes_per_row,
+                             uint8_t threshold, int suppress_non_max, imgfd_points *out);
+IMGFD_API imgfd_status imgfd_canny_i32(imgfd_ctx *ctx, const int32_t *image, int nx, int ny, double s, double low_thr,
+                             double high_thr, int accGrad, uint8_t *edges, int64_t *pixels_nonzero);
+IMGFD_API imgfd_status imgfd_fhog_i32(imgfd_ctx *ctx, const int32_t *x, int rows, int cols, int cell_size,
+                            int filter_rows_padding, int filter_cols_padding, float **hog, int *hog_nr, int *hog_nc);
+IMGFD_API imgfd_status imgfd_surf_i32(imgfd_ctx *ctx, const int32_t *x, int rows, int cols, long max_points,
+                            double detection_threshold, imgfd_surf_out *out);
+
 /* ------------------------------------------------------------------ device-resident batch path
  * Frames live in HBM: frame f starts at (char*)d_frames + f*frame_stride_bytes, rows are row_stride
  * bytes apart.  Results stay on the device in caller-provided buffers so that a stream of frames can
