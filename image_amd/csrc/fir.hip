@@ -108,7 +108,7 @@ template <int R, int MODE, int TW, int CH, bool FMA, int FIR_PX, int FIR_NT, boo
 // or it trades VGPRs for an occupancy the LDS footprint can never reach (and spills)
 #define FIR_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #endif
-__global__ void __launch_bounds__(FIR_NT) FIR_WAVES_PER_EU(FIR_NT / 128) fir_march(FirParams p)
+__global__ void __launch_bounds__(FIR_NT) FIR_WAVES_PER_EU(FIR_NT == 192 ? 3 : FIR_NT / 128) fir_march(FirParams p)
 {
     using G = FirGeom<R, MODE, TW, CH, FIR_PX, FIR_NT>;
     constexpr int NI = G::NI, NP = G::NP, W4 = G::W4, RPITCH = G::RPITCH, RING = G::RING, HALO = G::HALO;
@@ -538,11 +538,7 @@ imgfd_status launch_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const fl
     p.in_pitch = nx; p.in_frame_stride = (long)nx * ny; p.out_frame_stride = (long)nx * ny;
     if (fir_has_fast_path(R, 2)) {
         switch (R) {
-            case 7: {
-                static const char *e = getenv("IMGFD_K3_PX4");
-                if (e && atoi(e)) return launch_march<7, 2, 128, 16, 4, 512>(ctx, p, n_frames);
-                return launch_march<7, 2, 128, 16>(ctx, p, n_frames);
-            }
+            case 7: return launch_march<7, 2, 128, 16>(ctx, p, n_frames);
             case 3: return launch_march<3, 2, 128, 16>(ctx, p, n_frames);
             case 1: return launch_march<1, 2, 128, 16>(ctx, p, n_frames);
         }
