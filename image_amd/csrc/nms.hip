@@ -68,16 +68,16 @@ imgfd_status launch_harris_nms(imgfd_ctx *ctx, const float *d_R, int nx, int ny,
 }
 
 // ------------------------------------------------------------------ K4 + K5 fused (batch path)
-// The response plane is never materialised.  One workgroup owns a 64x32 tile: (1) R of the tile plus a halo of
+// The response plane is never materialised.  One workgroup owns a 64x64 tile: (1) R of the tile plus a halo of
 // `radius` (<= RN_HALO) pixels is computed from A, B, C into LDS; (2) every pixel applies the threshold and the 3x3
 // part of the window rule from LDS, survivors go to an LDS candidate list; (3) the waves take candidates in turn and
 // test the full (2r+1)^2 window with all 64 lanes (2 window positions per lane, __any as the verdict): no lane waits
 // for a neighbour's long loop; (4) one __ballot per tile row is the mask word.  HBM traffic: the 12 B/px of A, B, C
 // (halo re-reads are L2 hits).
 #define RN_TX 64
-#define RN_TY 32
+#define RN_TY 64
 #define RN_HALO 6
-#define RN_MAXC 512  // 3x3 local maxima cannot be denser than one per 2x2 block: 64*32/4
+#define RN_MAXC 1024  // 3x3 local maxima cannot be denser than one per 2x2 block: 64*64/4
 
 // HC > 0: the window radius is the compile-time constant HC (index arithmetic by constants); HC == 0: any radius <= RN_HALO
 template <int MEASURE, int HC>
@@ -151,16 +151,30 @@ __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__res
     // (3) full window, one candidate per wave at a time, window positions spread over the lanes
     const int n = min((int)ncand, RN_MAXC);
     const int side = 2 * radius + 1, npos = side * side;
+    // every lane owns up to two window positions (lane, lane + 64 of the (2r+1)^2 <= 169): offsets and the side of the
+    // tie rule are candidate-independent, so they are set up once
+    int off[3];
+    bool strict[3], live[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int pidx = lane + 64 * j;
+        const int dy = pidx / side - radius, dx = pidx % side - radius;
+        live[j] = pidx < npos && !(dy == 0 && dx == 0);
+        off[j] = dy * LP + dx;
+        strict[j] = dy < 0 || (dy == 0 && dx > 0);  // above, or to the right on the same row: must be <
+    }
+    const float *flat = &sR[0][0];
     for (int ci = wv; ci < n; ci += 4) {
         const int r = cand[ci] >> 8, c = cand[ci] & 255;
-        const float v = sR[r + H][c + XO];
+        const int base = (r + H) * LP + (c + XO);
+        const float v = flat[base];
         bool fail = false;
-        for (int pidx = lane; pidx < npos; pidx += 64) {
-            const int dy = pidx / side - radius, dx = pidx % side - radius;
-            if (dy == 0 && dx == 0) continue;
-            const float q = sR[r + H + dy][c + XO + dx];
-            const bool strict = dy < 0 || (dy == 0 && dx > 0);  // above, or to the right on the same row: must be <
-            fail = fail || (strict ? (q >= v) : (q > v));
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            if (live[j]) {
+                const float q = flat[base + off[j]];
+                fail = fail || (strict[j] ? (q >= v) : (q > v));
+            }
         }
         if (!__any(fail) && lane == 0) keep[r][c] = 1;
     }
