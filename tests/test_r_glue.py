@@ -1,0 +1,41 @@
+"""The .Call glue a maintainer drops into the four R packages (r/<pkg>/src/glue.c): R is not installed here, so the files
+are compile-checked against r/stub/Rinternals.h (R's own signatures) and include/imgfd.h, and the registered symbols
+and arities are compared with the reference's RcppExports."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKGS = {
+    "image.CornerDetectionHarris": {"_image_CornerDetectionHarris_detect_corners": 16},
+    "image.CornerDetectionF9": {"_image_CornerDetectionF9_detect_corners": 6},
+    "image.CannyEdges": {"_image_CannyEdges_canny_edge_detector": 7},
+    "image.dlib": {"_image_dlib_dlib_fhog": 6, "_image_dlib_dlib_surf_points": 5},
+}
+
+
+@pytest.mark.parametrize("pkg", sorted(PKGS))
+def test_glue_compiles_against_the_c_abi(pkg):
+    src = os.path.join(ROOT, "r", pkg, "src", "glue.c")
+    cmd = ["gcc", "-std=gnu99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "r", "stub"),
+           "-I", os.path.join(ROOT, "include"), src]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.parametrize("pkg", sorted(PKGS))
+def test_registered_symbols_and_arity_match_the_reference(pkg):
+    txt = open(os.path.join(ROOT, "r", pkg, "src", "glue.c")).read()
+    entries = dict((m.group(1), int(m.group(2))) for m in re.finditer(r'\{"(_image_\w+)",\s*\(DL_FUNC\)&\w+,\s*(\d+)\}', txt))
+    assert entries == PKGS[pkg]
+    for name, arity in PKGS[pkg].items():   # the C definition takes that many SEXPs
+        sig = re.search(r"SEXP %s\(([^)]*)\)" % name, txt, re.S).group(1)
+        assert sig.count("SEXP") == arity, name
+    assert ("R_init_" + pkg.replace(".", "_")) in txt
+    ref = os.path.join("/root/reference", pkg, "src", "RcppExports.cpp")
+    if os.path.exists(ref):                 # only in the build container
+        rtxt = open(ref).read()
+        for name, arity in PKGS[pkg].items():
+            assert re.search(r'\{"%s",\s*\(DL_FUNC\)\s*&%s,\s*%d\}' % (name, name, arity), rtxt), name
