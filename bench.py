@@ -26,9 +26,11 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 TENSOR_BYTES_PER_PX = 20        # read Ix,Iy (8 B), write A,B,C (12 B)
 
 
-def cpu_baseline(frames_host):
+def cpu_baseline(frames_host, gpu_frame0=None):
     """Reference CPU path on this host: Harris = reference sources + OpenMP on all cores, FAST-9 =
-    reference f9.cpp (single-threaded code), Canny = oracle restatement (reference needs FFTW3)."""
+    reference f9.cpp (single-threaded code), Canny = oracle restatement (reference needs FFTW3).
+    gpu_frame0: the device results for the same frame (corner list, FAST-9 list, edge map): the CPU outputs computed
+    here anyway double as the metric's "feature-coordinate match vs CPU" check."""
     import numpy as np
 
     import oracle
@@ -67,6 +69,18 @@ def cpu_baseline(frames_host):
         parts["canny_ms"] = round(1e3 * t_c, 2)
     except Exception:
         pass
+    if gpu_frame0 is not None:
+        rh = oracle.ref_harris(f32, threads=cores) if have_ref else oracle.harris(f32)
+        rf = oracle.ref_fast9(img, 20, True) if have_ref else oracle.fast9(img, 20, True)
+        gh, gf, ge = gpu_frame0
+        same_h = gh.shape == rh.shape and bool(np.array_equal(gh[:, :2], rh[:, :2]))
+        par = {"harris_corners": int(len(rh)), "harris_coordinates_match": same_h,
+               "harris_strength_max_rel_err": float(np.max(np.abs(gh[:, 2] - rh[:, 2]) / np.maximum(1.0, np.abs(rh[:, 2])))) if same_h and len(rh) else None,
+               "fast9_corners": int(len(rf)), "fast9_coordinates_match": bool(gf.shape == rf.shape and np.array_equal(gf, rf))}
+        if t_c is not None:
+            re_, rn = oracle.canny(img)
+            par.update({"canny_edge_pixels": int(rn), "canny_mismatching_pixels": int(np.count_nonzero(ge != re_))})
+        out["parity_frame0"] = par
     total = t_h + t_f + (t_c or 0.0)
     out.update({"value": round(px / total / 1e6, 3), "kind": kind, "cores": cores,
                 "sample": f"1 frame {NX}x{NY}, best of 2 after warm-up; Harris: reference src + OpenMP x{cores} (best of 8/16/32/64 threads, {avail} available); "
@@ -185,8 +199,12 @@ def main():
                          "algorithmic_bytes_per_launch": k3_bytes},
         }
         if world == 1 and not args.no_cpu:
-            host = np.stack([synth.frame(50000, NX, NY)])
-            res["cpu_baseline"] = cpu_baseline(host)
+            host = np.stack([synth.frame(stream.frame_seed(50000, 0), NX, NY)])   # host twin of device frame 0
+            assert np.array_equal(frames[0].cpu().numpy(), host[0]), "device and host frame generators diverged"
+            n_h, n_f = int(h_out[1][0]), int(f_out[1][0])
+            gpu0 = (h_out[0][0, :min(n_h, cap_h)].cpu().numpy(), f_out[0][0, :min(n_f, cap_f)].cpu().numpy(),
+                    c_out[0][0].cpu().numpy() if have_canny else None)
+            res["cpu_baseline"] = cpu_baseline(host, gpu0)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
