@@ -18,16 +18,28 @@ template <int R, bool FMA, int FIR_PX>
 __device__ __forceinline__ void fir_window8(const double (&d)[FIR_PX + 2 * R], const double *B,
                                             float (&out)[FIR_PX])
 {
+#ifndef FIR_ILP
+#define FIR_ILP 1
+#endif
+    // FIR_ILP independent output chains advance together (each chain keeps the reference's own operation order)
 #pragma unroll
-    for (int o = 0; o < FIR_PX; o++) {
-        double sum = B[0] * d[o + R];
+    for (int o0 = 0; o0 < FIR_PX; o0 += FIR_ILP) {
+        double sum[FIR_ILP];
+#pragma unroll
+        for (int g = 0; g < FIR_ILP; g++) sum[g] = B[0] * d[o0 + g + R];
 #pragma unroll
         for (int j = 1; j <= R; j++) {
-            double pair = d[o + R - j] + d[o + R + j];
-            if (FMA) sum = __builtin_fma(B[j], pair, sum);
-            else sum += B[j] * pair;
+            double pair[FIR_ILP];
+#pragma unroll
+            for (int g = 0; g < FIR_ILP; g++) pair[g] = d[o0 + g + R - j] + d[o0 + g + R + j];
+#pragma unroll
+            for (int g = 0; g < FIR_ILP; g++) {
+                if (FMA) sum[g] = __builtin_fma(B[j], pair[g], sum[g]);
+                else sum[g] += B[j] * pair[g];
+            }
         }
-        out[o] = (float)sum;
+#pragma unroll
+        for (int g = 0; g < FIR_ILP; g++) out[o0 + g] = (float)sum[g];
     }
 }
 
