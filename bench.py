@@ -97,6 +97,10 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--fir-mode", type=int, default=1)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; nccl (= RCCL) is the product path, gloo is a functional check")
+    ap.add_argument("--share-device", action="store_true",
+                    help="test hook: every rank uses cuda:0 (functional check of the N>1 path on a 1-GPU box; not a measurement)")
     args = ap.parse_args()
 
     import numpy as np
@@ -108,10 +112,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the backend has no CPU path")
+    if args.share_device:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group("gloo")
 
     from image_amd import stream, synth
     from image_amd.device import DeviceDetector
@@ -186,7 +195,8 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64-accumulate/f32 (Harris), u8 (FAST-9), f64 (Canny)", "data": "synthetic",
-            "config": {"workload": f"configs[1]+Canny: image_harris() defaults + FAST-9 thr 20 nonmax"
+            "config": {**({"note": "functional check only: ranks share one device / gloo collectives"} if (args.share_device or args.backend != "nccl") else {}),
+                       "workload": f"configs[1]+Canny: image_harris() defaults + FAST-9 thr 20 nonmax"
                                    f"{' + Canny s=2 3/10 accGrad' if have_canny else ' (Canny not implemented yet: EXCLUDED)'}"
                                    f" on {NX}x{NY} u8 frames resident in HBM",
                        "frames_per_step_per_gpu": B, "fir_mode": "fused-accumulate" if args.fir_mode else "strict",

@@ -28,6 +28,11 @@ def reduce_counts(counts, elapsed_s: float, dist=None, device=None):
     import torch
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=counts.device if device is None else device)
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "gloo" and counts.is_cuda:  # functional checks: gloo reduces host tensors
+            c, tt = counts.cpu(), t.cpu()
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return c.to(counts.device), float(tt.item())
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return counts, float(t.item())
