@@ -283,10 +283,14 @@ __global__ void __launch_bounds__(64) fhog_cell_hist(const unsigned *__restrict_
             else if (iyp + 2 == hr) wy = vy0;
             else continue;
             const unsigned *row = pk + (size_t)y * g.cols + xc;
+            // fetch the whole candidate row first (independent loads in flight), then vote in raster order
+            unsigned pv[FHOG_MAXW];
+#pragma unroll
+            for (int k = 0; k < FHOG_MAXW; k++) pv[k] = row[min(k, x_hi - xc)];
 #pragma unroll
             for (int k = 0; k < FHOG_MAXW; k++) {
                 if (vx[k] >= 0.f) {  // weights are in [0, 1]; -1 marks "no vote"
-                    const unsigned p = row[k];
+                    const unsigned p = pv[k];
                     const float v = sqrtf((float)(p >> 5));
                     // :863-870 weights vy*(vx*v)  vs  :951-954 (vy*vx)*v
                     b[p & 31] += body[k] ? wy * (vx[k] * v) : wy * vx[k] * v;
