@@ -107,8 +107,6 @@ imgfd_status launch_gradient(imgfd_ctx *ctx, const float *d_I, float *d_Ix, floa
                              int n_frames, int type);
 imgfd_status launch_response(imgfd_ctx *ctx, const float *d_A, const float *d_B, const float *d_C,
                              float *d_R, int nx, int ny, int n_frames, int measure, float k);
-imgfd_status launch_convert_u8_f32(imgfd_ctx *ctx, const uint8_t *d_in, int in_pitch,
-                                   size_t in_frame_stride, float *d_out, int nx, int ny, int n_frames);
 // compact.hip: ordered (raster) stream compaction from a per-pixel bit mask
 struct CompactBuffers {
     unsigned long long *mask;  // n_frames * ny * words_per_row
@@ -133,5 +131,4 @@ imgfd_status launch_harris_nms(imgfd_ctx *ctx, const float *d_R, int nx, int ny,
                                int radius, const CompactBuffers &cb);
 // fast9.hip
 imgfd_status launch_fast9(imgfd_ctx *ctx, const uint8_t *d_img, int w, int h, int stride,
-                          size_t frame_stride, int n_frames, int threshold, int nonmax,
-                          uint8_t *d_score, const CompactBuffers &cb);
+                          size_t frame_stride, int n_frames, int threshold, int nonmax, const CompactBuffers &cb);

@@ -135,12 +135,9 @@ __global__ void __launch_bounds__(256) fast9_tile(const unsigned char *__restric
     }
 }
 
-// d_score is no longer used (kept in the signature for the callers' workspace layout)
 imgfd_status launch_fast9(imgfd_ctx *ctx, const uint8_t *d_img, int w, int h, int stride,
-                          size_t frame_stride, int n_frames, int threshold, int nonmax,
-                          uint8_t *d_score, const CompactBuffers &cb)
+                          size_t frame_stride, int n_frames, int threshold, int nonmax, const CompactBuffers &cb)
 {
-    (void)d_score;
     dim3 grid(cb.words_per_row, ceil_div(h, F9_TY), n_frames);
     const int aligned4 = ((size_t)d_img % 4 == 0) && stride % 4 == 0 && frame_stride % 4 == 0;
     if (!nonmax)

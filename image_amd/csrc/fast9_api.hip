@@ -19,19 +19,18 @@ static imgfd_status fast9_host(imgfd_ctx *ctx, const void *img, int kind, int wi
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
     const size_t img_bytes = (size_t)bytes_per_row * height;
     const int64_t cap = (int64_t)(width - 6) * (height - 6);
-    const size_t need = align_up(img_bytes, 256) + align_up((size_t)width * height, 256) + compact_bytes(width, height, 1) +
+    const size_t need = align_up(img_bytes, 256) + compact_bytes(width, height, 1) +
                         align_up(sizeof(imgfd_point) * (size_t)cap, 256) + upload_stage_bytes(kind, img_bytes) + 4096;
     IMGFD_TRY(ws_reserve(ctx, need));
     uint8_t *d_img = (uint8_t *)ws_alloc(ctx, img_bytes);
-    uint8_t *d_score = (uint8_t *)ws_alloc(ctx, (size_t)width * height);
     CompactBuffers cb;
     IMGFD_TRY(compact_carve(ctx, width, height, 1, &cb));
     imgfd_point *d_points = (imgfd_point *)ws_alloc(ctx, sizeof(imgfd_point) * (size_t)cap);
     int64_t *d_count = (int64_t *)ws_alloc(ctx, sizeof(int64_t));
-    if (!d_img || !d_score || !d_points || !d_count) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    if (!d_img || !d_points || !d_count) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
     IMGFD_TRY(upload_image(ctx, img, kind, img_bytes, d_img));
     IMGFD_TRY(compact_clear(ctx, cb, height, 1));
-    IMGFD_TRY(launch_fast9(ctx, d_img, width, height, bytes_per_row, img_bytes, 1, threshold, suppress_non_max, d_score, cb));
+    IMGFD_TRY(launch_fast9(ctx, d_img, width, height, bytes_per_row, img_bytes, 1, threshold, suppress_non_max, cb));
     IMGFD_TRY(compact_emit(ctx, cb, width, height, 1, 1, nullptr, d_points, cap, d_count));
     int64_t n = 0;
     IMGFD_HIP(ctx, hipMemcpyAsync(&n, d_count, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
@@ -69,19 +68,17 @@ imgfd_status imgfd_fast9_dev(imgfd_ctx *ctx, const imgfd_frames *fr, uint8_t thr
     if (fr->n_frames == 0) return IMGFD_OK;
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
     const int w = fr->nx, h = fr->ny;
-    const size_t per_frame = (size_t)w * h + compact_bytes(w, h, 1);
+    const size_t per_frame = compact_bytes(w, h, 1);
     int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)fr->n_frames, ((size_t)1 << 30) / per_frame));
-    IMGFD_TRY(ws_reserve(ctx, align_up((size_t)w * h * chunk, 256) + compact_bytes(w, h, chunk) + 4096));
-    uint8_t *d_score = (uint8_t *)ws_alloc(ctx, (size_t)w * h * chunk);
+    IMGFD_TRY(ws_reserve(ctx, compact_bytes(w, h, chunk) + 4096));
     CompactBuffers cb;
     IMGFD_TRY(compact_carve(ctx, w, h, chunk, &cb));
-    if (!d_score) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
     for (int f0 = 0; f0 < fr->n_frames; f0 += chunk) {
         const int nf = std::min(chunk, fr->n_frames - f0);
         const uint8_t *base = (const uint8_t *)fr->d_frames + (size_t)f0 * fr->frame_stride_bytes;
         IMGFD_TRY(compact_clear(ctx, cb, h, nf));
         IMGFD_TRY(launch_fast9(ctx, base, w, h, fr->row_stride_bytes, fr->frame_stride_bytes, nf, threshold,
-                               suppress_non_max, d_score, cb));
+                               suppress_non_max, cb));
         IMGFD_TRY(compact_emit(ctx, cb, w, h, nf, 1, nullptr, d_points + (size_t)f0 * cap, cap, d_counts + f0));
     }
     return IMGFD_OK;
