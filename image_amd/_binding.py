@@ -37,6 +37,22 @@ class Frames(C.Structure):
                 ("frame_stride_bytes", C.c_size_t), ("row_stride_bytes", C.c_int), ("dtype", C.c_int)]
 
 
+class StreamParams(C.Structure):
+    _fields_ = [("harris", C.c_int), ("fast9", C.c_int), ("canny", C.c_int),
+                ("k", C.c_float), ("sigma_d", C.c_float), ("sigma_i", C.c_float), ("threshold", C.c_float),
+                ("gaussian", C.c_int), ("gradient", C.c_int), ("measure", C.c_int),
+                ("fast9_threshold", C.c_int), ("suppress_non_max", C.c_int),
+                ("s", C.c_double), ("low_thr", C.c_double), ("high_thr", C.c_double), ("accGrad", C.c_int),
+                ("corner_cap", C.c_int64), ("point_cap", C.c_int64), ("keep_edges", C.c_int)]
+
+
+class StreamResult(C.Structure):
+    _fields_ = [("n_frames", C.c_int), ("first_frame", C.c_int64),
+                ("harris_counts", C.POINTER(C.c_int64)), ("fast9_counts", C.POINTER(C.c_int64)),
+                ("canny_counts", C.POINTER(C.c_int64)),
+                ("corners", C.POINTER(Corner)), ("points", C.POINTER(Point)), ("edges", C.POINTER(C.c_uint8))]
+
+
 # every symbol include/imgfd.h declares: (restype, argtypes)
 c_float_pp = C.POINTER(C.POINTER(C.c_float))
 c_int_p = C.POINTER(C.c_int)
@@ -91,6 +107,13 @@ SIGNATURES = {
     "imgfd_profile_k3_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "imgfd_synth_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_uint32,
                                      C.c_void_p, C.c_int]),
+    "imgfd_stream_default_params": (None, [C.POINTER(StreamParams)]),
+    "imgfd_stream_open": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(StreamParams), c_void_pp]),
+    "imgfd_stream_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
+    "imgfd_stream_collect": (C.c_int, [C.c_void_p, C.POINTER(StreamResult)]),
+    "imgfd_stream_close": (None, [C.c_void_p]),
+    "imgfd_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "imgfd_host_free": (None, [C.c_void_p]),
 }
 
 

@@ -261,6 +261,57 @@ IMGFD_API imgfd_status imgfd_synth_frames(imgfd_ctx *ctx, uint8_t *d_frames, int
                                 size_t frame_stride_bytes, uint32_t seed0, const int32_t *d_rects,
                                 int n_rect);
 
+/* ------------------------------------------------------------------ host frame streams
+ * A sequence of u8 gray frames that lives in HOST memory (decoded PGMs, a camera ring) run through Harris / FAST-9 /
+ * Canny batch by batch: while batch i is in the kernels, batch i+1 crosses PCIe on a second HIP stream into the other
+ * device buffer.  The reference has no counterpart -- image_harris(), image_detect_corners() and
+ * image_canny_edge_detector() take one image per call (H/R/pkg.R:76-90, F9/R/image_detect_corners.R:10-27,
+ * CE/R/canny_edges_detector.R:63) -- this is the driver loop a caller of those functions writes around them, moved below the boundary
+ * so that the upload overlaps the compute.  Results of every frame are those of imgfd_harris_dev / imgfd_fast9_dev /
+ * imgfd_canny_dev on the same frame.
+ *
+ * Frames handed to imgfd_stream_submit may be ordinary (pageable) memory; they are then staged through pinned
+ * buffers by a helper thread.  Memory from imgfd_host_alloc (pinned) is read by the DMA engine directly. */
+typedef struct imgfd_stream imgfd_stream;
+
+typedef struct {
+    int harris, fast9, canny;              /* which detectors run (non-zero = on) */
+    float k, sigma_d, sigma_i, threshold;  /* Harris, as imgfd_harris_dev */
+    int gaussian, gradient, measure;
+    int fast9_threshold, suppress_non_max; /* FAST-9, as imgfd_fast9_dev */
+    double s, low_thr, high_thr;           /* Canny, as imgfd_canny_dev */
+    int accGrad;
+    int64_t corner_cap, point_cap;         /* records kept per frame (0: counts only) */
+    int keep_edges;                        /* non-zero: the 0/255 edge maps are copied back too */
+} imgfd_stream_params;
+
+typedef struct {
+    int n_frames;                /* frames in this batch */
+    int64_t first_frame;         /* index of its first frame in submission order */
+    const int64_t *harris_counts, *fast9_counts, *canny_counts; /* n_frames each; NULL when the detector is off */
+    const imgfd_corner *corners; /* frame f: corners + f*corner_cap, min(count, cap) records; NULL when cap is 0 */
+    const imgfd_point *points;   /* frame f: points + f*point_cap */
+    const uint8_t *edges;        /* n_frames * nx*ny bytes; NULL unless keep_edges */
+} imgfd_stream_result;
+
+/* defaults of the three R functions, all detectors on, counts only */
+IMGFD_API void imgfd_stream_default_params(imgfd_stream_params *p);
+IMGFD_API imgfd_status imgfd_stream_open(imgfd_ctx *ctx, int nx, int ny, int batch_frames,
+                                         const imgfd_stream_params *params, imgfd_stream **out);
+/* Start the upload of n_frames (1..batch_frames) frames, frame f at frames + f*frame_stride_bytes (rows contiguous),
+ * and launch the kernels of the batch submitted before it.  Does not wait for either.  At most two batches can be
+ * pending; a third submit without a collect fails with IMGFD_ERR_INVALID.  `frames` must stay valid until the
+ * batch has been collected. */
+IMGFD_API imgfd_status imgfd_stream_submit(imgfd_stream *st, const uint8_t *frames, int n_frames,
+                                           size_t frame_stride_bytes);
+/* Wait for the oldest pending batch and describe its results.  The arrays live in pinned memory owned by the stream
+ * and stay valid until the second imgfd_stream_submit after this call.  res->n_frames == 0 when nothing is pending. */
+IMGFD_API imgfd_status imgfd_stream_collect(imgfd_stream *st, imgfd_stream_result *res);
+IMGFD_API void imgfd_stream_close(imgfd_stream *st);
+/* pinned host memory for frames (hipHostMalloc); NULL on failure */
+IMGFD_API void *imgfd_host_alloc(size_t bytes);
+IMGFD_API void imgfd_host_free(void *p);
+
 #ifdef __cplusplus
 }
 #endif

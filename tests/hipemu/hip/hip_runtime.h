@@ -22,6 +22,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
+#include <set>
 #include <vector>
 
 #define __global__
@@ -321,6 +323,12 @@ struct hipDeviceProp_t {
 #define hipHostMallocDefault 0
 #define hipStreamNonBlocking 1
 #define hipEventDefault 0
+#define hipEventDisableTiming 2
+enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
+struct hipPointerAttribute_t { hipMemoryType type; };
+// pinned allocations (hipHostMalloc) are remembered so that hipPointerGetAttributes can tell them from pageable memory
+inline std::mutex &hipemu_pinned_lock() { static std::mutex m; return m; }
+inline std::set<const void *> &hipemu_pinned() { static std::set<const void *> s; return s; }
 
 static inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
@@ -338,9 +346,21 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <typename T> static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
-static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
-template <typename T> static inline hipError_t hipHostMalloc(T **p, size_t n, unsigned f = 0) { return hipMalloc((void **)p, n); }
-static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) {
+    hipError_t e = hipMalloc(p, n);
+    if (e == hipSuccess) { std::lock_guard<std::mutex> g(hipemu_pinned_lock()); hipemu_pinned().insert(*p); }
+    return e;
+}
+template <typename T> static inline hipError_t hipHostMalloc(T **p, size_t n, unsigned f = 0) { return hipHostMalloc((void **)p, n, f); }
+static inline hipError_t hipHostFree(void *p) {
+    { std::lock_guard<std::mutex> g(hipemu_pinned_lock()); hipemu_pinned().erase(p); }
+    free(p); return hipSuccess;
+}
+static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *p) {
+    std::lock_guard<std::mutex> g(hipemu_pinned_lock());
+    if (!hipemu_pinned().count(p)) return hipErrorInvalidValue;
+    a->type = hipMemoryTypeHost; return hipSuccess;
+}
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t = 0) { return hipMemcpy(d, s, n, k); }
 static inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t = 0) {
@@ -360,6 +380,7 @@ static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { retu
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = 0) { e->t = hipemu_now(); return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
