@@ -67,6 +67,10 @@ SIGNATURES = {
     "imgfd_surf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_double, C.POINTER(SurfOut)]),
     "imgfd_surf_interest_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "imgfd_surf_points_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_double, C.c_void_p, C.c_int64, C.c_void_p]),
+    "imgfd_surf_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_long, C.c_double, C.c_void_p, C.c_int64, C.c_void_p]),
+    "imgfd_knn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "imgfd_knn_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "imgfd_k_surf_integral": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "imgfd_fhog": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_float_pp, c_int_p, c_int_p]),
     "imgfd_fhog_size": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, c_int_p]),

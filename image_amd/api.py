@@ -243,3 +243,22 @@ def image_surf(x, max_points=1000, detection_threshold=30, ctx=None):
         ctx.lib.imgfd_free(out.data)
     res["surf"][np.isnan(res["surf"])] = 0  # out$surf[is.nan(out$surf)] <- 0, image_surf.R:88
     return res
+
+
+def get_knnx(data, query, k=1, ctx=None):
+    """The matching step of the reference's README (image.dlib/README.md:19-37): ``FNN::get.knnx(sp1$surf, sp2$surf, k)``.
+    Returns, like FNN, ``nn.index`` (1-based rows of ``data``, shape (n_query, k)) and ``nn.dist`` (Euclidean, ascending)."""
+    ctx = _ctx(ctx)
+    data = np.ascontiguousarray(data, np.float64)
+    query = np.ascontiguousarray(query, np.float64)
+    if data.ndim != 2 or query.ndim != 2 or data.shape[1] != query.shape[1]:
+        raise ValueError("data and query must be matrices with the same number of columns")
+    if k > data.shape[0]:
+        raise ValueError("k must not exceed the number of data points")  # FNN: "ANN: ERROR------->" / stop()
+    nq = query.shape[0]
+    idx = np.zeros((nq, k), np.int32)
+    dist = np.zeros((nq, k), np.float64)
+    st = ctx.lib.imgfd_knn(ctx.handle, data.ctypes.data_as(C.c_void_p), data.shape[0], query.ctypes.data_as(C.c_void_p), nq,
+                           data.shape[1], int(k), 0, idx.ctypes.data_as(C.c_void_p), dist.ctypes.data_as(C.c_void_p))
+    ctx.check(st, "imgfd_knn")
+    return RList({"nn.index": idx + 1, "nn.dist": dist})

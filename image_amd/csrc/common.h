@@ -29,6 +29,9 @@ struct imgfd_ctx {
     // pinned host staging
     char *pin = nullptr;
     size_t pin_size = 0;
+    // second grow-only device buffer for stages that start after the workspace arena has been carved (SURF K19)
+    char *aux = nullptr;
+    size_t aux_size = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // in-pipeline K3 timing (imgfd_profile_k3)
     bool prof_on = false;
@@ -68,6 +71,7 @@ imgfd_status ws_reserve(imgfd_ctx *ctx, size_t bytes);
 void *ws_alloc(imgfd_ctx *ctx, size_t bytes);  // 256-byte aligned; nullptr if the reservation is exceeded
 static inline void ws_reset(imgfd_ctx *ctx) { ctx->ws_used = 0; }
 imgfd_status pin_reserve(imgfd_ctx *ctx, size_t bytes);
+imgfd_status aux_reserve(imgfd_ctx *ctx, size_t bytes);
 // records a profiling event on the stream when K3 profiling is on (no-op otherwise)
 imgfd_status prof_mark(imgfd_ctx *ctx);
 

@@ -54,6 +54,7 @@ void imgfd_ctx_destroy(imgfd_ctx *ctx)
     for (void *p : ctx->ws_old) (void)hipFree(p);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
+    if (ctx->aux) (void)hipFree(ctx->aux);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -146,6 +147,24 @@ void *ws_alloc(imgfd_ctx *ctx, size_t bytes)
     if (off + bytes > ctx->ws_size) return nullptr;
     ctx->ws_used = off + bytes;
     return ctx->ws + off;
+}
+
+imgfd_status aux_reserve(imgfd_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->aux_size) return IMGFD_OK;
+    IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->aux) (void)hipFree(ctx->aux);
+    ctx->aux = nullptr;
+    ctx->aux_size = 0;
+    void *p = nullptr;
+    bytes = align_up(bytes, (size_t)1 << 20);
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        ctx->err = "hipMalloc of the auxiliary device buffer failed";
+        return IMGFD_ERR_OOM;
+    }
+    ctx->aux = (char *)p;
+    ctx->aux_size = bytes;
+    return IMGFD_OK;
 }
 
 imgfd_status pin_reserve(imgfd_ctx *ctx, size_t bytes)

@@ -14,10 +14,12 @@
 //                        reference's operation order (no contraction).  Survivors are appended with a sort key
 //                        (octave, interval, row, column); the host orders them by that key = the order in which the
 //                        reference pushes them, then applies surf.h:268's std::sort over reverse iterators.
-//   K19 orientation + 64-d descriptor (surf.h:75-232): per-point libm work (atan2, exp, sin, cos) on <= max_points
-//                        points; done on the host in surf_host.cpp from the integral image (glibc gives the
-//                        reference's bits; moving it to the device is listed as next in SURVEY.md 8f).
+//   K19 orientation + 64-d descriptor (surf.h:75-232): surf_describe.hip, one workgroup per point.  imgfd_surf keeps
+//                        the handful of libm calls (atan2 of the 109 samples, sin/cos of the winner) on the host's
+//                        glibc (surf_host.cpp) so the result stays bit-identical; imgfd_surf_dev runs them on the
+//                        device as well.
 #include "common.h"
+#include "surf_describe.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -221,7 +223,11 @@ __global__ void __launch_bounds__(256) surf_nms_interp(const double *__restrict_
 }
 
 // surf_host.cpp
-void surf_describe_host(const int32_t *I, int rows, int cols, double x, double y, double scale, double *angle, double *des64);
+// surf_describe.hip
+imgfd_status launch_surf_orient(imgfd_ctx *ctx, const unsigned *d_I, int rows, int cols, const double *d_pts, int m,
+                                double *d_samples, double *d_trig);
+imgfd_status launch_surf_desc(imgfd_ctx *ctx, const unsigned *d_I, int rows, int cols, const double *d_pts,
+                              const double *d_trig, int m, double *d_des, int des_stride, double *d_angle);
 
 namespace {
 
@@ -263,9 +269,9 @@ imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const Surf
 }
 
 // uploads the image, runs the device stages, returns the interest points in the reference's emission order
-// (and, if want_integral, the integral image for the host descriptor stage)
+// (and, if asked, where the integral image sits in the workspace: valid until the next call carves the arena)
 imgfd_status surf_points_host(imgfd_ctx *ctx, const void *rgb, int kind, int rows, int cols, double thr,
-                              std::vector<SurfRecord> &pts, const int32_t **integral)
+                              std::vector<SurfRecord> &pts, const unsigned **d_integral)
 {
     pts.clear();
     if (rows < 1 || cols < 1) return IMGFD_OK;
@@ -292,11 +298,7 @@ imgfd_status surf_points_host(imgfd_ctx *ctx, const void *rgb, int kind, int row
         if (cnt > d.cap) { d.cap = cnt + 1024; continue; }  // rare: more candidates than the record buffer holds
         pts.resize((size_t)cnt);
         if (cnt) IMGFD_HIP(ctx, hipMemcpyAsync(pts.data(), d.rec, sizeof(SurfRecord) * cnt, hipMemcpyDeviceToHost, ctx->stream));
-        if (integral && cnt) {  // the host descriptor stage reads the table from the context's pinned staging buffer
-            IMGFD_TRY(pin_reserve(ctx, 4 * n));
-            IMGFD_HIP(ctx, hipMemcpyAsync(ctx->pin, d.integral, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
-            *integral = reinterpret_cast<const int32_t *>(ctx->pin);
-        }
+        if (d_integral) *d_integral = d.integral;
         IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
         break;
     }
@@ -308,6 +310,79 @@ imgfd_status surf_points_host(imgfd_ctx *ctx, const void *rgb, int kind, int row
 struct ScoreLess {
     bool operator()(const SurfRecord &a, const SurfRecord &b) const { return a.score < b.score; }
 };
+
+// get_surf_points, surf.h:268-285: strongest first (std::sort over reverse iterators, as the reference calls it), at
+// most max_points, and only points whose 32*scale box lies inside the image
+void surf_select(std::vector<SurfRecord> &pts, long max_points, int rows, int cols, std::vector<size_t> &keep)
+{
+    std::sort(pts.rbegin(), pts.rend(), ScoreLess());
+    const size_t lim = std::min((size_t)max_points, pts.size());
+    keep.clear();
+    for (size_t k = 0; k < lim; k++) {
+        const unsigned long bs = (unsigned long)(32.0 * pts[k].scale);
+        const long px = (long)floor(pts[k].x + 0.5), py = (long)floor(pts[k].y + 0.5);
+        const long l = px - (long)bs / 2, t = py - (long)bs / 2, r = l + (long)bs - 1, b = t + (long)bs - 1;
+        if (l >= 0 && t >= 0 && r <= cols - 1 && b <= rows - 1) keep.push_back(k);
+    }
+}
+
+// K19 buffers for m points: device side in the context's aux buffer, host side in its pinned buffer
+struct SurfK19 {
+    double *d_pts, *d_samples, *d_trig, *d_des;  // m x 3, m x 218, m x 5, m x 64
+    double *h_pts, *h_samples, *h_trig, *h_des;
+};
+
+imgfd_status surf_k19_carve(imgfd_ctx *ctx, size_t m, SurfK19 *k)
+{
+    const size_t per = 3 + 2 * SURF_NSAMP + 5 + 64;
+    IMGFD_TRY(aux_reserve(ctx, sizeof(double) * per * m));
+    IMGFD_TRY(pin_reserve(ctx, sizeof(double) * per * m));
+    double *d = reinterpret_cast<double *>(ctx->aux), *h = reinterpret_cast<double *>(ctx->pin);
+    k->d_pts = d; k->d_samples = d + 3 * m; k->d_trig = k->d_samples + 2 * SURF_NSAMP * m; k->d_des = k->d_trig + 5 * m;
+    k->h_pts = h; k->h_samples = h + 3 * m; k->h_trig = k->h_samples + 2 * SURF_NSAMP * m; k->h_des = k->h_trig + 5 * m;
+    return IMGFD_OK;
+}
+
+// imgfd_surf's K19: Haar sampling and the descriptor on the device, atan2 / sin / cos on the host's glibc
+imgfd_status surf_describe_assisted(imgfd_ctx *ctx, const unsigned *d_I, int rows, int cols, const std::vector<SurfRecord> &pts,
+                                    const std::vector<size_t> &keep, imgfd_surf_out *out)
+{
+    const size_t m = keep.size();
+    SurfK19 k;
+    IMGFD_TRY(surf_k19_carve(ctx, m, &k));
+    for (size_t j = 0; j < m; j++) {
+        const SurfRecord &p = pts[keep[j]];
+        k.h_pts[3 * j] = p.x; k.h_pts[3 * j + 1] = p.y; k.h_pts[3 * j + 2] = p.scale;
+    }
+    IMGFD_HIP(ctx, hipMemcpyAsync(k.d_pts, k.h_pts, sizeof(double) * 3 * m, hipMemcpyHostToDevice, ctx->stream));
+    IMGFD_TRY(launch_surf_orient(ctx, d_I, rows, cols, k.d_pts, (int)m, k.d_samples, nullptr));
+    IMGFD_HIP(ctx, hipMemcpyAsync(k.h_samples, k.d_samples, sizeof(double) * 2 * SURF_NSAMP * m, hipMemcpyDeviceToHost, ctx->stream));
+    IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // points are independent: share them out over a few threads; every point runs the code one thread would run
+    unsigned nthr = std::min<unsigned>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())), (unsigned)(m / 64 + 1));
+    auto work = [&](size_t j0, size_t j1) {
+        for (size_t j = j0; j < j1; j++)
+            surf_orient_host(k.h_samples + 2 * SURF_NSAMP * j, k.h_samples + 2 * SURF_NSAMP * j + SURF_NSAMP, k.h_trig + 5 * j);
+    };
+    if (nthr <= 1) {
+        work(0, m);
+    } else {
+        std::vector<std::thread> pool;
+        const size_t per = (m + nthr - 1) / nthr;
+        for (unsigned t = 0; t < nthr; t++) {
+            const size_t j0 = std::min(m, t * per), j1 = std::min(m, j0 + per);
+            if (j0 < j1) pool.emplace_back(work, j0, j1);
+        }
+        for (auto &th : pool) th.join();
+    }
+    IMGFD_HIP(ctx, hipMemcpyAsync(k.d_trig, k.h_trig, sizeof(double) * 5 * m, hipMemcpyHostToDevice, ctx->stream));
+    IMGFD_TRY(launch_surf_desc(ctx, d_I, rows, cols, k.d_pts, k.d_trig, (int)m, k.d_des, 64, nullptr));
+    IMGFD_HIP(ctx, hipMemcpyAsync(k.h_des, k.d_des, sizeof(double) * 64 * m, hipMemcpyDeviceToHost, ctx->stream));
+    IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t j = 0; j < m; j++) out->angle[j] = k.h_trig[5 * j];
+    memcpy(out->surf, k.h_des, sizeof(double) * 64 * m);
+    return IMGFD_OK;
+}
 
 }  // namespace
 
@@ -375,6 +450,74 @@ imgfd_status imgfd_surf_points_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_f
     return IMGFD_OK;
 }
 
+imgfd_status imgfd_surf_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, int rows, int cols, size_t frame_stride_bytes,
+                            long max_points, double detection_threshold, double *d_features, int64_t cap, int64_t *d_counts)
+{
+    if (!ctx) return IMGFD_ERR_INVALID;
+    if (!d_rgb || !d_features || !d_counts || n_frames < 0 || rows < 1 || cols < 1 || cap < 1 || !(max_points > 0) ||
+        !(detection_threshold >= 0))
+        return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_surf_dev: bad argument");
+    if (!n_frames) return IMGFD_OK;
+    IMGFD_HIP(ctx, hipSetDevice(ctx->device));
+    SurfGeom g;
+    const size_t total = surf_geometry(rows, cols, &g);
+    const size_t n = (size_t)rows * cols;
+    SurfDevice d;
+    d.cap = 1ull << 16;
+    std::vector<SurfRecord> pts;
+    std::vector<size_t> keep;
+    std::vector<int64_t> counts((size_t)n_frames, 0);
+    const long lim = (long)std::min<int64_t>((int64_t)max_points, cap);
+    for (int f = 0; f < n_frames;) {
+        IMGFD_TRY(ws_reserve(ctx, surf_ws_bytes(g, total, d.cap)));
+        (void)ws_alloc(ctx, 3 * n);  // the slot imgfd_surf uses for the uploaded image (same carving, same size function)
+        d.integral = (unsigned *)ws_alloc(ctx, 4 * n);
+        d.pyr = (double *)ws_alloc(ctx, 8 * std::max<size_t>(total, 1));
+        d.rec = (SurfRecord *)ws_alloc(ctx, sizeof(SurfRecord) * d.cap);
+        d.count = (unsigned long long *)ws_alloc(ctx, 256);
+        if (!d.integral || !d.pyr || !d.rec || !d.count) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+        IMGFD_TRY(surf_device_stages(ctx, d_rgb + (size_t)f * frame_stride_bytes, g, detection_threshold, d));
+        unsigned long long cnt = 0;
+        IMGFD_HIP(ctx, hipMemcpyAsync(&cnt, d.count, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+        IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (cnt > d.cap) { d.cap = cnt + 1024; continue; }  // redo the frame with a larger record buffer
+        pts.resize((size_t)cnt);
+        if (cnt) {
+            IMGFD_HIP(ctx, hipMemcpyAsync(pts.data(), d.rec, sizeof(SurfRecord) * cnt, hipMemcpyDeviceToHost, ctx->stream));
+            IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        std::sort(pts.begin(), pts.end(), [](const SurfRecord &a, const SurfRecord &b) { return a.key < b.key; });
+        keep.clear();
+        if (cnt) surf_select(pts, lim, rows, cols, keep);
+        const size_t m = keep.size();
+        counts[(size_t)f] = (int64_t)m;
+        if (m) {
+            SurfK19 k;
+            IMGFD_TRY(surf_k19_carve(ctx, m, &k));
+            double *feat = d_features + (size_t)f * (size_t)cap * 70;
+            // head of every record: x, y, (angle), pyramid_scale, score, laplacian -- staged in the pinned des area
+            double *h_head = k.h_des;
+            for (size_t j = 0; j < m; j++) {
+                const SurfRecord &p = pts[keep[j]];
+                k.h_pts[3 * j] = p.x; k.h_pts[3 * j + 1] = p.y; k.h_pts[3 * j + 2] = p.scale;
+                double *h = h_head + 6 * j;
+                h[0] = p.x; h[1] = p.y; h[2] = 0.0; h[3] = p.scale; h[4] = p.score; h[5] = p.laplacian;
+            }
+            IMGFD_HIP(ctx, hipMemcpyAsync(k.d_pts, k.h_pts, sizeof(double) * 3 * m, hipMemcpyHostToDevice, ctx->stream));
+            IMGFD_HIP(ctx, hipMemcpy2DAsync(feat, 70 * sizeof(double), h_head, 6 * sizeof(double), 6 * sizeof(double), m,
+                                            hipMemcpyHostToDevice, ctx->stream));
+            IMGFD_TRY(launch_surf_orient(ctx, d.integral, rows, cols, k.d_pts, (int)m, nullptr, k.d_trig));
+            IMGFD_TRY(launch_surf_desc(ctx, d.integral, rows, cols, k.d_pts, k.d_trig, (int)m, feat + 6, 70, feat + 2));
+            // the pinned staging is reused by the next frame
+            IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        f++;
+    }
+    IMGFD_HIP(ctx, hipMemcpyAsync(d_counts, counts.data(), sizeof(int64_t) * (size_t)n_frames, hipMemcpyHostToDevice, ctx->stream));
+    IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IMGFD_OK;
+}
+
 static imgfd_status surf_host(imgfd_ctx *ctx, const void *rgb, int kind, int rows, int cols, long max_points,
                               double detection_threshold, imgfd_surf_out *out)
 {
@@ -383,18 +526,11 @@ static imgfd_status surf_host(imgfd_ctx *ctx, const void *rgb, int kind, int row
     if (!rgb || rows < 0 || cols < 0 || !(max_points > 0) || !(detection_threshold >= 0))
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_surf: bad argument (DLIB_ASSERT of surf.h:243-248)");
     std::vector<SurfRecord> pts;
-    const int32_t *I = nullptr;
-    IMGFD_TRY(surf_points_host(ctx, rgb, kind, rows, cols, detection_threshold, pts, &I));
+    const unsigned *d_I = nullptr;
+    IMGFD_TRY(surf_points_host(ctx, rgb, kind, rows, cols, detection_threshold, pts, &d_I));
     if (pts.empty()) return IMGFD_OK;
-    std::sort(pts.rbegin(), pts.rend(), ScoreLess());  // surf.h:268
-    const size_t lim = std::min((size_t)max_points, pts.size());
     std::vector<size_t> keep;
-    for (size_t k = 0; k < lim; k++) {  // :271-285: drop points whose 32*scale box leaves the image
-        const unsigned long bs = (unsigned long)(32.0 * pts[k].scale);
-        const long px = (long)floor(pts[k].x + 0.5), py = (long)floor(pts[k].y + 0.5);
-        const long l = px - (long)bs / 2, t = py - (long)bs / 2, r = l + (long)bs - 1, b = t + (long)bs - 1;
-        if (l >= 0 && t >= 0 && r <= cols - 1 && b <= rows - 1) keep.push_back(k);
-    }
+    surf_select(pts, max_points, rows, cols, keep);
     const size_t m = keep.size();
     if (!m) return IMGFD_OK;
     double *data = (double *)malloc(sizeof(double) * m * 70);
@@ -406,27 +542,12 @@ static imgfd_status surf_host(imgfd_ctx *ctx, const void *rgb, int kind, int row
         const SurfRecord &p = pts[keep[j]];
         out->x[j] = p.x; out->y[j] = p.y; out->pyramid_scale[j] = p.scale; out->score[j] = p.score; out->laplacian[j] = p.laplacian;
     }
-    // K19 on the host: points are independent (each writes its own angle and descriptor), so they are shared out over
-    // a few threads; every point is computed by exactly the code a single thread would run (same bits)
-    unsigned nthr = std::min<unsigned>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())), (unsigned)(m / 16 + 1));
-    auto work = [&](size_t j0, size_t j1) {
-        for (size_t j = j0; j < j1; j++) {
-            const SurfRecord &p = pts[keep[j]];
-            surf_describe_host(I, rows, cols, p.x, p.y, p.scale, &out->angle[j], out->surf + 64 * j);
-        }
-    };
-    if (nthr <= 1) {
-        work(0, m);
-    } else {
-        std::vector<std::thread> pool;
-        const size_t per = (m + nthr - 1) / nthr;
-        for (unsigned t = 0; t < nthr; t++) {
-            const size_t j0 = std::min(m, t * per), j1 = std::min(m, j0 + per);
-            if (j0 < j1) pool.emplace_back(work, j0, j1);
-        }
-        for (auto &th : pool) th.join();
+    const imgfd_status st = surf_describe_assisted(ctx, d_I, rows, cols, pts, keep, out);
+    if (st != IMGFD_OK) {
+        free(data);
+        memset(out, 0, sizeof *out);
     }
-    return IMGFD_OK;
+    return st;
 }
 
 imgfd_status imgfd_surf(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, long max_points, double detection_threshold,

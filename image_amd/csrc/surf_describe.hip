@@ -1,0 +1,218 @@
+// image_amd/csrc/surf_describe.hip -- K19 on the device: dominant orientation and 64-d SURF descriptor per interest point.
+//
+// Replaces compute_dominant_angle / compute_surf_descriptor, image.dlib/inst/dlib-19.20/dlib/image_keypoint/surf.h:
+// 75-232, with haar_x / haar_y of dlib/image_transforms/integral_image.h:124-183, the float->integer point rounding
+// floor(v+0.5) of dlib/geometry/vector.h:138-149 and point_rotator (dlib/geometry/point_transforms.h:22-49).
+//
+// One workgroup per point, two kernels:
+//   surf_orient  109 Gaussian-weighted Haar samples on the radius-6 disc (:88-105), one lane each; then either
+//                  (assisted) the weighted responses (sx, sy) are written out and the HOST forms atan2 / the 45 sliding
+//                             windows / sin / cos with glibc -- the bits the reference gets -- and sends 5 doubles back;
+//                  (device)   lanes 0..44 own one pi/3 window each and add the samples in the reference's order
+//                             (:111-137), lane 0 picks the longest; atan2/sin/cos come from the device libm.
+//   surf_desc    the 20x20 grid of rotated Haar samples is evaluated once (the reference re-samples the padding ring
+//                of neighbouring buckets), then 16 buckets x 4 sums are accumulated by one lane each in the
+//                reference's sample order (:163-212), then the length normalisation (:216-219, sequential sum).
+// Everything but atan2/sin/cos is integer arithmetic or single IEEE double operations in the reference's order
+// (library built -ffp-contract=off), so the assisted mode reproduces the reference bit for bit, and the device mode
+// differs only through the last bits of the device libm's trigonometry (tests: <= 1e-9 on descriptors).
+#include "common.h"
+#include "surf_describe.h"
+
+#include <math.h>
+
+namespace {
+
+struct Haar {
+    const unsigned *I;
+    int rows, cols;
+    __device__ __forceinline__ unsigned at(long r, long c) const
+    {
+        // valid points never leave the image (surf.h:271-285 drops those whose 32*scale box does); the clamp only keeps
+        // a corrupt record from reading outside the table
+        r = r < 0 ? 0 : (r >= rows ? rows - 1 : r);
+        c = c < 0 ? 0 : (c >= cols ? cols - 1 : c);
+        return I[(size_t)r * cols + c];
+    }
+    // get_sum_of_area(rectangle(l,t,r,b)), integral_image.h:64-96; unsigned arithmetic = the reference's wrapping int32
+    __device__ __forceinline__ unsigned box(long l, long t, long r, long b) const
+    {
+        unsigned tl = 0, tr = 0, bl = 0;
+        const unsigned br = at(b, r);
+        if (l >= 1 && t >= 1) { tl = at(t - 1, l - 1); bl = at(b, l - 1); tr = at(t - 1, r); }
+        else if (l >= 1) bl = at(b, l - 1);
+        else if (t >= 1) tr = at(t - 1, r);
+        return br - bl - tr + tl;
+    }
+    __device__ __forceinline__ int haar_x(long x, long y, long width) const  // :124-152
+    {
+        const long left = x - width / 2, top = y - width / 2, bottom = top + width - 1;
+        return (int)(box(x, top, left + width - 1, bottom) - box(left, top, x - 1, bottom));
+    }
+    __device__ __forceinline__ int haar_y(long x, long y, long width) const  // :154-183
+    {
+        const long left = x - width / 2, top = y - width / 2, right = left + width - 1;
+        return (int)(box(left, y, right, top + width - 1) - box(left, top, right, y - 1));
+    }
+};
+
+__device__ __forceinline__ long surf_to_long(double v) { return (long)floor(v + 0.5); }
+
+}  // namespace
+
+// pts: m x 3 (x, y, scale).  samples != nullptr: write sx[109], sy[109] per point (assisted mode).
+// trig != nullptr: write angle, sin, cos, sin(-), cos(-) per point (device mode).
+__global__ void __launch_bounds__(128) surf_orient(const unsigned *__restrict__ I, int rows, int cols,
+                                                   const double *__restrict__ pts, SurfOrientTable T,
+                                                   double *__restrict__ samples, double *__restrict__ trig)
+{
+    __shared__ double sx[SURF_NSAMP], sy[SURF_NSAMP], sa[SURF_NSAMP];
+    __shared__ double wx[45], wy[45];
+    const size_t p = blockIdx.x;
+    const int i = threadIdx.x;
+    const double x = pts[3 * p], y = pts[3 * p + 1], scale = pts[3 * p + 2];
+    const long sc = (long)(scale + 0.5);
+    const Haar H{I, rows, cols};
+    if (i < SURF_NSAMP) {
+        const long r = T.r[i], c = T.c[i];
+        const long px = surf_to_long((double)(sc * c) + x), py = surf_to_long((double)(sc * r) + y);
+        const double vx = T.w[i] * H.haar_x(px, py, 4 * sc);
+        const double vy = T.w[i] * H.haar_y(px, py, 4 * sc);
+        if (samples) {
+            samples[p * (2 * SURF_NSAMP) + i] = vx;
+            samples[p * (2 * SURF_NSAMP) + SURF_NSAMP + i] = vy;
+        }
+        sx[i] = vx;
+        sy[i] = vy;
+        if (trig) sa[i] = atan2(vy, vx);
+    }
+    if (!trig) return;
+    __syncthreads();
+    const double pi = 3.1415926535897932384626433832795;
+    if (i < 45) {  // :111-131
+        const double ang_step = (2 * pi) / 45;
+        const double a1 = ang_step * i - pi, a2 = a1 + pi / 3;
+        double vx = 0, vy = 0;
+        for (int s = 0; s < SURF_NSAMP; s++) {
+            const double a = sa[s];
+            const bool in = (a1 <= a && a <= a2) || (a2 > pi && (a >= a1 || a <= (-2 * pi + a2)));
+            if (in) { vx += sx[s]; vy += sy[s]; }
+        }
+        wx[i] = vx;
+        wy[i] = vy;
+    }
+    __syncthreads();
+    if (i == 0) {  // :132-137: first strictly longest window
+        double best_len = 0, best_ang = 0;
+        for (int k = 0; k < 45; k++) {
+            const double len = wx[k] * wx[k] + wy[k] * wy[k];
+            if (len > best_len) { best_len = len; best_ang = atan2(wy[k], wx[k]); }
+        }
+        double *t = trig + 5 * p;
+        t[0] = best_ang;
+        t[1] = sin(best_ang);
+        t[2] = cos(best_ang);
+        t[3] = sin(-best_ang);
+        t[4] = cos(-best_ang);
+    }
+}
+
+// trig: m x 5 (angle, sin, cos, sin(-angle), cos(-angle)); point p's descriptor goes to des[p*des_stride .. +64) and, if
+// angle_out, its angle to angle_out[p*des_stride]
+__global__ void __launch_bounds__(64) surf_desc(const unsigned *__restrict__ I, int rows, int cols,
+                                                const double *__restrict__ pts, const double *__restrict__ trig,
+                                                double *__restrict__ des, int des_stride, double *__restrict__ angle_out)
+{
+    __shared__ int hx[400], hy[400];
+    __shared__ double rx[16 * 49], ry[16 * 49];
+    __shared__ double d[64];
+    __shared__ double inv_len_s;
+    const size_t p = blockIdx.x;
+    const int lane = threadIdx.x;
+    const double x = pts[3 * p], y = pts[3 * p + 1], scale = pts[3 * p + 2];
+    const double sn = trig[5 * p + 1], cs = trig[5 * p + 2], isn = trig[5 * p + 3], ics = trig[5 * p + 4];
+    const long sc = (long)(scale + 0.5);
+    const Haar H{I, rows, cols};
+    // the 20 x 20 sample grid (:176-186)
+    for (int s = lane; s < 400; s += 64) {
+        const long yy = s / 20 - 10, xx = s % 20 - 10;
+        const double qx = xx * scale, qy = yy * scale;
+        const long px = surf_to_long((cs * qx - sn * qy) + x), py = surf_to_long((sn * qx + cs * qy) + y);
+        hx[s] = H.haar_x(px, py, 2 * sc);
+        hy[s] = H.haar_y(px, py, 2 * sc);
+    }
+    __syncthreads();
+    // weighted, rotated back (:188-199), per bucket slot j = (yy - (r-1))*7 + (xx - (c-1))
+    for (int slot = lane; slot < 16 * 49; slot += 64) {
+        const int bucket = slot / 49, j = slot % 49;
+        const long r = -10 + 5 * (bucket >> 2), c = -10 + 5 * (bucket & 3);
+        const long yy = r - 1 + j / 7, xx = c - 1 + j % 7;
+        double vx = 0, vy = 0;
+        if (yy >= -10 && yy < 10 && xx >= -10 && xx < 10) {
+            const int s = (int)((yy + 10) * 20 + (xx + 10));
+            const double weight = 1.0 / (double)(4 + labs(r + 2 - yy) + labs(c + 2 - xx));
+            const double wxh = weight * hx[s], wyh = weight * hy[s];
+            vx = ics * wxh - isn * wyh;
+            vy = isn * wxh + ics * wyh;
+        }
+        rx[slot] = vx;
+        ry[slot] = vy;
+    }
+    __syncthreads();
+    {   // lane = bucket*4 + {vx, vy, |vx|, |vy|} (:201-212), samples in the reference's order
+        const int bucket = lane >> 2, comp = lane & 3;
+        const long r = -10 + 5 * (bucket >> 2), c = -10 + 5 * (bucket & 3);
+        const double *src = (comp & 1) ? ry + bucket * 49 : rx + bucket * 49;
+        double acc = 0;
+        for (int j = 0; j < 49; j++) {
+            const long yy = r - 1 + j / 7, xx = c - 1 + j % 7;
+            if (yy < -10 || yy >= 10 || xx < -10 || xx >= 10) continue;
+            const double v = src[j];
+            acc += (comp & 2) ? fabs(v) : v;
+        }
+        d[lane] = acc;
+    }
+    __syncthreads();
+    if (lane == 0) {  // :216-219
+        double ss = 0;
+        for (int k = 0; k < 64; k++) ss += d[k] * d[k];
+        inv_len_s = 1.0 / (sqrt(ss) + 1e-7);
+    }
+    __syncthreads();
+    des[p * des_stride + lane] = d[lane] * inv_len_s;
+    if (angle_out && lane == 0) angle_out[p * des_stride] = trig[5 * p];
+}
+
+// host side ---------------------------------------------------------------------------------------------------------
+void surf_orient_table(SurfOrientTable *T)
+{
+    int n = 0;
+    for (long r = -6; r <= 6; r++)
+        for (long c = -6; c <= 6; c++) {
+            if (r * r + c * c >= 36) continue;
+            T->w[n] = surf_gauss_weight((double)c, (double)r);  // glibc exp, as the reference evaluates it
+            T->r[n] = (signed char)r;
+            T->c[n] = (signed char)c;
+            n++;
+        }
+}
+
+imgfd_status launch_surf_orient(imgfd_ctx *ctx, const unsigned *d_I, int rows, int cols, const double *d_pts, int m,
+                                double *d_samples, double *d_trig)
+{
+    if (m < 1) return IMGFD_OK;
+    SurfOrientTable T;
+    surf_orient_table(&T);
+    hipLaunchKernelGGL(surf_orient, dim3(m), dim3(128), 0, ctx->stream, d_I, rows, cols, d_pts, T, d_samples, d_trig);
+    IMGFD_HIP(ctx, hipGetLastError());
+    return IMGFD_OK;
+}
+
+imgfd_status launch_surf_desc(imgfd_ctx *ctx, const unsigned *d_I, int rows, int cols, const double *d_pts,
+                              const double *d_trig, int m, double *d_des, int des_stride, double *d_angle)
+{
+    if (m < 1) return IMGFD_OK;
+    hipLaunchKernelGGL(surf_desc, dim3(m), dim3(64), 0, ctx->stream, d_I, rows, cols, d_pts, d_trig, d_des, des_stride, d_angle);
+    IMGFD_HIP(ctx, hipGetLastError());
+    return IMGFD_OK;
+}

@@ -172,7 +172,34 @@ IMGFD_API imgfd_status imgfd_surf_points_dev(imgfd_ctx *ctx, const uint8_t *d_rg
                                    size_t frame_stride_bytes, double detection_threshold, imgfd_surf_point *d_points,
                                    int64_t cap, int64_t *d_counts);
 /* stage doorway: the int32 integral image (integral_image.h:33-62) of the (r+g+b)/3 gray image, rows*cols values */
+/* Batch form with K19 (orientation + descriptor, surf.h:75-232) on the device as well: n_frames RGB tiles in HBM in,
+ * finished SURF features in HBM out.  d_features holds n_frames*cap records of 70 doubles -- x, y, angle,
+ * pyramid_scale, score, laplacian, surf[64]: the columns dlib_surf_points returns (rcpp_surf.cpp:31-52) -- strongest
+ * first as get_surf_points orders them (surf.h:268-285); d_counts[f] = records of frame f (<= min(max_points, cap)).
+ * atan2/sin/cos come from the device libm here, so angles and descriptors agree with imgfd_surf to ~1e-12 rather than
+ * bit for bit (SURVEY.md 8d asks for 1e-6); the interest points themselves are identical.  The call synchronises the
+ * context's stream once per frame (the point list is ranked on the host). */
+IMGFD_API imgfd_status imgfd_surf_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, int rows, int cols,
+                                      size_t frame_stride_bytes, long max_points, double detection_threshold,
+                                      double *d_features, int64_t cap, int64_t *d_counts);
 IMGFD_API imgfd_status imgfd_k_surf_integral(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, int32_t *out);
+
+/* ------------------------------------------------------------------ descriptor matching
+ * Exact k nearest neighbours of every query row among the data rows, Euclidean distance: what the reference's README
+ * does with two images' `surf` matrices, FNN::get.knnx(sp1$surf, sp2$surf, k = 1) (image.dlib/README.md:19-37; FNN is a
+ * CRAN package outside the reference tree).  nn_index: n_query*k, row-major, 0-BASED data row (R glue adds 1), -1 when
+ * fewer than k data rows exist; nn_dist: the distances, ascending; equal distances rank by ascending index.
+ * 1 <= dim <= 64, 1 <= k <= 8.  column_major != 0: the matrices are R matrices (n rows, dim columns, column-major);
+ * otherwise rows are contiguous (imgfd_surf_out.surf). */
+IMGFD_API imgfd_status imgfd_knn(imgfd_ctx *ctx, const double *data, int64_t n_data, const double *query, int64_t n_query,
+                                 int dim, int k, int column_major, int32_t *nn_index, double *nn_dist);
+/* Device pointers; element (i, j) of a matrix is p[i*row_stride + j*col_stride] (strides in doubles), so the records
+ * of imgfd_surf_dev can be matched in place (p = d_features + 6, row_stride 70, col_stride 1).  Asynchronous on the
+ * context's stream. */
+IMGFD_API imgfd_status imgfd_knn_dev(imgfd_ctx *ctx, const double *d_data, int64_t n_data, int64_t data_row_stride,
+                                     int64_t data_col_stride, const double *d_query, int64_t n_query,
+                                     int64_t query_row_stride, int64_t query_col_stride, int dim, int k,
+                                     int32_t *d_nn_index, double *d_nn_dist);
 
 /* ------------------------------------------------------------------ R-native vectors
  * The same entry points for the vectors R actually holds -- what REAL(x) / INTEGER(x) point to -- so the glue needs no

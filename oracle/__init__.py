@@ -271,3 +271,17 @@ def surf(rgb, max_points: int = 1000, threshold: float = 30.0, use_ref: bool = F
     L, name = (ref("dlib"), "ref_surf") if use_ref else (lib(), "orc_surf")
     r = _surf_call(L, name, rgb, C.c_long(max_points), C.c_double(threshold), rec=71, cap=max(16, min(int(max_points), 400000)))
     return dict(x=r[:, 0], y=r[:, 1], angle=r[:, 2], pyramid_scale=r[:, 3], score=r[:, 4], laplacian=r[:, 5], surf=r[:, 7:])
+
+
+# ----------------------------------------------------------------------- kNN (descriptor matching)
+def knn(data, query, k: int = 1):
+    """Exact k nearest rows of `data` for every row of `query` (Euclidean).  Returns (index int32 (nq,k) 0-based,
+    dist float64 (nq,k)); restates FNN::get.knnx as image.dlib/README.md:19-37 uses it (parity unpinned: FNN absent)."""
+    data = np.ascontiguousarray(data, np.float64); query = np.ascontiguousarray(query, np.float64)
+    nd, dim = data.shape
+    nq = query.shape[0]
+    assert query.shape[1] == dim
+    idx = np.zeros((nq, k), np.int32); dist = np.zeros((nq, k), np.float64)
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    lib().orc_knn(vp(data), C.c_long(nd), vp(query), C.c_long(nq), dim, k, vp(idx), vp(dist))
+    return idx, dist

@@ -161,6 +161,45 @@ class _Base:
             out.append(r[np.argsort(keys, kind="stable")][:, 1:])
         return out, cnt
 
+    def knn(self, data, query, k=1, column_major=False):
+        data = np.asarray(data, np.float64); query = np.asarray(query, np.float64)
+        nd, dim = data.shape
+        nq = query.shape[0]
+        a = np.asfortranarray(data) if column_major else np.ascontiguousarray(data)
+        b = np.asfortranarray(query) if column_major else np.ascontiguousarray(query)
+        idx = np.full((nq, k), -7, np.int32); dist = np.zeros((nq, k), np.float64)
+        self.check(self.lib.imgfd_knn(self.ctx, a.ctypes.data_as(C.c_void_p), nd, b.ctypes.data_as(C.c_void_p), nq, dim, k,
+                                      int(column_major), idx.ctypes.data_as(C.c_void_p), dist.ctypes.data_as(C.c_void_p)), "imgfd_knn")
+        return idx, dist
+
+    def knn_dev(self, data, query, k, data_strides, query_strides, dim):
+        """data/query: flat float64 arrays already laid out by the caller; strides = (row, col) in doubles"""
+        nd = data[1]; nq = query[1]
+        d = self.to_dev(data[0]); q = self.to_dev(query[0])
+        idx = self.empty((nq, k), np.int32); dist = self.empty((nq, k), np.float64)
+        self.check(self.lib.imgfd_knn_dev(self.ctx, self.ptr(d), nd, data_strides[0], data_strides[1], self.ptr(q), nq,
+                                          query_strides[0], query_strides[1], dim, k, self.ptr(idx), self.ptr(dist)), "imgfd_knn_dev")
+        self.sync()
+        return self.to_host(idx), self.to_host(dist)
+
+    def surf_dev(self, frames, max_points=1000, threshold=30.0, cap=None):
+        """batch path with K19 on the device; per tile a dict like surf()"""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, rows, cols, _ = frames.shape
+        cap = cap or max_points
+        d = self.to_dev(frames)
+        feat = self.empty((n, cap, 70), np.float64); cnt = self.empty((n,), np.int64)
+        self.check(self.lib.imgfd_surf_dev(self.ctx, self.ptr(d), n, rows, cols, rows * cols * 3, max_points, threshold,
+                                           self.ptr(feat), cap, self.ptr(cnt)), "imgfd_surf_dev")
+        self.sync()
+        feat = self.to_host(feat); cnt = self.to_host(cnt)
+        out = []
+        for f in range(n):
+            r = feat[f, :int(cnt[f])]
+            out.append(dict(x=r[:, 0], y=r[:, 1], angle=r[:, 2], pyramid_scale=r[:, 3], score=r[:, 4], laplacian=r[:, 5],
+                            surf=r[:, 6:]))
+        return out
+
     def surf(self, rgb, max_points=1000, threshold=30.0):
         rgb = np.ascontiguousarray(rgb, np.uint8)
         rows, cols, _ = rgb.shape

@@ -71,6 +71,23 @@ def test_batch_points_dev(be):
         assert counts[f] == len(ref) and np.array_equal(lists[f], ref)
 
 
+def test_batch_surf_dev_descriptors_on_the_device(be):
+    """imgfd_surf_dev: K19 with the device libm.  Points are exact; angles and descriptors may differ from the
+    reference in the last bits of atan2/sin/cos (SURVEY 8d asks for 1e-6; we hold 1e-9)."""
+    frames = np.stack([blobs(120 + f, 320, 256) for f in range(3)])
+    got = be.surf_dev(frames, max_points=200, threshold=10.0)
+    for f in range(3):
+        ref = oracle.surf(frames[f], 200, 10.0)
+        assert len(ref["x"]) > 3
+        for k in ("x", "y", "pyramid_scale", "score", "laplacian"):
+            assert np.array_equal(got[f][k], ref[k]), k
+        assert np.allclose(got[f]["angle"], ref["angle"], rtol=0, atol=1e-9)
+        assert np.abs(got[f]["surf"] - ref["surf"]).max() <= 1e-9
+    # cap below max_points truncates the ranked list
+    few = be.surf_dev(frames[:1], max_points=200, threshold=10.0, cap=7)[0]
+    assert len(few["x"]) <= 7 and np.array_equal(few["score"], np.sort(few["score"])[::-1])
+
+
 def test_golden_dlib(be, golden):
     """vectors written by dlib's own get_surf_points on the reference's example image"""
     g = golden("surf_cruise_boat")
