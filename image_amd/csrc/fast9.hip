@@ -9,8 +9,8 @@
 //     score = max( max_arcs(min_9 ring) - p - 1 ,  p - min_arcs(max_9 ring) - 1 ).
 // nonMaxSuppression keeps a corner iff none of its 8 neighbours is a corner with score >= its own.
 // All integer arithmetic: results are bit-exact, and compact.hip emits them in the reference's raster
-// order.  One workgroup per 64x16 tile staged in LDS; a wave covers 64 pixels of a row (the __ballot word is the
-// mask word).
+// order.  One workgroup per 64x64 tile staged in LDS; a tile row is 64 pixels wide = one 64-bit word of the
+// compaction mask.
 #include "common.h"
 
 // ring offsets in the order of makeOffsets(): (dx,dy)
@@ -48,13 +48,21 @@ __device__ __forceinline__ int f9_score(const int (&v)[16], int p)
 }
 
 #define F9_TX 64   // tile width = one __ballot word
-#define F9_TY 16
+#ifndef F9_TY
+#define F9_TY 64  // sweep on MI355X, 4K frames: 16 -> 780 us, 32 -> 631, 64 -> 555, 96 -> 583, 128 -> 660 (per 32 frames)
+#endif
 #define F9_HALO 4  // ring radius 3 + 1 (the 3x3 non-max neighbourhood needs the scores of the neighbours)
 
-// One workgroup per 64x16 tile.  The u8 tile (+4 halo) is staged in LDS once (HBM traffic = the algorithmic
-// 1 B/px + halo); the ring test reads LDS; with non-max suppression the scores of the tile (+1 halo) go to a
-// second LDS tile and the 3x3 test runs on it, so neither a score plane nor a second kernel touch HBM.
-// Wave w handles tile rows w, w+4, ...: lane <-> column, so one __ballot is the 64-bit mask word.
+// One workgroup per 64 x F9_TY tile.  The u8 tile (+4 halo) is staged in LDS once (HBM traffic = the algorithmic
+// 1 B/px + halo).  Three phases:
+//   1. compass pre-test on packed dwords: a thread takes 4 consecutive pixels (5 LDS dword reads instead of 20 byte
+//      reads); any 9 contiguous ring pixels contain at least two of the four compass points, so a pixel with fewer
+//      than two brighter and fewer than two darker compass points cannot be a corner.  Survivors (a few percent of a
+//      natural frame) are appended to a candidate list in LDS.
+//   2. the full ring test (+ score) runs over the candidate list with all lanes busy and writes the score tile
+//      (+1 halo for the 3x3 test) in LDS.
+//   3. the 3x3 non-max test reads the score tile, again for the candidates only; survivors set their bit in the
+//      row's 64-bit mask word (tile width = word width).  Neither a score plane nor a second kernel touch HBM.
 template <int NONMAX>
 __global__ void __launch_bounds__(256) fast9_tile(const unsigned char *__restrict__ img, int w, int h, int stride,
                                                   size_t frame_stride, int b, int aligned4,
@@ -62,15 +70,21 @@ __global__ void __launch_bounds__(256) fast9_tile(const unsigned char *__restric
                                                   unsigned *__restrict__ rowcount, int words_per_row)
 {
     constexpr int LW = F9_TX + 2 * F9_HALO, LH = F9_TY + 2 * F9_HALO;  // 72 x 24
-    __shared__ unsigned tile32[LH][LW / 4];
-    __shared__ unsigned char sc[F9_TY + 2][F9_TX + 2 + 2];
+    constexpr int LQ = LW / 4;                                         // 18 dwords per tile row
+    constexpr int SR = F9_TY + 2, SCW = F9_TX + 4;                     // score tile: 18 rows of 68 bytes (66 used)
+    __shared__ unsigned tile32[LH][LQ];
+    __shared__ unsigned sc32[SR][SCW / 4];
+    __shared__ unsigned short cand[SR * LW];
+    __shared__ unsigned ncand;
+    __shared__ unsigned long long rowmask[F9_TY];
     unsigned char(*tile)[LW] = reinterpret_cast<unsigned char(*)[LW]>(tile32);
+    unsigned char(*sc)[SCW] = reinterpret_cast<unsigned char(*)[SCW]>(sc32);
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * F9_TX, y0 = blockIdx.y * F9_TY;
     const unsigned char *fr = img + (size_t)blockIdx.z * frame_stride;
     // ---- stage the tile; out-of-image positions repeat the border pixel (they are never tested, only loaded)
-    for (int i = tid; i < LH * (LW / 4); i += 256) {
-        const int r = i / (LW / 4), q = i - r * (LW / 4);
+    for (int i = tid; i < LH * LQ; i += 256) {
+        const int r = i / LQ, q = i - r * LQ;
         const int gy = min(max(y0 - F9_HALO + r, 0), h - 1);
         const int gx = x0 - F9_HALO + 4 * q;
         const unsigned char *row = fr + (size_t)gy * stride;
@@ -84,54 +98,85 @@ __global__ void __launch_bounds__(256) fast9_tile(const unsigned char *__restric
         }
         tile32[r][q] = v;
     }
+    for (int i = tid; i < SR * (SCW / 4); i += 256) (&sc32[0][0])[i] = 0u;
+    for (int i = tid; i < F9_TY; i += 256) rowmask[i] = 0ull;
+    if (tid == 0) ncand = 0u;
     __syncthreads();
-    // corner test (+ score) of the pixel at tile position (ty, tx), image position (gx, gy)
-    auto corner_score = [&](int ty, int tx, int gx, int gy) -> int {
-        if (gx < 3 || gx >= w - 3 || gy < 3 || gy >= h - 3) return 0;
-        const unsigned char *c = &tile[ty][tx];
+    // ---- phase 1: compass pre-test; score-tile row r <-> tile row r + 3, score column cx <-> tile column cx + 3
+    for (int i = tid; i < SR * LQ; i += 256) {
+        const int r = i / LQ, q = i - r * LQ;
+        const int ty = r + F9_HALO - 1;
+        const int gy = y0 + r - 1;
+        const unsigned cur = tile32[ty][q], prev = tile32[ty][max(q - 1, 0)], next = tile32[ty][min(q + 1, LQ - 1)];
+        const unsigned up = tile32[ty - 3][q], dn = tile32[ty + 3][q];
+        const unsigned lf = (prev >> 8) | (cur << 24);  // byte e = pixel (4q + e) - 3
+        const unsigned rt = (cur >> 24) | (next << 8);  // byte e = pixel (4q + e) + 3
+        unsigned pass = 0;
+        if (gy >= 3 && gy < h - 3 && (NONMAX || (r >= 1 && r <= F9_TY))) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int tx = 4 * q + e, gx = x0 - F9_HALO + tx;
+                const int lo = NONMAX ? F9_HALO - 1 : F9_HALO, hi = NONMAX ? F9_HALO + F9_TX + 1 : F9_HALO + F9_TX;
+                const int p = (int)((cur >> (8 * e)) & 0xffu);
+                const int d0 = (int)((dn >> (8 * e)) & 0xffu) - p, d4 = (int)((rt >> (8 * e)) & 0xffu) - p;
+                const int d8 = (int)((up >> (8 * e)) & 0xffu) - p, d12 = (int)((lf >> (8 * e)) & 0xffu) - p;
+                const int nb = (d0 > b) + (d4 > b) + (d8 > b) + (d12 > b);
+                const int nd = (d0 < -b) + (d4 < -b) + (d8 < -b) + (d12 < -b);
+                const bool ok = (nb >= 2 || nd >= 2) && tx >= lo && tx < hi && gx >= 3 && gx < w - 3;
+                pass |= (unsigned)ok << e;
+            }
+        }
+        // append the survivors (order inside the list is irrelevant: every candidate writes its own score cell); only
+        // a few percent of the threads get here, so a returning LDS atomic is cheaper than a wave-wide prefix sum
+        if (pass) {
+            unsigned at = atomicAdd(&ncand, (unsigned)__popc(pass));
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (pass & (1u << e)) cand[at++] = (unsigned short)(r * LW + 4 * q + e);
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: ring test and score of the candidates
+    const unsigned nc = ncand;
+    for (unsigned i = tid; i < nc; i += 256) {
+        const int pos = cand[i];
+        const int r = pos / LW, tx = pos - r * LW;
+        const unsigned char *c = &tile[r + F9_HALO - 1][tx];
         const int p = *c;
         const int cb = min(255, p + b), c_b = max(0, p - b);
-        // any 9 contiguous ring pixels contain at least two of the four compass points
-        const int n0 = c[3 * LW], n4 = c[3], n8 = c[-3 * LW], n12 = c[-3];
-        const int nb = (n0 > cb) + (n4 > cb) + (n8 > cb) + (n12 > cb);
-        const int nd = (n0 < c_b) + (n4 < c_b) + (n8 < c_b) + (n12 < c_b);
-        if (nb < 2 && nd < 2) return 0;
         int v[16];
 #define F9_LOAD(i, dx, dy) v[i] = c[(dx) + LW * (dy)];
         F9_RING(F9_LOAD)
 #undef F9_LOAD
         unsigned brighter = 0, darker = 0;
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            brighter |= (unsigned)(v[i] > cb) << i;
-            darker |= (unsigned)(v[i] < c_b) << i;
+        for (int k = 0; k < 16; k++) {
+            brighter |= (unsigned)(v[k] > cb) << k;
+            darker |= (unsigned)(v[k] < c_b) << k;
         }
-        if (!(f9_has_arc9(brighter) || f9_has_arc9(darker))) return 0;
-        return NONMAX ? f9_score(v, p) + 1 : 1;  // score + 1 in 1..255; 0 = not a corner
-    };
-    const int lane = tid & 63, wv = tid >> 6;
-    if (NONMAX) {
-        for (int i = tid; i < (F9_TY + 2) * (F9_TX + 2); i += 256) {
-            const int r = i / (F9_TX + 2), cx = i - r * (F9_TX + 2);
-            sc[r][cx] = (unsigned char)corner_score(r + F9_HALO - 1, cx + F9_HALO - 1, x0 + cx - 1, y0 + r - 1);
-        }
-        __syncthreads();
+        if (f9_has_arc9(brighter) || f9_has_arc9(darker))
+            sc[r][tx - (F9_HALO - 1)] = (unsigned char)(NONMAX ? f9_score(v, p) + 1 : 1);  // score + 1 in 1..255; 0 = no corner
     }
-    for (int r = wv; r < F9_TY; r += 4) {
+    __syncthreads();
+    // ---- phase 3: 3x3 non-max test, again over the candidates only; survivors set their bit in the row's mask word
+    for (unsigned i = tid; i < nc; i += 256) {
+        const int pos = cand[i];
+        const int r = pos / LW, cx = pos - r * LW - (F9_HALO - 1);
+        if (r < 1 || r > F9_TY || cx < 1 || cx > F9_TX) continue;  // the ring of the score tile only serves its neighbours
+        const int s = sc[r][cx];
+        bool keep = s != 0;
+        if (NONMAX && keep)
+            keep = sc[r - 1][cx - 1] < s && sc[r - 1][cx] < s && sc[r - 1][cx + 1] < s && sc[r][cx - 1] < s &&
+                   sc[r][cx + 1] < s && sc[r + 1][cx - 1] < s && sc[r + 1][cx] < s && sc[r + 1][cx + 1] < s;
+        if (keep) atomicOr(&rowmask[r - 1], 1ull << (cx - 1));
+    }
+    __syncthreads();
+    for (int r = tid; r < F9_TY; r += 256) {
         const int gy = y0 + r;
-        bool keep;
-        if (NONMAX) {
-            const int s = sc[r + 1][lane + 1];
-            keep = s && sc[r][lane] < s && sc[r][lane + 1] < s && sc[r][lane + 2] < s && sc[r + 1][lane] < s &&
-                   sc[r + 1][lane + 2] < s && sc[r + 2][lane] < s && sc[r + 2][lane + 1] < s && sc[r + 2][lane + 2] < s;
-        } else {
-            keep = corner_score(r + F9_HALO, lane + F9_HALO, x0 + lane, gy) != 0;
-        }
-        const unsigned long long word = __ballot(keep);
-        if (lane == 0 && gy < h) {
-            mask[((size_t)blockIdx.z * h + gy) * words_per_row + blockIdx.x] = word;
-            if (word) atomicAdd(&rowcount[(size_t)blockIdx.z * h + gy], (unsigned)__popcll(word));
-        }
+        if (gy >= h) continue;
+        const unsigned long long word = rowmask[r];
+        mask[((size_t)blockIdx.z * h + gy) * words_per_row + blockIdx.x] = word;
+        if (word) atomicAdd(&rowcount[(size_t)blockIdx.z * h + gy], (unsigned)__popcll(word));
     }
 }
 

@@ -3,7 +3,7 @@
 //
 // Replaces gaussian(I, I, sigma_d) + gradient(I, Ix, Iy), image.CornerDetectionHarris/src/harris.cpp:511-514, i.e.
 // discrete_gaussian (gaussian.cpp:289-395) followed by central_differences / sobel_operator (gradient.cpp:17-106).
-// The smoothed image never reaches HBM: one workgroup owns a 64x32 tile of Ix, Iy; it stages the (64+3+2R)x(32+3+2R)
+// The smoothed image never reaches HBM: one workgroup owns a 64x24 tile of Ix, Iy; it stages the (64+3+2R)x(32+3+2R)
 // input pixels in LDS (reflected like the reference's borders), runs the row pass and the column pass with the
 // reference's arithmetic (f64 accumulate, one rounding to float per pass, fir_window8) on the tile plus a one-pixel
 // ring, and differentiates from LDS.  The gradient's border rule -- a border pixel takes the gradient of the nearest
@@ -12,8 +12,12 @@
 #include "common.h"
 #include "fir_device.h"
 
+#include <type_traits>
+
 #define GG_TX 64
-#define GG_TY 32
+#ifndef GG_TY
+#define GG_TY 24  // MI355X, 32 x 4K frames, u8: 8 -> 1004 us, 16 -> 757, 24 -> 696, 32 -> 755 (LDS 19 KB: 8 workgroups per CU)
+#endif
 #define GG_PX 4  // outputs per thread and pass (register window of GG_PX + 2R values)
 
 struct GaussGradParams {
@@ -28,14 +32,18 @@ struct GaussGradParams {
 template <int R, int GRAD, bool U8, bool FMA>
 __global__ void __launch_bounds__(256) gauss_grad_tile(GaussGradParams p)
 {
-    // smoothed tile: the 64x32 outputs plus a ring of 2 pixels left/top and 1 right/bottom (a tile that starts on the
+    // smoothed tile: the 64 x GG_TY outputs plus a ring of 2 pixels left/top and 1 right/bottom (a tile that starts on the
     // last image column/row evaluates its clamped gradient one pixel further inside)
     constexpr int SW = GG_TX + 3, SH = GG_TY + 3;
     // raw tile: columns x0-8 .. x0+71 (first column 4-pixel aligned: interior tiles load whole dwords / float4s),
     // rows y0-2-R .. y0+TY+R
     constexpr int XO = 8, RW = GG_TX + 2 * XO, RH = SH + 2 * R, OFFX = XO - 2 - R;
     static_assert(OFFX >= 0 && SW + 2 * R + OFFX <= RW, "raw tile too narrow for this radius");
-    __shared__ __attribute__((aligned(16))) float raw[RH][RW + 4];
+    static_assert(GG_PX == 4 && ((SW + GG_PX - 1) / GG_PX * GG_PX + OFFX + 2 * R + 3) / 4 * 4 <= RW + 4, "dword window reads stay inside the row");
+    // raw tile: bytes for u8 frames (a quarter of the LDS: the kernel is occupancy-bound, not bandwidth-bound), floats else
+    constexpr int RP = RW + 4;  // row pitch in elements
+    using raw_t = typename std::conditional<U8, unsigned char, float>::type;
+    __shared__ __attribute__((aligned(16))) raw_t raw[RH][RP];
     __shared__ float rowf[RH][SW + 1];
     __shared__ float is[SH][SW + 1];
     const int tid = threadIdx.x;
@@ -47,21 +55,19 @@ __global__ void __launch_bounds__(256) gauss_grad_tile(GaussGradParams p)
             const int r = i / (RW / 4), q = i - r * (RW / 4);
             const int gy = fir_reflect(y0 - 2 - R + r, p.ny);
             const size_t off = fin + (size_t)gy * p.in_pitch + (x0 - XO + 4 * q);
-            float4 v;
-            if (U8) {
-                const unsigned w = *reinterpret_cast<const unsigned *>(reinterpret_cast<const unsigned char *>(p.in) + off);
-                v = make_float4((float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24));
-            } else {
-                v = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(p.in) + off);
-            }
-            *reinterpret_cast<float4 *>(&raw[r][4 * q]) = v;
+            if (U8)
+                *reinterpret_cast<unsigned *>(&raw[r][4 * q]) =
+                    *reinterpret_cast<const unsigned *>(reinterpret_cast<const unsigned char *>(p.in) + off);
+            else
+                *reinterpret_cast<float4 *>(&raw[r][4 * q]) = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(p.in) + off);
         }
     } else {
         for (int i = tid; i < RH * RW; i += 256) {
             const int r = i / RW, c = i - r * RW;
             const int gy = fir_reflect(y0 - 2 - R + r, p.ny), gx = fir_reflect(x0 - XO + c, p.nx);
             const size_t off = fin + (size_t)gy * p.in_pitch + gx;
-            raw[r][c] = U8 ? (float)reinterpret_cast<const unsigned char *>(p.in)[off] : reinterpret_cast<const float *>(p.in)[off];
+            if (U8) raw[r][c] = (raw_t) reinterpret_cast<const unsigned char *>(p.in)[off];
+            else raw[r][c] = (raw_t) reinterpret_cast<const float *>(p.in)[off];
         }
     }
     __syncthreads();
@@ -70,8 +76,22 @@ __global__ void __launch_bounds__(256) gauss_grad_tile(GaussGradParams p)
     for (int i = tid; i < RH * RG; i += 256) {
         const int r = i / RG, c0 = (i - r * RG) * GG_PX;
         double d[GG_PX + 2 * R];
+        if (U8) {
+            // the window starts at byte c0 + OFFX of the row (c0 % 4 == 0): whole dwords, bytes picked at compile time
+            constexpr int NW = (OFFX % 4 + GG_PX + 2 * R + 3) / 4;
+            const unsigned *row32 = reinterpret_cast<const unsigned *>(&raw[r][0]) + ((c0 + OFFX) >> 2);
+            unsigned wv[NW];
 #pragma unroll
-        for (int k = 0; k < GG_PX + 2 * R; k++) d[k] = (double)raw[r][min(c0 + OFFX + k, RW - 1)];
+            for (int k = 0; k < NW; k++) wv[k] = row32[k];
+#pragma unroll
+            for (int k = 0; k < GG_PX + 2 * R; k++) {
+                constexpr int sh = OFFX % 4;
+                d[k] = (double)(float)((wv[(sh + k) >> 2] >> (8 * ((sh + k) & 3))) & 0xffu);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < GG_PX + 2 * R; k++) d[k] = (double)raw[r][min(c0 + OFFX + k, RW - 1)];
+        }
         float o[GG_PX];
         fir_window8<R, FMA, GG_PX>(d, p.B, o);
 #pragma unroll

@@ -72,12 +72,14 @@ imgfd_status launch_harris_nms(imgfd_ctx *ctx, const float *d_R, int nx, int ny,
 // `radius` (<= RN_HALO) pixels is computed from A, B, C into LDS; (2) every pixel applies the threshold and the 3x3
 // part of the window rule from LDS, survivors go to an LDS candidate list; (3) the waves take candidates in turn and
 // test the full (2r+1)^2 window with all 64 lanes (2 window positions per lane, __any as the verdict): no lane waits
-// for a neighbour's long loop; (4) one __ballot per tile row is the mask word.  HBM traffic: the 12 B/px of A, B, C
+// for a neighbour's long loop; (4) keepers set their bit in the tile row's mask word (LDS), written out at the end.  HBM traffic: the 12 B/px of A, B, C
 // (halo re-reads are L2 hits).
 #define RN_TX 64
+#ifndef RN_TY
 #define RN_TY 64
+#endif
 #define RN_HALO 6
-#define RN_MAXC 1024  // 3x3 local maxima cannot be denser than one per 2x2 block: 64*64/4
+#define RN_MAXC (RN_TX * RN_TY / 4)  // 3x3 local maxima cannot be denser than one per 2x2 block
 
 // HC > 0: the window radius is the compile-time constant HC (index arithmetic by constants); HC == 0: any radius <= RN_HALO
 template <int MEASURE, int HC>
@@ -92,7 +94,7 @@ __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__res
     constexpr int XO = 8, LW = RN_TX + 2 * XO, LH = RN_TY + 2 * RN_HALO, LP = LW + 4;
     __shared__ __attribute__((aligned(16))) float sR[LH][LP];
     __shared__ unsigned cand[RN_MAXC];            // (row << 8) | column, tile coordinates
-    __shared__ unsigned char keep[RN_TY][RN_TX];
+    __shared__ unsigned long long rowmask[RN_TY];  // tile width = 64 = one mask word per tile row
     __shared__ unsigned ncand;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int x0 = blockIdx.x * RN_TX, y0 = blockIdx.y * RN_TY;
@@ -100,7 +102,7 @@ __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__res
     const float *Af = A + fo, *Bf = B + fo, *Cf = C + fo;
     const int H = radius;  // <= RN_HALO (the launcher falls back to the two-kernel path otherwise)
     if (tid == 0) ncand = 0;
-    for (int i = tid; i < RN_TY * RN_TX; i += 256) keep[i / RN_TX][i % RN_TX] = 0;
+    for (int i = tid; i < RN_TY; i += 256) rowmask[i] = 0ull;
     const int hgt = RN_TY + 2 * H;
     const bool vec = vec4 && x0 - XO >= 0 && x0 - XO + LW <= nx;  // workgroup-uniform
     if (vec) {
@@ -176,17 +178,16 @@ __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__res
                 fail = fail || (strict[j] ? (q >= v) : (q > v));
             }
         }
-        if (!__any(fail) && lane == 0) keep[r][c] = 1;
+        if (!__any(fail) && lane == 0) atomicOr(&rowmask[r], 1ull << c);
     }
     __syncthreads();
     // (4) mask words
-    for (int r = wv; r < RN_TY; r += 4) {
+    for (int r = tid; r < RN_TY; r += 256) {
         const int y = y0 + r;
-        const unsigned long long word = __ballot(keep[r][lane] != 0);
-        if (lane == 0 && y < ny) {
-            mask[((size_t)blockIdx.z * ny + y) * words_per_row + blockIdx.x] = word;
-            if (word) atomicAdd(&rowcount[(size_t)blockIdx.z * ny + y], (unsigned)__popcll(word));
-        }
+        if (y >= ny) continue;
+        const unsigned long long word = rowmask[r];
+        mask[((size_t)blockIdx.z * ny + y) * words_per_row + blockIdx.x] = word;
+        if (word) atomicAdd(&rowcount[(size_t)blockIdx.z * ny + y], (unsigned)__popcll(word));
     }
 }
 
