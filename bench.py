@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--fir-mode", type=int, default=1)
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run the three detectors back to back on one stream instead of imgfd_detect_dev's two-stream schedule")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; nccl (= RCCL) is the product path, gloo is a functional check")
     ap.add_argument("--share-device", action="store_true",
@@ -135,9 +137,13 @@ def main():
     f_out = (torch.empty((B, cap_f, 2), dtype=torch.int32, device="cuda"), torch.empty((B,), dtype=torch.int64, device="cuda"))
     c_out = (torch.empty((B, NY, NX), dtype=torch.uint8, device="cuda"), torch.empty((B,), dtype=torch.int64, device="cuda"))
     have_canny = True
+    all_counts = torch.zeros((3, B), dtype=torch.int64, device="cuda")
 
     def step():
         nonlocal have_canny
+        if not args.no_overlap:
+            det.detect_all(frames, h_out[0], f_out[0], c_out[0], all_counts, fast9_threshold=20, suppress_non_max=1)
+            return
         det.harris(frames, out=h_out)
         det.fast9(frames, threshold=20, suppress_non_max=True, out=f_out)
         if have_canny:
@@ -168,7 +174,10 @@ def main():
     det.ctx.check(det.lib.imgfd_profile_k3_read(det.ctx.handle, C.byref(k3_us), C.byref(k3_n)), "profile read")
     det.lib.imgfd_profile_k3(det.ctx.handle, 0)
 
-    counts = torch.stack([h_out[1].sum(), f_out[1].sum(), c_out[1].sum() if have_canny else torch.zeros((), dtype=torch.int64, device="cuda")])
+    if args.no_overlap:
+        counts = torch.stack([h_out[1].sum(), f_out[1].sum(), c_out[1].sum() if have_canny else torch.zeros((), dtype=torch.int64, device="cuda")])
+    else:
+        counts = all_counts.sum(dim=1)
     # the path's only collective: feature counts (sum) and the elapsed time (max over ranks)
     counts, dt = stream.reduce_counts(counts, dt, dist if world > 1 else None)
 
@@ -199,7 +208,7 @@ def main():
                        "workload": f"configs[1]+Canny: image_harris() defaults + FAST-9 thr 20 nonmax"
                                    f"{' + Canny s=2 3/10 accGrad' if have_canny else ' (Canny not implemented yet: EXCLUDED)'}"
                                    f" on {NX}x{NY} u8 frames resident in HBM",
-                       "frames_per_step_per_gpu": B, "fir_mode": "fused-accumulate" if args.fir_mode else "strict",
+                       "frames_per_step_per_gpu": B, "schedule": "one stream" if args.no_overlap else "two streams (imgfd_detect_dev)", "fir_mode": "fused-accumulate" if args.fir_mode else "strict",
                        "feature_counts": {"harris_corners": int(counts[0]), "fast9_corners": int(counts[1]),
                                           "canny_edge_pixels": int(counts[2])}},
             "roofline": {"kernel": "fir_march<7,tensor> (Harris structure-tensor pass)", "bound": "hbm",
@@ -211,7 +220,7 @@ def main():
         if world == 1 and not args.no_cpu:
             host = np.stack([synth.frame(stream.frame_seed(50000, 0), NX, NY)])   # host twin of device frame 0
             assert np.array_equal(frames[0].cpu().numpy(), host[0]), "device and host frame generators diverged"
-            n_h, n_f = int(h_out[1][0]), int(f_out[1][0])
+            n_h, n_f = (int(h_out[1][0]), int(f_out[1][0])) if args.no_overlap else (int(all_counts[0, 0]), int(all_counts[1, 0]))
             gpu0 = (h_out[0][0, :min(n_h, cap_h)].cpu().numpy(), f_out[0][0, :min(n_f, cap_f)].cpu().numpy(),
                     c_out[0][0].cpu().numpy() if have_canny else None)
             res["cpu_baseline"] = cpu_baseline(host, gpu0)

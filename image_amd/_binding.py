@@ -111,6 +111,7 @@ SIGNATURES = {
     "imgfd_profile_k3_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "imgfd_synth_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_uint32,
                                      C.c_void_p, C.c_int]),
+    "imgfd_detect_dev": (C.c_int, [C.c_void_p, C.POINTER(Frames), C.POINTER(StreamParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "imgfd_stream_default_params": (None, [C.POINTER(StreamParams)]),
     "imgfd_stream_open": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(StreamParams), c_void_pp]),
     "imgfd_stream_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),

@@ -232,7 +232,9 @@ __global__ void __launch_bounds__(BM_NT) canny_blur_march(BlurMarchParams p)
 
 // ------------------------------------------------------------------ K10+K11
 #define GN_TX 64  // tile width = one __ballot word
+#ifndef GN_TY
 #define GN_TY 16
+#endif
 
 #define GN_XO 4  // the LDS tile of the blurred image starts at x0-4 (16-byte aligned in the plane), y0-2
 
@@ -627,7 +629,7 @@ size_t canny_ws_bytes(int nx, int ny, int nf)
 // all device work for nf frames; d_edges / d_counts are device buffers
 imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, size_t frame_stride, int nx, int ny,
                           int nf, double s, double low_thr, double high_thr, int accGrad, uint8_t *d_edges,
-                          int64_t *d_counts)
+                          int64_t *d_counts, const std::function<imgfd_status()> *after_front = nullptr)
 {
     if (!(s > 0)) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "canny: s must be positive");
     const size_t n = (size_t)nx * ny * nf;
@@ -671,6 +673,7 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
     hipLaunchKernelGGL(canny_grad_nms, g2, dim3(256), 0, ctx->stream, blur, S, Wm, nx, ny, wpr, accGrad, (int)low_thr,
                        (int)high_thr, (int)(nx % 4 == 0 && (size_t)blur % 16 == 0));
     IMGFD_HIP(ctx, hipGetLastError());
+    if (after_front) IMGFD_TRY((*after_front)());
     // hysteresis: rounds of HY_ROUND sweeps; converged when the last sweep of a round was idle
     const int tiles_x = ceil_div(wpr, HY_WORDS), tiles_y = ceil_div(ny, 64);
     dim3 g3(ceil_div(tiles_x * tiles_y, 4), nf);
@@ -734,9 +737,17 @@ imgfd_status imgfd_canny_i32(imgfd_ctx *ctx, const int32_t *image, int nx, int n
 imgfd_status imgfd_canny_dev(imgfd_ctx *ctx, const imgfd_frames *fr, double s, double low_thr,
                              double high_thr, int accGrad, uint8_t *d_edges, int64_t *d_counts)
 {
+    return canny_dev_hooked(ctx, fr, s, low_thr, high_thr, accGrad, d_edges, d_counts, nullptr);
+}
+
+}  // extern "C"
+
+imgfd_status canny_dev_hooked(imgfd_ctx *ctx, const imgfd_frames *fr, double s, double low_thr, double high_thr, int accGrad,
+                              uint8_t *d_edges, int64_t *d_counts, const std::function<imgfd_status()> *after_front)
+{
     if (!ctx || !fr || !fr->d_frames || !d_edges || !d_counts || fr->n_frames < 0 || fr->dtype != 0 || fr->nx < 1 || fr->ny < 1)
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_canny_dev: bad argument (frames must be u8)");
-    if (!fr->n_frames) return IMGFD_OK;
+    if (!fr->n_frames) return after_front ? (*after_front)() : IMGFD_OK;
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
     const int nx = fr->nx, ny = fr->ny;
     const size_t per_frame = canny_ws_bytes(nx, ny, 1);
@@ -747,9 +758,7 @@ imgfd_status imgfd_canny_dev(imgfd_ctx *ctx, const imgfd_frames *fr, double s, d
         ctx->ws_used = 0;
         IMGFD_TRY(canny_device(ctx, (const uint8_t *)fr->d_frames + (size_t)f0 * fr->frame_stride_bytes,
                                fr->row_stride_bytes, fr->frame_stride_bytes, nx, ny, nf, s, low_thr, high_thr, accGrad,
-                               d_edges + (size_t)f0 * nx * ny, d_counts + f0));
+                               d_edges + (size_t)f0 * nx * ny, d_counts + f0, f0 == 0 ? after_front : nullptr));
     }
     return IMGFD_OK;
 }
-
-}  // extern "C"

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -33,6 +34,9 @@ struct imgfd_ctx {
     char *aux = nullptr;
     size_t aux_size = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // second context (own stream and workspace) for work that overlaps this context's stream (imgfd_detect_dev)
+    imgfd_ctx *side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_gate = nullptr, ev_join = nullptr;
     // in-pipeline K3 timing (imgfd_profile_k3)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;  // pairs
@@ -72,6 +76,8 @@ void *ws_alloc(imgfd_ctx *ctx, size_t bytes);  // 256-byte aligned; nullptr if t
 static inline void ws_reset(imgfd_ctx *ctx) { ctx->ws_used = 0; }
 imgfd_status pin_reserve(imgfd_ctx *ctx, size_t bytes);
 imgfd_status aux_reserve(imgfd_ctx *ctx, size_t bytes);
+// the context's companion (created on first use): same device, own non-blocking stream, own workspace
+imgfd_status ctx_side(imgfd_ctx *ctx, imgfd_ctx **side);
 // records a profiling event on the stream when K3 profiling is on (no-op otherwise)
 imgfd_status prof_mark(imgfd_ctx *ctx);
 
@@ -136,3 +142,7 @@ imgfd_status launch_harris_nms(imgfd_ctx *ctx, const float *d_R, int nx, int ny,
 // fast9.hip
 imgfd_status launch_fast9(imgfd_ctx *ctx, const uint8_t *d_img, int w, int h, int stride,
                           size_t frame_stride, int n_frames, int threshold, int nonmax, const CompactBuffers &cb);
+// canny.hip: imgfd_canny_dev with a hook that runs on the host right after the blur and gradient/NMS kernels of the
+// (first chunk of the) batch have been queued, i.e. before the hysteresis rounds block the host
+imgfd_status canny_dev_hooked(imgfd_ctx *ctx, const imgfd_frames *fr, double s, double low_thr, double high_thr, int accGrad,
+                              uint8_t *d_edges, int64_t *d_counts, const std::function<imgfd_status()> *after_front);

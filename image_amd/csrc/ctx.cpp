@@ -50,6 +50,9 @@ void imgfd_ctx_destroy(imgfd_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->side) imgfd_ctx_destroy(ctx->side);
+    for (hipEvent_t e : {ctx->ev_fork, ctx->ev_gate, ctx->ev_join})
+        if (e) (void)hipEventDestroy(e);
     (void)hipStreamSynchronize(ctx->stream);
     for (void *p : ctx->ws_old) (void)hipFree(p);
     if (ctx->ws) (void)hipFree(ctx->ws);
@@ -68,6 +71,10 @@ void *imgfd_ctx_stream(imgfd_ctx *ctx) { return ctx ? (void *)ctx->stream : null
 imgfd_status imgfd_ctx_sync(imgfd_ctx *ctx)
 {
     if (!ctx) return IMGFD_ERR_INVALID;
+    if (ctx->side) {
+        const imgfd_status st = imgfd_ctx_sync(ctx->side);
+        if (st != IMGFD_OK) { ctx->err = ctx->side->err; return st; }
+    }
     IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (void *p : ctx->ws_old) (void)hipFree(p);
     ctx->ws_old.clear();
@@ -147,6 +154,22 @@ void *ws_alloc(imgfd_ctx *ctx, size_t bytes)
     if (off + bytes > ctx->ws_size) return nullptr;
     ctx->ws_used = off + bytes;
     return ctx->ws + off;
+}
+
+imgfd_status ctx_side(imgfd_ctx *ctx, imgfd_ctx **side)
+{
+    if (!ctx->side) {
+        imgfd_ctx *s = nullptr;
+        const imgfd_status st = imgfd_ctx_create(ctx->device, &s);
+        if (st != IMGFD_OK) return imgfd_fail(ctx, st, "could not create the companion context");
+        s->fir_mode = ctx->fir_mode;
+        ctx->side = s;
+        IMGFD_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        IMGFD_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_gate, hipEventDisableTiming));
+        IMGFD_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    *side = ctx->side;
+    return IMGFD_OK;
 }
 
 imgfd_status aux_reserve(imgfd_ctx *ctx, size_t bytes)

@@ -1,0 +1,56 @@
+// image_amd/csrc/detect.hip -- Harris + FAST-9 + Canny on one device-resident batch, overlapped on two HIP streams.
+//
+// Host-side scheduling only; the kernels are those of imgfd_harris_dev / imgfd_fast9_dev / imgfd_canny_dev and every
+// result is what those calls return.  Why overlap: Canny's hysteresis (rcpp_canny.cpp:184-215) is a fixpoint iteration
+// whose later sweeps touch a handful of tiles -- a few waves on a 256-CU device -- and whose convergence the host has to
+// read back.  The batch's Canny front (blur, gradient + NMS) runs first on the context's companion stream; once it is
+// queued, the context's own stream is gated on it and receives FAST-9 and the Harris chain, which then fill the machine
+// while the hysteresis rounds trickle along on the companion stream.
+//
+//      companion stream :  blur | grad+NMS | hysteresis sweeps ......... | expand, count |
+//      context stream   :                  | FAST-9 | gauss+grad | structure tensor | response+NMS | compaction |
+#include "common.h"
+
+extern "C" {
+
+imgfd_status imgfd_detect_dev(imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_stream_params *p, imgfd_corner *d_corners,
+                              imgfd_point *d_points, uint8_t *d_edges, int64_t *d_counts)
+{
+    if (!ctx) return IMGFD_ERR_INVALID;
+    if (!fr || !p || !d_counts || fr->n_frames < 0 || (!p->harris && !p->fast9 && !p->canny) || (p->harris && p->corner_cap < 0) ||
+        (p->fast9 && p->point_cap < 0) || (p->canny && !d_edges) || p->fast9_threshold < 0 || p->fast9_threshold > 255)
+        return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_detect_dev: bad argument");
+    IMGFD_HIP(ctx, hipSetDevice(ctx->device));
+    const int B = fr->n_frames;
+    auto front = [&]() -> imgfd_status {  // FAST-9 and Harris on the context's stream
+        if (p->fast9)
+            IMGFD_TRY(imgfd_fast9_dev(ctx, fr, (uint8_t)p->fast9_threshold, p->suppress_non_max, d_points, p->point_cap, d_counts + B));
+        if (p->harris)
+            IMGFD_TRY(imgfd_harris_dev(ctx, fr, p->k, p->sigma_d, p->sigma_i, p->threshold, p->gaussian, p->gradient, p->measure,
+                                       d_corners, p->corner_cap, d_counts));
+        return IMGFD_OK;
+    };
+    if (!p->canny) return front();
+    if (!p->harris && !p->fast9) return imgfd_canny_dev(ctx, fr, p->s, p->low_thr, p->high_thr, p->accGrad, d_edges, d_counts + 2 * B);
+    imgfd_ctx *side = nullptr;
+    IMGFD_TRY(ctx_side(ctx, &side));
+    // the frames (and anything else queued on the context's stream) come first
+    IMGFD_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    IMGFD_HIP(ctx, hipStreamWaitEvent(side->stream, ctx->ev_fork, 0));
+    const std::function<imgfd_status()> gate = [&]() -> imgfd_status {
+        IMGFD_HIP(ctx, hipEventRecord(ctx->ev_gate, side->stream));
+        IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gate, 0));
+        return front();
+    };
+    const imgfd_status st = canny_dev_hooked(side, fr, p->s, p->low_thr, p->high_thr, p->accGrad, d_edges, d_counts + 2 * B, &gate);
+    if (st != IMGFD_OK) {
+        if (ctx->err.empty() || !side->err.empty()) ctx->err = side->err.empty() ? ctx->err : side->err;
+        return st;
+    }
+    // whoever waits for the context's stream waits for the edges too
+    IMGFD_HIP(ctx, hipEventRecord(ctx->ev_join, side->stream));
+    IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    return IMGFD_OK;
+}
+
+}  // extern "C"

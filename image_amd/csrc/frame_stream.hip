@@ -111,15 +111,9 @@ imgfd_status run_slot(imgfd_stream *st, Slot &s)
     fr.frame_stride_bytes = fb;
     fr.row_stride_bytes = st->nx;
     fr.dtype = 0;
-    int64_t *cnt = s.d_counts;
-    const int B = st->batch;
-    if (p.harris)
-        IMGFD_TRY(imgfd_harris_dev(ctx, &fr, p.k, p.sigma_d, p.sigma_i, p.threshold, p.gaussian, p.gradient, p.measure,
-                                   s.d_corners, p.corner_cap, cnt));
-    if (p.fast9)
-        IMGFD_TRY(imgfd_fast9_dev(ctx, &fr, (uint8_t)p.fast9_threshold, p.suppress_non_max, s.d_points, p.point_cap, cnt + B));
-    if (p.canny) IMGFD_TRY(imgfd_canny_dev(ctx, &fr, p.s, p.low_thr, p.high_thr, p.accGrad, s.d_edges, cnt + 2 * B));
-    IMGFD_HIP(ctx, hipMemcpyAsync(s.h_res + st->off_counts, cnt, sizeof(int64_t) * 3 * B, hipMemcpyDeviceToHost, ctx->stream));
+    int64_t *cnt = s.d_counts;  // three arrays of s.n counts, back to back
+    IMGFD_TRY(imgfd_detect_dev(ctx, &fr, &p, s.d_corners, s.d_points, s.d_edges, cnt));
+    IMGFD_HIP(ctx, hipMemcpyAsync(s.h_res + st->off_counts, cnt, sizeof(int64_t) * 3 * s.n, hipMemcpyDeviceToHost, ctx->stream));
     if (p.harris && p.corner_cap > 0)
         IMGFD_HIP(ctx, hipMemcpyAsync(s.h_res + st->off_corners, s.d_corners, sizeof(imgfd_corner) * p.corner_cap * s.n,
                                       hipMemcpyDeviceToHost, ctx->stream));
@@ -281,7 +275,7 @@ imgfd_status imgfd_stream_collect(imgfd_stream *st, imgfd_stream_result *res)
     Slot &s = st->slot[st->collected % FS_SLOTS];
     IMGFD_HIP(ctx, hipEventSynchronize(s.done));
     const imgfd_stream_params &p = st->p;
-    const int B = st->batch;
+    const int B = s.n;  // stride of the three count arrays of this batch
     const int64_t *cnt = (const int64_t *)(s.h_res + st->off_counts);
     res->n_frames = s.n;
     res->first_frame = s.first;

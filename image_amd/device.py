@@ -87,6 +87,22 @@ class DeviceDetector:
                        "imgfd_canny_dev")
         return edges, counts
 
+    def detect_all(self, frames: torch.Tensor, corners: torch.Tensor, points: torch.Tensor, edges: torch.Tensor,
+                   counts: torch.Tensor, **params):
+        """Harris + FAST-9 + Canny on one batch, overlapped on two HIP streams (imgfd_detect_dev).  corners [n, cap, 3]
+        f32, points [n, cap, 2] i32, edges [n, ny, nx] u8, counts [3, n] i64 (harris, fast9, canny); params are fields of
+        imgfd_stream_params (defaults: the three R functions' defaults)."""
+        fr = self._frames(frames)
+        p = _binding.StreamParams()
+        self.lib.imgfd_stream_default_params(C.byref(p))
+        p.corner_cap, p.point_cap = corners.shape[1], points.shape[1]
+        for k, v in params.items():
+            setattr(p, k, v)
+        assert counts.is_contiguous() and counts.numel() == 3 * fr.n_frames
+        self.ctx.check(self.lib.imgfd_detect_dev(self.ctx.handle, C.byref(fr), C.byref(p), corners.data_ptr(), points.data_ptr(),
+                                                 edges.data_ptr(), counts.data_ptr()), "imgfd_detect_dev")
+        return counts
+
     def time_structure_tensor(self, ix: torch.Tensor, iy: torch.Tensor, sigma=2.5, gauss=0, warmup=5, iters=50):
         """Mean microseconds per launch of the structure-tensor kernel (HIP events on the ctx stream)."""
         ny, nx = ix.shape[-2:]

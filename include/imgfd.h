@@ -321,6 +321,16 @@ typedef struct {
     const uint8_t *edges;        /* n_frames * nx*ny bytes; NULL unless keep_edges */
 } imgfd_stream_result;
 
+/* One device-resident batch through the selected detectors, overlapped on two HIP streams (the Canny hysteresis
+ * rounds, which occupy a few waves and need host read-backs, run beside FAST-9 and the Harris chain).  Results are
+ * exactly those of imgfd_harris_dev / imgfd_fast9_dev / imgfd_canny_dev with the parameters in *p (keep_edges is
+ * ignored: d_edges is required whenever Canny is on).  d_counts: 3*n_frames int64 -- Harris counts, then FAST-9, then
+ * Canny pixels_nonzero; the third of a detector that is off is left untouched.  Work queued on the context's stream
+ * before the call is waited for; after the call the context's stream (imgfd_ctx_sync) covers all results. */
+IMGFD_API imgfd_status imgfd_detect_dev(imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_stream_params *p,
+                                        imgfd_corner *d_corners, imgfd_point *d_points, uint8_t *d_edges,
+                                        int64_t *d_counts);
+
 /* defaults of the three R functions, all detectors on, counts only */
 IMGFD_API void imgfd_stream_default_params(imgfd_stream_params *p);
 IMGFD_API imgfd_status imgfd_stream_open(imgfd_ctx *ctx, int nx, int ny, int batch_frames,

@@ -96,6 +96,22 @@ def test_counts_only_and_single_detector(be, frames, expected):
         assert counts == [len(e[0]) for e in expected]
 
 
+def test_canny_only_and_two_detectors(be, frames, expected):
+    be.set_fir_mode(0)
+    with framestream.FrameStream(NX, NY, batch=4, ctx=_ctx(be), harris=False, fast9=False, keep_edges=True) as fs:
+        fs.submit(frames[:4])
+        r = fs.collect()
+        assert r["harris_counts"] is None and list(r["canny_counts"]) == [e[3] for e in expected[:4]]
+        assert all(np.array_equal(r["edges"][f], expected[f][2]) for f in range(4))
+    with framestream.FrameStream(NX, NY, batch=4, ctx=_ctx(be), harris=False, point_cap=512, fast9_threshold=20,
+                                 suppress_non_max=1) as fs:                     # FAST-9 beside Canny: the two-stream schedule
+        fs.submit(frames[4:8])
+        r = fs.collect()
+        assert list(r["canny_counts"]) == [e[3] for e in expected[4:8]]
+        assert list(r["fast9_counts"]) == [len(e[1]) for e in expected[4:8]]
+        assert np.array_equal(r["points"][2]["x"], expected[6][1][:, 0])
+
+
 def test_pipeline_depth_and_argument_errors(be, frames):
     with _open(be) as fs:
         fs.submit(frames[0:2])
