@@ -184,7 +184,10 @@ def main():
     if rank == 0:
         px_per_step = B * NX * NY * world
         k3_avg_us = k3_us.value / max(1, k3_n.value)
-        k3_bytes = TENSOR_BYTES_PER_PX * NX * NY * B       # algorithmic bytes of one launch (B frames)
+        # algorithmic bytes of one launch: a step's B frames go through the kernel in launches/steps launches (large
+        # batches are split by the library's workspace cap), so divide the step's bytes accordingly
+        launches_per_step = max(1, round(k3_n.value / max(1, args.steps)))
+        k3_bytes = TENSOR_BYTES_PER_PX * NX * NY * B // launches_per_step
         achieved = k3_bytes / (k3_avg_us * 1e-6) / 1e9 if k3_avg_us > 0 else 0.0
         # parity spot-check of frame 0 against the host generator + oracle happens in tests/ (-m gpu)
         # HBM traffic of one K3 launch from the PMC counters: collected offline in separate rocprofv3 --pmc passes on
@@ -192,7 +195,7 @@ def main():
         traffic = None
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "k3_traffic.json")))
-            if tr.get("batch") == B:
+            if tr.get("batch") == B and launches_per_step == 1:
                 traffic = int(tr["traffic_bytes_per_launch"])
         except Exception:
             pass

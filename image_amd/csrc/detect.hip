@@ -3,12 +3,12 @@
 // Host-side scheduling only; the kernels are those of imgfd_harris_dev / imgfd_fast9_dev / imgfd_canny_dev and every
 // result is what those calls return.  Why overlap: Canny's hysteresis (rcpp_canny.cpp:184-215) is a fixpoint iteration
 // whose later sweeps touch a handful of tiles -- a few waves on a 256-CU device -- and whose convergence the host has to
-// read back.  The batch's Canny front (blur, gradient + NMS) runs first on the context's companion stream; once it is
-// queued, the context's own stream is gated on it and receives FAST-9 and the Harris chain, which then fill the machine
-// while the hysteresis rounds trickle along on the companion stream.
+// read back.  The batch's Canny front (blur, gradient + NMS) runs on the context's companion stream, beside FAST-9 on
+// the context's own stream; that stream is then gated on the Canny front and receives the Harris chain, which fills the
+// machine while the hysteresis rounds trickle along on the companion stream.
 //
-//      companion stream :  blur | grad+NMS | hysteresis sweeps ......... | expand, count |
-//      context stream   :                  | FAST-9 | gauss+grad | structure tensor | response+NMS | compaction |
+//      companion stream :  blur | grad+NMS | hysteresis sweeps ............ | expand, count |
+//      context stream   :  FAST-9 ....     | gauss+grad | structure tensor | response+NMS | compaction |
 #include "common.h"
 
 extern "C" {
@@ -22,25 +22,31 @@ imgfd_status imgfd_detect_dev(imgfd_ctx *ctx, const imgfd_frames *fr, const imgf
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_detect_dev: bad argument");
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
     const int B = fr->n_frames;
-    auto front = [&]() -> imgfd_status {  // FAST-9 and Harris on the context's stream
-        if (p->fast9)
-            IMGFD_TRY(imgfd_fast9_dev(ctx, fr, (uint8_t)p->fast9_threshold, p->suppress_non_max, d_points, p->point_cap, d_counts + B));
-        if (p->harris)
-            IMGFD_TRY(imgfd_harris_dev(ctx, fr, p->k, p->sigma_d, p->sigma_i, p->threshold, p->gaussian, p->gradient, p->measure,
-                                       d_corners, p->corner_cap, d_counts));
-        return IMGFD_OK;
+    auto fast9 = [&]() -> imgfd_status {
+        if (!p->fast9) return IMGFD_OK;
+        return imgfd_fast9_dev(ctx, fr, (uint8_t)p->fast9_threshold, p->suppress_non_max, d_points, p->point_cap, d_counts + B);
     };
-    if (!p->canny) return front();
+    auto harris = [&]() -> imgfd_status {
+        if (!p->harris) return IMGFD_OK;
+        return imgfd_harris_dev(ctx, fr, p->k, p->sigma_d, p->sigma_i, p->threshold, p->gaussian, p->gradient, p->measure, d_corners,
+                                p->corner_cap, d_counts);
+    };
+    if (!p->canny) {
+        IMGFD_TRY(fast9());
+        return harris();
+    }
     if (!p->harris && !p->fast9) return imgfd_canny_dev(ctx, fr, p->s, p->low_thr, p->high_thr, p->accGrad, d_edges, d_counts + 2 * B);
     imgfd_ctx *side = nullptr;
     IMGFD_TRY(ctx_side(ctx, &side));
     // the frames (and anything else queued on the context's stream) come first
     IMGFD_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     IMGFD_HIP(ctx, hipStreamWaitEvent(side->stream, ctx->ev_fork, 0));
+    // FAST-9 (integer work, latency-bound) shares the machine with the Canny blur (f64 issue-bound) from the start
+    IMGFD_TRY(fast9());
     const std::function<imgfd_status()> gate = [&]() -> imgfd_status {
         IMGFD_HIP(ctx, hipEventRecord(ctx->ev_gate, side->stream));
         IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gate, 0));
-        return front();
+        return harris();
     };
     const imgfd_status st = canny_dev_hooked(side, fr, p->s, p->low_thr, p->high_thr, p->accGrad, d_edges, d_counts + 2 * B, &gate);
     if (st != IMGFD_OK) {
