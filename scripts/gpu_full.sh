@@ -10,4 +10,7 @@ echo "=== bench"; timeout 900 python bench.py 2>&1 | tail -1 | tee "$O/bench_$TA
 echo "=== kernel trace"
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_$TAG" -o t -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu > "$O/trace_$TAG.log" 2>&1
 f=$(find "$O/trace_$TAG" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python "$R/scripts/kstats.py" "$f" | head -24
+echo "=== kernel trace, one stream (per-kernel durations without concurrent kernels)"
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace1s_$TAG" -o t -- python "$R/bench.py" --steps 5 --warmup 2 --no-cpu --no-overlap > "$O/trace1s_$TAG.log" 2>&1
+f=$(find "$O/trace1s_$TAG" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && python "$R/scripts/kstats.py" "$f" | head -16
 exit 0
