@@ -28,7 +28,8 @@ TENSOR_BYTES_PER_PX = 20        # read Ix,Iy (8 B), write A,B,C 
 
 def cpu_baseline(frames_host, gpu_frame0=None):
     """Reference CPU path on this host: Harris = reference sources + OpenMP on all cores, FAST-9 =
-    reference f9.cpp (single-threaded code), Canny = oracle restatement (reference needs FFTW3).
+    reference f9.cpp (single-threaded code), Canny = oracle restatement (the reference's blur needs FFTW3, absent; the restatement is pinned against the
+    reference sources over a stand-in DFT in tests/test_oracle.py, but that build's O(n^3) DFT is no timing baseline).
     gpu_frame0: the device results for the same frame (corner list, FAST-9 list, edge map): the CPU outputs computed
     here anyway double as the metric's "feature-coordinate match vs CPU" check."""
     import numpy as np
@@ -84,7 +85,7 @@ def cpu_baseline(frames_host, gpu_frame0=None):
     total = t_h + t_f + (t_c or 0.0)
     out.update({"value": round(px / total / 1e6, 3), "kind": kind, "cores": cores,
                 "sample": f"1 frame {NX}x{NY}, best of 2 after warm-up; Harris: reference src + OpenMP x{cores} (best of 8/16/32/64 threads, {avail} available); "
-                          "FAST-9: reference f9.cpp (1 thread); Canny: oracle restatement, 1 thread "
+                          "FAST-9: reference f9.cpp (1 thread); Canny: oracle restatement (pinned against the reference sources), 1 thread "
                           "(reference needs FFTW3)", "parts": parts})
     return out
 

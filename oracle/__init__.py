@@ -199,6 +199,21 @@ def canny(img, s: float = 2.0, low_thr: float = 3.0, high_thr: float = 10.0, acc
     return edges, int(n)
 
 
+def ref_canny(img, s: float = 2.0, low_thr: float = 3.0, high_thr: float = 10.0, accGrad: bool = True):
+    """The reference's own canny_edge_detector() (rcpp_canny.cpp:122-244 + tools.c + adsf.c compiled in place into
+    oracle/_ref/libref_canny.so; FFTW3 replaced by the plain DFT of oracle/fftw_stub.c).  Slow: O(n^3) transforms.
+    Returns (edges uint8 (ny,nx) of 0/255, pixels_nonzero)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    ny, nx = img.shape
+    as_int = np.ascontiguousarray(img, dtype=np.int32)         # as.integer(x), canny_edges_detector.R
+    edges = np.zeros((ny, nx), np.uint8)
+    fn = ref("canny").ref_canny
+    fn.restype = C.c_long
+    n = fn(as_int.ctypes.data_as(C.c_void_p), nx, ny, C.c_double(s), C.c_double(low_thr), C.c_double(high_thr),
+           int(bool(accGrad)), edges.ctypes.data_as(C.c_void_p))
+    return edges, int(n)
+
+
 # ----------------------------------------------------------------------- fHOG
 def _rgb(img):
     img = np.ascontiguousarray(img, dtype=np.uint8)

@@ -7,21 +7,25 @@
  * src/adsf.c (union-find == 8-connected components).  Only tests/, smoke() and
  * bench.py's cpu_baseline leg may call this file.
  *
- * PARITY UNPINNED.  The reference's blur multiplies FFTs computed by FFTW3
- * (system library, version not pinned by the reference: CannyEdges/DESCRIPTION:21
- * "SystemRequirements: libpng, fftw3"; src/Makevars:1).  FFTW3 is not vendored
- * and not installed here, so the reference path cannot be compiled; the
- * reference holds no test or golden vector for this function either.  The blur
- * is restated as what tools.c:166-185 computes mathematically:
+ * PINNING.  The reference's blur multiplies FFTs computed by FFTW3 (system library, version not pinned by the
+ * reference: CannyEdges/DESCRIPTION:21 "SystemRequirements: libpng, fftw3"; src/Makevars:1), which is neither
+ * vendored nor installed here, and the reference holds no test or golden vector for this function.  The pin is
+ * therefore the reference's OWN sources -- rcpp_canny.cpp, tools.c, adsf.c -- compiled where they lie into
+ * oracle/_ref/libref_canny.so (oracle/Makefile, ref_shim_canny.cpp) with two stand-ins: stub/Rcpp.h for the glue
+ * types and fftw_stub.c, plain DFT sums in long double, behind the six FFTW calls of tools.c:89-135.  What is pinned:
+ * kernel construction and normalisation, the float cast of the blurred image, gradient, hypot/atan2, bilinear
+ * non-maximum suppression, integer-truncated thresholds, union-find hysteresis -- everything but FFTW's own rounding
+ * (~1e-13 on 0..255 data, far below the float cast).  tests/test_oracle.py compares edge maps pixel for pixel on
+ * synthetic frames, noise and chairs.pgm (0 mismatches observed; bound 1e-5 as SURVEY.md 8d); tests/golden/canny_*.npz
+ * were written by that reference build (scripts/make_golden.py).
+ *
+ * The blur is restated as what tools.c:166-185 computes mathematically:
  *     y = float( x (*) g ),  (*) = 2-D circular convolution,
  *     g[j][i] = exp(-(xi^2+yj^2)/s^2) / sum(g),  xi = i<w/2 ? i : i-w  (:146-163)
  * and because g is an outer product, as two 1-D circular convolutions with the
  * FULL-length wrapped kernels (no truncation), accumulated in double, rounded
  * to float once at the end like crealf does (tools.c:129).
- * tests/test_oracle_canny.py cross-checks this against a literal numpy
- * fft2/ifft2 restatement (pocketfft): agreement to < 1 float ulp is expected,
- * bit equality after the float rounding is not guaranteed (an FFT carries
- * ~1e-13 absolute error on 0..255 data).
+ * tests/test_oracle.py also cross-checks this against a literal numpy fft2/ifft2 restatement (pocketfft).
  */
 #include <math.h>
 #include <stdlib.h>

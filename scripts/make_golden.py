@@ -5,9 +5,10 @@ and on seeded synthetic frames.  Run in the build container only:
     python scripts/make_golden.py
 
 The .npz files carry the input image (so the GPU box, which has no
-/root/reference, can replay them) and the expected outputs.  Canny has no
-compilable reference (FFTW3 absent): its vectors come from the restatement in
-oracle/canny_oracle.c and are labelled ``unpinned``.
+/root/reference, can replay them) and the expected outputs.  Canny's vectors
+come from the reference's own rcpp_canny.cpp / tools.c / adsf.c compiled in
+place (oracle/_ref/libref_canny.so); the FFTW3 calls of tools.c are served by
+the plain DFT of oracle/fftw_stub.c, as FFTW3 itself is absent here.
 """
 import os
 import sys
@@ -77,12 +78,24 @@ def fast9_golden(name, img, thresholds):
     print(name, {k: v.shape for k, v in out.items()})
 
 
-def canny_golden(name, img):
-    out = {"image": img.astype(np.uint8), "pinned": np.array(0)}
-    for acc in (0, 1):
-        edges, n = oracle.canny(img, accGrad=bool(acc))
-        out[f"edges_bits_a{acc}"] = np.packbits(edges > 0)
-        out[f"nonzero_a{acc}"] = np.array(n)
+CANNY_CASES = {
+    "a0": dict(accGrad=False),                       # the C++ default
+    "a1": dict(accGrad=True),                        # the R wrapper's default (canny_edges_detector.R:63)
+    "s1_t2_6": dict(s=1.0, low_thr=2, high_thr=6),
+    "s3p5_t1_4": dict(s=3.5, low_thr=1, high_thr=4),
+}
+
+
+def canny_golden(name, img, cases=("a0", "a1")):
+    """edge maps written by the reference's own canny_edge_detector(); the restatement must agree before anything is saved"""
+    out = {"image": img.astype(np.uint8), "pinned": np.array(1)}
+    for case in cases:
+        kw = CANNY_CASES[case]
+        edges, n = oracle.ref_canny(img, **kw)
+        o_edges, o_n = oracle.canny(img, **kw)
+        assert n == o_n and np.array_equal(edges, o_edges), f"oracle/canny_oracle.c disagrees with the reference on {name}/{case}"
+        out[f"edges_bits_{case}"] = np.packbits(edges > 0)
+        out[f"nonzero_{case}"] = np.array(n)
     np.savez_compressed(os.path.join(OUT, name), **out)
     print(name, {k: (v.shape, int(v) if v.ndim == 0 else None) for k, v in out.items()})
 
@@ -98,6 +111,7 @@ def main():
     fast9_golden("fast9_synth_640x480_seed1", synth.frame(1, 640, 480), (10, 20, 50))
     # R hands Canny the column-major memory of grey[row, col], i.e. the transposed raster
     canny_golden("canny_chairs", np.ascontiguousarray(chairs.T))
+    canny_golden("canny_synth_320x240_seed7", synth.frame(7, 320, 240, n_rect=20), tuple(CANNY_CASES))
 
 
 if __name__ == "__main__":

@@ -1,7 +1,8 @@
-"""Canny: the device path against the oracle restatement (PARITY UNPINNED: the reference needs FFTW3,
-see oracle/canny_oracle.c).  The blur is summed in the oracle's own tap order, so the blurred plane --
-and with it almost every decision -- is reproduced exactly; the NMS replaces atan2->cos/sin by the unit
-vector, which can flip exact ties only: the edge map is compared through a mismatch-rate bound."""
+"""Canny: the device path against the oracle restatement and against edge maps written by the reference's own
+canny_edge_detector() (compiled in place with a stand-in DFT for the absent FFTW3, see oracle/canny_oracle.c and
+tests/test_oracle.py).  The blur is summed in the oracle's own tap order, so the blurred plane -- and with it almost every
+decision -- is reproduced exactly; the NMS replaces atan2->cos/sin by the unit vector, which can flip exact ties only: the
+edge map is compared through a mismatch-rate bound."""
 import numpy as np
 import pytest
 
@@ -23,6 +24,17 @@ def test_chairs_golden(be, golden, acc):
     bad = mismatch(edges, ref)
     assert bad <= 1e-4 * edges.size, (bad, n, int(g[f"nonzero_a{acc}"]))
     assert abs(n - int(g[f"nonzero_a{acc}"])) <= 1e-3 * int(g[f"nonzero_a{acc}"])
+
+
+def test_reference_golden_all_parameter_sets(be, golden):
+    """edge maps of the reference's own code on a synthetic frame, four parameter sets (scripts/make_golden.py)"""
+    from scripts_path import CANNY_CASES
+    g = golden("canny_synth_320x240_seed7")
+    for case, kw in CANNY_CASES.items():
+        edges, n = be.canny(g["image"], **kw)
+        ref = np.unpackbits(g[f"edges_bits_{case}"]).reshape(edges.shape) * 255
+        assert mismatch(edges, ref) <= 1e-5 * edges.size + 1, case     # SURVEY 8d config 3: mismatch rate <= 1e-5
+        assert abs(n - int(g[f"nonzero_{case}"])) <= 1, case
 
 
 def test_chairs_anchor(be, golden):

@@ -103,7 +103,47 @@ def test_fast9_against_compiled_reference():
                 assert np.array_equal(oracle.fast9(img, thr, nms), oracle.ref_fast9(img, thr, nms)), (i, thr, nms)
 
 
-# ------------------------------------------------------------------ Canny (parity unpinned)
+# ------------------------------------------------------------------ Canny
+# pinned by the reference's own rcpp_canny.cpp + tools.c + adsf.c compiled in place (oracle/_ref/libref_canny.so); FFTW3,
+# which the reference links but does not vendor, is replaced by the plain DFT of oracle/fftw_stub.c
+needs_ref_canny = pytest.mark.skipif(not oracle.have_ref("canny"), reason="oracle/_ref/libref_canny.so not built (needs /root/reference)")
+
+
+@needs_ref_canny
+@pytest.mark.parametrize("nx,ny,kw", [(160, 120, {}), (200, 131, dict(accGrad=False)), (97, 64, dict(s=3.5)),
+                                      (131, 90, dict(s=1.0, low_thr=2, high_thr=6)), (64, 64, dict(s=0.7, low_thr=0, high_thr=1)),
+                                      (33, 47, dict(s=5.0, low_thr=0.5, high_thr=2.5)), (16, 9, {})])
+def test_canny_restatement_matches_reference(nx, ny, kw):
+    img = synth.frame(60 + nx, max(nx, 16), max(ny, 16), n_rect=9)[:ny, :nx]
+    ref_e, ref_n = oracle.ref_canny(img, **kw)
+    e, n = oracle.canny(img, **kw)
+    assert ref_n == int(np.count_nonzero(ref_e))
+    assert n == ref_n and np.array_equal(e, ref_e)
+
+
+@needs_ref_canny
+def test_canny_reference_on_noise():
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (70, 101)).astype(np.uint8)
+    for kw in (dict(), dict(accGrad=False, low_thr=20, high_thr=60)):
+        ref_e, ref_n = oracle.ref_canny(img, **kw)
+        e, n = oracle.canny(img, **kw)
+        assert np.count_nonzero(e != ref_e) <= 1e-5 * e.size + 1 and abs(n - ref_n) <= 1      # <= 1e-5
+
+
+@pytest.mark.parametrize("fixture,cases", [("canny_chairs", ("a0", "a1")),
+                                           ("canny_synth_320x240_seed7", ("a0", "a1", "s1_t2_6", "s3p5_t1_4"))])
+def test_canny_restatement_matches_reference_golden(golden, fixture, cases):
+    """goldens written by the reference's own canny_edge_detector() (scripts/make_golden.py)"""
+    from scripts_path import CANNY_CASES
+    g = golden(fixture)
+    assert int(g["pinned"]) == 1
+    for case in cases:
+        e, n = oracle.canny(g["image"], **CANNY_CASES[case])
+        assert n == int(g[f"nonzero_{case}"]), case
+        assert np.array_equal(np.packbits(e > 0), g[f"edges_bits_{case}"]), case
+
+
 def _numpy_gblur(img, s):
     """tools.c:146-185 literally: y = float(ifft2(fft2(x) * fft2(g)) / (w h)) with the wrapped Gaussian."""
     h, w = img.shape
