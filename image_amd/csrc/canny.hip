@@ -138,44 +138,52 @@ __global__ void __launch_bounds__(BM_NT) canny_blur_march(BlurMarchParams p)
     const unsigned char *in = p.in + (size_t)blockIdx.z * p.frame_stride;
     float *out = p.out + (size_t)blockIdx.z * p.nx * p.ny;
 
+    // tile loads: slot l of a thread is always dword q[l] of tile row r[l]; only the image row moves (by BM_CH rows per
+    // chunk, wrapping around the image), so the column offset and the LDS address are fixed up front and the row index
+    // is advanced incrementally -- no division in the loop
     unsigned pre[NLD];
-    auto prefetch = [&](int chunk) {
+    int ld_row[NLD], ld_col[NLD], ld_lds[NLD];
+#pragma unroll
+    for (int l = 0; l < NLD; l++) {
+        const int i = tid + l * BM_NT;
+        const int r = i / WD, q = i - r * WD;
+        ld_lds[l] = i < BM_CH * WD ? r * PITCH + q : -1;
+        ld_row[l] = wrap_idx(ybase + r, p.ny);
+        ld_col[l] = wrap_idx(x0 - HL + 4 * q, p.nx);  // aligned4: nx % 4 == 0, so a dword never straddles the wrap
+    }
+    const int row_step = BM_CH % p.ny;
+    auto prefetch = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int l = 0; l < NLD; l++) {
-            const int i = tid + l * BM_NT;
             pre[l] = 0;
-            if (i < BM_CH * WD) {
-                const int r = i / WD, q = i - r * WD;
-                const int gy = wrap_idx(ybase + chunk * BM_CH + r, p.ny);
-                const int gx = x0 - HL + 4 * q;
-                const unsigned char *row = in + (size_t)gy * p.row_stride;
+            if (ld_lds[l] >= 0) {
+                const unsigned char *row = in + (size_t)ld_row[l] * p.row_stride;
                 if (p.aligned4) {
-                    pre[l] = *reinterpret_cast<const unsigned *>(row + wrap_idx(gx, p.nx));
+                    pre[l] = *reinterpret_cast<const unsigned *>(row + ld_col[l]);
                 } else {
                     unsigned v = 0;
 #pragma unroll
-                    for (int b = 0; b < 4; b++) v |= (unsigned)row[wrap_idx(gx + b, p.nx)] << (8 * b);
+                    for (int b = 0; b < 4; b++) {
+                        v |= (unsigned)row[(ld_col[l] + b) % p.nx] << (8 * b);
+                    }
                     pre[l] = v;
                 }
+                ld_row[l] += row_step;
+                ld_row[l] = ld_row[l] >= p.ny ? ld_row[l] - p.ny : ld_row[l];
             }
         }
     };
-    auto commit = [&]() {
+    auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int l = 0; l < NLD; l++) {
-            const int i = tid + l * BM_NT;
-            if (i < BM_CH * WD) {
-                const int r = i / WD, q = i - r * WD;
-                raw[r * PITCH + q] = pre[l];
-            }
-        }
+        for (int l = 0; l < NLD; l++)
+            if (ld_lds[l] >= 0) raw[ld_lds[l]] = pre[l];
     };
 
-    prefetch(0);
+    prefetch();
     for (int chunk = 0; chunk < nchunks; chunk++) {
         commit();
         __syncthreads();
-        if (chunk + 1 < nchunks) prefetch(chunk + 1);
+        if (chunk + 1 < nchunks) prefetch();
 
         // ---- row pass: thread = (row r, 8-pixel strip s)
         {
@@ -202,7 +210,7 @@ __global__ void __launch_bounds__(BM_NT) canny_blur_march(BlurMarchParams p)
 
         // ---- column pass: thread = (8-row group g, column col)
         {
-            const int g = tid >> 6, col = tid & 63;
+            const int g = __builtin_amdgcn_readfirstlane(tid >> 6), col = tid & 63;  // the wave index: ring rows in SGPRs
             const int oi0 = chunk * BM_CH - 2 * R + BM_PX * g;  // first output row of the group, relative to y0
             if (oi0 + BM_PX > 0 && oi0 < nrows) {
                 double acc[BM_PX];
@@ -243,7 +251,7 @@ __global__ void __launch_bounds__(BM_NT) canny_blur_march(BlurMarchParams p)
 // whole tile neighbourhood lies in the image (no clamping needed).
 struct CannyGrad { double h, v; };
 template <bool INSIDE>
-__device__ __forceinline__ CannyGrad canny_gradient(const float (*sb)[GN_TX + 2 * GN_XO + 4], int gx, int gy, int x0, int y0,
+__device__ __forceinline__ CannyGrad canny_gradient(const double (*sb)[GN_TX + 2 * GN_XO + 4], int gx, int gy, int x0, int y0,
                                                     int nx, int ny, int accGrad)
 {
     int xm, xp, xc, ym, yp, yc;
@@ -256,13 +264,11 @@ __device__ __forceinline__ CannyGrad canny_gradient(const float (*sb)[GN_TX + 2 
     }
     CannyGrad g;
     if (accGrad) {  // :157-163, evaluation order preserved
-        g.h = 2 * ((double)sb[yc][xp] - (double)sb[yc][xm]) + (double)sb[yp][xp] - (double)sb[yp][xm] +
-              (double)sb[ym][xp] - (double)sb[ym][xm];
-        g.v = 2 * ((double)sb[yp][xc] - (double)sb[ym][xc]) + (double)sb[yp][xp] - (double)sb[ym][xp] +
-              (double)sb[yp][xm] - (double)sb[ym][xm];
+        g.h = 2 * (sb[yc][xp] - sb[yc][xm]) + sb[yp][xp] - sb[yp][xm] + sb[ym][xp] - sb[ym][xm];
+        g.v = 2 * (sb[yp][xc] - sb[ym][xc]) + sb[yp][xp] - sb[ym][xp] + sb[yp][xm] - sb[ym][xm];
     } else {        // :167-169
-        g.h = (double)sb[yc][xp] - (double)sb[yc][xm];
-        g.v = (double)sb[yp][xc] - (double)sb[ym][xc];
+        g.h = sb[yc][xp] - sb[yc][xm];
+        g.v = sb[yp][xc] - sb[ym][xc];
     }
     return g;
 }
@@ -271,7 +277,7 @@ __device__ __forceinline__ double canny_mag(const CannyGrad &g) { return sqrt(__
 
 // strong / marked bit planes: word (y, bx) covers pixels x = 64*bx .. 64*bx+63 of row y
 template <bool INSIDE>
-__device__ __forceinline__ void canny_grad_nms_tile(float (*sb)[GN_TX + 2 * GN_XO + 4], double (*sg)[GN_TX + 2 + 1],
+__device__ __forceinline__ void canny_grad_nms_tile(double (*sb)[GN_TX + 2 * GN_XO + 4], double (*sg)[GN_TX + 2 + 1],
                                                     const float *__restrict__ blur, unsigned long long *__restrict__ S,
                                                     unsigned long long *__restrict__ Wm, int nx, int ny, int words_per_row,
                                                     int accGrad, int low_thr, int high_thr)
@@ -284,15 +290,17 @@ __device__ __forceinline__ void canny_grad_nms_tile(float (*sb)[GN_TX + 2 * GN_X
     if (INSIDE) {
         for (int i = tid; i < (GN_TY + 4) * (LW / 4); i += 256) {
             const int r = i / (LW / 4), q = i - r * (LW / 4);
-            *reinterpret_cast<float4 *>(&sb[r][4 * q]) =
-                *reinterpret_cast<const float4 *>(pl + (size_t)(y0 - 2 + r) * nx + (x0 - GN_XO + 4 * q));
+            // the blurred values are widened once here (the reference keeps them in doubles, rcpp_canny.cpp:145-146)
+            const float4 v = *reinterpret_cast<const float4 *>(pl + (size_t)(y0 - 2 + r) * nx + (x0 - GN_XO + 4 * q));
+            double *d = &sb[r][4 * q];
+            d[0] = (double)v.x; d[1] = (double)v.y; d[2] = (double)v.z; d[3] = (double)v.w;
         }
     } else {
         // clamp-to-edge (extend(), rcpp_canny.cpp:38-55)
         for (int i = tid; i < (GN_TY + 4) * LW; i += 256) {
             const int r = i / LW, c = i - r * LW;
             const int gx = min(max(x0 + c - GN_XO, 0), nx - 1), gy = min(max(y0 + r - 2, 0), ny - 1);
-            sb[r][c] = pl[(size_t)gy * nx + gx];
+            sb[r][c] = (double)pl[(size_t)gy * nx + gx];
         }
     }
     __syncthreads();
@@ -328,19 +336,21 @@ __device__ __forceinline__ void canny_grad_nms_tile(float (*sb)[GN_TX + 2 * GN_X
             // unit direction (cos t, sin t) with t = atan2(v,h) (:69-70,173); atan2(0,0) = 0 -> (1,0)
             double ux = 1.0, uy = 0.0;
             if (now > 0) { const double rn = 1.0 / now; ux = own[q].h * rn; uy = own[q].v * rn; }
-            // bilin(), :65-85, for dir = +1: x1 = floor(ux) is -1, 0 or (only when ux == 1 exactly) 1; in that last
-            // case the far tap has weight 0, so x1 = 0 gives the same sum from the 3x3 neighbourhood.  dir = -1
-            // mirrors the offsets.
+            // bilin(), :65-85, at (c,r) -/+ (ux,uy): x1 = floor(xt) is -1 or 0 (for xt == 1 exactly the far tap has weight
+            // 0, so x1 = 0 gives the same sum), hence the weights (x2 - xt, xt - x1) are (1 - |xt|, |xt|) for xt >= 0 and
+            // (|xt|, 1 - |xt|) for xt < 0 -- the same two numbers for both taps: the pixel's own column/row always
+            // weighs 1 - |.|, the neighbour on the side of sign(xt) weighs |.|.  Every product and two-term sum below
+            // is one of bilin()'s own (at most with its two terms swapped), so the value has bilin()'s bits for this
+            // (ux, uy) -- with 19 instead of 26 double operations for the two taps.
+            const double ax = fabs(ux), ay = fabs(uy), bx = 1.0 - ax, by = 1.0 - ay;
             double val[2];
 #pragma unroll
             for (int d = 0; d < 2; d++) {
                 const double xt = d ? ux : -ux, yt = d ? uy : -uy;
-                const int ix = xt < 0 ? -1 : 0, iy = yt < 0 ? -1 : 0;
-                const double x1 = (double)ix, y1 = (double)iy, x2 = x1 + 1, y2 = y1 + 1;
-                const int cx = c + 1 + ix, cy = r + 1 + iy;
-                const double gx1 = (x2 - xt) * sg[cy][cx] + (xt - x1) * sg[cy][cx + 1];
-                const double gx2 = (x2 - xt) * sg[cy + 1][cx] + (xt - x1) * sg[cy + 1][cx + 1];
-                val[d] = (y2 - yt) * gx1 + (yt - y1) * gx2;
+                const int cxn = c + 1 + (xt < 0 ? -1 : 1), cyn = r + 1 + (yt < 0 ? -1 : 1);
+                const double g_own = bx * sg[r + 1][c + 1] + ax * sg[r + 1][cxn];
+                const double g_nb = bx * sg[cyn][c + 1] + ax * sg[cyn][cxn];
+                val[d] = by * g_own + ay * g_nb;
             }
             const double prev = val[0], next = val[1];
             if ((now <= prev) || (now <= next) || (now <= (double)low_thr)) o = 0;  // maxima(), :88-106
@@ -360,7 +370,7 @@ __global__ void __launch_bounds__(256) canny_grad_nms(const float *__restrict__ 
                                                       unsigned long long *__restrict__ Wm, int nx, int ny,
                                                       int words_per_row, int accGrad, int low_thr, int high_thr, int vec4)
 {
-    __shared__ __attribute__((aligned(16))) float sb[GN_TY + 4][GN_TX + 2 * GN_XO + 4];
+    __shared__ __attribute__((aligned(16))) double sb[GN_TY + 4][GN_TX + 2 * GN_XO + 4];
     __shared__ double sg[GN_TY + 2][GN_TX + 2 + 1];
     const int x0 = blockIdx.x * GN_TX, y0 = blockIdx.y * GN_TY;
     // workgroup-uniform: interior tiles skip every clamp and fetch the blurred tile as float4s

@@ -310,6 +310,9 @@ static inline float max(float a, float b) { return fmaxf(a, b); }
 static inline double min(double a, double b) { return fmin(a, b); }
 static inline double max(double a, double b) { return fmax(a, b); }
 
+// wave-uniform values are what kernels pass here: every emulated lane already holds the same value
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+
 // ------------------------------------------------------------------ host API
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100 };
