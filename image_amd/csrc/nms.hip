@@ -68,17 +68,18 @@ imgfd_status launch_harris_nms(imgfd_ctx *ctx, const float *d_R, int nx, int ny,
 }
 
 // ------------------------------------------------------------------ K4 + K5 fused (batch path)
-// The response plane is never materialised.  One workgroup owns a 64x64 tile: (1) R of the tile plus a halo of
-// `radius` (<= RN_HALO) pixels is computed from A, B, C into LDS; (2) every pixel applies the threshold and the 3x3
-// part of the window rule from LDS, survivors go to an LDS candidate list; (3) the waves take candidates in turn and
-// test the full (2r+1)^2 window with all 64 lanes (2 window positions per lane, __any as the verdict): no lane waits
-// for a neighbour's long loop; (4) keepers set their bit in the tile row's mask word (LDS), written out at the end.  HBM traffic: the 12 B/px of A, B, C
-// (halo re-reads are L2 hits).
+// The response plane is never materialised.  One workgroup owns a 64x64 tile: (1) R of the tile plus a ring of ONE pixel
+// is computed from A, B, C into LDS -- the kernel is bound by this fill (L2 -> CU bytes), so the wide halo of the
+// (2r+1)^2 window is not fetched for everybody; (2) every pixel applies the threshold and the 3x3 part of the window
+// rule from LDS, survivors (a few per tile) go to an LDS candidate list; (3) the waves take candidates in turn and test
+// the full window with all 64 lanes (up to three window positions per lane, __any as the verdict); a position outside
+// the staged region is fetched from A, B, C on the spot; (4) keepers set their bit in the tile row's mask word (LDS),
+// written out at the end.  HBM traffic: the 12 B/px of A, B, C (ring re-reads are L2 hits).
 #define RN_TX 64
 #ifndef RN_TY
 #define RN_TY 64
 #endif
-#define RN_HALO 6
+#define RN_HALO 6  // largest window radius served
 #define RN_MAXC (RN_TX * RN_TY / 4)  // 3x3 local maxima cannot be denser than one per 2x2 block
 
 // HC > 0: the window radius is the compile-time constant HC (index arithmetic by constants); HC == 0: any radius <= RN_HALO
@@ -89,9 +90,9 @@ __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__res
                                                               unsigned *__restrict__ rowcount, int words_per_row)
 {
     const int radius = HC > 0 ? HC : radius_rt;
-    // LDS tile of R: columns x0-8 .. x0+71 (the left offset 8 keeps the tile's first column 16-byte aligned in the
-    // planes, so interior tiles fetch whole float4s), rows y0-radius .. y0+31+radius
-    constexpr int XO = 8, LW = RN_TX + 2 * XO, LH = RN_TY + 2 * RN_HALO, LP = LW + 4;
+    // LDS tile of R: columns x0-4 .. x0+67 (the left offset 4 keeps the tile's first column 16-byte aligned in the
+    // planes, so interior tiles fetch whole float4s), rows y0-1 .. y0+64
+    constexpr int XO = 4, YO = 1, LW = RN_TX + 2 * XO, LH = RN_TY + 2 * YO, LP = LW + 4;
     __shared__ __attribute__((aligned(16))) float sR[LH][LP];
     __shared__ unsigned cand[RN_MAXC];            // (row << 8) | column, tile coordinates
     __shared__ unsigned long long rowmask[RN_TY];  // tile width = 64 = one mask word per tile row
@@ -100,15 +101,13 @@ __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__res
     const int x0 = blockIdx.x * RN_TX, y0 = blockIdx.y * RN_TY;
     const size_t fo = (size_t)blockIdx.z * nx * ny;
     const float *Af = A + fo, *Bf = B + fo, *Cf = C + fo;
-    const int H = radius;  // <= RN_HALO (the launcher falls back to the two-kernel path otherwise)
     if (tid == 0) ncand = 0;
     for (int i = tid; i < RN_TY; i += 256) rowmask[i] = 0ull;
-    const int hgt = RN_TY + 2 * H;
     const bool vec = vec4 && x0 - XO >= 0 && x0 - XO + LW <= nx;  // workgroup-uniform
     if (vec) {
-        for (int i = tid; i < hgt * (LW / 4); i += 256) {
+        for (int i = tid; i < LH * (LW / 4); i += 256) {
             const int r = i / (LW / 4), q = i - r * (LW / 4);
-            const int gy = y0 + r - H;
+            const int gy = y0 + r - YO;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gy >= 0 && gy < ny) {
                 const size_t p = (size_t)gy * nx + (x0 - XO + 4 * q);
@@ -120,9 +119,9 @@ __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__res
             *reinterpret_cast<float4 *>(&sR[r][4 * q]) = v;
         }
     } else {
-        for (int i = tid; i < hgt * LW; i += 256) {
+        for (int i = tid; i < LH * LW; i += 256) {
             const int r = i / LW, c = i - r * LW;
-            const int gx = x0 + c - XO, gy = y0 + r - H;
+            const int gx = x0 + c - XO, gy = y0 + r - YO;
             float v = 0.f;  // outside the image: never compared (the search domain stays `radius` away from the border)
             if (gx >= 0 && gx < nx && gy >= 0 && gy < ny) {
                 const size_t p = (size_t)gy * nx + gx;
@@ -136,7 +135,7 @@ __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__res
     for (int r = wv; r < RN_TY; r += 4) {
         const int x = x0 + lane, y = y0 + r;
         if (y < ny && x >= radius && x < nx - radius && y >= radius && y < ny - radius) {
-            const int rr = r + H, cc = lane + XO;
+            const int rr = r + YO, cc = lane + XO;
             const float v = sR[rr][cc];
             if (!(v < Th)) {  // skip[] = R < Th, harris.cpp:160-162
                 const bool ok = !(sR[rr - 1][cc - 1] >= v) && !(sR[rr - 1][cc] >= v) && !(sR[rr - 1][cc + 1] >= v) &&
@@ -153,28 +152,33 @@ __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__res
     // (3) full window, one candidate per wave at a time, window positions spread over the lanes
     const int n = min((int)ncand, RN_MAXC);
     const int side = 2 * radius + 1, npos = side * side;
-    // every lane owns up to two window positions (lane, lane + 64 of the (2r+1)^2 <= 169): offsets and the side of the
-    // tie rule are candidate-independent, so they are set up once
-    int off[3];
+    // every lane owns up to three window positions (lane, lane + 64, lane + 128 of the (2r+1)^2 <= 169): offsets and
+    // the side of the tie rule are candidate-independent, so they are set up once
+    int wdy[3], wdx[3];
     bool strict[3], live[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         const int pidx = lane + 64 * j;
-        const int dy = pidx / side - radius, dx = pidx % side - radius;
-        live[j] = pidx < npos && !(dy == 0 && dx == 0);
-        off[j] = dy * LP + dx;
-        strict[j] = dy < 0 || (dy == 0 && dx > 0);  // above, or to the right on the same row: must be <
+        wdy[j] = pidx / side - radius;
+        wdx[j] = pidx % side - radius;
+        live[j] = pidx < npos && !(wdy[j] == 0 && wdx[j] == 0);
+        strict[j] = wdy[j] < 0 || (wdy[j] == 0 && wdx[j] > 0);  // above, or to the right on the same row: must be <
     }
-    const float *flat = &sR[0][0];
     for (int ci = wv; ci < n; ci += 4) {
         const int r = cand[ci] >> 8, c = cand[ci] & 255;
-        const int base = (r + H) * LP + (c + XO);
-        const float v = flat[base];
+        const float v = sR[r + YO][c + XO];
         bool fail = false;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             if (live[j]) {
-                const float q = flat[base + off[j]];
+                const int ty = r + wdy[j], tx = c + wdx[j];  // tile coordinates of the neighbour
+                float q;
+                if (ty >= -YO && ty < RN_TY + YO && tx >= -XO && tx < RN_TX + XO) {
+                    q = sR[ty + YO][tx + XO];
+                } else {  // beyond the staged ring: the candidate is >= radius away from the image border, so this is inside
+                    const size_t p = (size_t)(y0 + ty) * nx + (x0 + tx);
+                    q = harris_response_value<MEASURE>(Af[p], Bf[p], Cf[p], k);
+                }
                 fail = fail || (strict[j] ? (q >= v) : (q > v));
             }
         }
