@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(256) fhog_grad_orient4(const unsigned char *__
 // K14: hist[(hr*HC + hc)*18 + o] for 1 <= hr <= cells_nr, 1 <= hc <= cells_nc (HC = cells_nc+2), and the
 // cell energy norm[(hr-1)*cells_nc + hc-1].  The column part of every vote (which of the two bilinear weights this
 // cell receives from column x, :838-841 / :946-949) does not depend on the row: it is tabulated once per thread.
-#define FHOG_MAXW 20  // candidate columns per cell: 2*cs + 3 <= 19 for cs <= 8 (larger cells loop over chunks)
+#define FHOG_MAXW 24  // candidate columns per cell: 2*cs + 3 <= 19 for cs <= 8, plus up to 3 for the 16-byte alignment of the row fetch
 __global__ void __launch_bounds__(64) fhog_cell_hist(const unsigned *__restrict__ packed, float *__restrict__ hist,
                                                      float *__restrict__ norm, FhogGeom g)
 {
@@ -209,7 +209,10 @@ __global__ void __launch_bounds__(64) fhog_cell_hist(const unsigned *__restrict_
     // candidate rows / columns: every pixel whose bilinear footprint can touch this cell, widened by one
     const int y_lo = max(1, cs * (hr - 2) + cs / 2 - 1), y_hi = min(g.visible_nr - 1, cs * hr + cs / 2 + 1);
     const int x_lo = max(1, cs * (hc - 2) + cs / 2 - 1), x_hi = min(g.visible_nc - 1, cs * hc + cs / 2 + 1);
-    if (x_hi - x_lo + 1 > FHOG_MAXW) {
+    // the row fetch starts on a 16-byte boundary when rows are 16-byte multiples: 6 dwordx4 loads instead of 20 dwords
+    const bool vec = (g.cols & 3) == 0;
+    const int xc = vec ? (x_lo & ~3) : x_lo;
+    if (x_hi - xc + 1 > FHOG_MAXW) {
         // large cells: the column table does not fit; evaluate the column weights per vote (same order, same values)
         for (int y = y_lo; y <= y_hi; y++) {
             const float yp = ((float)y + 0.5) / (float)cs - 0.5;
@@ -246,8 +249,7 @@ __global__ void __launch_bounds__(64) fhog_cell_hist(const unsigned *__restrict_
             }
         }
     } else {
-        const int xc = x_lo;
-        // per column: vx (0 = this column does not vote into the cell) and whether it takes the 8-wide path
+        // per column: vx (-1 = this column does not vote into the cell) and whether it takes the 8-wide path
         float vx[FHOG_MAXW];
         bool body[FHOG_MAXW];
 #pragma unroll
@@ -255,7 +257,7 @@ __global__ void __launch_bounds__(64) fhog_cell_hist(const unsigned *__restrict_
             const int x = xc + k;
             vx[k] = -1.f;
             body[k] = x < g.body_end;
-            if (x <= x_hi) {
+            if (x >= x_lo && x <= x_hi) {
                 if (body[k]) {  // :838-841: hist column ixp / ixp+1
                     const float xp = ((float)x + 0.5f) / (float)cs + 0.5f;
                     const int ixp = (int)xp;
@@ -285,8 +287,16 @@ __global__ void __launch_bounds__(64) fhog_cell_hist(const unsigned *__restrict_
             const unsigned *row = pk + (size_t)y * g.cols + xc;
             // fetch the whole candidate row first (independent loads in flight), then vote in raster order
             unsigned pv[FHOG_MAXW];
+            if (vec) {
 #pragma unroll
-            for (int k = 0; k < FHOG_MAXW; k++) pv[k] = row[min(k, x_hi - xc)];
+                for (int m = 0; m < FHOG_MAXW / 4; m++) {  // a load clamped at the row end only feeds slots beyond x_hi
+                    const uint4 q = *reinterpret_cast<const uint4 *>(row + min(4 * m, g.cols - 4 - xc));
+                    pv[4 * m] = q.x; pv[4 * m + 1] = q.y; pv[4 * m + 2] = q.z; pv[4 * m + 3] = q.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < FHOG_MAXW; k++) pv[k] = row[min(k, x_hi - xc)];
+            }
 #pragma unroll
             for (int k = 0; k < FHOG_MAXW; k++) {
                 if (vx[k] >= 0.f) {  // weights are in [0, 1]; -1 marks "no vote"
