@@ -65,16 +65,18 @@ __device__ __forceinline__ int f9_score(const int (&v)[16], int p)
 //      row's 64-bit mask word (tile width = word width).  Neither a score plane nor a second kernel touch HBM.
 template <int NONMAX>
 __global__ void __launch_bounds__(256) fast9_tile(const unsigned char *__restrict__ img, int w, int h, int stride,
-                                                  size_t frame_stride, int b, int aligned4,
+                                                  size_t frame_stride, int b, int aligned4, int aligned16,
                                                   unsigned long long *__restrict__ mask,
                                                   unsigned *__restrict__ rowcount, int words_per_row)
 {
-    constexpr int LW = F9_TX + 2 * F9_HALO, LH = F9_TY + 2 * F9_HALO;  // 72 x 24
-    constexpr int LQ = LW / 4;                                         // 18 dwords per tile row
+    // LDS tile: rows y0-4 .. y0+TY+3; columns x0-16 .. x0+79 (the left margin of 16 keeps the first column 16-byte
+    // aligned in the frame, so interior tiles are staged with 16-byte loads; only x0-4 .. x0+67 are ever looked at)
+    constexpr int XL = 16, LW = F9_TX + 2 * XL, LH = F9_TY + 2 * F9_HALO;
+    constexpr int LQ = LW / 4, QL = (XL - F9_HALO) / 4, NQ = (F9_TX + 2 * F9_HALO) / 4;  // dwords per row; the 18 in use
     constexpr int SR = F9_TY + 2, SCW = F9_TX + 4;                     // score tile: 18 rows of 68 bytes (66 used)
-    __shared__ unsigned tile32[LH][LQ];
+    __shared__ __attribute__((aligned(16))) unsigned tile32[LH][LQ];
     __shared__ unsigned sc32[SR][SCW / 4];
-    __shared__ unsigned short cand[SR * LW];
+    __shared__ unsigned short cand[SR * (F9_TX + 2)];
     __shared__ unsigned ncand;
     __shared__ unsigned long long rowmask[F9_TY];
     unsigned char(*tile)[LW] = reinterpret_cast<unsigned char(*)[LW]>(tile32);
@@ -83,31 +85,39 @@ __global__ void __launch_bounds__(256) fast9_tile(const unsigned char *__restric
     const int x0 = blockIdx.x * F9_TX, y0 = blockIdx.y * F9_TY;
     const unsigned char *fr = img + (size_t)blockIdx.z * frame_stride;
     // ---- stage the tile; out-of-image positions repeat the border pixel (they are never tested, only loaded)
-    for (int i = tid; i < LH * LQ; i += 256) {
-        const int r = i / LQ, q = i - r * LQ;
-        const int gy = min(max(y0 - F9_HALO + r, 0), h - 1);
-        const int gx = x0 - F9_HALO + 4 * q;
-        const unsigned char *row = fr + (size_t)gy * stride;
-        unsigned v;
-        if (aligned4 && gx >= 0 && gx + 3 < w) {
-            v = *reinterpret_cast<const unsigned *>(row + gx);
-        } else {
-            v = 0;
-#pragma unroll
-            for (int e = 0; e < 4; e++) v |= (unsigned)row[min(max(gx + e, 0), w - 1)] << (8 * e);
+    if (aligned16 && x0 - XL >= 0 && x0 - XL + LW <= w) {  // workgroup-uniform
+        for (int i = tid; i < LH * (LW / 16); i += 256) {
+            const int r = i / (LW / 16), q = i - r * (LW / 16);
+            const int gy = min(max(y0 - F9_HALO + r, 0), h - 1);
+            *reinterpret_cast<uint4 *>(&tile32[r][4 * q]) = *reinterpret_cast<const uint4 *>(fr + (size_t)gy * stride + (x0 - XL + 16 * q));
         }
-        tile32[r][q] = v;
+    } else {
+        for (int i = tid; i < LH * NQ; i += 256) {
+            const int r = i / NQ, q = QL + i - r * NQ;
+            const int gy = min(max(y0 - F9_HALO + r, 0), h - 1);
+            const int gx = x0 - XL + 4 * q;
+            const unsigned char *row = fr + (size_t)gy * stride;
+            unsigned v;
+            if (aligned4 && gx >= 0 && gx + 3 < w) {
+                v = *reinterpret_cast<const unsigned *>(row + gx);
+            } else {
+                v = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) v |= (unsigned)row[min(max(gx + e, 0), w - 1)] << (8 * e);
+            }
+            tile32[r][q] = v;
+        }
     }
     for (int i = tid; i < SR * (SCW / 4); i += 256) (&sc32[0][0])[i] = 0u;
     for (int i = tid; i < F9_TY; i += 256) rowmask[i] = 0ull;
     if (tid == 0) ncand = 0u;
     __syncthreads();
     // ---- phase 1: compass pre-test; score-tile row r <-> tile row r + 3, score column cx <-> tile column cx + 3
-    for (int i = tid; i < SR * LQ; i += 256) {
-        const int r = i / LQ, q = i - r * LQ;
+    for (int i = tid; i < SR * NQ; i += 256) {
+        const int r = i / NQ, q = QL + i - r * NQ;
         const int ty = r + F9_HALO - 1;
         const int gy = y0 + r - 1;
-        const unsigned cur = tile32[ty][q], prev = tile32[ty][max(q - 1, 0)], next = tile32[ty][min(q + 1, LQ - 1)];
+        const unsigned cur = tile32[ty][q], prev = tile32[ty][q - 1], next = tile32[ty][q + 1];
         const unsigned up = tile32[ty - 3][q], dn = tile32[ty + 3][q];
         const unsigned lf = (prev >> 8) | (cur << 24);  // byte e = pixel (4q + e) - 3
         const unsigned rt = (cur >> 24) | (next << 8);  // byte e = pixel (4q + e) + 3
@@ -115,8 +125,8 @@ __global__ void __launch_bounds__(256) fast9_tile(const unsigned char *__restric
         if (gy >= 3 && gy < h - 3 && (NONMAX || (r >= 1 && r <= F9_TY))) {
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const int tx = 4 * q + e, gx = x0 - F9_HALO + tx;
-                const int lo = NONMAX ? F9_HALO - 1 : F9_HALO, hi = NONMAX ? F9_HALO + F9_TX + 1 : F9_HALO + F9_TX;
+                const int tx = 4 * q + e, gx = x0 - XL + tx;
+                const int lo = NONMAX ? XL - 1 : XL, hi = NONMAX ? XL + F9_TX + 1 : XL + F9_TX;
                 const int p = (int)((cur >> (8 * e)) & 0xffu);
                 const int d0 = (int)((dn >> (8 * e)) & 0xffu) - p, d4 = (int)((rt >> (8 * e)) & 0xffu) - p;
                 const int d8 = (int)((up >> (8 * e)) & 0xffu) - p, d12 = (int)((lf >> (8 * e)) & 0xffu) - p;
@@ -155,13 +165,13 @@ __global__ void __launch_bounds__(256) fast9_tile(const unsigned char *__restric
             darker |= (unsigned)(v[k] < c_b) << k;
         }
         if (f9_has_arc9(brighter) || f9_has_arc9(darker))
-            sc[r][tx - (F9_HALO - 1)] = (unsigned char)(NONMAX ? f9_score(v, p) + 1 : 1);  // score + 1 in 1..255; 0 = no corner
+            sc[r][tx - (XL - 1)] = (unsigned char)(NONMAX ? f9_score(v, p) + 1 : 1);  // score + 1 in 1..255; 0 = no corner
     }
     __syncthreads();
     // ---- phase 3: 3x3 non-max test, again over the candidates only; survivors set their bit in the row's mask word
     for (unsigned i = tid; i < nc; i += 256) {
         const int pos = cand[i];
-        const int r = pos / LW, cx = pos - r * LW - (F9_HALO - 1);
+        const int r = pos / LW, cx = pos - r * LW - (XL - 1);
         if (r < 1 || r > F9_TY || cx < 1 || cx > F9_TX) continue;  // the ring of the score tile only serves its neighbours
         const int s = sc[r][cx];
         bool keep = s != 0;
@@ -185,12 +195,13 @@ imgfd_status launch_fast9(imgfd_ctx *ctx, const uint8_t *d_img, int w, int h, in
 {
     dim3 grid(cb.words_per_row, ceil_div(h, F9_TY), n_frames);
     const int aligned4 = ((size_t)d_img % 4 == 0) && stride % 4 == 0 && frame_stride % 4 == 0;
+    const int aligned16 = ((size_t)d_img % 16 == 0) && stride % 16 == 0 && frame_stride % 16 == 0;
     if (!nonmax)
         hipLaunchKernelGGL(fast9_tile<0>, grid, dim3(256), 0, ctx->stream, d_img, w, h, stride, frame_stride, threshold,
-                           aligned4, cb.mask, cb.rowcount, cb.words_per_row);
+                           aligned4, aligned16, cb.mask, cb.rowcount, cb.words_per_row);
     else
         hipLaunchKernelGGL(fast9_tile<1>, grid, dim3(256), 0, ctx->stream, d_img, w, h, stride, frame_stride, threshold,
-                           aligned4, cb.mask, cb.rowcount, cb.words_per_row);
+                           aligned4, aligned16, cb.mask, cb.rowcount, cb.words_per_row);
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }

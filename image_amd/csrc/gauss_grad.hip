@@ -25,6 +25,7 @@ struct GaussGradParams {
     float *Ix, *Iy;
     int nx, ny, in_pitch;
     int vec4;  // input base, pitch and frame stride allow aligned 4-pixel loads
+    int vec16; // ... aligned 16-pixel loads (u8 frames)
     long in_frame_stride;
     double B[8];
 };
@@ -35,13 +36,14 @@ __global__ void __launch_bounds__(256) gauss_grad_tile(GaussGradParams p)
     // smoothed tile: the 64 x GG_TY outputs plus a ring of 2 pixels left/top and 1 right/bottom (a tile that starts on the
     // last image column/row evaluates its clamped gradient one pixel further inside)
     constexpr int SW = GG_TX + 3, SH = GG_TY + 3;
-    // raw tile: columns x0-8 .. x0+71 (first column 4-pixel aligned: interior tiles load whole dwords / float4s),
-    // rows y0-2-R .. y0+TY+R
-    constexpr int XO = 8, RW = GG_TX + 2 * XO, RH = SH + 2 * R, OFFX = XO - 2 - R;
+    // raw tile: u8 frames columns x0-16 .. x0+79 (first column 16-byte aligned: interior tiles load 16 pixels at a time),
+    // f32 frames x0-8 .. x0+71 (float4s); rows y0-2-R .. y0+TY+R
+    constexpr int XO = U8 ? 16 : 8, RW = GG_TX + 2 * XO, RH = SH + 2 * R, OFFX = XO - 2 - R;
     static_assert(OFFX >= 0 && SW + 2 * R + OFFX <= RW, "raw tile too narrow for this radius");
     static_assert(GG_PX == 4 && ((SW + GG_PX - 1) / GG_PX * GG_PX + OFFX + 2 * R + 3) / 4 * 4 <= RW + 4, "dword window reads stay inside the row");
+    static_assert(OFFX % 4 == 3 || !U8, "byte window of the u8 row pass starts on byte 3 of a dword");
     // raw tile: bytes for u8 frames (a quarter of the LDS: the kernel is occupancy-bound, not bandwidth-bound), floats else
-    constexpr int RP = RW + 4;  // row pitch in elements
+    constexpr int RP = U8 ? RW + 16 : RW + 4;  // row pitch in elements (u8: rows stay 16-byte aligned for ds_write_b128)
     using raw_t = typename std::conditional<U8, unsigned char, float>::type;
     __shared__ __attribute__((aligned(16))) raw_t raw[RH][RP];
     __shared__ float rowf[RH][SW + 1];
@@ -50,7 +52,14 @@ __global__ void __launch_bounds__(256) gauss_grad_tile(GaussGradParams p)
     const int x0 = blockIdx.x * GG_TX, y0 = blockIdx.y * GG_TY;
     const size_t fin = (size_t)blockIdx.z * p.in_frame_stride;
     // ---- input tile; logical index outside the image -> the reference's reflection (gaussian.cpp:345-349, 376-380)
-    if (p.vec4 && x0 - XO >= 0 && x0 - XO + RW <= p.nx) {  // workgroup-uniform: no column reflection in this tile
+    if (U8 && p.vec16 && x0 - XO >= 0 && x0 - XO + RW <= p.nx) {  // workgroup-uniform: no column reflection in this tile
+        for (int i = tid; i < RH * (RW / 16); i += 256) {
+            const int r = i / (RW / 16), q = i - r * (RW / 16);
+            const int gy = fir_reflect(y0 - 2 - R + r, p.ny);
+            const size_t off = fin + (size_t)gy * p.in_pitch + (x0 - XO + 16 * q);
+            *reinterpret_cast<uint4 *>(&raw[r][16 * q]) = *reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(p.in) + off);
+        }
+    } else if (p.vec4 && x0 - XO >= 0 && x0 - XO + RW <= p.nx) {
         for (int i = tid; i < RH * (RW / 4); i += 256) {
             const int r = i / (RW / 4), q = i - r * (RW / 4);
             const int gy = fir_reflect(y0 - 2 - R + r, p.ny);
@@ -152,6 +161,7 @@ imgfd_status launch_gauss_grad_fused(imgfd_ctx *ctx, const void *d_in, int in_is
     p.in = d_in; p.Ix = d_Ix; p.Iy = d_Iy; p.nx = nx; p.ny = ny; p.in_pitch = in_pitch; p.in_frame_stride = (long)in_frame_stride;
     const size_t esz = in_is_u8 ? 1 : 4;
     p.vec4 = ((size_t)d_in % (4 * esz) == 0) && in_pitch % 4 == 0 && in_frame_stride % 4 == 0 && nx % 4 == 0;
+    p.vec16 = in_is_u8 && ((size_t)d_in % 16 == 0) && in_pitch % 16 == 0 && in_frame_stride % 16 == 0 && nx % 16 == 0;
     dim3 grid(ceil_div(nx, GG_TX), ceil_div(ny, GG_TY), n_frames);
     const bool sobel = grad_type == IMGFD_SOBEL_OPERATOR;
 #define GG_LAUNCH(G, U, F) hipLaunchKernelGGL((gauss_grad_tile<3, G, U, F>), grid, dim3(256), 0, ctx->stream, p)
