@@ -274,6 +274,31 @@ __device__ __forceinline__ CannyGrad canny_gradient(const double (*sb)[GN_TX + 2
 }
 // |g|: h and v are exact in f64 (sums of a few floats); sqrt(fma(h,h,v*v)) is within one ulp of hypot(h,v) (:172)
 __device__ __forceinline__ double canny_mag(const CannyGrad &g) { return sqrt(__builtin_fma(g.h, g.h, g.v * g.v)); }
+// |g| and 1/|g| together: one v_rsq_f64 seed and two coupled Newton steps (Goldschmidt) give sqrt(s) and 1/(2 sqrt(s)) to
+// full double precision, a last residual step rounds sqrt(s) -- 11 double operations instead of a separate IEEE sqrt
+// (~15) and division (~11).  The magnitude agrees with sqrt() to the last bit except for rare 1-ulp cases, the reciprocal
+// to within an ulp: the same size of perturbation as dropping atan2/cos/sin already is (only exact ties can flip).
+__device__ __forceinline__ double canny_mag_rcp(const CannyGrad &g, double *rcp)
+{
+    const double s = __builtin_fma(g.h, g.h, g.v * g.v);
+    if (!(s > 0)) { *rcp = 0.0; return 0.0; }
+#ifdef HIPEMU
+    const double y0 = 1.0 / sqrt(s);
+#else
+    const double y0 = __builtin_amdgcn_rsq(s);
+#endif
+    double gq = s * y0, hq = 0.5 * y0;
+    double r = __builtin_fma(-hq, gq, 0.5);
+    gq = __builtin_fma(gq, r, gq);
+    hq = __builtin_fma(hq, r, hq);
+    r = __builtin_fma(-hq, gq, 0.5);
+    gq = __builtin_fma(gq, r, gq);
+    hq = __builtin_fma(hq, r, hq);
+    const double d = __builtin_fma(-gq, gq, s);
+    gq = __builtin_fma(d, hq, gq);
+    *rcp = hq + hq;
+    return gq;
+}
 
 // strong / marked bit planes: word (y, bx) covers pixels x = 64*bx .. 64*bx+63 of row y
 template <bool INSIDE>
@@ -309,12 +334,13 @@ __device__ __forceinline__ void canny_grad_nms_tile(double (*sb)[GN_TX + 2 * GN_
     // stands for the clamped pixel, whose own neighbourhood is clamped again: evaluate at clamped coordinates.
     const int c = tid & 63, wv = tid >> 6;
     CannyGrad own[GN_TY / 4];
+    double own_rcp[GN_TY / 4];
 #pragma unroll
     for (int q = 0; q < GN_TY / 4; q++) {
         const int r = wv + 4 * q;
         own[q] = canny_gradient<INSIDE>(sb, INSIDE ? x0 + c : min(x0 + c, nx - 1), INSIDE ? y0 + r : min(y0 + r, ny - 1), x0, y0,
                                         nx, ny, accGrad);
-        sg[r + 1][c + 1] = canny_mag(own[q]);
+        sg[r + 1][c + 1] = canny_mag_rcp(own[q], &own_rcp[q]);
     }
     constexpr int RING = 2 * (GN_TX + 2) + 2 * GN_TY;
     if (tid < RING) {
@@ -323,7 +349,8 @@ __device__ __forceinline__ void canny_grad_nms_tile(double (*sb)[GN_TX + 2 * GN_
         else if (tid < 2 * (GN_TX + 2)) { r = GN_TY + 1; cc = tid - (GN_TX + 2); }
         else { const int k = tid - 2 * (GN_TX + 2); r = 1 + (k >> 1); cc = (k & 1) ? GN_TX + 1 : 0; }
         const int gx = INSIDE ? x0 + cc - 1 : min(max(x0 + cc - 1, 0), nx - 1), gy = INSIDE ? y0 + r - 1 : min(max(y0 + r - 1, 0), ny - 1);
-        sg[r][cc] = canny_mag(canny_gradient<INSIDE>(sb, gx, gy, x0, y0, nx, ny, accGrad));
+        double unused;
+        sg[r][cc] = canny_mag_rcp(canny_gradient<INSIDE>(sb, gx, gy, x0, y0, nx, ny, accGrad), &unused);
     }
     __syncthreads();
 #pragma unroll
@@ -335,7 +362,7 @@ __device__ __forceinline__ void canny_grad_nms_tile(double (*sb)[GN_TX + 2 * GN_
             const double now = sg[r + 1][c + 1];
             // unit direction (cos t, sin t) with t = atan2(v,h) (:69-70,173); atan2(0,0) = 0 -> (1,0)
             double ux = 1.0, uy = 0.0;
-            if (now > 0) { const double rn = 1.0 / now; ux = own[q].h * rn; uy = own[q].v * rn; }
+            if (now > 0) { const double rn = own_rcp[q]; ux = own[q].h * rn; uy = own[q].v * rn; }
             // bilin(), :65-85, at (c,r) -/+ (ux,uy): x1 = floor(xt) is -1 or 0 (for xt == 1 exactly the far tap has weight
             // 0, so x1 = 0 gives the same sum), hence the weights (x2 - xt, xt - x1) are (1 - |xt|, |xt|) for xt >= 0 and
             // (|xt|, 1 - |xt|) for xt < 0 -- the same two numbers for both taps: the pixel's own column/row always
