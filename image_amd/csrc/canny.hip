@@ -447,7 +447,9 @@ __device__ __forceinline__ unsigned long long lane_below(unsigned long long v)
 #endif
 }
 
-#define HY_WORDS 4  // tile = 256 columns x 64 rows per wave
+#ifndef HY_WORDS
+#define HY_WORDS 4  // tile = 256 columns x 64 rows per wave; MI355X sweep (avg us of the 12 sweeps of a round): 1 -> 134, 2 -> 82, 4 -> 55, 8 -> 62
+#endif
 
 // One sweep.  flags[sweep] is raised when any tile changed; a sweep whose predecessor (same round) was
 // idle returns at once, so the host may queue a whole round of sweeps behind one read-back.  act[] holds one byte per
