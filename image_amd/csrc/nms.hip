@@ -68,13 +68,14 @@ imgfd_status launch_harris_nms(imgfd_ctx *ctx, const float *d_R, int nx, int ny,
 }
 
 // ------------------------------------------------------------------ K4 + K5 fused (batch path)
-// The response plane is never materialised.  One workgroup owns a 64x64 tile: (1) R of the tile plus a ring of ONE pixel
-// is computed from A, B, C into LDS -- the kernel is bound by this fill (L2 -> CU bytes), so the wide halo of the
-// (2r+1)^2 window is not fetched for everybody; (2) every pixel applies the threshold and the 3x3 part of the window
-// rule from LDS, survivors (a few per tile) go to an LDS candidate list; (3) the waves take candidates in turn and test
-// the full window with all 64 lanes (up to three window positions per lane, __any as the verdict); a position outside
-// the staged region is fetched from A, B, C on the spot; (4) keepers set their bit in the tile row's mask word (LDS),
-// written out at the end.  HBM traffic: the 12 B/px of A, B, C (ring re-reads are L2 hits).
+// The response plane is never materialised.  One workgroup owns a 64x64 tile: (1) R of exactly the tile is computed from
+// A, B, C into LDS: 64 floats = 256 bytes per row and plane, i.e. whole cache lines only -- the kernel is bound by this
+// fill, and a tile widened by a halo of even one pixel touches twice as many lines; (2) every pixel applies the threshold
+// and the 3x3 part of the window rule, survivors (a few per tile) go to an LDS candidate list; (3) the waves take
+// candidates in turn and test the full (2r+1)^2 window with all 64 lanes (up to three window positions per lane, __any as
+// the verdict).  In (2) and (3) a neighbour outside the tile is computed from A, B, C on the spot: only pixels above the
+// threshold ever look at neighbours, so this is rare; (4) keepers set their bit in the tile row's mask word (LDS),
+// written out at the end.  HBM traffic: the 12 B/px of A, B, C.
 #define RN_TX 64
 #ifndef RN_TY
 #define RN_TY 64
@@ -90,9 +91,8 @@ __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__res
                                                               unsigned *__restrict__ rowcount, int words_per_row)
 {
     const int radius = HC > 0 ? HC : radius_rt;
-    // LDS tile of R: columns x0-4 .. x0+67 (the left offset 4 keeps the tile's first column 16-byte aligned in the
-    // planes, so interior tiles fetch whole float4s), rows y0-1 .. y0+64
-    constexpr int XO = 4, YO = 1, LW = RN_TX + 2 * XO, LH = RN_TY + 2 * YO, LP = LW + 4;
+    // LDS tile of R: exactly the tile, columns x0 .. x0+63, rows y0 .. y0+TY-1
+    constexpr int XO = 0, YO = 0, LW = RN_TX + 2 * XO, LH = RN_TY + 2 * YO, LP = LW + 4;
     __shared__ __attribute__((aligned(16))) float sR[LH][LP];
     __shared__ unsigned cand[RN_MAXC];            // (row << 8) | column, tile coordinates
     __shared__ unsigned long long rowmask[RN_TY];  // tile width = 64 = one mask word per tile row
@@ -105,18 +105,34 @@ __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__res
     for (int i = tid; i < RN_TY; i += 256) rowmask[i] = 0ull;
     const bool vec = vec4 && x0 - XO >= 0 && x0 - XO + LW <= nx;  // workgroup-uniform
     if (vec) {
-        for (int i = tid; i < LH * (LW / 4); i += 256) {
+        // all of a thread's loads are issued before the first use (straight-line, clamped instead of branched around):
+        // the fill is latency-bound otherwise, one exposed round trip per 256 float4 triples
+        typedef float v4f __attribute__((vector_size(16)));  // a native vector: arrays of HIP's float4 struct may land in scratch
+        constexpr int NI = LH * (LW / 4), NR = (NI + 255) / 256;
+        v4f a[NR], b[NR], c[NR];
+#pragma unroll
+        for (int u = 0; u < NR; u++) {
+            const int i = min(tid + 256 * u, NI - 1);
             const int r = i / (LW / 4), q = i - r * (LW / 4);
-            const int gy = y0 + r - YO;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < ny) {
-                const size_t p = (size_t)gy * nx + (x0 - XO + 4 * q);
-                const float4 a = *reinterpret_cast<const float4 *>(Af + p), b = *reinterpret_cast<const float4 *>(Bf + p),
-                             c = *reinterpret_cast<const float4 *>(Cf + p);
-                v = make_float4(harris_response_value<MEASURE>(a.x, b.x, c.x, k), harris_response_value<MEASURE>(a.y, b.y, c.y, k),
-                                harris_response_value<MEASURE>(a.z, b.z, c.z, k), harris_response_value<MEASURE>(a.w, b.w, c.w, k));
+            const int gy = min(max(y0 + r - YO, 0), ny - 1);
+            const size_t p = (size_t)gy * nx + (x0 - XO + 4 * q);
+            a[u] = *reinterpret_cast<const v4f *>(Af + p);
+            b[u] = *reinterpret_cast<const v4f *>(Bf + p);
+            c[u] = *reinterpret_cast<const v4f *>(Cf + p);
+        }
+#pragma unroll
+        for (int u = 0; u < NR; u++) {
+            const int i = tid + 256 * u;
+            if (i < NI) {
+                const int r = i / (LW / 4), q = i - r * (LW / 4);
+                const int gy = y0 + r - YO;
+                v4f v = {0.f, 0.f, 0.f, 0.f};
+                if (gy >= 0 && gy < ny) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = harris_response_value<MEASURE>(a[u][e], b[u][e], c[u][e], k);
+                }
+                *reinterpret_cast<v4f *>(&sR[r][4 * q]) = v;
             }
-            *reinterpret_cast<float4 *>(&sR[r][4 * q]) = v;
         }
     } else {
         for (int i = tid; i < LH * LW; i += 256) {
@@ -131,16 +147,21 @@ __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__res
         }
     }
     __syncthreads();
+    // R at tile coordinates (ty, tx): from LDS inside the tile, from the planes beyond it (callers stay inside the image)
+    auto R_at = [&](int ty, int tx) __attribute__((always_inline)) -> float {
+        if (ty >= 0 && ty < RN_TY && tx >= 0 && tx < RN_TX) return sR[ty][tx];
+        const size_t p = (size_t)(y0 + ty) * nx + (x0 + tx);
+        return harris_response_value<MEASURE>(Af[p], Bf[p], Cf[p], k);
+    };
     // (2) threshold + 3x3 pre-test with the window rule's own comparisons
     for (int r = wv; r < RN_TY; r += 4) {
         const int x = x0 + lane, y = y0 + r;
         if (y < ny && x >= radius && x < nx - radius && y >= radius && y < ny - radius) {
-            const int rr = r + YO, cc = lane + XO;
-            const float v = sR[rr][cc];
+            const float v = sR[r][lane];
             if (!(v < Th)) {  // skip[] = R < Th, harris.cpp:160-162
-                const bool ok = !(sR[rr - 1][cc - 1] >= v) && !(sR[rr - 1][cc] >= v) && !(sR[rr - 1][cc + 1] >= v) &&
-                                !(sR[rr][cc + 1] >= v) && !(sR[rr][cc - 1] > v) && !(sR[rr + 1][cc - 1] > v) &&
-                                !(sR[rr + 1][cc] > v) && !(sR[rr + 1][cc + 1] > v);
+                const bool ok = !(R_at(r - 1, lane - 1) >= v) && !(R_at(r - 1, lane) >= v) && !(R_at(r - 1, lane + 1) >= v) &&
+                                !(R_at(r, lane + 1) >= v) && !(R_at(r, lane - 1) > v) && !(R_at(r + 1, lane - 1) > v) &&
+                                !(R_at(r + 1, lane) > v) && !(R_at(r + 1, lane + 1) > v);
                 if (ok) {
                     const unsigned slot = atomicAdd(&ncand, 1u);
                     if (slot < RN_MAXC) cand[slot] = ((unsigned)r << 8) | (unsigned)lane;
@@ -166,19 +187,12 @@ __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__res
     }
     for (int ci = wv; ci < n; ci += 4) {
         const int r = cand[ci] >> 8, c = cand[ci] & 255;
-        const float v = sR[r + YO][c + XO];
+        const float v = sR[r][c];
         bool fail = false;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             if (live[j]) {
-                const int ty = r + wdy[j], tx = c + wdx[j];  // tile coordinates of the neighbour
-                float q;
-                if (ty >= -YO && ty < RN_TY + YO && tx >= -XO && tx < RN_TX + XO) {
-                    q = sR[ty + YO][tx + XO];
-                } else {  // beyond the staged ring: the candidate is >= radius away from the image border, so this is inside
-                    const size_t p = (size_t)(y0 + ty) * nx + (x0 + tx);
-                    q = harris_response_value<MEASURE>(Af[p], Bf[p], Cf[p], k);
-                }
+                const float q = R_at(r + wdy[j], c + wdx[j]);
                 fail = fail || (strict[j] ? (q >= v) : (q > v));
             }
         }
