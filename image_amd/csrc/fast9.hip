@@ -47,6 +47,54 @@ __device__ __forceinline__ int f9_score(const int (&v)[16], int p)
     return max(best_min - p - 1, p - best_max - 1);
 }
 
+// packed arithmetic on two unsigned 16-bit lanes of a dword (v_pk_sub_u16 clamp / v_pk_max_u16 / v_pk_min_u16)
+#ifdef HIPEMU
+__device__ __forceinline__ unsigned f9_pk_subs(unsigned a, unsigned b)
+{
+    const unsigned al = a & 0xffffu, bl = b & 0xffffu, ah = a >> 16, bh = b >> 16;
+    return (al > bl ? al - bl : 0u) | ((ah > bh ? ah - bh : 0u) << 16);
+}
+__device__ __forceinline__ unsigned f9_pk_max(unsigned a, unsigned b)
+{
+    return max(a & 0xffffu, b & 0xffffu) | (max(a >> 16, b >> 16) << 16);
+}
+__device__ __forceinline__ unsigned f9_pk_min(unsigned a, unsigned b)
+{
+    return min(a & 0xffffu, b & 0xffffu) | (min(a >> 16, b >> 16) << 16);
+}
+#else
+typedef unsigned short f9_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned f9_pk_subs(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(f9_u16x2, a), __builtin_bit_cast(f9_u16x2, b)));
+}
+__device__ __forceinline__ unsigned f9_pk_max(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(f9_u16x2, a), __builtin_bit_cast(f9_u16x2, b)));
+}
+__device__ __forceinline__ unsigned f9_pk_min(unsigned a, unsigned b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(f9_u16x2, a), __builtin_bit_cast(f9_u16x2, b)));
+}
+#endif
+// two pixels at a time (16-bit lanes): non-zero lane <=> at least two of the four compass values exceed the centre by
+// more than b, i.e. the second largest of max(n_i - p, 0) is > b
+__device__ __forceinline__ unsigned f9_two_above(unsigned p, unsigned n0, unsigned n1, unsigned n2, unsigned n3, unsigned bb)
+{
+    const unsigned t0 = f9_pk_subs(n0, p), t1 = f9_pk_subs(n1, p), t2 = f9_pk_subs(n2, p), t3 = f9_pk_subs(n3, p);
+    const unsigned m1 = f9_pk_max(t0, t1), m2 = f9_pk_max(t2, t3), l1 = f9_pk_min(t0, t1), l2 = f9_pk_min(t2, t3);
+    const unsigned second = f9_pk_max(f9_pk_min(m1, m2), f9_pk_max(l1, l2));
+    return f9_pk_subs(second, bb);
+}
+// ... or at least two are below it by more than b
+__device__ __forceinline__ unsigned f9_two_below(unsigned p, unsigned n0, unsigned n1, unsigned n2, unsigned n3, unsigned bb)
+{
+    const unsigned t0 = f9_pk_subs(p, n0), t1 = f9_pk_subs(p, n1), t2 = f9_pk_subs(p, n2), t3 = f9_pk_subs(p, n3);
+    const unsigned m1 = f9_pk_max(t0, t1), m2 = f9_pk_max(t2, t3), l1 = f9_pk_min(t0, t1), l2 = f9_pk_min(t2, t3);
+    const unsigned second = f9_pk_max(f9_pk_min(m1, m2), f9_pk_max(l1, l2));
+    return f9_pk_subs(second, bb);
+}
+
 #define F9_TX 64   // tile width = one __ballot word
 #ifndef F9_TY
 #define F9_TY 64  // sweep on MI355X, 4K frames: 16 -> 780 us, 32 -> 631, 64 -> 555, 96 -> 583, 128 -> 660 (per 32 frames)
@@ -56,8 +104,9 @@ __device__ __forceinline__ int f9_score(const int (&v)[16], int p)
 // One workgroup per 64 x F9_TY tile.  The u8 tile (+4 halo) is staged in LDS once (HBM traffic = the algorithmic
 // 1 B/px + halo).  Three phases:
 //   1. compass pre-test on packed dwords: a thread takes 4 consecutive pixels (5 LDS dword reads instead of 20 byte
-//      reads); any 9 contiguous ring pixels contain at least two of the four compass points, so a pixel with fewer
-//      than two brighter and fewer than two darker compass points cannot be a corner.  Survivors (a few percent of a
+//      reads) and evaluates them two at a time in the 16-bit lanes of packed instructions; any 9 contiguous ring
+//      pixels contain at least two of the four compass points, so a pixel with fewer than two brighter and fewer than
+//      two darker compass points cannot be a corner ("at least two above" = the second largest difference is above).  Survivors (a few percent of a
 //      natural frame) are appended to a candidate list in LDS.
 //   2. the full ring test (+ score) runs over the candidate list with all lanes busy and writes the score tile
 //      (+1 halo for the 3x3 test) in LDS.
@@ -123,18 +172,19 @@ __global__ void __launch_bounds__(256) fast9_tile(const unsigned char *__restric
         const unsigned rt = (cur >> 24) | (next << 8);  // byte e = pixel (4q + e) + 3
         unsigned pass = 0;
         if (gy >= 3 && gy < h - 3 && (NONMAX || (r >= 1 && r <= F9_TY))) {
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int tx = 4 * q + e, gx = x0 - XL + tx;
-                const int lo = NONMAX ? XL - 1 : XL, hi = NONMAX ? XL + F9_TX + 1 : XL + F9_TX;
-                const int p = (int)((cur >> (8 * e)) & 0xffu);
-                const int d0 = (int)((dn >> (8 * e)) & 0xffu) - p, d4 = (int)((rt >> (8 * e)) & 0xffu) - p;
-                const int d8 = (int)((up >> (8 * e)) & 0xffu) - p, d12 = (int)((lf >> (8 * e)) & 0xffu) - p;
-                const int nb = (d0 > b) + (d4 > b) + (d8 > b) + (d12 > b);
-                const int nd = (d0 < -b) + (d4 < -b) + (d8 < -b) + (d12 < -b);
-                const bool ok = (nb >= 2 || nd >= 2) && tx >= lo && tx < hi && gx >= 3 && gx < w - 3;
-                pass |= (unsigned)ok << e;
-            }
+            // pixels 0, 2 of the dword in the 16-bit lanes of the "even" words, pixels 1, 3 in the "odd" ones
+            const unsigned M = 0x00ff00ffu, bb = (unsigned)b * 0x00010001u;
+            const unsigned pe = cur & M, po = (cur >> 8) & M;
+            const unsigned fe = f9_two_above(pe, dn & M, rt & M, up & M, lf & M, bb) | f9_two_below(pe, dn & M, rt & M, up & M, lf & M, bb);
+            const unsigned fo = f9_two_above(po, (dn >> 8) & M, (rt >> 8) & M, (up >> 8) & M, (lf >> 8) & M, bb) |
+                                f9_two_below(po, (dn >> 8) & M, (rt >> 8) & M, (up >> 8) & M, (lf >> 8) & M, bb);
+            pass = ((fe & 0xffffu) ? 1u : 0u) | ((fo & 0xffffu) ? 2u : 0u) | ((fe >> 16) ? 4u : 0u) | ((fo >> 16) ? 8u : 0u);
+            // pixels of this dword inside the tested range: tile columns [lo, hi) and image columns [3, w - 3)
+            const int lo = max(NONMAX ? XL - 1 : XL, 3 - (x0 - XL)), hi = min(NONMAX ? XL + F9_TX + 1 : XL + F9_TX, w - 3 - (x0 - XL));
+            const int a = lo - 4 * q, e_end = hi - 4 * q;  // valid e in [a, e_end)
+            const unsigned vlo = a <= 0 ? 0xfu : (a >= 4 ? 0u : (0xfu << a) & 0xfu);
+            const unsigned vhi = e_end >= 4 ? 0xfu : (e_end <= 0 ? 0u : (1u << e_end) - 1u);
+            pass &= vlo & vhi;
         }
         // append the survivors (order inside the list is irrelevant: every candidate writes its own score cell); only
         // a few percent of the threads get here, so a returning LDS atomic is cheaper than a wave-wide prefix sum
