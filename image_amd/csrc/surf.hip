@@ -5,7 +5,8 @@
 //   K16 integral image   integral_image_generic<int32>::load, dlib/image_transforms/integral_image.h:33-62, with
 //                        gray = (r+g+b)/3 (dlib/pixel.h:775-783).  int32 sums wrap (4096^2 bright tiles overflow);
 //                        wrap-around addition is associative, so a parallel scan gives the reference's bits:
-//                        surf_gray_rowscan (one workgroup per row) + surf_colscan (thread per column).
+//                        surf_gray_rowscan4 (one workgroup per row, 16-byte stores) + surf_colscan_sums/_apply (columns
+//                        cut into row segments); surf_gray_rowscan / surf_colscan serve unaligned or small images.
 //   K17 Hessian pyramid  hessian_pyramid::build_pyramid(img, 4, 6, 2), dlib/image_keypoint/hessian_pyramid.h:87-178:
 //                        24 levels of box-filter determinants in f64, one thread per level pixel, 32 integral-image
 //                        look-ups each (the 67 MB table of a 4096^2 tile lives in the Infinity Cache).
@@ -110,6 +111,77 @@ __global__ void __launch_bounds__(64) surf_colscan(unsigned *__restrict__ I, int
         for (int k = 0; k < 8; k++) { acc += v[k]; I[(size_t)(r + k) * cols + c] = acc; }
     }
     for (; r < rows; r++) { acc += I[(size_t)r * cols + c]; I[(size_t)r * cols + c] = acc; }
+}
+
+// ---- K16, fast forms (wrap-around addition is associative: any scan order gives the reference's bits)
+// Row scan: one workgroup per row, 4 consecutive pixels per thread and 1024 per trip: 12-byte RGB loads and 16-byte
+// stores, coalesced; a trip's 256 thread totals are scanned with wave shuffles + one LDS exchange.
+__global__ void __launch_bounds__(256) surf_gray_rowscan4(const unsigned char *__restrict__ rgb, unsigned *__restrict__ out,
+                                                          int cols)
+{
+    __shared__ unsigned wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t r = blockIdx.x;
+    const unsigned *src = reinterpret_cast<const unsigned *>(rgb + 3 * (r * cols));  // cols % 4 == 0: the row is dword aligned
+    unsigned carry = 0;
+    for (int c0 = 0; c0 < cols; c0 += 1024) {
+        const int c = c0 + 4 * tid;
+        unsigned g[4] = {0u, 0u, 0u, 0u};
+        if (c < cols) {  // 4 pixels = 12 bytes = 3 dwords
+            const unsigned w0 = src[3 * (c >> 2)], w1 = src[3 * (c >> 2) + 1], w2 = src[3 * (c >> 2) + 2];
+            g[0] = ((w0 & 0xffu) + ((w0 >> 8) & 0xffu) + ((w0 >> 16) & 0xffu)) / 3u;
+            g[1] = ((w0 >> 24) + (w1 & 0xffu) + ((w1 >> 8) & 0xffu)) / 3u;
+            g[2] = (((w1 >> 16) & 0xffu) + (w1 >> 24) + (w2 & 0xffu)) / 3u;
+            g[3] = (((w2 >> 8) & 0xffu) + ((w2 >> 16) & 0xffu) + (w2 >> 24)) / 3u;
+        }
+        g[1] += g[0]; g[2] += g[1]; g[3] += g[2];
+        unsigned incl = g[3];  // inclusive scan of the thread totals over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        unsigned base = carry;
+        for (int k = 0; k < wv; k++) base += wsum[k];
+        const unsigned total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        base += incl - g[3];  // exclusive prefix of this thread inside the trip
+        if (c < cols) *reinterpret_cast<uint4 *>(out + r * cols + c) = make_uint4(base + g[0], base + g[1], base + g[2], base + g[3]);
+        carry += total;
+        __syncthreads();
+    }
+}
+
+// Column scan in two kernels: the rows are cut into segments; (1) every (segment, column) adds up its segment,
+// (2) every (segment, column) re-reads it, starting from the sum of the segments above.  part: nseg x cols.
+__global__ void __launch_bounds__(256) surf_colscan_sums(const unsigned *__restrict__ I, unsigned *__restrict__ part, int rows,
+                                                         int cols, int seg_rows)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x, sgm = blockIdx.y;
+    if (c >= cols) return;
+    const int r0 = sgm * seg_rows, r1 = min(rows, r0 + seg_rows);
+    unsigned acc = 0;
+    for (int r = r0; r < r1; r++) acc += I[(size_t)r * cols + c];
+    part[(size_t)sgm * cols + c] = acc;
+}
+__global__ void __launch_bounds__(256) surf_colscan_apply(unsigned *__restrict__ I, const unsigned *__restrict__ part, int rows,
+                                                          int cols, int seg_rows)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x, sgm = blockIdx.y;
+    if (c >= cols) return;
+    unsigned acc = 0;
+    for (int k = 0; k < sgm; k++) acc += part[(size_t)k * cols + c];
+    const int r0 = sgm * seg_rows, r1 = min(rows, r0 + seg_rows);
+    int r = r0;
+    for (; r + 8 <= r1; r += 8) {
+        unsigned v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = I[(size_t)(r + k) * cols + c];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { acc += v[k]; I[(size_t)(r + k) * cols + c] = acc; }
+    }
+    for (; r < r1; r++) { acc += I[(size_t)r * cols + c]; I[(size_t)r * cols + c] = acc; }
 }
 
 // get_sum_of_area, integral_image.h:64-96 (uint32 arithmetic = the reference's wrapping int32)
@@ -234,6 +306,7 @@ namespace {
 struct SurfDevice {
     unsigned *integral = nullptr;
     double *pyr = nullptr;
+    size_t pyr_bytes = 0;
     SurfRecord *rec = nullptr;
     unsigned long long *count = nullptr;
     unsigned long long cap = 0;
@@ -246,10 +319,28 @@ size_t surf_ws_bytes(const SurfGeom &g, size_t pyr_total, unsigned long long cap
 }
 
 // K16-K18 for one image already in device memory; leaves the records (unordered) + count on the device
+// K16 on the stream; scratch (optional): room for the column scan's segment sums
+void launch_surf_integral(imgfd_ctx *ctx, const uint8_t *d_rgb, unsigned *d_I, int rows, int cols, void *scratch, size_t scratch_bytes)
+{
+    if (cols % 4 == 0 && (size_t)d_rgb % 4 == 0 && (size_t)d_I % 16 == 0)
+        hipLaunchKernelGGL(surf_gray_rowscan4, dim3(rows), dim3(256), 0, ctx->stream, d_rgb, d_I, cols);
+    else
+        hipLaunchKernelGGL(surf_gray_rowscan, dim3(rows), dim3(256), 0, ctx->stream, d_rgb, d_I, cols);
+    const int nseg = rows >= 1024 ? 32 : (rows >= 256 ? 8 : 1);
+    if (nseg > 1 && scratch && scratch_bytes >= sizeof(unsigned) * (size_t)nseg * cols) {
+        const int seg_rows = ceil_div(rows, nseg);
+        dim3 grid(ceil_div(cols, 256), ceil_div(rows, seg_rows));
+        hipLaunchKernelGGL(surf_colscan_sums, grid, dim3(256), 0, ctx->stream, d_I, (unsigned *)scratch, rows, cols, seg_rows);
+        hipLaunchKernelGGL(surf_colscan_apply, grid, dim3(256), 0, ctx->stream, d_I, (const unsigned *)scratch, rows, cols, seg_rows);
+    } else {
+        hipLaunchKernelGGL(surf_colscan, dim3(ceil_div(cols, 64)), dim3(64), 0, ctx->stream, d_I, rows, cols);
+    }
+}
+
 imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const SurfGeom &g, double thr, const SurfDevice &d)
 {
-    hipLaunchKernelGGL(surf_gray_rowscan, dim3(g.rows), dim3(256), 0, ctx->stream, d_rgb, d.integral, g.cols);
-    hipLaunchKernelGGL(surf_colscan, dim3(ceil_div(g.cols, 64)), dim3(64), 0, ctx->stream, d.integral, g.rows, g.cols);
+    // the pyramid buffer is idle until the integral image is complete: it lends the column scan its scratch
+    launch_surf_integral(ctx, d_rgb, d.integral, g.rows, g.cols, d.pyr, d.pyr_bytes);
     IMGFD_HIP(ctx, hipMemsetAsync(d.count, 0, sizeof(unsigned long long), ctx->stream));
     for (int o = 0; o < SURF_OCT; o++) {
         if (g.nr[o] < 1 || g.nc[o] < 1) continue;
@@ -287,6 +378,7 @@ imgfd_status surf_points_host(imgfd_ctx *ctx, const void *rgb, int kind, int row
         uint8_t *d_rgb = (uint8_t *)ws_alloc(ctx, 3 * n);
         d.integral = (unsigned *)ws_alloc(ctx, 4 * n);
         d.pyr = (double *)ws_alloc(ctx, 8 * std::max<size_t>(total, 1));
+        d.pyr_bytes = 8 * std::max<size_t>(total, 1);
         d.rec = (SurfRecord *)ws_alloc(ctx, sizeof(SurfRecord) * d.cap);
         d.count = (unsigned long long *)ws_alloc(ctx, 256);
         if (!d_rgb || !d.integral || !d.pyr || !d.rec || !d.count) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
@@ -394,13 +486,14 @@ imgfd_status imgfd_k_surf_integral(imgfd_ctx *ctx, const uint8_t *rgb, int rows,
     if (!rgb || !out || rows < 1 || cols < 1) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_k_surf_integral: bad argument");
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)rows * cols;
-    IMGFD_TRY(ws_reserve(ctx, align_up(3 * n, 256) + align_up(4 * n, 256) + 512));
+    const size_t part_bytes = sizeof(unsigned) * 32 * (size_t)cols;  // segment sums of the column scan
+    IMGFD_TRY(ws_reserve(ctx, align_up(3 * n, 256) + align_up(4 * n, 256) + align_up(part_bytes, 256) + 512));
     uint8_t *d_rgb = (uint8_t *)ws_alloc(ctx, 3 * n);
     unsigned *d_I = (unsigned *)ws_alloc(ctx, 4 * n);
-    if (!d_rgb || !d_I) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    void *d_part = ws_alloc(ctx, part_bytes);
+    if (!d_rgb || !d_I || !d_part) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
     IMGFD_HIP(ctx, hipMemcpyAsync(d_rgb, rgb, 3 * n, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(surf_gray_rowscan, dim3(rows), dim3(256), 0, ctx->stream, d_rgb, d_I, cols);
-    hipLaunchKernelGGL(surf_colscan, dim3(ceil_div(cols, 64)), dim3(64), 0, ctx->stream, d_I, rows, cols);
+    launch_surf_integral(ctx, d_rgb, d_I, rows, cols, d_part, part_bytes);
     IMGFD_HIP(ctx, hipGetLastError());
     IMGFD_HIP(ctx, hipMemcpyAsync(out, d_I, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
     IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -440,6 +533,7 @@ imgfd_status imgfd_surf_points_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_f
     SurfDevice d;
     d.integral = (unsigned *)ws_alloc(ctx, 4 * n);
     d.pyr = (double *)ws_alloc(ctx, 8 * std::max<size_t>(total, 1));
+    d.pyr_bytes = 8 * std::max<size_t>(total, 1);
     if (!d.integral || !d.pyr) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
     d.cap = (unsigned long long)cap;
     for (int f = 0; f < n_frames; f++) {  // tiles are processed back to back on the context's stream, no host sync
@@ -473,6 +567,7 @@ imgfd_status imgfd_surf_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, 
         (void)ws_alloc(ctx, 3 * n);  // the slot imgfd_surf uses for the uploaded image (same carving, same size function)
         d.integral = (unsigned *)ws_alloc(ctx, 4 * n);
         d.pyr = (double *)ws_alloc(ctx, 8 * std::max<size_t>(total, 1));
+        d.pyr_bytes = 8 * std::max<size_t>(total, 1);
         d.rec = (SurfRecord *)ws_alloc(ctx, sizeof(SurfRecord) * d.cap);
         d.count = (unsigned long long *)ws_alloc(ctx, 256);
         if (!d.integral || !d.pyr || !d.rec || !d.count) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
