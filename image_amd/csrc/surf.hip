@@ -184,21 +184,88 @@ __global__ void __launch_bounds__(256) surf_colscan_apply(unsigned *__restrict__
     for (; r < r1; r++) { acc += I[(size_t)r * cols + c]; I[(size_t)r * cols + c] = acc; }
 }
 
-// get_sum_of_area, integral_image.h:64-96 (uint32 arithmetic = the reference's wrapping int32)
-__device__ __forceinline__ unsigned surf_sum(const unsigned *__restrict__ I, int cols, int l, int t, int r, int b)
+// (get_sum_of_area, integral_image.h:64-96, in uint32 arithmetic = the reference's wrapping int32, appears below in
+// its interior form: br - bl - tr + tl.)
+
+// ---- K17, first octave (step 2, lobes 3..13: three quarters of all level pixels): the integral-image window of a
+// 64 x 16 block of level pixels -- 166 x 70 entries with the widest filter's reach -- is staged in LDS once and serves all
+// six intervals (6 x 4 x 32 look-ups per thread from LDS instead of scattered global loads).  Same arithmetic as
+// surf_pyramid below.
+#define SP0_LX 64
+#define SP0_LY 16
+#define SP0_HL 20  // reach of the widest box (3 * 13 wide) to the left / above, including the "- 1" corner
+#define SP0_HR 19
+#define SP0_W (2 * (SP0_LX - 1) + 1 + SP0_HL + SP0_HR)  // 166
+#define SP0_H (2 * (SP0_LY - 1) + 1 + SP0_HL + SP0_HR)  // 70
+#define SP0_P 168
+// One interval of the first octave for the level pixel whose centre sits at window word `ctr` (row-major, even and odd
+// columns of a row stored apart, the centre column is even).  The lobe is a compile-time constant, so every look-up is a
+// ds_read with an immediate offset from `ctr` -- no address arithmetic.  For a centre at least border_px inside the
+// image all four corners of every box exist (l - 1 >= 3*lobe/2 - 1 > 0), so integral_image.h:64-96's border cases
+// cannot occur here and br - bl - tr + tl is evaluated directly.
+template <int IT>
+__device__ __forceinline__ double sp0_interval(const unsigned *__restrict__ ctr, double area_inv)
 {
-    unsigned tl = 0, tr = 0, bl = 0;
-    const unsigned br = I[(size_t)b * cols + r];
-    if (l - 1 >= 0 && t - 1 >= 0) { tl = I[(size_t)(t - 1) * cols + (l - 1)]; bl = I[(size_t)b * cols + (l - 1)]; tr = I[(size_t)(t - 1) * cols + r]; }
-    else if (l - 1 >= 0) bl = I[(size_t)b * cols + (l - 1)];
-    else if (t - 1 >= 0) tr = I[(size_t)(t - 1) * cols + r];
-    return br - bl - tr + tl;
+    constexpr int lobe = 2 * (IT + 1) + 1, off = lobe / 2 + 1;  // hessian_pyramid.h:119-128 for octave 0
+    auto at = [&](int dy, int dx) __attribute__((always_inline)) -> unsigned {
+        // floor division by 2 of dx for the even/odd split
+        return ctr[dy * SP0_P + (dx & 1) * (SP0_P / 2) + ((dx - (dx & 1)) / 2)];
+    };
+    auto box = [&](int cx, int cy, int w, int h) __attribute__((always_inline)) -> int {  // centered_rect(cx, cy, w, h), relative to the centre
+        const int l = cx - w / 2, t = cy - h / 2, r = l + w - 1, b = t + h - 1;
+        return (int)(at(b, r) - at(b, l - 1) - at(t - 1, r) + at(t - 1, l - 1));
+    };
+    double Dxx = box(0, 0, lobe * 3, 2 * lobe - 1) - box(0, 0, lobe, 2 * lobe - 1) * 3.0;
+    double Dyy = box(0, 0, 2 * lobe - 1, lobe * 3) - box(0, 0, 2 * lobe - 1, lobe) * 3.0;
+    double Dxy = (int)((unsigned)box(-off, off, lobe, lobe) + (unsigned)box(off, -off, lobe, lobe) - (unsigned)box(-off, -off, lobe, lobe) -
+                       (unsigned)box(off, off, lobe, lobe));
+    Dxx *= area_inv; Dyy *= area_inv; Dxy *= area_inv;
+    double sign = +1;
+    if (Dxx + Dyy < 0) sign = -1;
+    double det = Dxx * Dyy - 0.81 * Dxy * Dxy;
+    if (det < 0) det = 0;
+    return sign * det;
 }
-// get_sum_of_area(centered_rect(x, y, w, h)), rectangle.h:363-376
-__device__ __forceinline__ int surf_csum(const unsigned *__restrict__ I, int cols, int x, int y, int w, int h)
+
+__global__ void __launch_bounds__(256) surf_pyramid_o0(const unsigned *__restrict__ I, double *__restrict__ pyr, SurfGeom g)
 {
-    const int l = x - w / 2, t = y - h / 2;
-    return (int)surf_sum(I, cols, l, t, l + w - 1, t + h - 1);
+    __shared__ __attribute__((aligned(16))) unsigned win[SP0_H * SP0_P];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lc0 = blockIdx.x * SP0_LX, lr0 = blockIdx.y * SP0_LY;
+    const int x0 = 2 * lc0 - SP0_HL, y0 = 2 * lr0 - SP0_HL;
+    const int cols = g.cols, rows = g.rows;
+    if (x0 >= 0 && y0 >= 0 && x0 + SP0_P <= cols && y0 + SP0_H <= rows && (cols & 3) == 0) {  // workgroup-uniform; x0 % 4 == 0
+        for (int i = tid; i < SP0_H * (SP0_P / 4); i += 256) {
+            const int ry = i / (SP0_P / 4), q = i - ry * (SP0_P / 4);
+            const uint4 v = *reinterpret_cast<const uint4 *>(I + (size_t)(y0 + ry) * cols + x0 + 4 * q);
+            *reinterpret_cast<uint2 *>(&win[ry * SP0_P + 2 * q]) = make_uint2(v.x, v.z);                // columns 4q, 4q+2
+            *reinterpret_cast<uint2 *>(&win[ry * SP0_P + SP0_P / 2 + 2 * q]) = make_uint2(v.y, v.w);  // columns 4q+1, 4q+3
+        }
+    } else {  // at the image border: clamped coordinates (entries outside the image are never used by a valid centre)
+        for (int i = tid; i < SP0_H * SP0_P; i += 256) {
+            const int ry = i / SP0_P, rx = i - ry * SP0_P;
+            const int gy = min(max(y0 + ry, 0), rows - 1), gx = min(max(x0 + rx, 0), cols - 1);
+            win[ry * SP0_P + (rx & 1) * (SP0_P / 2) + (rx >> 1)] = I[(size_t)gy * cols + gx];
+        }
+    }
+    __syncthreads();
+    const int lc = lc0 + lane;
+#pragma unroll
+    for (int k = 0; k < SP0_LY / 4; k++) {
+        const int lr = lr0 + wv * (SP0_LY / 4) + k;
+        const int r = lr * 2, c = lc * 2;
+        if (lr >= g.nr[0] || lc >= g.nc[0]) continue;
+        // the centre (c, r) in the window: column c - x0 = 2*lane + 20 (even), row r - y0
+        const unsigned *ctr = win + (r - y0) * SP0_P + ((c - x0) >> 1);
+        double *dst = pyr + (size_t)lr * g.nc[0] + lc;
+#define SP0_DO(IT)                                                                                                        \
+        {                                                                                                                  \
+            const int bp = g.lev[IT].border_px;                                                                            \
+            if (!(r < bp || r >= rows - bp || c < bp || c >= cols - bp)) dst[g.lev[IT].plane] = sp0_interval<IT>(ctr, g.lev[IT].area_inv); \
+        }
+        SP0_DO(0) SP0_DO(1) SP0_DO(2) SP0_DO(3) SP0_DO(4) SP0_DO(5)
+#undef SP0_DO
+    }
 }
 
 // ---- K17: one launch per octave, blockIdx.z = interval
@@ -211,10 +278,19 @@ __global__ void __launch_bounds__(256) surf_pyramid(const unsigned *__restrict__
     if (lr >= g.nr[o] || lc >= g.nc[o]) return;
     if (r < L.border_px || r >= g.rows - L.border_px || c < L.border_px || c >= g.cols - L.border_px) return;
     const int lobe = L.lobe, off = L.off, cols = g.cols;
-    double Dxx = surf_csum(I, cols, c, r, lobe * 3, 2 * lobe - 1) - surf_csum(I, cols, c, r, lobe, 2 * lobe - 1) * 3.0;       // :141-142
-    double Dyy = surf_csum(I, cols, c, r, 2 * lobe - 1, lobe * 3) - surf_csum(I, cols, c, r, 2 * lobe - 1, lobe) * 3.0;       // :144-145
-    double Dxy = (int)((unsigned)surf_csum(I, cols, c - off, r + off, lobe, lobe) + (unsigned)surf_csum(I, cols, c + off, r - off, lobe, lobe) -
-                       (unsigned)surf_csum(I, cols, c - off, r - off, lobe, lobe) - (unsigned)surf_csum(I, cols, c + off, r + off, lobe, lobe));  // :147-150
+    // A centre at least border_px = ceil(3(2i+3)/2) * step inside the image keeps every box corner inside it in every
+    // octave (3*lobe/2 + 1 < border_px), so the border cases of integral_image.h:64-96 cannot occur: the 32 look-ups
+    // are issued without branches in between (one memory round trip instead of sixteen).
+    const unsigned *ctr = I + (size_t)r * cols + c;
+    auto box = [&](int cx, int cy, int w, int h) __attribute__((always_inline)) -> int {  // centered_rect relative to the centre
+        const int l = cx - w / 2, t = cy - h / 2, rr = l + w - 1, b = t + h - 1;
+        const long rowb = (long)b * cols, rowt = (long)(t - 1) * cols;
+        return (int)(ctr[rowb + rr] - ctr[rowb + l - 1] - ctr[rowt + rr] + ctr[rowt + l - 1]);
+    };
+    double Dxx = box(0, 0, lobe * 3, 2 * lobe - 1) - box(0, 0, lobe, 2 * lobe - 1) * 3.0;       // :141-142
+    double Dyy = box(0, 0, 2 * lobe - 1, lobe * 3) - box(0, 0, 2 * lobe - 1, lobe) * 3.0;       // :144-145
+    double Dxy = (int)((unsigned)box(-off, off, lobe, lobe) + (unsigned)box(off, -off, lobe, lobe) -
+                       (unsigned)box(-off, -off, lobe, lobe) - (unsigned)box(off, off, lobe, lobe));  // :147-150
     Dxx *= L.area_inv; Dyy *= L.area_inv; Dxy *= L.area_inv;
     double sign = +1;
     if (Dxx + Dyy < 0) sign = -1;
@@ -344,6 +420,13 @@ imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const Surf
     IMGFD_HIP(ctx, hipMemsetAsync(d.count, 0, sizeof(unsigned long long), ctx->stream));
     for (int o = 0; o < SURF_OCT; o++) {
         if (g.nr[o] < 1 || g.nc[o] < 1) continue;
+        static_assert(SURF_INT == 6, "surf_pyramid_o0 unrolls six intervals");
+        if (o == 0 && g.lev[0].step == 2 && g.lev[0].lobe == 3 && g.lev[SURF_INT - 1].lobe == 13 && (size_t)d.integral % 16 == 0) {
+            // the widest first-octave filter reaches 20 entries left/up and 19 right/down: what surf_pyramid_o0 stages
+            hipLaunchKernelGGL(surf_pyramid_o0, dim3(ceil_div(g.nc[0], SP0_LX), ceil_div(g.nr[0], SP0_LY)), dim3(256), 0, ctx->stream,
+                               d.integral, d.pyr, g);
+            continue;
+        }
         dim3 grid(ceil_div(g.nc[o], 64), ceil_div(g.nr[o], 4), SURF_INT);
         hipLaunchKernelGGL(surf_pyramid, grid, dim3(256), 0, ctx->stream, d.integral, d.pyr, g, o);
     }
