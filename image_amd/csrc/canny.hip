@@ -6,7 +6,8 @@
 //  K9  blur      tools.c:166-185 multiplies FFTs (FFTW3): y = float(x (*) g) with (*) the 2-D CIRCULAR
 //                convolution and g[j][i] = exp(-(xi^2+yj^2)/s^2)/sum, xi = i<w/2 ? i : i-w (:146-163).
 //                g is an outer product, so this is two 1-D circular convolutions with the wrapped
-//                kernels; taps below 1e-22 cannot move a double sum of 0..255 data and are dropped.
+//                kernels; taps below 1e-17 are dropped: together they move a blurred value by < 1e-16 (a unit in the
+//                last place of the double sum; the reference's FFT itself carries ~1e-13), see make_taps.
 //                Accumulated in double in the oracle's tap order (no contraction), rounded to float
 //                once (crealf, tools.c:129).  No FFT needed.
 //  K10+K11 grad_nms   rcpp_canny.cpp:153-175 (3x3 gradient, clamp-to-edge, hypot) fused with maxima()
@@ -597,7 +598,11 @@ __global__ void __launch_bounds__(256) canny_count_bits(const unsigned long long
 
 namespace {
 
-// wrapped, normalised 1-D kernel (tools.c:146-163) reduced to the taps >= 1e-22, in the oracle's order
+// Wrapped, normalised 1-D kernel (tools.c:146-163) reduced to the taps >= 1e-17, in the oracle's order.  The oracle keeps
+// taps down to 1e-22 (for s = 2: radius 14 instead of 12); the two extra pairs weigh 1.3e-19 and 1.5e-22 and contribute
+// at most 510 * 1.3e-19 = 7e-17 to a value of order 1..255 -- below half a unit in the last place of the double
+// accumulator except for near-black neighbourhoods, and thirteen orders below the float the result is rounded to.
+#define CANNY_TAP_MIN 1e-17
 imgfd_status make_taps(imgfd_ctx *ctx, int n, double s, BlurTaps *t)
 {
     std::vector<double> k(n);
@@ -611,7 +616,7 @@ imgfd_status make_taps(imgfd_ctx *ctx, int n, double s, BlurTaps *t)
     t->n = 0;
     for (int i = 0; i < n; i++) {
         const double w = k[i] / sum;
-        if (w >= 1e-22) {
+        if (w >= CANNY_TAP_MIN) {
             if (t->n == CANNY_MAX_TAPS) return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "canny: sigma too large (more than 129 taps)");
             t->off[t->n] = i;
             t->w[t->n] = w;
@@ -699,6 +704,7 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
         if (R <= 4) IMGFD_TRY(launch_blur_march<4>(ctx, p, nf));
         else if (R <= 7) IMGFD_TRY(launch_blur_march<7>(ctx, p, nf));
         else if (R <= 10) IMGFD_TRY(launch_blur_march<10>(ctx, p, nf));
+        else if (R <= 12) IMGFD_TRY(launch_blur_march<12>(ctx, p, nf));
         else if (R <= 14) IMGFD_TRY(launch_blur_march<14>(ctx, p, nf));
         else if (R <= 18) IMGFD_TRY(launch_blur_march<18>(ctx, p, nf));
         else if (R <= 24) IMGFD_TRY(launch_blur_march<24>(ctx, p, nf));

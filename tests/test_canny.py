@@ -1,8 +1,9 @@
 """Canny: the device path against the oracle restatement and against edge maps written by the reference's own
 canny_edge_detector() (compiled in place with a stand-in DFT for the absent FFTW3, see oracle/canny_oracle.c and
-tests/test_oracle.py).  The blur is summed in the oracle's own tap order, so the blurred plane -- and with it almost every
-decision -- is reproduced exactly; the NMS replaces atan2->cos/sin by the unit vector, which can flip exact ties only: the
-edge map is compared through a mismatch-rate bound."""
+tests/test_oracle.py).  The device blur keeps the taps >= 1e-17 (the oracle >= 1e-22) and accumulates with fused
+multiply-adds: the blurred doubles agree to ~1e-16 and, after the float cast, in all but astronomically rare values, so
+almost every decision is reproduced exactly; the NMS replaces atan2->cos/sin by the unit vector, which can flip exact ties
+only: the edge map is compared through a mismatch-rate bound."""
 import numpy as np
 import pytest
 
