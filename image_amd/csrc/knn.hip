@@ -6,8 +6,8 @@
 // every data row, squared differences added in ascending dimension order in f64 (no contraction), sqrt at the end;
 // equal distances are ranked by ascending data index.
 //
-// One workgroup = 4 waves x 2 queries; a tile of 64 data rows is staged TRANSPOSED in LDS (dimension-major, so lane j
-// reads row j conflict-free) and shared by the 8 queries.  Lane j of a wave sees the data rows j, j+64, ... and keeps a
+// One workgroup = 4 waves x 2 or 4 queries; a tile of 64 data rows is staged TRANSPOSED in LDS (dimension-major, so lane j
+// reads row j conflict-free) and shared by the workgroup's queries.  Lane j of a wave sees the data rows j, j+64, ... and keeps a
 // sorted list of its k best per query in LDS; at the end the 64 lists of a query are merged by k rounds of a wave-wide
 // lexicographic (distance, index) minimum.
 #include "common.h"
@@ -18,9 +18,7 @@
 
 #define KNN_KMAX 8
 #define KNN_DMAX 64
-#define KNN_QPW 2   // queries per wave
 #define KNN_WAVES 4
-#define KNN_QPB (KNN_QPW * KNN_WAVES)
 
 struct KnnView {
     const double *p;
@@ -28,13 +26,22 @@ struct KnnView {
     long long n;
 };
 
+// KNN_QPW queries per wave (independent accumulators per lane): 4 for large query sets, 2 when the grid would otherwise
+// not fill the device
+template <int KNN_QPW>
 __global__ void __launch_bounds__(64 * KNN_WAVES) knn_kernel(KnnView data, KnnView query, int dim, int k,
                                                               int *__restrict__ nn_index, double *__restrict__ nn_dist)
 {
+    constexpr int KNN_QPB = KNN_QPW * KNN_WAVES;
     __shared__ double tile[KNN_DMAX][65];                 // [dimension][data row of the tile]
     __shared__ double qv[KNN_QPB][KNN_DMAX];
-    __shared__ double ld[KNN_QPB][KNN_KMAX][64];          // per query, per slot, per lane: squared distance
-    __shared__ int li[KNN_QPB][KNN_KMAX][64];
+    // per query, per slot, per lane: squared distance and index -- sized by the k of this launch (dynamic LDS), so that
+    // the usual k = 1, 2 leave room for three workgroups per CU
+    HIP_DYNAMIC_SHARED(double, knn_dyn)
+    double *ld = knn_dyn;                                                   // [KNN_QPB][k][64]
+    int *li = reinterpret_cast<int *>(knn_dyn + (size_t)KNN_QPB * k * 64);  // [KNN_QPB][k][64]
+#define LD(q, s_, l) ld[((q) * k + (s_)) * 64 + (l)]
+#define LI(q, s_, l) li[((q) * k + (s_)) * 64 + (l)]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long q0 = (long long)blockIdx.x * KNN_QPB;
     for (int e = tid; e < KNN_QPB * dim; e += blockDim.x) {
@@ -42,9 +49,9 @@ __global__ void __launch_bounds__(64 * KNN_WAVES) knn_kernel(KnnView data, KnnVi
         const long long q = q0 + ql;
         qv[ql][t] = q < query.n ? query.p[q * query.rs + t * query.cs] : 0.0;
     }
-    for (int e = tid; e < KNN_QPB * KNN_KMAX * 64; e += blockDim.x) {
-        (&ld[0][0][0])[e] = INFINITY;
-        (&li[0][0][0])[e] = 0x7fffffff;
+    for (int e = tid; e < KNN_QPB * k * 64; e += blockDim.x) {
+        ld[e] = INFINITY;
+        li[e] = 0x7fffffff;
     }
     __syncthreads();
     for (long long j0 = 0; j0 < data.n; j0 += 64) {
@@ -72,15 +79,15 @@ __global__ void __launch_bounds__(64 * KNN_WAVES) knn_kernel(KnnView data, KnnVi
 #pragma unroll
             for (int u = 0; u < KNN_QPW; u++) {
                 const int ql = wave * KNN_QPW + u;
-                if (acc[u] < ld[ql][k - 1][lane]) {  // beats this lane's k-th best: insert (equal distances keep the earlier row)
+                if (acc[u] < LD(ql, k - 1, lane)) {  // beats this lane's k-th best: insert (equal distances keep the earlier row)
                     int s = k - 1;
-                    while (s > 0 && acc[u] < ld[ql][s - 1][lane]) {
-                        ld[ql][s][lane] = ld[ql][s - 1][lane];
-                        li[ql][s][lane] = li[ql][s - 1][lane];
+                    while (s > 0 && acc[u] < LD(ql, s - 1, lane)) {
+                        LD(ql, s, lane) = LD(ql, s - 1, lane);
+                        LI(ql, s, lane) = LI(ql, s - 1, lane);
                         s--;
                     }
-                    ld[ql][s][lane] = acc[u];
-                    li[ql][s][lane] = (int)j;
+                    LD(ql, s, lane) = acc[u];
+                    LI(ql, s, lane) = (int)j;
                 }
             }
         }
@@ -92,8 +99,8 @@ __global__ void __launch_bounds__(64 * KNN_WAVES) knn_kernel(KnnView data, KnnVi
         const long long q = q0 + ql;
         int head = 0;
         for (int round = 0; round < k; round++) {
-            double d = head < k ? ld[ql][head][lane] : INFINITY;
-            int ix = head < k ? li[ql][head][lane] : 0x7fffffff;
+            double d = head < k ? LD(ql, head, lane) : INFINITY;
+            int ix = head < k ? LI(ql, head, lane) : 0x7fffffff;
             double bd = d;
             int bi = ix;
 #pragma unroll
@@ -112,13 +119,24 @@ __global__ void __launch_bounds__(64 * KNN_WAVES) knn_kernel(KnnView data, KnnVi
     }
 }
 
+#undef LD
+#undef LI
+
 static imgfd_status knn_launch(imgfd_ctx *ctx, const KnnView &data, const KnnView &query, int dim, int k, int *d_index,
                                double *d_dist)
 {
     if (query.n < 1) return IMGFD_OK;
-    const long long blocks = (query.n + KNN_QPB - 1) / KNN_QPB;
-    hipLaunchKernelGGL(knn_kernel, dim3((unsigned)blocks), dim3(64 * KNN_WAVES), 0, ctx->stream, data, query, dim, k, d_index,
-                       d_dist);
+    const bool wide = query.n >= 16 * 1024 / 2;  // >= 512 workgroups of 16 queries: two per CU
+    const int qpb = (wide ? 4 : 2) * KNN_WAVES;
+    const long long blocks = (query.n + qpb - 1) / qpb;
+    const size_t dyn = (size_t)qpb * k * 64 * (sizeof(double) + sizeof(int));
+    if (wide) {
+        IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)knn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        hipLaunchKernelGGL(knn_kernel<4>, dim3((unsigned)blocks), dim3(64 * KNN_WAVES), dyn, ctx->stream, data, query, dim, k, d_index, d_dist);
+    } else {
+        IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)knn_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        hipLaunchKernelGGL(knn_kernel<2>, dim3((unsigned)blocks), dim3(64 * KNN_WAVES), dyn, ctx->stream, data, query, dim, k, d_index, d_dist);
+    }
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }

@@ -26,7 +26,8 @@ def test_oracle_agrees_with_an_independent_exact_search():
 
 
 @pytest.mark.parametrize("nd,nq,dim,k", [(500, 333, 64, 1), (500, 333, 64, 2), (1000, 70, 64, 8), (129, 65, 5, 3),
-                                          (64, 8, 64, 1), (3, 9, 64, 1), (1, 1, 1, 1)])
+                                          (64, 8, 64, 1), (3, 9, 64, 1), (1, 1, 1, 1),
+                                          (200, 8200, 64, 2)])   # >= 8192 queries: the four-queries-per-wave kernel
 def test_knn_matches_oracle_exactly(be, nd, nq, dim, k):
     rng = np.random.default_rng(nd * 7 + nq)
     data, query = unit_rows(rng, nd, dim), unit_rows(rng, nq, dim)
