@@ -3,12 +3,13 @@
 // Host-side scheduling only; the kernels are those of imgfd_harris_dev / imgfd_fast9_dev / imgfd_canny_dev and every
 // result is what those calls return.  Why overlap: Canny's hysteresis (rcpp_canny.cpp:184-215) is a fixpoint iteration
 // whose later sweeps touch a handful of tiles -- a few waves on a 256-CU device -- and whose convergence the host has to
-// read back.  The batch's Canny front (blur, gradient + NMS) runs on the context's companion stream, beside FAST-9 on
-// the context's own stream; that stream is then gated on the Canny front and receives the Harris chain, which fills the
-// machine while the hysteresis rounds trickle along on the companion stream.
+// read back.  The batch's Canny front (blur, gradient + NMS: f64 issue-bound, they want the device to themselves) runs
+// on the context's companion stream; the context's own stream is gated on it and then receives FAST-9 and the Harris
+// chain, which fill the machine while the hysteresis rounds trickle along on the companion stream.  FAST-9 goes first:
+// it needs few wave slots and so suffers least from the heavy first two sweeps.
 //
-//      companion stream :  blur | grad+NMS | hysteresis sweeps ............ | expand, count |
-//      context stream   :  FAST-9 ....     | gauss+grad | structure tensor | response+NMS | compaction |
+//      companion stream :  blur | grad+NMS | hysteresis sweeps ................... | expand, count |
+//      context stream   :                  | FAST-9 | gauss+grad | structure tensor | response+NMS | compaction |
 #include "common.h"
 
 extern "C" {
@@ -41,11 +42,10 @@ imgfd_status imgfd_detect_dev(imgfd_ctx *ctx, const imgfd_frames *fr, const imgf
     // the frames (and anything else queued on the context's stream) come first
     IMGFD_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     IMGFD_HIP(ctx, hipStreamWaitEvent(side->stream, ctx->ev_fork, 0));
-    // FAST-9 (integer work, latency-bound) shares the machine with the Canny blur (f64 issue-bound) from the start
-    IMGFD_TRY(fast9());
     const std::function<imgfd_status()> gate = [&]() -> imgfd_status {
         IMGFD_HIP(ctx, hipEventRecord(ctx->ev_gate, side->stream));
         IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gate, 0));
+        IMGFD_TRY(fast9());  // light on wave slots: it takes the heavy first hysteresis sweeps as neighbours, not Gaussian+gradient
         return harris();
     };
     const imgfd_status st = canny_dev_hooked(side, fr, p->s, p->low_thr, p->high_thr, p->accGrad, d_edges, d_counts + 2 * B, &gate);
