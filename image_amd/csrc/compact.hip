@@ -131,6 +131,10 @@ static imgfd_status compact_emit_impl(imgfd_ctx *ctx, const CompactBuffers &cb, 
 {
     hipLaunchKernelGGL(rows_scan, dim3(n_frames), dim3(SCAN_NT), 0, ctx->stream, cb.rowcount, cb.rowoff, ny,
                        (long long *)d_counts);
+    if (cap <= 0) {  // counts only: nothing to emit
+        IMGFD_HIP(ctx, hipGetLastError());
+        return IMGFD_OK;
+    }
     dim3 grid(ceil_div(ny, 4), n_frames);
 #define SC_LAUNCH(K) hipLaunchKernelGGL(scatter_rows<K>, grid, dim3(256), 0, ctx->stream, cb.mask, cb.rowoff, cb.words_per_row, nx, ny, d_R, abc, d_out, (long long)cap)
     switch (kind) {

@@ -63,7 +63,7 @@ imgfd_status imgfd_fast9_i32(imgfd_ctx *ctx, const int32_t *x, int width, int he
 imgfd_status imgfd_fast9_dev(imgfd_ctx *ctx, const imgfd_frames *fr, uint8_t threshold,
                              int suppress_non_max, imgfd_point *d_points, int64_t cap, int64_t *d_counts)
 {
-    if (!ctx || !fr || !fr->d_frames || !d_points || !d_counts || cap < 0 || fr->n_frames < 0 || fr->dtype != 0)
+    if (!ctx || !fr || !fr->d_frames || (!d_points && cap > 0) || !d_counts || cap < 0 || fr->n_frames < 0 || fr->dtype != 0)
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_fast9_dev: bad argument (frames must be u8)");
     if (fr->n_frames == 0) return IMGFD_OK;
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));

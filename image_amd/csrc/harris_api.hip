@@ -397,7 +397,7 @@ imgfd_status imgfd_harris_dev(imgfd_ctx *ctx, const imgfd_frames *fr, float k, f
                               float sigma_i, float threshold, int gaussian, int gradient, int measure,
                               imgfd_corner *d_corners, int64_t cap, int64_t *d_counts)
 {
-    if (!ctx || !fr || !fr->d_frames || !d_corners || !d_counts || cap < 0 || fr->n_frames < 0)
+    if (!ctx || !fr || !fr->d_frames || (!d_corners && cap > 0) || !d_counts || cap < 0 || fr->n_frames < 0)
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_harris_dev: bad argument");
     const int nx = fr->nx, ny = fr->ny;
     if (fr->n_frames == 0) return IMGFD_OK;

@@ -237,7 +237,8 @@ typedef struct {
 /* Harris, reference default path and every enum code that runs on the device (gaussian 0/1/2,
  * gradient 0/1, measure 0/1/2); strategy "all corners", no sub-pixel, one scale: exactly what every
  * public image_harris() call executes.  d_corners: n_frames*cap records, raster order;
- * d_counts[f] = number of corners found in frame f (may exceed cap; only cap are stored). */
+ * d_counts[f] = number of corners found in frame f (may exceed cap; only cap are stored).  cap = 0 asks for the
+ * counts only; d_corners may then be NULL (likewise d_points of imgfd_fast9_dev). */
 IMGFD_API imgfd_status imgfd_harris_dev(imgfd_ctx *ctx, const imgfd_frames *fr, float k, float sigma_d,
                               float sigma_i, float threshold, int gaussian, int gradient, int measure,
                               imgfd_corner *d_corners, int64_t cap, int64_t *d_counts);

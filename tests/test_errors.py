@@ -76,3 +76,32 @@ def test_dev_api_rejects_wrong_dtype(be):
     assert be.lib.imgfd_fast9_dev(be.ctx, C.byref(fr), 20, 0, be.ptr(pts), 16, be.ptr(cnt)) == INVALID
     edges = be.empty((1, 48, 64), np.uint8)
     assert be.lib.imgfd_canny_dev(be.ctx, C.byref(fr), 2.0, 3.0, 10.0, 1, be.ptr(edges), be.ptr(cnt)) == INVALID
+
+
+def test_counts_only_batch_calls_accept_null_record_buffers(be):
+    """cap = 0 means counts only: the record buffers may be NULL (imgfd_harris_dev, imgfd_fast9_dev, imgfd_detect_dev)"""
+    import oracle
+    frames = np.stack([synth.frame(640 + f, 96, 72, n_rect=8) for f in range(2)])
+    d = be.to_dev(frames)
+    fr = be.frames(d, 2, 96, 72, 0)
+    cnt = be.empty((3, 2), np.int64)
+    edges = be.empty((2, 72, 96), np.uint8)
+    p = _binding.StreamParams()
+    be.lib.imgfd_stream_default_params(C.byref(p))
+    p.threshold, p.fast9_threshold, p.suppress_non_max = 40.0, 15, 1
+    be.set_fir_mode(0)
+    st = be.lib.imgfd_detect_dev(be.ctx, C.byref(fr), C.byref(p), None, None, be.ptr(edges), be.ptr(cnt))
+    assert st == OK, msg(be)
+    be.sync()
+    got = be.to_host(cnt)
+    for f in range(2):
+        assert got[0, f] == len(oracle.harris(frames[f].astype(np.float32), threshold=40.0))
+        assert got[1, f] == len(oracle.fast9(frames[f], 15, True))
+        assert got[2, f] == oracle.canny(frames[f])[1]
+    # a record buffer is still required as soon as records are asked for
+    p.corner_cap = 4
+    assert be.lib.imgfd_detect_dev(be.ctx, C.byref(fr), C.byref(p), None, None, be.ptr(edges), be.ptr(cnt)) == INVALID
+    # an empty batch is not an error
+    fr0 = be.frames(d, 0, 96, 72, 0)
+    p.corner_cap = 0
+    assert be.lib.imgfd_detect_dev(be.ctx, C.byref(fr0), C.byref(p), None, None, be.ptr(edges), be.ptr(cnt)) == OK, msg(be)
