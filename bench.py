@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 
 NX, NY = 3840, 2160
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
+MEASURED_COPY_GBS = 6300.0      # float4 device-to-device copy on this part (profiles/r01/ubench.txt; MI355X_MICROARCH.md quotes the same)
 TENSOR_BYTES_PER_PX = 20        # read Ix,Iy (8 B), write A,B,C (12 B)
 
 
@@ -57,6 +58,7 @@ def cpu_baseline(frames_host, gpu_frame0=None):
             t = best(lambda: oracle.ref_harris(f32, threads=th), reps=1)
             if t_h is None or t < t_h:
                 t_h, cores = t, th
+        t_h1 = best(lambda: oracle.ref_harris(f32, threads=1), reps=1)   # state the single-thread time too
         t_f = best(lambda: oracle.ref_fast9(img, 20, True))
         kind = "reference"
     else:
@@ -64,6 +66,8 @@ def cpu_baseline(frames_host, gpu_frame0=None):
         t_f = best(lambda: oracle.fast9(img, 20, True))
         kind = "port"
     parts = {"harris_ms": round(1e3 * t_h, 2), "fast9_ms": round(1e3 * t_f, 2)}
+    if have_ref:
+        parts["harris_1_thread_ms"] = round(1e3 * t_h1, 2)
     t_c = None
     try:
         t_c = best(lambda: oracle.canny(img), reps=1)
@@ -217,7 +221,9 @@ def main():
                                           "canny_edge_pixels": int(counts[2])}},
             "roofline": {"kernel": "fir_march<7,tensor> (Harris structure-tensor pass)", "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/k3_traffic.json)",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "frac_of_measured_copy": round(achieved / MEASURED_COPY_GBS, 4), "measured_copy_GBps": MEASURED_COPY_GBS,
+                         "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/k3_traffic.json)",
                          "avg_launch_us": round(k3_avg_us, 2), "launches": k3_n.value,
                          "algorithmic_bytes_per_launch": k3_bytes},
         }
