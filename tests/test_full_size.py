@@ -96,3 +96,31 @@ def test_surf_tile_4096(gpu):
     r = oracle.surf(tile, 1000, 30.0)
     for k in r:
         assert s[k].shape == r[k].shape and np.array_equal(s[k], r[k]), k
+
+
+def test_config5_stream_of_4k_frames_sampled_against_the_oracle():
+    """config 5 shape: frames G(50000+f) generated on the device, Harris defaults + FAST-9 + Canny defaults through
+    imgfd_detect_dev (what bench.py times); per-frame counts, and a sample frame checked in full against the oracle"""
+    import torch
+    from image_amd.device import DeviceDetector
+    det = DeviceDetector(0)
+    det.ctx.set_fir_mode(0)
+    n, sample = 8, 5
+    frames = det.synth_frames(n, NX, NY, seed0=50000)
+    corners = torch.zeros((n, 16384, 3), dtype=torch.float32, device="cuda")
+    points = torch.zeros((n, 16384, 2), dtype=torch.int32, device="cuda")
+    edges = torch.zeros((n, NY, NX), dtype=torch.uint8, device="cuda")
+    counts = torch.zeros((3, n), dtype=torch.int64, device="cuda")
+    det.detect_all(frames, corners, points, edges, counts, fast9_threshold=20, suppress_non_max=1)
+    det.ctx.sync()
+    host = synth.frame(50000 + sample, NX, NY)
+    assert np.array_equal(frames[sample].cpu().numpy(), host)          # device and host generators agree
+    ref_h = oracle.harris(host.astype(np.float32))
+    ref_f = oracle.fast9(host, 20, True)
+    ref_e, ref_n = oracle.canny(host)
+    c = counts.cpu().numpy()
+    assert (c[0, sample], c[1, sample], c[2, sample]) == (len(ref_h), len(ref_f), ref_n)
+    assert np.array_equal(bits(corners[sample, :len(ref_h)].cpu().numpy()), bits(ref_h))
+    assert np.array_equal(points[sample, :len(ref_f)].cpu().numpy(), ref_f)
+    assert np.array_equal(edges[sample].cpu().numpy(), ref_e)
+    assert np.all(c > 0)                                               # every frame of the stream produced features
