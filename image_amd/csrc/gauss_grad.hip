@@ -18,7 +18,9 @@
 #ifndef GG_TY
 #define GG_TY 24  // MI355X, 32 x 4K frames, u8: 8 -> 1004 us, 16 -> 757, 24 -> 696, 32 -> 755 (LDS 19 KB: 8 workgroups per CU)
 #endif
+#ifndef GG_PX
 #define GG_PX 4  // outputs per thread and pass (register window of GG_PX + 2R values)
+#endif
 
 struct GaussGradParams {
     const void *in;
@@ -40,7 +42,7 @@ __global__ void __launch_bounds__(256) gauss_grad_tile(GaussGradParams p)
     // f32 frames x0-8 .. x0+71 (float4s); rows y0-2-R .. y0+TY+R
     constexpr int XO = U8 ? 16 : 8, RW = GG_TX + 2 * XO, RH = SH + 2 * R, OFFX = XO - 2 - R;
     static_assert(OFFX >= 0 && SW + 2 * R + OFFX <= RW, "raw tile too narrow for this radius");
-    static_assert(GG_PX == 4 && ((SW + GG_PX - 1) / GG_PX * GG_PX + OFFX + 2 * R + 3) / 4 * 4 <= RW + 4, "dword window reads stay inside the row");
+    static_assert(GG_PX % 4 == 0 && ((SW + GG_PX - 1) / GG_PX * GG_PX + OFFX + 2 * R + 3) / 4 * 4 <= RW + 4, "dword window reads stay inside the row");
     static_assert(OFFX % 4 == 3 || !U8, "byte window of the u8 row pass starts on byte 3 of a dword");
     // raw tile: bytes for u8 frames (a quarter of the LDS: the kernel is occupancy-bound, not bandwidth-bound), floats else
     constexpr int RP = U8 ? RW + 16 : RW + 4;  // row pitch in elements (u8: rows stay 16-byte aligned for ds_write_b128)
