@@ -187,29 +187,40 @@ __global__ void __launch_bounds__(256) surf_colscan_apply(unsigned *__restrict__
 // (get_sum_of_area, integral_image.h:64-96, in uint32 arithmetic = the reference's wrapping int32, appears below in
 // its interior form: br - bl - tr + tl.)
 
-// ---- K17, first octave (step 2, lobes 3..13: three quarters of all level pixels): the integral-image window of a
-// 64 x 16 block of level pixels -- 166 x 70 entries with the widest filter's reach -- is staged in LDS once and serves all
-// six intervals (6 x 4 x 32 look-ups per thread from LDS instead of scattered global loads).  Same arithmetic as
-// surf_pyramid below.
-#define SP0_LX 64
-#define SP0_LY 16
-#define SP0_HL 20  // reach of the widest box (3 * 13 wide) to the left / above, including the "- 1" corner
-#define SP0_HR 19
-#define SP0_W (2 * (SP0_LX - 1) + 1 + SP0_HL + SP0_HR)  // 166
-#define SP0_H (2 * (SP0_LY - 1) + 1 + SP0_HL + SP0_HR)  // 70
-#define SP0_P 168
-// One interval of the first octave for the level pixel whose centre sits at window word `ctr` (row-major, even and odd
-// columns of a row stored apart, the centre column is even).  The lobe is a compile-time constant, so every look-up is a
-// ds_read with an immediate offset from `ctr` -- no address arithmetic.  For a centre at least border_px inside the
-// image all four corners of every box exist (l - 1 >= 3*lobe/2 - 1 > 0), so integral_image.h:64-96's border cases
-// cannot occur here and br - bl - tr + tl is evaluated directly.
-template <int IT>
-__device__ __forceinline__ double sp0_interval(const unsigned *__restrict__ ctr, double area_inv)
+// ---- K17, first octave (step 2: three quarters of all level pixels; the template also instantiates for octave 1, where
+// it loses to the gather kernel): the integral-image window of a block of level
+// pixels, with the widest filter's reach around it, is staged in LDS once and serves all six intervals (6 x 32 look-ups
+// per level pixel from LDS instead of scattered global loads).  Same arithmetic as surf_pyramid below.
+template <int O>
+struct SurfPyrLds {
+    static constexpr int STEP = 2 << O;
+    static constexpr int LX = O == 0 ? 64 : 32, LY = O == 0 ? 16 : 8;  // level pixels per workgroup
+    static constexpr int LOBE_MAX = STEP * SURF_INT + 1;               // hessian_pyramid.h:119-128: lobe = step*(i+1) + 1
+    static constexpr int REACH = (3 * LOBE_MAX) / 2;                   // half of the widest box; "+1" for the l-1 / t-1 corner
+    static constexpr int HL = (REACH + 1 + 3) / 4 * 4;                 // left / top margin: a multiple of 4 (16-byte loads) and of STEP
+    static constexpr int HR = REACH;
+    static constexpr int W = STEP * (LX - 1) + 1 + HL + HR, H = STEP * (LY - 1) + 1 + HL + HR;
+    static constexpr int P = (W + 3) / 4 * 4;                          // row pitch in words, a multiple of 4 and of STEP
+    static constexpr int PX_PER_THREAD = LX * LY / 256;
+    static_assert(HL % STEP == 0 && P % STEP == 0 && (LX * LY) % 256 == 0 && LX <= 64 && 64 % LX == 0, "tile geometry");
+    static_assert(sizeof(unsigned) * (size_t)H * P <= 120 * 1024, "window fits the LDS");
+    // window word of image column x0 + dx: columns are stored by residue mod STEP, so that the lanes of a look-up
+    // (columns STEP*lane + const) sit on consecutive words
+    static __device__ __forceinline__ int col(int dx) { return (dx % STEP) * (P / STEP) + dx / STEP; }
+};
+
+// One interval for the level pixel whose centre sits at window word `ctr` (its column is a multiple of STEP inside the
+// window).  The lobe is a compile-time constant, so every look-up is a ds_read with an immediate offset from `ctr`.
+// For a centre at least border_px inside the image all four corners of every box exist (l - 1 >= 3*lobe/2 - 1 > 0), so
+// integral_image.h:64-96's border cases cannot occur here and br - bl - tr + tl is evaluated directly.
+template <int O, int IT>
+__device__ __forceinline__ double surf_lds_interval(const unsigned *__restrict__ ctr, double area_inv)
 {
-    constexpr int lobe = 2 * (IT + 1) + 1, off = lobe / 2 + 1;  // hessian_pyramid.h:119-128 for octave 0
+    using G = SurfPyrLds<O>;
+    constexpr int lobe = G::STEP * (IT + 1) + 1, off = lobe / 2 + 1;
     auto at = [&](int dy, int dx) __attribute__((always_inline)) -> unsigned {
-        // floor division by 2 of dx for the even/odd split
-        return ctr[dy * SP0_P + (dx & 1) * (SP0_P / 2) + ((dx - (dx & 1)) / 2)];
+        const int m = ((dx % G::STEP) + G::STEP) % G::STEP;  // residue of a possibly negative offset
+        return ctr[dy * G::P + m * (G::P / G::STEP) + (dx - m) / G::STEP];
     };
     auto box = [&](int cx, int cy, int w, int h) __attribute__((always_inline)) -> int {  // centered_rect(cx, cy, w, h), relative to the centre
         const int l = cx - w / 2, t = cy - h / 2, r = l + w - 1, b = t + h - 1;
@@ -227,45 +238,57 @@ __device__ __forceinline__ double sp0_interval(const unsigned *__restrict__ ctr,
     return sign * det;
 }
 
-__global__ void __launch_bounds__(256) surf_pyramid_o0(const unsigned *__restrict__ I, double *__restrict__ pyr, SurfGeom g)
+template <int O>
+__global__ void __launch_bounds__(256) surf_pyramid_lds(const unsigned *__restrict__ I, double *__restrict__ pyr, SurfGeom g)
 {
-    __shared__ __attribute__((aligned(16))) unsigned win[SP0_H * SP0_P];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int lc0 = blockIdx.x * SP0_LX, lr0 = blockIdx.y * SP0_LY;
-    const int x0 = 2 * lc0 - SP0_HL, y0 = 2 * lr0 - SP0_HL;
+    using G = SurfPyrLds<O>;
+    HIP_DYNAMIC_SHARED(unsigned, win)  // [G::H][G::P]
+    const int tid = threadIdx.x;
+    const int lc0 = blockIdx.x * G::LX, lr0 = blockIdx.y * G::LY;
+    const int x0 = G::STEP * lc0 - G::HL, y0 = G::STEP * lr0 - G::HL;
     const int cols = g.cols, rows = g.rows;
-    if (x0 >= 0 && y0 >= 0 && x0 + SP0_P <= cols && y0 + SP0_H <= rows && (cols & 3) == 0) {  // workgroup-uniform; x0 % 4 == 0
-        for (int i = tid; i < SP0_H * (SP0_P / 4); i += 256) {
-            const int ry = i / (SP0_P / 4), q = i - ry * (SP0_P / 4);
+    if (x0 >= 0 && y0 >= 0 && x0 + G::P <= cols && y0 + G::H <= rows && (cols & 3) == 0) {  // workgroup-uniform; x0 % 4 == 0
+        for (int i = tid; i < G::H * (G::P / 4); i += 256) {
+            const int ry = i / (G::P / 4), q = i - ry * (G::P / 4);
             const uint4 v = *reinterpret_cast<const uint4 *>(I + (size_t)(y0 + ry) * cols + x0 + 4 * q);
-            *reinterpret_cast<uint2 *>(&win[ry * SP0_P + 2 * q]) = make_uint2(v.x, v.z);                // columns 4q, 4q+2
-            *reinterpret_cast<uint2 *>(&win[ry * SP0_P + SP0_P / 2 + 2 * q]) = make_uint2(v.y, v.w);  // columns 4q+1, 4q+3
+            unsigned *row = win + ry * G::P;
+            row[G::col(4 * q)] = v.x; row[G::col(4 * q + 1)] = v.y; row[G::col(4 * q + 2)] = v.z; row[G::col(4 * q + 3)] = v.w;
         }
     } else {  // at the image border: clamped coordinates (entries outside the image are never used by a valid centre)
-        for (int i = tid; i < SP0_H * SP0_P; i += 256) {
-            const int ry = i / SP0_P, rx = i - ry * SP0_P;
+        for (int i = tid; i < G::H * G::P; i += 256) {
+            const int ry = i / G::P, rx = i - ry * G::P;
             const int gy = min(max(y0 + ry, 0), rows - 1), gx = min(max(x0 + rx, 0), cols - 1);
-            win[ry * SP0_P + (rx & 1) * (SP0_P / 2) + (rx >> 1)] = I[(size_t)gy * cols + gx];
+            win[ry * G::P + G::col(rx)] = I[(size_t)gy * cols + gx];
         }
     }
     __syncthreads();
-    const int lc = lc0 + lane;
 #pragma unroll
-    for (int k = 0; k < SP0_LY / 4; k++) {
-        const int lr = lr0 + wv * (SP0_LY / 4) + k;
-        const int r = lr * 2, c = lc * 2;
-        if (lr >= g.nr[0] || lc >= g.nc[0]) continue;
-        // the centre (c, r) in the window: column c - x0 = 2*lane + 20 (even), row r - y0
-        const unsigned *ctr = win + (r - y0) * SP0_P + ((c - x0) >> 1);
-        double *dst = pyr + (size_t)lr * g.nc[0] + lc;
-#define SP0_DO(IT)                                                                                                        \
-        {                                                                                                                  \
-            const int bp = g.lev[IT].border_px;                                                                            \
-            if (!(r < bp || r >= rows - bp || c < bp || c >= cols - bp)) dst[g.lev[IT].plane] = sp0_interval<IT>(ctr, g.lev[IT].area_inv); \
+    for (int k = 0; k < G::PX_PER_THREAD; k++) {
+        const int e = tid + 256 * k;  // level pixel of the block: row-major, LX per row
+        const int lr = lr0 + e / G::LX, lc = lc0 + e % G::LX;
+        const int r = lr * G::STEP, c = lc * G::STEP;
+        if (lr >= g.nr[O] || lc >= g.nc[O]) continue;
+        const unsigned *ctr = win + (r - y0) * G::P + (c - x0) / G::STEP;  // (c - x0) is a multiple of STEP: residue plane 0
+        double *dst = pyr + (size_t)lr * g.nc[O] + lc;
+#define SPL_DO(IT)                                                                                        \
+        {                                                                                                  \
+            const SurfLevel &L = g.lev[O * SURF_INT + IT];                                                 \
+            const int bp = L.border_px;                                                                    \
+            if (!(r < bp || r >= rows - bp || c < bp || c >= cols - bp)) dst[L.plane] = surf_lds_interval<O, IT>(ctr, L.area_inv); \
         }
-        SP0_DO(0) SP0_DO(1) SP0_DO(2) SP0_DO(3) SP0_DO(4) SP0_DO(5)
-#undef SP0_DO
+        SPL_DO(0) SPL_DO(1) SPL_DO(2) SPL_DO(3) SPL_DO(4) SPL_DO(5)
+#undef SPL_DO
     }
+}
+
+template <int O>
+static imgfd_status launch_surf_pyramid_lds(imgfd_ctx *ctx, const unsigned *d_I, double *d_pyr, const SurfGeom &g)
+{
+    using G = SurfPyrLds<O>;
+    const size_t lds = sizeof(unsigned) * (size_t)G::H * G::P;
+    IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)surf_pyramid_lds<O>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(surf_pyramid_lds<O>, dim3(ceil_div(g.nc[O], G::LX), ceil_div(g.nr[O], G::LY)), dim3(256), lds, ctx->stream, d_I, d_pyr, g);
+    return IMGFD_OK;
 }
 
 // ---- K17: one launch per octave, blockIdx.z = interval
@@ -420,13 +443,13 @@ imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const Surf
     IMGFD_HIP(ctx, hipMemsetAsync(d.count, 0, sizeof(unsigned long long), ctx->stream));
     for (int o = 0; o < SURF_OCT; o++) {
         if (g.nr[o] < 1 || g.nc[o] < 1) continue;
-        static_assert(SURF_INT == 6, "surf_pyramid_o0 unrolls six intervals");
-        if (o == 0 && g.lev[0].step == 2 && g.lev[0].lobe == 3 && g.lev[SURF_INT - 1].lobe == 13 && (size_t)d.integral % 16 == 0) {
-            // the widest first-octave filter reaches 20 entries left/up and 19 right/down: what surf_pyramid_o0 stages
-            hipLaunchKernelGGL(surf_pyramid_o0, dim3(ceil_div(g.nc[0], SP0_LX), ceil_div(g.nr[0], SP0_LY)), dim3(256), 0, ctx->stream,
-                               d.integral, d.pyr, g);
-            continue;
-        }
+        static_assert(SURF_INT == 6, "surf_pyramid_lds unrolls six intervals");
+        // the LDS kernels assume dlib's level geometry (lobe = step*(i+1) + 1); anything else takes the gather kernel
+        const bool std_geom = g.lev[o * SURF_INT].step == (2 << o) && g.lev[o * SURF_INT].lobe == (2 << o) + 1 &&
+                              g.lev[o * SURF_INT + SURF_INT - 1].lobe == (2 << o) * SURF_INT + 1 && (size_t)d.integral % 16 == 0;
+        if (o == 0 && std_geom) { IMGFD_TRY(launch_surf_pyramid_lds<0>(ctx, d.integral, d.pyr, g)); continue; }
+        // (octave 1 through the same kernel -- an 86 KB window, one workgroup per CU -- measured 219 us against 164 us for
+        // the gather kernel on a 4096^2 tile: not used)
         dim3 grid(ceil_div(g.nc[o], 64), ceil_div(g.nr[o], 4), SURF_INT);
         hipLaunchKernelGGL(surf_pyramid, grid, dim3(256), 0, ctx->stream, d.integral, d.pyr, g, o);
     }
