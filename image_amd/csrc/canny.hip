@@ -770,13 +770,13 @@ static imgfd_status canny_host(imgfd_ctx *ctx, const void *img, int kind, int nx
 imgfd_status imgfd_canny(imgfd_ctx *ctx, const uint8_t *img, int nx, int ny, double s, double low_thr,
                          double high_thr, int accGrad, uint8_t *edges, int64_t *pixels_nonzero)
 {
-    return canny_host(ctx, img, IMGFD_SRC_U8, nx, ny, s, low_thr, high_thr, accGrad, edges, pixels_nonzero);
+    return imgfd_guard(ctx, [&] { return canny_host(ctx, img, IMGFD_SRC_U8, nx, ny, s, low_thr, high_thr, accGrad, edges, pixels_nonzero); });
 }
 
 imgfd_status imgfd_canny_i32(imgfd_ctx *ctx, const int32_t *image, int nx, int ny, double s, double low_thr,
                              double high_thr, int accGrad, uint8_t *edges, int64_t *pixels_nonzero)
 {
-    return canny_host(ctx, image, IMGFD_SRC_I32, nx, ny, s, low_thr, high_thr, accGrad, edges, pixels_nonzero);
+    return imgfd_guard(ctx, [&] { return canny_host(ctx, image, IMGFD_SRC_I32, nx, ny, s, low_thr, high_thr, accGrad, edges, pixels_nonzero); });
 }
 
 imgfd_status imgfd_canny_dev(imgfd_ctx *ctx, const imgfd_frames *fr, double s, double low_thr,
@@ -789,7 +789,7 @@ imgfd_status imgfd_canny_dev(imgfd_ctx *ctx, const imgfd_frames *fr, double s, d
 
 imgfd_status canny_dev_hooked(imgfd_ctx *ctx, const imgfd_frames *fr, double s, double low_thr, double high_thr, int accGrad,
                               uint8_t *d_edges, int64_t *d_counts, const std::function<imgfd_status()> *after_front)
-{
+try {
     if (!ctx || !fr || !fr->d_frames || !d_edges || !d_counts || fr->n_frames < 0 || fr->dtype != 0 || fr->nx < 1 || fr->ny < 1)
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_canny_dev: bad argument (frames must be u8)");
     if (!fr->n_frames) return after_front ? (*after_front)() : IMGFD_OK;
@@ -806,4 +806,8 @@ imgfd_status canny_dev_hooked(imgfd_ctx *ctx, const imgfd_frames *fr, double s, 
                                d_edges + (size_t)f0 * nx * ny, d_counts + f0, f0 == 0 ? after_front : nullptr));
     }
     return IMGFD_OK;
+} catch (const std::bad_alloc &) {
+    return imgfd_fail(ctx, IMGFD_ERR_OOM, "canny_dev_hooked: out of host memory");
+} catch (...) {
+    return imgfd_fail(ctx, IMGFD_ERR_HIP, "canny_dev_hooked: unexpected C++ exception");
 }

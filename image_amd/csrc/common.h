@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <functional>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -64,6 +65,22 @@ static inline imgfd_status imgfd_fail(imgfd_ctx *ctx, imgfd_status s, const char
 {
     if (ctx) ctx->err = msg;
     return s;
+}
+
+// No C++ exception may cross the C boundary: the entry points whose host side allocates (std::vector, std::thread,
+// std::string) run their body through this.
+template <typename F>
+static inline imgfd_status imgfd_guard(imgfd_ctx *ctx, F &&body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        try { if (ctx) ctx->err = "out of host memory"; } catch (...) {}
+        return IMGFD_ERR_OOM;
+    } catch (...) {
+        try { if (ctx) ctx->err = "unexpected C++ exception in the host stage"; } catch (...) {}
+        return IMGFD_ERR_HIP;
+    }
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -16,7 +16,7 @@ extern "C" {
 
 imgfd_status imgfd_detect_dev(imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_stream_params *p, imgfd_corner *d_corners,
                               imgfd_point *d_points, uint8_t *d_edges, int64_t *d_counts)
-{
+try {
     if (!ctx) return IMGFD_ERR_INVALID;
     if (!fr || !p || !d_counts || fr->n_frames < 0 || (!p->harris && !p->fast9 && !p->canny) || (p->harris && p->corner_cap < 0) ||
         (p->fast9 && p->point_cap < 0) || (p->canny && !d_edges) || p->fast9_threshold < 0 || p->fast9_threshold > 255)
@@ -57,6 +57,10 @@ imgfd_status imgfd_detect_dev(imgfd_ctx *ctx, const imgfd_frames *fr, const imgf
     IMGFD_HIP(ctx, hipEventRecord(ctx->ev_join, side->stream));
     IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     return IMGFD_OK;
+} catch (const std::bad_alloc &) {
+    return imgfd_fail(ctx, IMGFD_ERR_OOM, "imgfd_detect_dev: out of host memory");
+} catch (...) {
+    return imgfd_fail(ctx, IMGFD_ERR_HIP, "imgfd_detect_dev: unexpected C++ exception");
 }
 
 }  // extern "C"

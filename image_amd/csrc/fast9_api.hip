@@ -51,13 +51,13 @@ extern "C" {
 imgfd_status imgfd_fast9(imgfd_ctx *ctx, const uint8_t *img, int width, int height, int bytes_per_row,
                          uint8_t threshold, int suppress_non_max, imgfd_points *out)
 {
-    return fast9_host(ctx, img, IMGFD_SRC_U8, width, height, bytes_per_row, threshold, suppress_non_max, out);
+    return imgfd_guard(ctx, [&] { return fast9_host(ctx, img, IMGFD_SRC_U8, width, height, bytes_per_row, threshold, suppress_non_max, out); });
 }
 
 imgfd_status imgfd_fast9_i32(imgfd_ctx *ctx, const int32_t *x, int width, int height, int bytes_per_row,
                              uint8_t threshold, int suppress_non_max, imgfd_points *out)
 {
-    return fast9_host(ctx, x, IMGFD_SRC_I32, width, height, bytes_per_row, threshold, suppress_non_max, out);
+    return imgfd_guard(ctx, [&] { return fast9_host(ctx, x, IMGFD_SRC_I32, width, height, bytes_per_row, threshold, suppress_non_max, out); });
 }
 
 imgfd_status imgfd_fast9_dev(imgfd_ctx *ctx, const imgfd_frames *fr, uint8_t threshold,

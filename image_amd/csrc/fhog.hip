@@ -502,13 +502,13 @@ static imgfd_status fhog_host(imgfd_ctx *ctx, const void *rgb, int kind, int row
 imgfd_status imgfd_fhog(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, int cell_size, int filter_rows_padding,
                         int filter_cols_padding, float **hog, int *hog_nr, int *hog_nc)
 {
-    return fhog_host(ctx, rgb, IMGFD_SRC_U8, rows, cols, cell_size, filter_rows_padding, filter_cols_padding, hog, hog_nr, hog_nc);
+    return imgfd_guard(ctx, [&] { return fhog_host(ctx, rgb, IMGFD_SRC_U8, rows, cols, cell_size, filter_rows_padding, filter_cols_padding, hog, hog_nr, hog_nc); });
 }
 
 imgfd_status imgfd_fhog_i32(imgfd_ctx *ctx, const int32_t *x, int rows, int cols, int cell_size, int filter_rows_padding,
                             int filter_cols_padding, float **hog, int *hog_nr, int *hog_nc)
 {
-    return fhog_host(ctx, x, IMGFD_SRC_I32, rows, cols, cell_size, filter_rows_padding, filter_cols_padding, hog, hog_nr, hog_nc);
+    return imgfd_guard(ctx, [&] { return fhog_host(ctx, x, IMGFD_SRC_I32, rows, cols, cell_size, filter_rows_padding, filter_cols_padding, hog, hog_nr, hog_nc); });
 }
 
 imgfd_status imgfd_fhog_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, int rows, int cols, size_t frame_stride_bytes,

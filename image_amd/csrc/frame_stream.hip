@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -68,11 +69,17 @@ void staged_copy(uint8_t *dst, const uint8_t *src, size_t frame_bytes, size_t st
     }
     std::vector<std::thread> th;
     // split every frame into nt pieces so the split also helps a single large frame
-    for (int t = 0; t < nt; t++)
-        th.emplace_back([=] {
-            const size_t a = frame_bytes * (size_t)t / nt, b = frame_bytes * (size_t)(t + 1) / nt;
-            for (int f = 0; f < n; f++) memcpy(dst + (size_t)f * frame_bytes + a, src + (size_t)f * stride + a, b - a);
-        });
+    auto piece = [=](int t) {
+        const size_t a = frame_bytes * (size_t)t / nt, b = frame_bytes * (size_t)(t + 1) / nt;
+        for (int f = 0; f < n; f++) memcpy(dst + (size_t)f * frame_bytes + a, src + (size_t)f * stride + a, b - a);
+    };
+    for (int t = 0; t < nt; t++) {
+        try {
+            th.emplace_back(piece, t);
+        } catch (...) {  // thread limit reached: copy this piece here
+            piece(t);
+        }
+    }
     for (auto &t : th) t.join();
 }
 
@@ -177,7 +184,8 @@ imgfd_status imgfd_stream_open(imgfd_ctx *ctx, int nx, int ny, int batch_frames,
     if (!params->harris && !params->fast9 && !params->canny)
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_stream_open: no detector selected");
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
-    imgfd_stream *st = new imgfd_stream();
+    imgfd_stream *st = new (std::nothrow) imgfd_stream();
+    if (!st) return imgfd_fail(ctx, IMGFD_ERR_OOM, "imgfd_stream_open: out of memory");
     st->ctx = ctx;
     st->nx = nx;
     st->ny = ny;
@@ -240,7 +248,7 @@ imgfd_status imgfd_stream_submit(imgfd_stream *st, const uint8_t *frames, int n_
     const int device = ctx->device;
     hipStream_t copy = st->copy;
     Slot *sp = &s;
-    s.up = std::thread([=] {
+    auto upload = [=] {
         hipError_t e = hipSetDevice(device);
         if (e == hipSuccess) {
             if (pinned) {
@@ -256,7 +264,12 @@ imgfd_status imgfd_stream_submit(imgfd_stream *st, const uint8_t *frames, int n_
         }
         if (e == hipSuccess) e = hipEventRecord(sp->uploaded, copy);
         sp->up_err = e;
-    });
+    };
+    try {  // no C++ exception may cross the C boundary: without a helper thread the upload runs on the caller's
+        s.up = std::thread(upload);
+    } catch (...) {
+        upload();
+    }
     st->submitted++;
     st->frames_seen += n_frames;
     // the batch before this one goes into the kernels while this one is on the bus

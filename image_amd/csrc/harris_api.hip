@@ -380,8 +380,8 @@ imgfd_status imgfd_harris(imgfd_ctx *ctx, const float *img, int nx, int ny, floa
                           int Nselect, int measure, int Nscales, int precision, int cells, int verbose,
                           imgfd_corners *out)
 {
-    return harris_host(ctx, img, IMGFD_SRC_F32, nx, ny, k, sigma_d, sigma_i, threshold, gaussian, gradient, strategy, Nselect,
-                       measure, Nscales, precision, cells, verbose, out);
+    return imgfd_guard(ctx, [&] { return harris_host(ctx, img, IMGFD_SRC_F32, nx, ny, k, sigma_d, sigma_i, threshold, gaussian, gradient, strategy, Nselect,
+                       measure, Nscales, precision, cells, verbose, out); });
 }
 
 imgfd_status imgfd_harris_f64(imgfd_ctx *ctx, const double *x, int nx, int ny, float k, float sigma_d,
@@ -389,8 +389,8 @@ imgfd_status imgfd_harris_f64(imgfd_ctx *ctx, const double *x, int nx, int ny, f
                               int Nselect, int measure, int Nscales, int precision, int cells, int verbose,
                               imgfd_corners *out)
 {
-    return harris_host(ctx, x, IMGFD_SRC_F64, nx, ny, k, sigma_d, sigma_i, threshold, gaussian, gradient, strategy, Nselect,
-                       measure, Nscales, precision, cells, verbose, out);
+    return imgfd_guard(ctx, [&] { return harris_host(ctx, x, IMGFD_SRC_F64, nx, ny, k, sigma_d, sigma_i, threshold, gaussian, gradient, strategy, Nselect,
+                       measure, Nscales, precision, cells, verbose, out); });
 }
 
 imgfd_status imgfd_harris_dev(imgfd_ctx *ctx, const imgfd_frames *fr, float k, float sigma_d,

@@ -608,7 +608,7 @@ imgfd_status imgfd_k_surf_integral(imgfd_ctx *ctx, const uint8_t *rgb, int rows,
 
 imgfd_status imgfd_surf_interest_points(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, double detection_threshold,
                                         double *points, int64_t cap, int64_t *n)
-{
+try {
     if (!ctx) return IMGFD_ERR_INVALID;
     if (!rgb || !n || rows < 0 || cols < 0 || cap < 0 || (cap && !points) || !(detection_threshold >= 0))
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_surf_interest_points: bad argument");
@@ -620,6 +620,10 @@ imgfd_status imgfd_surf_interest_points(imgfd_ctx *ctx, const uint8_t *rgb, int 
         o[0] = pts[k].x; o[1] = pts[k].y; o[2] = pts[k].scale; o[3] = pts[k].score; o[4] = pts[k].laplacian;
     }
     return IMGFD_OK;
+} catch (const std::bad_alloc &) {
+    return imgfd_fail(ctx, IMGFD_ERR_OOM, "imgfd_surf_interest_points: out of host memory");
+} catch (...) {
+    return imgfd_fail(ctx, IMGFD_ERR_HIP, "imgfd_surf_interest_points: unexpected C++ exception");
 }
 
 imgfd_status imgfd_surf_points_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, int rows, int cols,
@@ -652,7 +656,7 @@ imgfd_status imgfd_surf_points_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_f
 
 imgfd_status imgfd_surf_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, int rows, int cols, size_t frame_stride_bytes,
                             long max_points, double detection_threshold, double *d_features, int64_t cap, int64_t *d_counts)
-{
+try {
     if (!ctx) return IMGFD_ERR_INVALID;
     if (!d_rgb || !d_features || !d_counts || n_frames < 0 || rows < 1 || cols < 1 || cap < 1 || !(max_points > 0) ||
         !(detection_threshold >= 0))
@@ -717,6 +721,10 @@ imgfd_status imgfd_surf_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, 
     IMGFD_HIP(ctx, hipMemcpyAsync(d_counts, counts.data(), sizeof(int64_t) * (size_t)n_frames, hipMemcpyHostToDevice, ctx->stream));
     IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return IMGFD_OK;
+} catch (const std::bad_alloc &) {
+    return imgfd_fail(ctx, IMGFD_ERR_OOM, "imgfd_surf_dev: out of host memory");
+} catch (...) {
+    return imgfd_fail(ctx, IMGFD_ERR_HIP, "imgfd_surf_dev: unexpected C++ exception");
 }
 
 static imgfd_status surf_host(imgfd_ctx *ctx, const void *rgb, int kind, int rows, int cols, long max_points,
@@ -754,13 +762,13 @@ static imgfd_status surf_host(imgfd_ctx *ctx, const void *rgb, int kind, int row
 imgfd_status imgfd_surf(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, long max_points, double detection_threshold,
                         imgfd_surf_out *out)
 {
-    return surf_host(ctx, rgb, IMGFD_SRC_U8, rows, cols, max_points, detection_threshold, out);
+    return imgfd_guard(ctx, [&] { return surf_host(ctx, rgb, IMGFD_SRC_U8, rows, cols, max_points, detection_threshold, out); });
 }
 
 imgfd_status imgfd_surf_i32(imgfd_ctx *ctx, const int32_t *x, int rows, int cols, long max_points, double detection_threshold,
                             imgfd_surf_out *out)
 {
-    return surf_host(ctx, x, IMGFD_SRC_I32, rows, cols, max_points, detection_threshold, out);
+    return imgfd_guard(ctx, [&] { return surf_host(ctx, x, IMGFD_SRC_I32, rows, cols, max_points, detection_threshold, out); });
 }
 
 }  // extern "C"
