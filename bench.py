@@ -1,105 +1,574 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X feature-detection backend.
+"""bench.py -- benchmarks of the MI355X feature-detection backend (driver contract: see the task description).
 
-Metric (BASELINE.json): Mpixels/s of Harris + FAST-9 + Canny on 3840x2160 gray frames.
-A *step* is one pass of the hot path -- image_harris() defaults, FAST-9 (threshold 20, non-max
-suppression) and Canny (s=2, 3/10, accGrad) -- over one batch of synthetic frames that is already
-resident in HBM (generated on the device by imgfd_synth_frames) when the timed region starts.
-N>1: one process per GPU (torchrun), every rank owns its own frames (weak scaling, no data-path
-collective); RCCL only sums the per-rank feature counts after the timed region.
+Default (no --config): BASELINE.json's metric, Mpixels/s of Harris + FAST-9 + Canny on 3840x2160 gray frames.
+A *step* is `--inner` passes of the hot path -- image_harris() defaults, FAST-9 (threshold 20, non-max suppression) and
+Canny (s=2, 3/10, accGrad) -- over one batch of `--batch` synthetic frames that is already resident in HBM (generated on
+the device by imgfd_synth_frames) when the timed region starts.
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task description), including
-  roofline     -- the Harris structure-tensor kernel, timed in-pipeline with HIP events
+  --config 2   configs[1] (+ Canny): the default above; `--batch 1` gives the literal single-frame case
+  --config 3   configs[2]: image_canny_edge_detector() on a 1024-frame 1920x1080 batch
+  --config 4   configs[3]: image.dlib fHOG + SURF on 4096x4096 RGB tiles, batch 256
+  --config 5   configs[4]: 10 000-frame 3840x2160 stream, Harris + Canny, sharded over the ranks (frames pre-staged in
+               HBM, per-frame counts gathered, a sample re-checked against the oracle)
+
+N>1: `--gpus N` without WORLD_SIZE in the environment launches N ranks itself (one process per GPU, rank r on GPU r);
+under torchrun (WORLD_SIZE set) the process is one of the ranks.  Every rank owns its own frames (weak scaling, no
+data-path collective); RCCL only gathers feature counts after the timed region and takes the max of the elapsed time.
+
+Prints ONE JSON line on rank 0, including
+  roofline     -- the Harris structure-tensor kernel (20 algorithmic B/px: reads Ix, Iy, writes A, B, C), timed with
+                  HIP events in this very run; configs 3/4 report the whole-function entries of SURVEY.md 8(d)
   cpu_baseline -- the reference's own code (oracle/_ref) timed on this host, rank 0, N=1 only
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-NX, NY = 3840, 2160
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
-MEASURED_COPY_GBS = 6300.0      # float4 device-to-device copy on this part (profiles/r01/ubench.txt; MI355X_MICROARCH.md quotes the same)
+MEASURED_COPY_GBS = 6300.0      # float4 device-to-device copy on this part (profiles/r01/ubench.txt; the guide quotes the same)
+F64_LANE_OPS_PER_S = 34.0e12    # sustained f64 VALU lane-op/s of the add+fmac pattern at 8 waves/SIMD (profiles/r01/ubench2.txt)
 TENSOR_BYTES_PER_PX = 20        # read Ix,Iy (8 B), write A,B,C (12 B)
+TENSOR_F64_OPS_PER_PX = 90      # 2 passes x 3 planes x (1 mul + 7 add + 7 fma), the reference's own arithmetic
 
 
-def cpu_baseline(frames_host, gpu_frame0=None):
-    """Reference CPU path on this host: Harris = reference sources + OpenMP on all cores, FAST-9 =
-    reference f9.cpp (single-threaded code), Canny = oracle restatement (the reference's blur needs FFTW3, absent; the restatement is pinned against the
-    reference sources over a stand-in DFT in tests/test_oracle.py, but that build's O(n^3) DFT is no timing baseline).
-    gpu_frame0: the device results for the same frame (corner list, FAST-9 list, edge map): the CPU outputs computed
-    here anyway double as the metric's "feature-coordinate match vs CPU" check."""
+# ------------------------------------------------------------------------------------------------ CPU legs
+def _best(fn, reps=2):
+    fn()  # warm-up (first run of a binary is several times slower in a VM)
+    ts = []
+    for _ in range(reps):
+        t = time.perf_counter(); fn(); ts.append(time.perf_counter() - t)
+    return min(ts)
+
+
+def _avail_cores():
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+
+def cpu_harris_fast9_canny(img, want_fast9=True, gpu_frame0=None):
+    """Reference CPU path on this host for one gray frame: Harris = reference sources + OpenMP (best of a few team
+    sizes), FAST-9 = reference f9.cpp (single-threaded code), Canny = oracle restatement (the reference's blur needs
+    FFTW3, absent here; the restatement is pinned against the reference sources over a stand-in DFT in
+    tests/test_oracle.py, but that build's O(n^3) DFT is no timing baseline).
+    gpu_frame0: the device results for the same frame: the CPU outputs computed here double as the metric's
+    "feature-coordinate match vs CPU" check."""
     import numpy as np
 
     import oracle
-    img = frames_host[0]
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ny, nx = img.shape
+    avail = _avail_cores()
     out = {"unit": "Mpixels/s"}
     px = img.size
     have_ref = oracle.have_ref("harris") and oracle.have_ref("f9")
     f32 = img.astype(np.float32)
-
-    def best(fn, reps=2):
-        fn()  # warm-up (first run of a binary is several times slower in a VM)
-        ts = []
-        for _ in range(reps):
-            t = time.perf_counter(); fn(); ts.append(time.perf_counter() - t)
-        return min(ts)
-
     cores = 1
+    t_f = 0.0
     if have_ref:
-        # the reference's OpenMP loops stop scaling well before a big host's core count: take the best of a few team sizes
         t_h = None
         for th in sorted({min(avail, 64), min(avail, 32), min(avail, 16), min(avail, 8)}):
-            t = best(lambda: oracle.ref_harris(f32, threads=th), reps=1)
+            t = _best(lambda: oracle.ref_harris(f32, threads=th), reps=1)
             if t_h is None or t < t_h:
                 t_h, cores = t, th
-        t_h1 = best(lambda: oracle.ref_harris(f32, threads=1), reps=1)   # state the single-thread time too
-        t_f = best(lambda: oracle.ref_fast9(img, 20, True))
+        t_h1 = _best(lambda: oracle.ref_harris(f32, threads=1), reps=1)   # state the single-thread time too
+        if want_fast9:
+            t_f = _best(lambda: oracle.ref_fast9(img, 20, True))
         kind = "reference"
     else:
-        t_h = best(lambda: oracle.harris(f32))
-        t_f = best(lambda: oracle.fast9(img, 20, True))
+        t_h = _best(lambda: oracle.harris(f32))
+        if want_fast9:
+            t_f = _best(lambda: oracle.fast9(img, 20, True))
         kind = "port"
-    parts = {"harris_ms": round(1e3 * t_h, 2), "fast9_ms": round(1e3 * t_f, 2)}
+    parts = {"harris_ms": round(1e3 * t_h, 2)}
+    if want_fast9:
+        parts["fast9_ms"] = round(1e3 * t_f, 2)
     if have_ref:
         parts["harris_1_thread_ms"] = round(1e3 * t_h1, 2)
-    t_c = None
-    try:
-        t_c = best(lambda: oracle.canny(img), reps=1)
-        parts["canny_ms"] = round(1e3 * t_c, 2)
-    except Exception:
-        pass
+    t_c = _best(lambda: oracle.canny(img), reps=1)
+    parts["canny_restatement_ms"] = round(1e3 * t_c, 2)
     if gpu_frame0 is not None:
         rh = oracle.ref_harris(f32, threads=cores) if have_ref else oracle.harris(f32)
-        rf = oracle.ref_fast9(img, 20, True) if have_ref else oracle.fast9(img, 20, True)
         gh, gf, ge = gpu_frame0
         same_h = gh.shape == rh.shape and bool(np.array_equal(gh[:, :2], rh[:, :2]))
         par = {"harris_corners": int(len(rh)), "harris_coordinates_match": same_h,
-               "harris_strength_max_rel_err": float(np.max(np.abs(gh[:, 2] - rh[:, 2]) / np.maximum(1.0, np.abs(rh[:, 2])))) if same_h and len(rh) else None,
-               "fast9_corners": int(len(rf)), "fast9_coordinates_match": bool(gf.shape == rf.shape and np.array_equal(gf, rf))}
-        if t_c is not None:
-            re_, rn = oracle.canny(img)
-            par.update({"canny_edge_pixels": int(rn), "canny_mismatching_pixels": int(np.count_nonzero(ge != re_))})
+               "harris_strength_max_rel_err": float(np.max(np.abs(gh[:, 2] - rh[:, 2]) / np.maximum(1.0, np.abs(rh[:, 2])))) if same_h and len(rh) else None}
+        if gf is not None:
+            rf = oracle.ref_fast9(img, 20, True) if have_ref else oracle.fast9(img, 20, True)
+            par.update({"fast9_corners": int(len(rf)), "fast9_coordinates_match": bool(gf.shape == rf.shape and np.array_equal(gf, rf))})
+        re_, rn = oracle.canny(img)
+        par.update({"canny_edge_pixels": int(rn), "canny_mismatching_pixels": int(np.count_nonzero(ge != re_))})
         out["parity_frame0"] = par
-    total = t_h + t_f + (t_c or 0.0)
+    total = t_h + t_f + t_c
     out.update({"value": round(px / total / 1e6, 3), "kind": kind, "cores": cores,
-                "sample": f"1 frame {NX}x{NY}, best of 2 after warm-up; Harris: reference src + OpenMP x{cores} (best of 8/16/32/64 threads, {avail} available); "
-                          "FAST-9: reference f9.cpp (1 thread); Canny: oracle restatement (pinned against the reference sources), 1 thread "
-                          "(reference needs FFTW3)", "parts": parts})
+                "reference_only": {"value": round(px / (t_h + t_f) / 1e6, 3), "unit": "Mpixels/s",
+                                   "what": "Harris" + (" + FAST-9" if want_fast9 else "") + ": the reference's own sources only (no restated leg)"},
+                "sample": f"1 frame {nx}x{ny}, best of 2 after warm-up; Harris: reference src + OpenMP x{cores} (best of 8/16/32/64 threads, "
+                          f"{avail} available); " + ("FAST-9: reference f9.cpp (1 thread); " if want_fast9 else "") +
+                          "Canny: oracle restatement (pinned against the reference sources), 1 thread (reference needs FFTW3)",
+                "parts": parts})
     return out
 
 
-def main():
+# ------------------------------------------------------------------------------------------------ workloads
+class Workload:
+    """One configuration of BASELINE.json: resident inputs, a step, counts, parity sample, roofline, CPU leg."""
+    metric = ""
+    unit = "Mpixels/s"
+
+    def __init__(self, args, det, rank, world):
+        self.args, self.det, self.rank, self.world = args, det, rank, world
+
+    def default_steps(self):
+        return 20
+
+
+class Detect4K(Workload):
+    """configs[1] + Canny (the metric's workload), or configs[4] (stream=True: Harris + Canny, every frame once)."""
+    NX, NY = 3840, 2160
+
+    def __init__(self, args, det, rank, world, stream_mode=False):
+        super().__init__(args, det, rank, world)
+        self.stream_mode = stream_mode
+        self.metric = "Mpixels/s Harris+FAST9+Canny on 3840x2160 gray" if not stream_mode else \
+            "Mpixels/s Harris+Canny on a 3840x2160 synthetic stream (configs[4])"
+
+    def prepare(self):
+        import torch
+
+        from image_amd import stream
+        a, det = self.args, self.det
+        NX, NY = self.NX, self.NY
+        self.B = B = a.batch if a.batch else 32
+        if self.stream_mode:
+            self.first, self.n_local = stream.rank_block(a.frames, self.rank, self.world)
+            self.inner = 1
+        else:
+            self.first, self.n_local = stream.rank_block(B * self.world, self.rank, self.world)  # weak scaling: B frames per rank
+            self.inner = a.inner
+        gen = 64
+        self.frames = torch.empty((self.n_local, NY, NX), dtype=torch.uint8, device="cuda")
+        for f0 in range(0, self.n_local, gen):   # pre-stage every frame of this rank in HBM (untimed)
+            n = min(gen, self.n_local - f0)
+            self.frames[f0:f0 + n] = det.synth_frames(n, NX, NY, seed0=stream.frame_seed(50000, self.first + f0))
+        self.cap_h, self.cap_f = (0, 0) if self.stream_mode else (65536, 262144)
+        dev = "cuda"
+        self.corners = torch.empty((B, max(1, self.cap_h), 3), dtype=torch.float32, device=dev)
+        self.points = torch.empty((B, max(1, self.cap_f), 2), dtype=torch.int32, device=dev)
+        self.edges = torch.empty((B, NY, NX), dtype=torch.uint8, device=dev)
+        self.counts = torch.zeros((3, B), dtype=torch.int64, device=dev)
+        self.frame_counts = torch.zeros((2, max(1, self.n_local)), dtype=torch.int64, device=dev)  # stream mode: harris, canny per frame
+        self.cursor = 0
+        self._counts_n = {}
+        self.params = dict(fast9_threshold=20, suppress_non_max=1)
+        if self.stream_mode:
+            self.params.update(fast9=0)
+
+    def default_steps(self):
+        return -(-self.n_local // self.B) if self.stream_mode else 20
+
+    def px_per_step(self):
+        return self.inner * self.B * self.NX * self.NY   # stream mode: the last batch may be short; total handled in px_total
+
+    def px_total(self, steps):
+        if self.stream_mode:
+            return min(self.n_local, steps * self.B) * self.NX * self.NY
+        return steps * self.px_per_step()
+
+    def reset(self):
+        self.cursor = 0
+
+    def step(self):
+        det = self.det
+        if self.stream_mode:
+            f0 = self.cursor
+            n = min(self.B, self.n_local - f0)
+            if n <= 0:
+                return
+            c = self._counts_n.get(n)
+            if c is None:
+                import torch
+                c = self._counts_n[n] = torch.zeros((3, n), dtype=torch.int64, device="cuda")
+            det.detect_all(self.frames[f0:f0 + n], self.corners, self.points, self.edges[:n], c, corner_cap=self.cap_h,
+                           point_cap=self.cap_f, **self.params)
+            self.frame_counts[0, f0:f0 + n] = c[0]
+            self.frame_counts[1, f0:f0 + n] = c[2]
+            self.cursor += n
+            return
+        for _ in range(self.inner):
+            if self.args.no_overlap:
+                det.harris(self.frames, out=(self.corners, self.counts[0]))
+                det.fast9(self.frames, threshold=20, suppress_non_max=True, out=(self.points, self.counts[1]))
+                det.canny(self.frames, out=(self.edges, self.counts[2]))
+            else:
+                det.detect_all(self.frames, self.corners, self.points, self.edges, self.counts, **self.params)
+
+    def count_vector(self):
+        """int64 totals of this rank: harris corners, fast9 corners, canny edge pixels"""
+        import torch
+        if self.stream_mode:
+            z = torch.zeros((), dtype=torch.int64, device="cuda")
+            return torch.stack([self.frame_counts[0, :self.cursor].sum(), z, self.frame_counts[1, :self.cursor].sum()])
+        return self.counts.sum(dim=1)
+
+    def describe(self, counts):
+        a = self.args
+        c = {"workload": ("configs[1]+Canny: image_harris() defaults + FAST-9 thr 20 nonmax + Canny s=2 3/10 accGrad" if not self.stream_mode else
+                          f"configs[4]: {a.frames}-frame stream, image_harris() defaults + Canny s=2 3/10 accGrad, contiguous blocks of frames per rank") +
+             f" on {self.NX}x{self.NY} u8 frames resident in HBM",
+             "frames_per_step_per_gpu": self.B, "passes_per_step": self.inner,
+             "schedule": "one stream" if a.no_overlap else "two streams (imgfd_detect_dev)",
+             "fir_mode": "fused-accumulate" if a.fir_mode else "strict",
+             "feature_counts": {"harris_corners": int(counts[0]), "fast9_corners": int(counts[1]), "canny_edge_pixels": int(counts[2])}}
+        if self.stream_mode:
+            c["frames_total"] = a.frames
+            c["frames_this_rank"] = self.n_local
+        return c
+
+    # ---- roofline: the 20 B/px structure-tensor kernel, timed in this run on this batch's own gradients
+    def roofline(self, k3_pipe_us, k3_pipe_n, steps):
+        import torch
+        det, NX, NY = self.det, self.NX, self.NY
+        B = min(self.B, self.n_local)
+        ix = torch.empty((B, NY, NX), dtype=torch.float32, device="cuda")
+        iy = torch.empty_like(ix)
+        for f in range(B):
+            det.gradients_of(self.frames[f], ix[f], iy[f])
+        us = det.time_structure_tensor_batch(ix, iy, warmup=3, iters=max(10, min(40, steps)))
+        del ix, iy
+        k3_bytes = TENSOR_BYTES_PER_PX * NX * NY * B
+        achieved = k3_bytes / (us * 1e-6) / 1e9
+        f64_floor_us = TENSOR_F64_OPS_PER_PX * NX * NY * B / F64_LANE_OPS_PER_S * 1e6
+        r = {"kernel": "fir_tensor (Harris structure-tensor pass: Ix,Iy -> A,B,C)", "bound": "f64-valu",
+             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+             "frac_of_measured_copy": round(achieved / MEASURED_COPY_GBS, 4), "measured_copy_GBps": MEASURED_COPY_GBS,
+             "frac_of_f64_issue_roof": round(f64_floor_us / us, 4),
+             "f64_issue_roof": f"{TENSOR_F64_OPS_PER_PX} f64 FIR lane-ops/px (the reference's double accumulation) at the {F64_LANE_OPS_PER_S / 1e12:.0f} T lane-op/s "
+                               "the vector pipe sustains for add+fmac chains (profiles/r01/ubench2.txt): the kernel is bound by f64 issue, HBM second",
+             "avg_launch_us": round(us, 2), "frames_per_launch": B, "algorithmic_bytes_per_launch": k3_bytes,
+             "timed": "HIP events on the context's stream around back-to-back launches of the stage doorway on this batch's gradients, after the timed region"}
+        tr = traffic_for("fir_tensor", B)
+        r["traffic"], r["traffic_unit"] = tr, "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/k3_traffic.json; refreshed by scripts/gpu_pmc_k3.sh)"
+        if k3_pipe_n:
+            per = k3_pipe_us / k3_pipe_n
+            launches_per_pass = max(1, round(k3_pipe_n / max(1, steps * self.inner)))
+            r["in_pipeline"] = {"kernel": det.tensor_kernel_name(), "avg_launch_us": round(per, 2), "launches": k3_pipe_n,
+                                "frames_per_launch": self.B // launches_per_pass,
+                                "note": "the structure-tensor launches of the timed region itself (HIP events on the context's stream)"}
+        return r
+
+    def parity_and_cpu(self, want_cpu):
+        """frame 0 (default) or a 1 % sample of this rank's frames (stream mode) against the CPU path"""
+        import numpy as np
+
+        from image_amd import stream, synth
+        if not self.stream_mode:
+            host = synth.frame(stream.frame_seed(50000, self.first), self.NX, self.NY)   # host twin of device frame 0
+            assert np.array_equal(self.frames[0].cpu().numpy(), host), "device and host frame generators diverged"
+            n_h, n_f = int(self.counts[0, 0]), int(self.counts[1, 0])
+            gpu0 = (self.corners[0, :min(n_h, self.cap_h)].cpu().numpy(), self.points[0, :min(n_f, self.cap_f)].cpu().numpy(),
+                    self.edges[0].cpu().numpy())
+            return cpu_harris_fast9_canny(host, True, gpu0) if want_cpu else None
+        return stream_sample_check(self, want_cpu)
+
+
+def _oracle_frame(job):
+    """worker of the sampled parity check (its own process): oracle outputs of one synthetic frame"""
+    seed, nx, ny = job
+    import numpy as np
+
+    import oracle
+    from image_amd import synth
+    img = synth.frame(seed, nx, ny)
+    h = oracle.ref_harris(img.astype(np.float32), threads=1) if oracle.have_ref("harris") else oracle.harris(img.astype(np.float32))
+    e, n = oracle.canny(img)
+    return h, np.packbits(e != 0), int(n)
+
+
+def stream_sample_check(wl, want_cpu):
+    """configs[4]: re-run 1 % of this rank's frames through the device path with full outputs and compare corner lists,
+    strengths and edge maps with the oracle (one process per frame on the host's cores)."""
+    import concurrent.futures as cf
+
+    import numpy as np
+    import torch
+
+    from image_amd import stream
+    n_s = min(wl.cursor, max(1, round(0.01 * wl.cursor)), wl.args.max_parity_frames)
+    if n_s <= 0:
+        return None
+    idx = np.unique(np.linspace(0, wl.cursor - 1, n_s).round().astype(int))
+    cap = 65536
+    res = {"frames_checked": int(len(idx)), "frame_indices": [int(wl.first + i) for i in idx[:8]] + (["..."] if len(idx) > 8 else [])}
+    t0 = time.perf_counter()
+    with cf.ProcessPoolExecutor(max_workers=min(len(idx), max(1, _avail_cores() // 2), 48)) as ex:
+        futs = [ex.submit(_oracle_frame, (stream.frame_seed(50000, wl.first + int(i)), wl.NX, wl.NY)) for i in idx]
+        # the device side of the sample, while the host works
+        corners = torch.empty((1, cap, 3), dtype=torch.float32, device="cuda")
+        edges = torch.empty((1, wl.NY, wl.NX), dtype=torch.uint8, device="cuda")
+        got = []
+        for i in idx:
+            (c, n) = wl.det.harris(wl.frames[int(i):int(i) + 1], out=(corners, torch.zeros(1, dtype=torch.int64, device="cuda")))
+            (e, m) = wl.det.canny(wl.frames[int(i):int(i) + 1], out=(edges, torch.zeros(1, dtype=torch.int64, device="cuda")))
+            got.append((c[0, :int(n[0])].cpu().numpy(), np.packbits(e[0].cpu().numpy() != 0), int(m[0]),
+                        int(wl.frame_counts[0, int(i)]), int(wl.frame_counts[1, int(i)])))
+        bad_xy = bad_R = bad_edges = bad_counts = 0
+        worst_rel = 0.0
+        for (gc, ge, gm, sc_h, sc_c), f in zip(got, futs):
+            rh, re_, rn = f.result()
+            if gc.shape != rh.shape or not np.array_equal(gc[:, :2], rh[:, :2]):
+                bad_xy += 1
+            elif len(rh):
+                rel = float(np.max(np.abs(gc[:, 2] - rh[:, 2]) / np.maximum(1.0, np.abs(rh[:, 2]))))
+                worst_rel = max(worst_rel, rel)
+                bad_R += rel > 1e-4
+            bad_edges += int(np.count_nonzero(np.unpackbits(ge ^ re_)))
+            bad_counts += (sc_h != len(rh)) + (sc_c != rn and gm != sc_c)
+    res.update({"frames_with_different_corner_coordinates": bad_xy, "frames_with_strength_rel_err_above_1e-4": int(bad_R),
+                "harris_strength_max_rel_err": worst_rel, "canny_mismatching_pixels_total": bad_edges,
+                "frames_whose_streamed_counts_differ": int(bad_counts), "oracle_seconds": round(time.perf_counter() - t0, 1)})
+    out = {"parity_sample": res}
+    if want_cpu:
+        from image_amd import synth
+        cpu = cpu_harris_fast9_canny(synth.frame(stream.frame_seed(50000, wl.first), wl.NX, wl.NY), want_fast9=False)
+        out.update(cpu)
+    return out
+
+
+class Canny1080p(Workload):
+    """configs[2]: image_canny_edge_detector() on a 1024-frame 1920x1080 batch."""
+    NX, NY = 1920, 1080
+    metric = "Mpixels/s image_canny_edge_detector() on a 1920x1080 batch (configs[2])"
+
+    def prepare(self):
+        import torch
+
+        from image_amd import stream
+        a, det = self.args, self.det
+        self.F = a.batch if a.batch else 1024
+        self.first, _ = stream.rank_block(self.F * self.world, self.rank, self.world)
+        self.frames = torch.empty((self.F, self.NY, self.NX), dtype=torch.uint8, device="cuda")
+        for f0 in range(0, self.F, 128):
+            n = min(128, self.F - f0)
+            self.frames[f0:f0 + n] = det.synth_frames(n, self.NX, self.NY, seed0=stream.frame_seed(1000, self.first + f0))
+        self.edges = torch.empty_like(self.frames)
+        self.counts = torch.zeros((self.F,), dtype=torch.int64, device="cuda")
+        self.inner = 1
+
+    def px_per_step(self):
+        return self.F * self.NX * self.NY
+
+    def px_total(self, steps):
+        return steps * self.px_per_step()
+
+    def reset(self):
+        pass
+
+    def step(self):
+        self.det.canny(self.frames, out=(self.edges, self.counts))
+
+    def count_vector(self):
+        import torch
+        z = torch.zeros((), dtype=torch.int64, device="cuda")
+        return torch.stack([z, z, self.counts.sum()])
+
+    def describe(self, counts):
+        return {"workload": f"configs[2]: image_canny_edge_detector() s=2 3/10 accGrad on {self.F} frames {self.NX}x{self.NY} u8 resident in HBM, one imgfd_canny_dev call per step",
+                "frames_per_step_per_gpu": self.F, "passes_per_step": 1, "feature_counts": {"canny_edge_pixels": int(counts[2])}}
+
+    def roofline(self, k3_us, k3_n, steps, ms_per_step=None):
+        alg = 2 * self.px_per_step()   # Canny compulsory traffic, u8 in + u8 edge map out
+        ach = alg / (ms_per_step * 1e-3) / 1e9
+        return {"kernel": "imgfd_canny_dev (whole function: blur, gradient+NMS, hysteresis, expansion)", "bound": "f64-valu",
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_step": alg, "traffic": None,
+                "note": "2 B/px compulsory traffic over the whole function's time; the f64 blur and gradient arithmetic of the reference bound it, not HBM"}
+
+    def parity_and_cpu(self, want_cpu):
+        import numpy as np
+
+        import oracle
+        from image_amd import stream, synth
+        idx = sorted({0, self.F // 2, self.F - 1})[: self.args.max_parity_frames]
+        mism = 0
+        cnt_ok = True
+        ts = []
+        for i in idx:
+            img = synth.frame(stream.frame_seed(1000, self.first + i), self.NX, self.NY)
+            t = time.perf_counter(); e, n = oracle.canny(img); ts.append(time.perf_counter() - t)
+            mism += int(np.count_nonzero(self.edges[i].cpu().numpy() != e))
+            cnt_ok &= int(self.counts[i]) == n
+        out = {"parity_sample": {"frames_checked": len(idx), "canny_mismatching_pixels_total": mism, "pixels_nonzero_equal": bool(cnt_ok)}}
+        if want_cpu:
+            t = min(ts)
+            out.update({"value": round(self.NX * self.NY / t / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+                        "sample": f"{len(idx)} frames {self.NX}x{self.NY}, best single frame; oracle restatement of canny_edge_detector() "
+                                  "(direct separable blur instead of FFTW3, which is absent), 1 thread as the reference is"})
+        return out
+
+
+class DlibTiles(Workload):
+    """configs[3]: image_fhog() + image_surf() on 4096x4096 RGB tiles, batch 256."""
+    S = 4096
+    metric = "Mpixels/s image.dlib fHOG + SURF on 4096x4096 RGB tiles (configs[3])"
+
+    def prepare(self):
+        import ctypes as C
+
+        import torch
+
+        from image_amd import stream
+        a, det = self.args, self.det
+        S = self.S = a.tile
+        self.T = a.batch if a.batch else 256
+        self.first, _ = stream.rank_block(self.T * self.world, self.rank, self.world)
+        self.tiles = torch.empty((self.T, S, S, 3), dtype=torch.uint8, device="cuda")
+        for t in range(self.T):   # channel c of tile t is G(3*seed + c), seed = 3 + global tile index (image_amd.synth.frame_rgb)
+            g = det.synth_frames(3, S, S, seed0=3 * (3 + self.first + t))
+            self.tiles[t] = g.permute(1, 2, 0)
+        nr, nc = C.c_int(), C.c_int()
+        det.lib.imgfd_fhog_size(S, S, 8, 1, 1, C.byref(nr), C.byref(nc))
+        self.hog = torch.empty((self.T, 31, nc.value, nr.value), dtype=torch.float32, device="cuda")
+        self.cap = 1000
+        self.feat = torch.zeros((self.T, self.cap, 70), dtype=torch.float64, device="cuda")
+        self.counts = torch.zeros((self.T,), dtype=torch.int64, device="cuda")
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        self.t_fhog = self.t_surf = 0.0
+        self.n_timed = 0
+        self.inner = 1
+
+    def px_per_step(self):
+        return self.T * self.S * self.S
+
+    def px_total(self, steps):
+        return steps * self.px_per_step()
+
+    def reset(self):
+        self.t_fhog = self.t_surf = 0.0
+        self.n_timed = 0
+
+    def step(self):
+        det = self.det
+        self.ev[0].record()
+        det.fhog(self.tiles, self.hog)
+        self.ev[1].record()
+        det.surf(self.tiles, self.feat, self.counts, max_points=1000, threshold=30.0)
+        self.ev[2].record()
+        self.ev[2].synchronize()
+        self.t_fhog += self.ev[0].elapsed_time(self.ev[1])
+        self.t_surf += self.ev[1].elapsed_time(self.ev[2])
+        self.n_timed += 1
+
+    def count_vector(self):
+        import torch
+        z = torch.zeros((), dtype=torch.int64, device="cuda")
+        return torch.stack([self.counts.sum(), z, z])
+
+    def describe(self, counts):
+        return {"workload": f"configs[3]: image_fhog() cell 8 padding 1/1 + image_surf() max_points 1000 threshold 30 on {self.T} RGB tiles {self.S}x{self.S} resident in HBM",
+                "tiles_per_step_per_gpu": self.T, "passes_per_step": 1, "feature_counts": {"surf_points": int(counts[0])}}
+
+    def roofline(self, k3_us, k3_n, steps, ms_per_step=None):
+        px = self.px_per_step()
+        n = max(1, self.n_timed)
+        tf, ts = self.t_fhog / n, self.t_surf / n
+        hog_bytes = 3 * px + self.hog.numel() * 4
+        surf_bytes = 43 * px   # RGB in, int32 integral write+read, f64 pyramid write + one read
+        af, asf = hog_bytes / (tf * 1e-3) / 1e9, surf_bytes / (ts * 1e-3) / 1e9
+        return {"kernel": "imgfd_fhog_dev (K13-K15, whole function)", "bound": "hbm", "achieved": round(af, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(af / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_step": hog_bytes, "ms_per_step": round(tf, 3), "traffic": None,
+                "surf": {"kernel": "imgfd_surf_dev (K16-K19, whole function)", "bound": "hbm", "achieved": round(asf, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(asf / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_step": surf_bytes, "ms_per_step": round(ts, 3),
+                         "ms_per_tile": round(ts / self.T, 4)},
+                "fhog_ms_per_tile": round(tf / self.T, 4)}
+
+    def parity_and_cpu(self, want_cpu):
+        import numpy as np
+
+        import oracle
+        from image_amd import synth
+        S = self.S
+        rgb = synth.frame_rgb(3 + self.first, S, S)
+        assert np.array_equal(self.tiles[0].cpu().numpy(), rgb), "device and host tile generators diverged"
+        use_ref = oracle.have_ref("dlib")
+        t = time.perf_counter(); rh = oracle.ref_fhog(rgb) if use_ref else oracle.fhog(rgb); t_h = time.perf_counter() - t
+        t = time.perf_counter(); rs = oracle.surf(rgb, 1000, 30.0, use_ref=use_ref); t_s = time.perf_counter() - t
+        gh = np.ascontiguousarray(self.hog[0].cpu().numpy().transpose(2, 1, 0))
+        n = int(self.counts[0])
+        gs = self.feat[0, :n].cpu().numpy()
+        same_pts = n == len(rs["x"]) and bool(np.array_equal(gs[:, 0], rs["x"]) and np.array_equal(gs[:, 1], rs["y"]) and np.array_equal(gs[:, 4], rs["score"]))
+        out = {"parity_sample": {"tile": int(self.first), "fhog_max_abs_err": float(np.max(np.abs(gh - rh))) if gh.shape == rh.shape else None,
+                                 "fhog_bit_equal": bool(gh.shape == rh.shape and np.array_equal(gh, rh)), "surf_points": n, "surf_points_equal": same_pts,
+                                 "surf_descriptor_max_abs_err": float(np.max(np.abs(gs[:, 6:] - np.nan_to_num(rs["surf"])))) if same_pts and n else None}}
+        if want_cpu:
+            out.update({"value": round(S * S / (t_h + t_s) / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "reference" if use_ref else "port",
+                        "sample": f"1 tile {S}x{S}, one run each: dlib's own extract_fhog_features ({1e3 * t_h:.0f} ms) and get_surf_points ({1e3 * t_s:.0f} ms) "
+                                  "compiled in place (oracle/_ref/libref_dlib.so), single-threaded as the reference is"})
+        return out
+
+
+def traffic_for(kernel, batch):
+    """HBM bytes per launch from the PMC passes (collected offline: PMC and timing must not share a run).  The file
+    records the hash of the kernel sources it was measured on; a stale file yields None."""
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "k3_traffic.json")))
+        if tr.get("kernel_source_sha1") != kernel_source_hash():
+            return None
+        per_frame = tr.get("traffic_bytes_per_frame")
+        if tr.get("batch") == batch:
+            return int(tr["traffic_bytes_per_launch"])
+        return int(per_frame * batch) if per_frame else None
+    except Exception:
+        return None
+
+
+def kernel_source_hash():
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("fir.hip", "fir_device.h"):
+        with open(os.path.join(ROOT, "image_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+# ------------------------------------------------------------------------------------------------ launch
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def spawn_ranks(n, argv):
+    """`--gpus N` outside torchrun: start the N ranks ourselves, rank r on GPU r, rendezvous on 127.0.0.1."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), IMGFD_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
+def parse(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configs[] entry (1-based as the judge counts them)")
+    ap.add_argument("--batch", type=int, default=0, help="frames (tiles) per step per GPU; default 32 (config 2/5), 1024 (config 3), 256 (config 4)")
+    ap.add_argument("--inner", type=int, default=10, help="config 2: passes over the batch inside one step (a longer timed region)")
+    ap.add_argument("--frames", type=int, default=10000, help="config 5: frames of the whole stream")
+    ap.add_argument("--tile", type=int, default=4096, help="config 4: tile edge")
+    ap.add_argument("--max-parity-frames", type=int, default=100)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--fir-mode", type=int, default=1)
     ap.add_argument("--no-overlap", action="store_true",
@@ -108,56 +577,61 @@ def main():
                     help="collective backend; nccl (= RCCL) is the product path, gloo is a functional check")
     ap.add_argument("--share-device", action="store_true",
                     help="test hook: every rank uses cuda:0 (functional check of the N>1 path on a 1-GPU box; not a measurement)")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="test hook: no device work at all -- launch, rendezvous and count reduction only (CPU, gloo)")
+    return ap.parse_args(argv)
 
-    import numpy as np
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, argv))
+
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    from image_amd import stream
+    if args.dry_run:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo")
+        counts = torch.tensor([rank + 1, 10 * (rank + 1), 100 * (rank + 1)], dtype=torch.int64)
+        counts, dt = stream.reduce_counts(counts, 1.0 + rank, dist if world > 1 else None)
+        if rank == 0:
+            print(json.dumps({"metric": "dry run (launch + reduction only)", "value": None, "n_gpus": world, "dry_run": True,
+                              "feature_counts": counts.tolist(), "max_elapsed_s": dt}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the backend has no CPU path")
     if args.share_device:
         local = 0
+    elif local >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: GPU {local} requested but only {torch.cuda.device_count()} visible "
+                         "(--share-device runs a functional check of the N>1 path on one GPU)")
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
+        if args.backend == "nccl" and not args.share_device:
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo")   # ranks sharing one device cannot form an RCCL communicator
 
-    from image_amd import stream, synth
     from image_amd.device import DeviceDetector
 
     det = DeviceDetector(local)
     det.ctx.set_fir_mode(args.fir_mode)
-    B = args.batch
-    first, _ = stream.rank_block(B * world, rank, world)  # weak scaling: B frames per rank, contiguous blocks
-    frames = det.synth_frames(B, NX, NY, seed0=stream.frame_seed(50000, first))
-    cap_h, cap_f = 65536, 262144
-    h_out = (torch.empty((B, cap_h, 3), dtype=torch.float32, device="cuda"), torch.empty((B,), dtype=torch.int64, device="cuda"))
-    f_out = (torch.empty((B, cap_f, 2), dtype=torch.int32, device="cuda"), torch.empty((B,), dtype=torch.int64, device="cuda"))
-    c_out = (torch.empty((B, NY, NX), dtype=torch.uint8, device="cuda"), torch.empty((B,), dtype=torch.int64, device="cuda"))
-    have_canny = True
-    all_counts = torch.zeros((3, B), dtype=torch.int64, device="cuda")
-
-    def step():
-        nonlocal have_canny
-        if not args.no_overlap:
-            det.detect_all(frames, h_out[0], f_out[0], c_out[0], all_counts, fast9_threshold=20, suppress_non_max=1)
-            return
-        det.harris(frames, out=h_out)
-        det.fast9(frames, threshold=20, suppress_non_max=True, out=f_out)
-        if have_canny:
-            try:
-                det.canny(frames, out=c_out)
-            except Exception as e:
-                if "not implemented" not in str(e):
-                    raise
-                have_canny = False
+    wl = {2: lambda: Detect4K(args, det, rank, world), 3: lambda: Canny1080p(args, det, rank, world),
+          4: lambda: DlibTiles(args, det, rank, world), 5: lambda: Detect4K(args, det, rank, world, stream_mode=True)}[args.config]()
+    wl.prepare()
+    steps = args.steps if args.steps is not None else wl.default_steps()
 
     def barrier():
         torch.cuda.synchronize()
@@ -166,76 +640,53 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step()
+        wl.step()
     barrier()
+    wl.reset()
     det.lib.imgfd_profile_k3(det.ctx.handle, 1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for _ in range(steps):
+        wl.step()
     barrier()
     dt = time.perf_counter() - t0
-    import ctypes as C
-    k3_us, k3_n = C.c_double(0), C.c_int(0)
-    det.ctx.check(det.lib.imgfd_profile_k3_read(det.ctx.handle, C.byref(k3_us), C.byref(k3_n)), "profile read")
+    k3_us, k3_n = det.profile_k3_read()
     det.lib.imgfd_profile_k3(det.ctx.handle, 0)
 
-    if args.no_overlap:
-        counts = torch.stack([h_out[1].sum(), f_out[1].sum(), c_out[1].sum() if have_canny else torch.zeros((), dtype=torch.int64, device="cuda")])
-    else:
-        counts = all_counts.sum(dim=1)
-    # the path's only collective: feature counts (sum) and the elapsed time (max over ranks)
-    counts, dt = stream.reduce_counts(counts, dt, dist if world > 1 else None)
+    # the path's only collectives: feature counts (sum; per-frame vectors are gathered in stream mode) and the elapsed time (max)
+    counts, dt = stream.reduce_counts(wl.count_vector(), dt, dist if world > 1 else None)
+    px_local = torch.tensor([wl.px_total(steps)], dtype=torch.int64, device="cuda")
+    px_all, _ = stream.reduce_counts(px_local, 0.0, dist if world > 1 else None)
+    per_frame = None
+    if args.config == 5:
+        per_frame = stream.gather_frame_counts(wl.frame_counts[:, :wl.cursor], dist if world > 1 else None)
 
     if rank == 0:
-        px_per_step = B * NX * NY * world
-        k3_avg_us = k3_us.value / max(1, k3_n.value)
-        # algorithmic bytes of one launch: a step's B frames go through the kernel in launches/steps launches (large
-        # batches are split by the library's workspace cap), so divide the step's bytes accordingly
-        launches_per_step = max(1, round(k3_n.value / max(1, args.steps)))
-        k3_bytes = TENSOR_BYTES_PER_PX * NX * NY * B // launches_per_step
-        achieved = k3_bytes / (k3_avg_us * 1e-6) / 1e9 if k3_avg_us > 0 else 0.0
-        # parity spot-check of frame 0 against the host generator + oracle happens in tests/ (-m gpu)
-        # HBM traffic of one K3 launch from the PMC counters: collected offline in separate rocprofv3 --pmc passes on
-        # this very command (PMC and timing must not share a run) and committed under profiles/
-        traffic = None
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "k3_traffic.json")))
-            if tr.get("batch") == B and launches_per_step == 1:
-                traffic = int(tr["traffic_bytes_per_launch"])
-        except Exception:
-            pass
+        ms_per_step = 1e3 * dt / steps
         res = {
-            "metric": "Mpixels/s Harris+FAST9+Canny on 3840x2160 gray",
-            "value": round(px_per_step * args.steps / dt / 1e6, 2),
-            "unit": "Mpixels/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64-accumulate/f32 (Harris), u8 (FAST-9), f64 (Canny)", "data": "synthetic",
+            "metric": wl.metric, "value": round(int(px_all[0]) / dt / 1e6, 2), "unit": "Mpixels/s",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak" if args.config != 5 else "strong", "vs_baseline": None,
+            "dtype": {2: "f64-accumulate/f32 (Harris), u8 (FAST-9), f64 (Canny)", 5: "f64-accumulate/f32 (Harris), f64 (Canny)",
+                      3: "f64 (Canny)", 4: "f32 (fHOG), int32/f64 (SURF)"}[args.config],
+            "data": "synthetic",
             "config": {**({"note": "functional check only: ranks share one device / gloo collectives"} if (args.share_device or args.backend != "nccl") else {}),
-                       "workload": f"configs[1]+Canny: image_harris() defaults + FAST-9 thr 20 nonmax"
-                                   f"{' + Canny s=2 3/10 accGrad' if have_canny else ' (Canny not implemented yet: EXCLUDED)'}"
-                                   f" on {NX}x{NY} u8 frames resident in HBM",
-                       "frames_per_step_per_gpu": B, "schedule": "one stream" if args.no_overlap else "two streams (imgfd_detect_dev)", "fir_mode": "fused-accumulate" if args.fir_mode else "strict",
-                       "feature_counts": {"harris_corners": int(counts[0]), "fast9_corners": int(counts[1]),
-                                          "canny_edge_pixels": int(counts[2])}},
-            "roofline": {"kernel": "fir_march<7,tensor> (Harris structure-tensor pass)", "bound": "hbm",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "frac_of_measured_copy": round(achieved / MEASURED_COPY_GBS, 4), "measured_copy_GBps": MEASURED_COPY_GBS,
-                         "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/k3_traffic.json)",
-                         "avg_launch_us": round(k3_avg_us, 2), "launches": k3_n.value,
-                         "algorithmic_bytes_per_launch": k3_bytes},
+                       **wl.describe(counts)},
         }
-        if world == 1 and not args.no_cpu:
-            host = np.stack([synth.frame(stream.frame_seed(50000, 0), NX, NY)])   # host twin of device frame 0
-            assert np.array_equal(frames[0].cpu().numpy(), host[0]), "device and host frame generators diverged"
-            n_h, n_f = (int(h_out[1][0]), int(f_out[1][0])) if args.no_overlap else (int(all_counts[0, 0]), int(all_counts[1, 0]))
-            gpu0 = (h_out[0][0, :min(n_h, cap_h)].cpu().numpy(), f_out[0][0, :min(n_f, cap_f)].cpu().numpy(),
-                    c_out[0][0].cpu().numpy() if have_canny else None)
-            res["cpu_baseline"] = cpu_baseline(host, gpu0)
+        if per_frame is not None:
+            res["config"]["per_frame_counts_gathered"] = int(per_frame.shape[1])
+            res["config"]["per_frame_counts_checksum"] = {"harris": int(per_frame[0].sum()), "canny": int(per_frame[1].sum())}
+        if args.config in (2, 5):
+            res["roofline"] = wl.roofline(k3_us, k3_n, steps)
+        else:
+            res["roofline"] = wl.roofline(k3_us, k3_n, steps, ms_per_step=ms_per_step)
+        if world == 1:
+            cb = wl.parity_and_cpu(not args.no_cpu)
+            if cb:
+                res["cpu_baseline" if not args.no_cpu else "parity"] = cb
         print(json.dumps(res))
+        sys.stdout.flush()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

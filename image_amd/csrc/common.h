@@ -116,6 +116,16 @@ imgfd_status launch_gaussian(imgfd_ctx *ctx, const void *d_in, int in_is_u8, int
 imgfd_status launch_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_A,
                                      float *d_B, float *d_C, int nx, int ny, int n_frames, float sigma,
                                      int gauss, float *d_tmp);
+// fir_tensor.hip: the marching structure-tensor kernel.  out_mode 0: A, B, C; 1: A, B, C stored as float4 rows through
+// LDS; 2: Harris corner response only (d_A receives R, d_B / d_C unused).  IMGFD_ERR_UNSUPPORTED (no error message set)
+// when no specialised instance serves the radius / alignment: the caller falls back.
+bool tensor_fast_path(int R);
+imgfd_status launch_tensor_march(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_A, float *d_B, float *d_C,
+                                 int nx, int ny, int n_frames, int R, const double *B, float k, int out_mode);
+// structure tensor + Harris response in one kernel (R plane only); false when that path does not apply
+bool tensor_response_supported(int nx, int ny, float sigma, int gauss, int measure, const float *d_Ix, const float *d_Iy, const float *d_R);
+imgfd_status launch_tensor_response(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_R, int nx, int ny,
+                                    int n_frames, float sigma, float k);
 // scratch (bytes) launch_gaussian / launch_structure_tensor need in d_tmp for `n_frames` frames
 size_t gaussian_tmp_bytes(int nx, int ny, int n_frames, float sigma, int type, int planes);
 // sii.hip
@@ -156,6 +166,9 @@ imgfd_status launch_harris_resp_nms(imgfd_ctx *ctx, const float *d_A, const floa
                                     int n_frames, int measure, float k, float Th, int radius, const CompactBuffers &cb);
 imgfd_status launch_harris_nms(imgfd_ctx *ctx, const float *d_R, int nx, int ny, int n_frames, float Th,
                                int radius, const CompactBuffers &cb);
+// the tiled NMS of launch_harris_resp_nms on a materialised R plane (the batch path after launch_tensor_response)
+imgfd_status launch_harris_nms_tiled(imgfd_ctx *ctx, const float *d_R, int nx, int ny, int n_frames, float Th, int radius,
+                                     const CompactBuffers &cb);
 // fast9.hip
 imgfd_status launch_fast9(imgfd_ctx *ctx, const uint8_t *d_img, int w, int h, int stride,
                           size_t frame_stride, int n_frames, int threshold, int nonmax, const CompactBuffers &cb);

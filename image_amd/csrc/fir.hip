@@ -507,6 +507,30 @@ imgfd_status launch_gaussian(imgfd_ctx *ctx, const void *d_in, int in_is_u8, int
     return launch_generic(ctx, src, d_tmp, d_out, nx, ny, n_frames, size, p.B);
 }
 
+// structure tensor + Harris response in one kernel: applies to the discrete Gaussian with a specialised radius on
+// 16-byte aligned planes whose rows are whole quads
+bool tensor_response_supported(int nx, int ny, float sigma, int gauss, int measure, const float *d_Ix, const float *d_Iy, const float *d_R)
+{
+    static const char *off = getenv("IMGFD_NO_FUSED_RESPONSE");
+    if (off && atoi(off)) return false;
+    if (gauss != IMGFD_STD_GAUSSIAN || measure != IMGFD_HARRIS_MEASURE || !(sigma > 0)) return false;
+    double B[IMGFD_MAX_TAPS];
+    const int size = fir_coeffs(sigma, 3, B);
+    if (size < 0 || size > nx || !tensor_fast_path(size - 1)) return false;
+    return nx % 4 == 0 && nx >= 4 && (size_t)d_Ix % 16 == 0 && (size_t)d_Iy % 16 == 0 && (size_t)d_R % 16 == 0;
+}
+
+imgfd_status launch_tensor_response(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_R, int nx, int ny,
+                                    int n_frames, float sigma, float k)
+{
+    double B[IMGFD_MAX_TAPS];
+    const int size = fir_coeffs(sigma, 3, B);
+    if (size < 0) return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "gaussian sigma too large (more than 64 taps)");
+    const imgfd_status st = launch_tensor_march(ctx, d_Ix, d_Iy, d_R, nullptr, nullptr, nx, ny, n_frames, size - 1, B, k, 2);
+    if (st == IMGFD_ERR_UNSUPPORTED) return imgfd_fail(ctx, st, "fused structure tensor + response: unsupported shape");
+    return st;
+}
+
 // compute_autocorrelation_matrix(): harris.cpp:44-70
 imgfd_status launch_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_A,
                                      float *d_B, float *d_C, int nx, int ny, int n_frames, float sigma,
@@ -536,6 +560,16 @@ imgfd_status launch_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const fl
     const int R = size - 1;
     p.in0 = d_Ix; p.in1 = d_Iy; p.out0 = d_A; p.out1 = d_B; p.out2 = d_C; p.nx = nx; p.ny = ny;
     p.in_pitch = nx; p.in_frame_stride = (long)nx * ny; p.out_frame_stride = (long)nx * ny;
+    static const char *impl = getenv("IMGFD_TENSOR_IMPL");  // experiment switch: "old" = the round-1 kernel, "wide" = float4 row stores
+    if (tensor_fast_path(R) && !(impl && !strcmp(impl, "old"))) {
+        const imgfd_status st = launch_tensor_march(ctx, d_Ix, d_Iy, d_A, d_B, d_C, nx, ny, n_frames, R, p.B, 0.f,
+                                                    impl && !strcmp(impl, "wide") ? 1 : 0);
+        if (st != IMGFD_ERR_UNSUPPORTED) return st;
+        if (impl && !strcmp(impl, "wide")) {
+            const imgfd_status st0 = launch_tensor_march(ctx, d_Ix, d_Iy, d_A, d_B, d_C, nx, ny, n_frames, R, p.B, 0.f, 0);
+            if (st0 != IMGFD_ERR_UNSUPPORTED) return st0;
+        }
+    }
     if (fir_has_fast_path(R, 2)) {
         switch (R) {
             case 7: return launch_march<7, 2, 128, 16>(ctx, p, n_frames);

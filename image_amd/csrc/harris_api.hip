@@ -223,12 +223,22 @@ imgfd_status harris_device_stages(imgfd_ctx *ctx, const void *d_in, int in_is_u8
         IMGFD_TRY(launch_gradient(ctx, hp.Is, hp.Ix, hp.Iy, nx, ny, n_frames, a.grad));
         IMGFD_TRY(tick(1));
     }
+    const int radius = (int)(2 * a.sigma_i + 0.5);  // harris.cpp:523, double -> int truncation
+    if (!stage_seconds && tensor_response_supported(nx, ny, a.sigma_i, a.gauss, a.measure, hp.Ix, hp.Iy, hp.R)) {
+        // the default path: the structure tensor never leaves the CU -- its kernel's epilogue evaluates the corner
+        // response (harris.cpp:78-133) and only R is stored; NMS then reads 4 B/px instead of 12
+        IMGFD_TRY(prof_mark(ctx));
+        IMGFD_TRY(launch_tensor_response(ctx, hp.Ix, hp.Iy, hp.R, nx, ny, n_frames, a.sigma_i, a.k));
+        IMGFD_TRY(prof_mark(ctx));
+        IMGFD_TRY(launch_harris_nms_tiled(ctx, hp.R, nx, ny, n_frames, a.Th, radius, hp.cb));
+        IMGFD_TRY(compact_emit(ctx, hp.cb, nx, ny, n_frames, 0, hp.R, d_corners, cap, d_counts));
+        return IMGFD_OK;
+    }
     IMGFD_TRY(prof_mark(ctx));
     IMGFD_TRY(launch_structure_tensor(ctx, hp.Ix, hp.Iy, hp.A, hp.B, hp.C, nx, ny, n_frames, a.sigma_i, a.gauss,
                                       hp.tmp));
     IMGFD_TRY(prof_mark(ctx));
     IMGFD_TRY(tick(2));
-    const int radius = (int)(2 * a.sigma_i + 0.5);  // harris.cpp:523, double -> int truncation
     if (!need_R_plane && harris_resp_nms_supports(nx, ny, radius)) {
         // batch path: response + NMS in one kernel, strengths recomputed for the corner records (no R plane)
         IMGFD_TRY(launch_harris_resp_nms(ctx, hp.A, hp.B, hp.C, nx, ny, n_frames, a.measure, a.k, a.Th, radius, hp.cb));
@@ -476,18 +486,43 @@ imgfd_status imgfd_k_nms(imgfd_ctx *ctx, const float *d_R, int nx, int ny, float
     return compact_emit(ctx, cb, nx, ny, 1, 0, d_R, d_corners, cap, d_count);
 }
 
+imgfd_status imgfd_k_tensor_response(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_R, int nx, int ny,
+                                     float sigma, float k)
+{
+    if (!ctx || !d_Ix || !d_Iy || !d_R || nx < 1 || ny < 1)
+        return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_k_tensor_response: bad argument");
+    if (!tensor_response_supported(nx, ny, sigma, IMGFD_STD_GAUSSIAN, IMGFD_HARRIS_MEASURE, d_Ix, d_Iy, d_R))
+        return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "imgfd_k_tensor_response: needs the discrete Gaussian with radius 7, 3 or 1, "
+                                                      "16-byte aligned planes and rows of whole quads");
+    return launch_tensor_response(ctx, d_Ix, d_Iy, d_R, nx, ny, 1, sigma, k);
+}
+
+const char *imgfd_tensor_kernel_name(imgfd_ctx *ctx)
+{
+    (void)ctx;
+    static const char *off = getenv("IMGFD_NO_FUSED_RESPONSE");
+    return off && atoi(off) ? "fir_tensor<7, fma, vec, A/B/C> (20 B/px)" : "fir_tensor<7, fma, vec, response> (structure tensor + Harris response, 12 B/px)";
+}
+
 imgfd_status imgfd_time_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy,
                                          float *d_A, float *d_B, float *d_C, int nx, int ny,
                                          float sigma, int gauss, int warmup, int iters, double *avg_us)
 {
-    if (!ctx || !avg_us || iters < 1) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_time_structure_tensor: bad argument");
-    IMGFD_TRY(ws_reserve(ctx, sizeof(float) * (size_t)nx * ny + 4096));
-    float *tmp = (float *)ws_alloc(ctx, sizeof(float) * (size_t)nx * ny);
+    return imgfd_time_structure_tensor_batch(ctx, d_Ix, d_Iy, d_A, d_B, d_C, nx, ny, 1, sigma, gauss, warmup, iters, avg_us);
+}
+
+imgfd_status imgfd_time_structure_tensor_batch(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy,
+                                               float *d_A, float *d_B, float *d_C, int nx, int ny, int n_frames,
+                                               float sigma, int gauss, int warmup, int iters, double *avg_us)
+{
+    if (!ctx || !avg_us || iters < 1 || n_frames < 1) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_time_structure_tensor: bad argument");
+    IMGFD_TRY(ws_reserve(ctx, sizeof(float) * (size_t)nx * ny * n_frames + 4096));
+    float *tmp = (float *)ws_alloc(ctx, sizeof(float) * (size_t)nx * ny * n_frames);
     for (int i = 0; i < warmup; i++)
-        IMGFD_TRY(launch_structure_tensor(ctx, d_Ix, d_Iy, d_A, d_B, d_C, nx, ny, 1, sigma, gauss, tmp));
+        IMGFD_TRY(launch_structure_tensor(ctx, d_Ix, d_Iy, d_A, d_B, d_C, nx, ny, n_frames, sigma, gauss, tmp));
     IMGFD_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     for (int i = 0; i < iters; i++)
-        IMGFD_TRY(launch_structure_tensor(ctx, d_Ix, d_Iy, d_A, d_B, d_C, nx, ny, 1, sigma, gauss, tmp));
+        IMGFD_TRY(launch_structure_tensor(ctx, d_Ix, d_Iy, d_A, d_B, d_C, nx, ny, n_frames, sigma, gauss, tmp));
     IMGFD_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     IMGFD_HIP(ctx, hipEventSynchronize(ctx->ev1));
     float ms = 0;

@@ -84,7 +84,8 @@ imgfd_status launch_harris_nms(imgfd_ctx *ctx, const float *d_R, int nx, int ny,
 #define RN_MAXC (RN_TX * RN_TY / 4)  // 3x3 local maxima cannot be denser than one per 2x2 block
 
 // HC > 0: the window radius is the compile-time constant HC (index arithmetic by constants); HC == 0: any radius <= RN_HALO
-template <int MEASURE, int HC>
+// FROM_R: A is a materialised response plane (written by fir_tensor's response epilogue): the tile is copied, not computed
+template <int MEASURE, int HC, bool FROM_R = false>
 __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                               const float *__restrict__ C, int nx, int ny, float k, float Th,
                                                               int radius_rt, int vec4, unsigned long long *__restrict__ mask,
@@ -117,8 +118,10 @@ __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__res
             const int gy = min(max(y0 + r - YO, 0), ny - 1);
             const size_t p = (size_t)gy * nx + (x0 - XO + 4 * q);
             a[u] = *reinterpret_cast<const v4f *>(Af + p);
-            b[u] = *reinterpret_cast<const v4f *>(Bf + p);
-            c[u] = *reinterpret_cast<const v4f *>(Cf + p);
+            if (!FROM_R) {
+                b[u] = *reinterpret_cast<const v4f *>(Bf + p);
+                c[u] = *reinterpret_cast<const v4f *>(Cf + p);
+            }
         }
 #pragma unroll
         for (int u = 0; u < NR; u++) {
@@ -129,7 +132,7 @@ __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__res
                 v4f v = {0.f, 0.f, 0.f, 0.f};
                 if (gy >= 0 && gy < ny) {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = harris_response_value<MEASURE>(a[u][e], b[u][e], c[u][e], k);
+                    for (int e = 0; e < 4; e++) v[e] = FROM_R ? a[u][e] : harris_response_value<MEASURE>(a[u][e], b[u][e], c[u][e], k);
                 }
                 *reinterpret_cast<v4f *>(&sR[r][4 * q]) = v;
             }
@@ -141,7 +144,7 @@ __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__res
             float v = 0.f;  // outside the image: never compared (the search domain stays `radius` away from the border)
             if (gx >= 0 && gx < nx && gy >= 0 && gy < ny) {
                 const size_t p = (size_t)gy * nx + gx;
-                v = harris_response_value<MEASURE>(Af[p], Bf[p], Cf[p], k);
+                v = FROM_R ? Af[p] : harris_response_value<MEASURE>(Af[p], Bf[p], Cf[p], k);
             }
             sR[r][c] = v;
         }
@@ -151,7 +154,7 @@ __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__res
     auto R_at = [&](int ty, int tx) __attribute__((always_inline)) -> float {
         if (ty >= 0 && ty < RN_TY && tx >= 0 && tx < RN_TX) return sR[ty][tx];
         const size_t p = (size_t)(y0 + ty) * nx + (x0 + tx);
-        return harris_response_value<MEASURE>(Af[p], Bf[p], Cf[p], k);
+        return FROM_R ? Af[p] : harris_response_value<MEASURE>(Af[p], Bf[p], Cf[p], k);
     };
     // (2) threshold + 3x3 pre-test with the window rule's own comparisons
     for (int r = wv; r < RN_TY; r += 4) {
@@ -235,6 +238,27 @@ imgfd_status launch_harris_resp_nms(imgfd_ctx *ctx, const float *d_A, const floa
     else if (radius == 5) RN_LAUNCH(0, 5);  // image_harris() defaults: sigma_i 2.5 -> radius 5
     else RN_LAUNCH(0, 0);
 #undef RN_LAUNCH
+    IMGFD_HIP(ctx, hipGetLastError());
+    return IMGFD_OK;
+}
+
+imgfd_status launch_harris_nms_tiled(imgfd_ctx *ctx, const float *d_R, int nx, int ny, int n_frames, float Th, int radius,
+                                     const CompactBuffers &cb)
+{
+    if (ny <= 2 * radius + 1 || nx <= 2 * radius + 1) {
+        IMGFD_HIP(ctx, hipMemsetAsync(cb.mask, 0, sizeof(unsigned long long) * (size_t)cb.words_per_row * ny * n_frames, ctx->stream));
+        return IMGFD_OK;
+    }
+    if (radius < 1) radius = 1;
+    if (radius > RN_HALO) return launch_harris_nms(ctx, d_R, nx, ny, n_frames, Th, radius, cb);
+    dim3 grid(cb.words_per_row, ceil_div(ny, RN_TY), n_frames);
+    const int vec4 = nx % 4 == 0 && (size_t)d_R % 16 == 0;
+    if (radius == 5)
+        hipLaunchKernelGGL((harris_resp_nms_kernel<0, 5, true>), grid, dim3(256), 0, ctx->stream, d_R, d_R, d_R, nx, ny, 0.f, Th, radius, vec4,
+                           cb.mask, cb.rowcount, cb.words_per_row);
+    else
+        hipLaunchKernelGGL((harris_resp_nms_kernel<0, 0, true>), grid, dim3(256), 0, ctx->stream, d_R, d_R, d_R, nx, ny, 0.f, Th, radius, vec4,
+                           cb.mask, cb.rowcount, cb.words_per_row);
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }

@@ -40,7 +40,7 @@ class DeviceDetector:
         """n frames G(seed0+f) generated on the device (host twin: image_amd.synth.frame)."""
         if n_rect is None:
             n_rect = synth.default_rects(nx, ny)
-        rects = np.stack([synth.rectangles(seed0 + f, nx, ny, n_rect) for f in range(n)]).astype(np.int32)
+        rects = synth.rectangles_batch(seed0, n, nx, ny, n_rect)
         d_rects = torch.from_numpy(rects).to(f"cuda:{self.device}")
         out = torch.empty((n, ny, nx), dtype=torch.uint8, device=f"cuda:{self.device}")
         self.ctx.check(self.lib.imgfd_synth_frames(self.ctx.handle, out.data_ptr(), n, nx, ny, nx * ny, seed0 & 0xFFFFFFFF,
@@ -102,6 +102,55 @@ class DeviceDetector:
         self.ctx.check(self.lib.imgfd_detect_dev(self.ctx.handle, C.byref(fr), C.byref(p), corners.data_ptr(), points.data_ptr(),
                                                  edges.data_ptr(), counts.data_ptr()), "imgfd_detect_dev")
         return counts
+
+    def fhog(self, tiles: torch.Tensor, out: torch.Tensor, cell_size=8, pad_r=1, pad_c=1):
+        """imgfd_fhog_dev: tiles [n, rows, cols, 3] u8 -> out [n, 31, hog_nc, hog_nr] f32 (the reference glue's layout)."""
+        n, rows, cols, _ = tiles.shape
+        assert tiles.is_contiguous() and out.is_contiguous()
+        self.ctx.check(self.lib.imgfd_fhog_dev(self.ctx.handle, tiles.data_ptr(), n, rows, cols, rows * cols * 3, cell_size,
+                                               pad_r, pad_c, out.data_ptr()), "imgfd_fhog_dev")
+        return out
+
+    def surf(self, tiles: torch.Tensor, feat: torch.Tensor, counts: torch.Tensor, max_points=1000, threshold=30.0):
+        """imgfd_surf_dev: tiles [n, rows, cols, 3] u8 -> feat [n, cap, 70] f64 (x, y, angle, scale, score, laplacian,
+        surf[64]), counts [n] i64."""
+        n, rows, cols, _ = tiles.shape
+        assert tiles.is_contiguous() and feat.is_contiguous()
+        self.ctx.check(self.lib.imgfd_surf_dev(self.ctx.handle, tiles.data_ptr(), n, rows, cols, rows * cols * 3, int(max_points),
+                                               float(threshold), feat.data_ptr(), feat.shape[1], counts.data_ptr()),
+                       "imgfd_surf_dev")
+        return feat, counts
+
+    def gradients_of(self, frame: torch.Tensor, ix: torch.Tensor, iy: torch.Tensor, sigma_d=1.0):
+        """Ix, Iy of one u8/f32 frame as image_harris() computes them (stage doorways K1 + K2), into ix / iy [ny, nx] f32."""
+        ny, nx = frame.shape
+        f = frame.to(torch.float32).contiguous()
+        sm = torch.empty_like(f)
+        self.ctx.check(self.lib.imgfd_k_gaussian(self.ctx.handle, f.data_ptr(), sm.data_ptr(), nx, ny, sigma_d, 0), "imgfd_k_gaussian")
+        self.ctx.check(self.lib.imgfd_k_gradient(self.ctx.handle, sm.data_ptr(), ix.data_ptr(), iy.data_ptr(), nx, ny, 0), "imgfd_k_gradient")
+        self.ctx.sync()  # f, sm die here
+
+    def time_structure_tensor_batch(self, ix: torch.Tensor, iy: torch.Tensor, sigma=2.5, gauss=0, warmup=3, iters=20):
+        """Mean microseconds per launch of the 20 B/px structure-tensor kernel over a batch [n, ny, nx] (HIP events on
+        the context's stream, back-to-back launches)."""
+        n, ny, nx = ix.shape
+        A, B, Cc = (torch.empty_like(ix) for _ in range(3))
+        us = C.c_double(0)
+        self.ctx.check(self.lib.imgfd_time_structure_tensor_batch(self.ctx.handle, ix.data_ptr(), iy.data_ptr(), A.data_ptr(),
+                                                                  B.data_ptr(), Cc.data_ptr(), nx, ny, n, sigma, gauss, warmup,
+                                                                  iters, C.byref(us)), "imgfd_time_structure_tensor_batch")
+        return us.value
+
+    def profile_k3_read(self):
+        """(summed microseconds, launches) of the structure-tensor launches since imgfd_profile_k3(ctx, 1)."""
+        us, n = C.c_double(0), C.c_int(0)
+        self.ctx.check(self.lib.imgfd_profile_k3_read(self.ctx.handle, C.byref(us), C.byref(n)), "imgfd_profile_k3_read")
+        return us.value, n.value
+
+    def tensor_kernel_name(self) -> str:
+        """which kernel imgfd_harris_dev / imgfd_detect_dev launch for the structure-tensor pass on the default path"""
+        name = self.lib.imgfd_tensor_kernel_name(self.ctx.handle)
+        return (name or b"?").decode()
 
     def time_structure_tensor(self, ix: torch.Tensor, iy: torch.Tensor, sigma=2.5, gauss=0, warmup=5, iters=50):
         """Mean microseconds per launch of the structure-tensor kernel (HIP events on the ctx stream)."""

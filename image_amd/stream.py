@@ -36,3 +36,24 @@ def reduce_counts(counts, elapsed_s: float, dist=None, device=None):
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return counts, float(t.item())
+
+
+def gather_frame_counts(frame_counts, dist=None):
+    """configs[4]: every rank holds a [k, n_local] int64 tensor of per-frame counts of its contiguous block of the
+    stream; returns the [k, n_total] tensor in stream order on every rank (one all_gather of padded blocks)."""
+    import torch
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return frame_counts
+    world = dist.get_world_size()
+    use_host = dist.get_backend() == "gloo" and frame_counts.is_cuda
+    fc = frame_counts.cpu() if use_host else frame_counts
+    n = torch.tensor([fc.shape[1]], dtype=torch.int64, device=fc.device)
+    ns = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(ns, n)
+    n_max = int(max(int(x) for x in ns))
+    pad = torch.zeros((fc.shape[0], n_max), dtype=torch.int64, device=fc.device)
+    pad[:, :fc.shape[1]] = fc
+    parts = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    out = torch.cat([p[:, :int(k)] for p, k in zip(parts, ns)], dim=1)
+    return out.to(frame_counts.device) if use_host else out

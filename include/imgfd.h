@@ -264,6 +264,11 @@ IMGFD_API imgfd_status imgfd_k_gradient(imgfd_ctx *ctx, const float *d_I, float 
  * reads Ix,Iy (8 B/px), writes the smoothed A,B,C (12 B/px) */
 IMGFD_API imgfd_status imgfd_k_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_A,
                                       float *d_B, float *d_C, int nx, int ny, float sigma, int gauss);
+/* K3 + K4 in one kernel, the form the batch path runs on image_harris() defaults: structure tensor and Harris corner
+ * response (harris.cpp:44-70, :78-105), only R is written.  Discrete Gaussian with radius 7, 3 or 1 (sigma_i 2.5, 1.25,
+ * 0.625), nx % 4 == 0, 16-byte aligned planes; IMGFD_ERR_UNSUPPORTED otherwise. */
+IMGFD_API imgfd_status imgfd_k_tensor_response(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_R, int nx,
+                                               int ny, float sigma, float k);
 /* K4: compute_corner_response harris.cpp:78-133 */
 IMGFD_API imgfd_status imgfd_k_response(imgfd_ctx *ctx, const float *d_A, const float *d_B, const float *d_C,
                               float *d_R, int nx, int ny, int measure, float k);
@@ -276,6 +281,13 @@ IMGFD_API imgfd_status imgfd_k_nms(imgfd_ctx *ctx, const float *d_R, int nx, int
 IMGFD_API imgfd_status imgfd_time_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy,
                                          float *d_A, float *d_B, float *d_C, int nx, int ny,
                                          float sigma, int gauss, int warmup, int iters, double *avg_us);
+
+/* same over a batch of n_frames packed planes (frame f at p + f*nx*ny): one launch covers the batch */
+IMGFD_API imgfd_status imgfd_time_structure_tensor_batch(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy,
+                                               float *d_A, float *d_B, float *d_C, int nx, int ny, int n_frames,
+                                               float sigma, int gauss, int warmup, int iters, double *avg_us);
+/* human-readable name of the kernel imgfd_harris_dev launches for the structure-tensor pass on image_harris() defaults */
+IMGFD_API const char *imgfd_tensor_kernel_name(imgfd_ctx *ctx);
 
 /* In-pipeline timing of the structure-tensor pass: while enabled, every launch of that kernel made by
  * imgfd_harris / imgfd_harris_dev on this context is bracketed by HIP events on the context's stream.

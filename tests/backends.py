@@ -57,6 +57,13 @@ class _Base:
                                                      self.ptr(Cc), nx, ny, sigma, gauss), "k_structure_tensor")
         return self.to_host(A), self.to_host(B), self.to_host(Cc)
 
+    def k_tensor_response(self, ix, iy, sigma, k=0.06):
+        ny, nx = ix.shape
+        dx = self.to_dev(np.ascontiguousarray(ix, np.float32)); dy = self.to_dev(np.ascontiguousarray(iy, np.float32))
+        R = self.empty((ny, nx), np.float32)
+        self.check(self.lib.imgfd_k_tensor_response(self.ctx, self.ptr(dx), self.ptr(dy), self.ptr(R), nx, ny, sigma, k), "k_tensor_response")
+        return self.to_host(R)
+
     def k_response(self, A, B, Cc, measure=0, k=0.06):
         ny, nx = A.shape
         d = [self.to_dev(np.ascontiguousarray(p, np.float32)) for p in (A, B, Cc)]

@@ -98,6 +98,37 @@ def test_structure_tensor_other_sigmas(be, sigma):
         assert_bits_equal(g, r, f"structure tensor {nm} sigma {sigma}")
 
 
+@pytest.mark.parametrize("nx,ny", [(128, 16), (132, 40), (256, 31), (388, 100), (8, 70), (1004, 37)])
+@pytest.mark.parametrize("sigma", [2.5, 1.25, 0.625])
+def test_tensor_response_kernel_bit_exact(be, nx, ny, sigma):
+    """K3 with the response epilogue (the kernel the batch path runs on image_harris() defaults): strips that end in the
+    middle of a tile, single-strip images, segments shorter than a chunk; strict mode is bit-exact"""
+    if nx < int(3 * sigma) + 1:
+        pytest.skip("kernel wider than the image: the reference skips the smoothing")
+    ix, iy = _gradients(23, nx, ny)
+    be.set_fir_mode(0)
+    A, B, Cc = oracle.harris_stage("autocorrelation", ix, iy, sigma=sigma, gauss=0)
+    ref = oracle.harris_stage("response", A, B, Cc, measure=0, k=0.06)
+    assert_bits_equal(be.k_tensor_response(ix, iy, sigma, 0.06), ref, f"tensor+response {nx}x{ny} sigma {sigma}")
+
+
+@pytest.mark.parametrize("nx,ny", [(130, 33), (67, 20), (259, 50)])
+def test_structure_tensor_rows_that_are_no_whole_quads(be, nx, ny):
+    """nx % 4 != 0: the element-load instance of the marching kernel"""
+    ix, iy = _gradients(24, nx, ny)
+    be.set_fir_mode(0)
+    got = be.k_structure_tensor(ix, iy, 2.5, 0)
+    ref = oracle.harris_stage("autocorrelation", ix, iy, sigma=2.5, gauss=0)
+    for g, r, nm in zip(got, ref, "ABC"):
+        assert_bits_equal(g, r, f"structure tensor {nm} {nx}x{ny}")
+
+
+def test_tensor_response_unsupported_shapes_are_refused(be):
+    ix, iy = _gradients(25, 130, 20)
+    with pytest.raises(Exception, match="imgfd_status 5"):
+        be.k_tensor_response(ix, iy, 2.5)
+
+
 def test_structure_tensor_fused_accumulate_within_tolerance(be):
     """fir_mode 1 (fma inside the f64 accumulation): north_star tolerance is 1e-4 relative; the
     planes differ from strict by at most 1 float ulp and almost nowhere."""
