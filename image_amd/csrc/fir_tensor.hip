@@ -31,6 +31,31 @@
 #include "fir_device.h"
 #include "harris_device.h"
 
+#include <algorithm>
+#include <type_traits>
+
+#ifdef FT_PROFILE
+// experiment build only (make EXTRA=-DFT_PROFILE): per-phase shader-clock sums over all waves of fir_tensor
+__device__ unsigned long long g_ft_prof[8];
+#define FT_T(i)                                                     \
+    do {                                                            \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        if ((threadIdx.x & 63) == 0) prof[i] += t_ - tlast;         \
+        tlast = t_;                                                 \
+    } while (0)
+extern "C" __attribute__((visibility("default"))) int imgfd_debug_ft_profile(unsigned long long *out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ft_prof), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_ft_prof), z, sizeof z) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#else
+#define FT_T(i)
+#endif
+
 typedef float ft_v4f __attribute__((vector_size(16)));  // native vector: always promoted to registers
 #ifdef HIPEMU
 typedef volatile ft_v4f ft_lds_v4f;
@@ -45,7 +70,9 @@ struct TensorParams {
     float *out0, *out1, *out2;  // A, B, C -- or R in out0 (OUT = 2)
     int nx, ny;
     long frame_stride;  // elements between frames (planes are packed: pitch nx)
-    int seg_rows;       // output rows per workgroup segment
+    int seg_rows;       // output rows per segment
+    int nstrips, nseg, n_frames;  // tiles = strips x segments x frames, numbered strip-fastest
+    int step_strip, step_seg, step_frame;  // the number of workers as (strips, segments, frames) digits: a worker's next tile
     int xcd_remap;
     float k;            // Harris constant (OUT = 2)
     double B[8];        // taps B[0..R], R <= 7
@@ -64,7 +91,7 @@ struct TensorGeom {
     static constexpr int NW4 = (OFF + NW + 3) / 4;
     static constexpr int TILE4 = 2 * CH * W4;     // float4 slots of one chunk's tile (Ix and Iy)
     static constexpr int NL = (TILE4 + NT - 1) / NT;
-    static constexpr size_t LDS_BYTES = sizeof(float4) * 2 * CH * P4 + sizeof(float) * 3 * CH * RPITCH;
+    static constexpr size_t lds_bytes(int out) { return sizeof(float4) * 2 * CH * P4 + sizeof(float) * 3 * CH * RPITCH * (out ? 2 : 1); }
     static_assert(TW == 128 || TW == 256, "strip widths with a conflict-free lane mapping");
     static_assert(2 * R <= CH, "the column pass reaches 2R rows back into the previous chunk");
     static_assert(16 * (NS - 1) + 4 * NW4 <= W, "row-pass window reads stay inside the tile row");
@@ -76,9 +103,41 @@ struct TensorGeom {
 __device__ __forceinline__ int ft_ring_slot4(int s, int h) { return 4 * s + ((h + (s >> 1)) & 3); }
 __device__ __forceinline__ int ft_ring_col(int c) { return 4 * ft_ring_slot4(c >> 4, (c >> 2) & 3) + (c & 3); }
 
-// row pass of one (row, strip) of plane PL: raw tile -> 16 row-filtered floats in the ring
-template <int R, int TW, bool FMA, int PL>
-__device__ __forceinline__ void ft_row_task(const float4 *raw4, float *ring, int r, int s, const double *B)
+// N outputs of one 1-D pass over a register window: out[o] = B[0]*d[o+R] + sum_j B[j]*(d[o+R-j] + d[o+R+j]), pair added
+// first, j ascending, in double, one rounding to float (gaussian.cpp:351-359).  One output is a chain of 2R+1 DEPENDENT
+// f64 instructions (15.4 cycles each when issued back to back, profiles/r01/ubench2.txt): ILP outputs advance together,
+// tap by tap, so that the chains of a wave cover each other's latency.  Each chain keeps the reference's own order.
+#ifndef FT_ILP
+#define FT_ILP 4
+#endif
+template <int R, bool FMA, int N, int ILP>
+__device__ __forceinline__ void ft_taps(const double (&d)[N + 2 * R], const double *B, float (&out)[N])
+{
+    static_assert(N % ILP == 0, "groups of ILP outputs");
+#pragma unroll
+    for (int o0 = 0; o0 < N; o0 += ILP) {
+        double sum[ILP];
+#pragma unroll
+        for (int g = 0; g < ILP; g++) sum[g] = B[0] * d[o0 + g + R];
+#pragma unroll
+        for (int j = 1; j <= R; j++) {
+            double pair[ILP];
+#pragma unroll
+            for (int g = 0; g < ILP; g++) pair[g] = d[o0 + g + R - j] + d[o0 + g + R + j];
+#pragma unroll
+            for (int g = 0; g < ILP; g++) {
+                if (FMA) sum[g] = __builtin_fma(B[j], pair[g], sum[g]);
+                else sum[g] += B[j] * pair[g];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < ILP; g++) out[o0 + g] = (float)sum[g];
+    }
+}
+
+// row pass, first half: the 16+2R float products of one (row, strip) of plane PL from the raw Ix/Iy tile
+template <int R, int TW, int PL>
+__device__ __forceinline__ void ft_row_products(const float4 *raw4, int r, int s, float (&pr)[TensorGeom<R, TW>::NW])
 {
     using G = TensorGeom<R, TW>;
     constexpr int NW = G::NW, NW4 = G::NW4, OFF = G::OFF;
@@ -99,20 +158,38 @@ __device__ __forceinline__ void ft_row_task(const float4 *raw4, float *ring, int
             wy[4 * q] = u[0]; wy[4 * q + 1] = u[1]; wy[4 * q + 2] = u[2]; wy[4 * q + 3] = u[3];
         }
     }
-    double d[NW];
 #pragma unroll
     for (int k = 0; k < NW; k++) {
-        float v;
-        if (PL == 0) v = wx[OFF + k] * wx[OFF + k];       // harris.cpp:59
-        else if (PL == 1) v = wx[OFF + k] * wy[OFF + k];  // harris.cpp:60
-        else v = wy[OFF + k] * wy[OFF + k];               // harris.cpp:61
-        d[k] = (double)v;
+        if (PL == 0) pr[k] = wx[OFF + k] * wx[OFF + k];       // harris.cpp:59
+        else if (PL == 1) pr[k] = wx[OFF + k] * wy[OFF + k];  // harris.cpp:60
+        else pr[k] = wy[OFF + k] * wy[OFF + k];               // harris.cpp:61
     }
-    float o[G::PX];
-    fir_window8<R, FMA, G::PX>(d, B, o);
-    float4 *dst = reinterpret_cast<float4 *>(ring + (PL * G::CH + r) * G::RPITCH);
+}
+
+// ILP outputs o0 .. o0+ILP-1 of one 1-D pass from the float window w (converted to double on first use: dw[] is the
+// same window in double, filled up to index `have`): the reference's sum, chains interleaved tap by tap.
+template <int R, bool FMA, int ILP, int NWIN>
+__device__ __forceinline__ void ft_group(const float (&w)[NWIN], double (&dw)[NWIN], int o0, const double *B, float (&out)[ILP])
+{
+    // the group needs dw[o0 .. o0 + ILP + 2R); everything below o0 + 2R was converted by the previous groups
 #pragma unroll
-    for (int h = 0; h < 4; h++) dst[ft_ring_slot4(s, h)] = make_float4(o[4 * h], o[4 * h + 1], o[4 * h + 2], o[4 * h + 3]);
+    for (int k = (o0 == 0 ? 0 : o0 + 2 * R); k < o0 + ILP + 2 * R; k++) dw[k] = (double)w[k];
+    double sum[ILP];
+#pragma unroll
+    for (int g = 0; g < ILP; g++) sum[g] = B[0] * dw[o0 + g + R];
+#pragma unroll
+    for (int j = 1; j <= R; j++) {
+        double pair[ILP];
+#pragma unroll
+        for (int g = 0; g < ILP; g++) pair[g] = dw[o0 + g + R - j] + dw[o0 + g + R + j];
+#pragma unroll
+        for (int g = 0; g < ILP; g++) {
+            if (FMA) sum[g] = __builtin_fma(B[j], pair[g], sum[g]);
+            else sum[g] += B[j] * pair[g];
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < ILP; g++) out[g] = (float)sum[g];
 }
 
 #ifdef HIPEMU
@@ -120,15 +197,33 @@ __device__ __forceinline__ void ft_row_task(const float4 *raw4, float *ring, int
 #else
 // Register budget = what the wave placement needs, not what the occupancy API answers.  A workgroup's waves are dealt to
 // the CU's four SIMDs in turn, so only multiples of 4 waves load the SIMDs evenly:
-//   TW 256: 12 waves = 3 per SIMD, one workgroup per CU (85 KB of LDS): 168 VGPRs.
-//   TW 128: 6 waves land 2,2,1,1; two workgroups can need FOUR slots on a SIMD: 128 VGPRs (with the allocator's own
-//           160 the hardware admitted ONE workgroup per CU: 1.4 resident waves per SIMD measured), and the SIMDs that
-//           hold two waves of a workgroup set the pace of its barriers -- 75 % of the f64 rate at best (measured).
-#define FT_WAVES_PER_EU(tw) __attribute__((amdgpu_waves_per_eu((tw) == 256 ? 3 : 4, (tw) == 256 ? 3 : 4)))
+//   TW 256: 12 waves = 3 per SIMD, one workgroup per CU (85 / 135 KB of LDS): up to 168 VGPRs.
+//   TW 128 (narrow images only): 6 waves land 2,2,1,1 -- the SIMDs that hold two waves of a workgroup set the pace of its
+//           barriers, 75 % of the f64 rate at best (measured: 48 us per 4K frame against 44); with 128 VGPRs two such
+//           workgroups share a CU but the allocator spills, with 160 the hardware admits ONE per CU whatever the
+//           occupancy API answers (1.4 resident waves per SIMD measured).  Same 168-register budget, no spills.
+#define FT_WAVES_PER_EU(tw) __attribute__((amdgpu_waves_per_eu(3, 3)))
 #endif
 // OUT 0: A, B, C stored straight from the column pass (one dword per lane and row, 256 B per wave)
-// OUT 1: A, B, C staged through the ring and stored as float4 rows
+// OUT 1: A, B, C staged through LDS and stored as float4 rows
 // OUT 2: corner response (Harris measure) computed from the staged A, B, C; only R is stored (float4 rows)
+//
+// Schedule.  The workgroup is persistent: it walks a list of (frame, strip, segment) tiles -- tile t of worker w is
+// w + t * workers -- as ONE sequence of steps (a step = one 16-row chunk of a tile), so consecutive tiles overlap like
+// consecutive chunks do and no CU idles between workgroups.  Step s, pipelined over three consecutive chunks:
+//     barrier 1
+//       small phase: every thread pulls its column's 16 row-filtered values of chunk s-1 out of the ring into registers,
+//                    writes the Ix/Iy tile of chunk s (fetched into registers during step s-1) to LDS, and -- OUT 1/2 --
+//                    stores the finished output rows of chunk s-2 from the output buffer
+//     barrier 2
+//       big phase:   row pass of chunk s (raw tile -> ring), global fetch of chunk s+1's tile into registers, column pass
+//                    of chunk s-1 from registers (-> global, or -> output buffer)
+// Everything that costs f64 issue slots sits in the big phase, where the 12 waves (three per SIMD) run ~600 independent
+// VALU instructions each without meeting a barrier.
+struct TensorPos {  // a step of a worker's sequence: chunk `chunk` of tile (strip, seg, frame); frame >= n_frames: past the end
+    int strip, seg, frame, chunk;
+};
+
 template <int R, int TW, bool FMA, bool VEC, int OUT>
 __global__ void __launch_bounds__(3 * TW) FT_WAVES_PER_EU(TW) fir_tensor(TensorParams p)
 {
@@ -138,60 +233,70 @@ __global__ void __launch_bounds__(3 * TW) FT_WAVES_PER_EU(TW) fir_tensor(TensorP
     HIP_DYNAMIC_SHARED(float4, smem4)
     float4 *raw4 = smem4;                                              // [2][CH][P4]
     float *ring = reinterpret_cast<float *>(smem4 + 2 * CH * P4);      // [3][CH][RP], columns permuted per strip
+    float *obuf = ring + 3 * CH * RP;                                  // [3][CH][RP] (OUT 1/2), same column permutation
 
     const int tid = threadIdx.x;
-    int bx = blockIdx.x, by = blockIdx.y;
+    // worker index: workgroup ids are dealt round-robin to the 8 XCDs; let XCD x own a contiguous run of workers, so that
+    // at any time the tiles in flight on one XCD are neighbours (shared halo columns / rows are re-read from its own L2)
+    int worker = blockIdx.x;
+    const int workers = gridDim.x;
     if (p.xcd_remap) {
-        // workgroup ids are dealt round-robin to the 8 XCDs: let XCD x own a contiguous run of (strip, segment) tiles, so
-        // the halo columns/rows two neighbouring workgroups share are re-read from that XCD's own L2
-        const int total = gridDim.x * gridDim.y;
-        const int id = bx + gridDim.x * by;
-        const int q = total >> 3, rem = total & 7;
-        const int xcd = id & 7, local = id >> 3;
-        const int nid = xcd * q + min(xcd, rem) + local;
-        bx = nid % (int)gridDim.x;
-        by = nid / (int)gridDim.x;
+        const int q = workers >> 3, rem = workers & 7;
+        const int xcd = worker & 7, local = worker >> 3;
+        worker = xcd * q + min(xcd, rem) + local;
     }
-    const int frame = blockIdx.z;
-    const int x0 = bx * TW;
-    const int y0 = by * p.seg_rows;
-    const int nrows = min(p.ny, y0 + p.seg_rows) - y0;
-    const int nchunks = (nrows + 2 * R + CH - 1) / CH;
-    const int ybase = y0 - R;
-    const float *ixf = p.ix + (size_t)frame * p.frame_stride;
-    const float *iyf = p.iy + (size_t)frame * p.frame_stride;
+    // geometry of a position, recomputed where needed (a handful of scalar operations; keeping it per pipeline stage in
+    // registers spilled the scalar file)
+#define FT_X0(t) ((t).strip * TW)
+#define FT_Y0(t) ((t).seg * p.seg_rows)
+#define FT_NROWS(t) (min(p.ny, FT_Y0(t) + p.seg_rows) - FT_Y0(t))
+#define FT_NCHUNKS(t) ((FT_NROWS(t) + 2 * R + CH - 1) / CH)
+    // the step after `t`: next chunk, or chunk 0 of the worker's next tile = tile + workers, advanced digit by digit
+    // (p.step_* = `workers` decomposed in the mixed radix (strips, segments, frames) by the host: no divisions here)
+    auto next_pos = [&](const TensorPos &t) __attribute__((always_inline)) -> TensorPos {
+        TensorPos n = t;
+        if (t.chunk + 1 < FT_NCHUNKS(t)) { n.chunk++; return n; }
+        n.chunk = 0;
+        n.strip += p.step_strip;
+        if (n.strip >= p.nstrips) { n.strip -= p.nstrips; n.seg++; }
+        n.seg += p.step_seg;
+        if (n.seg >= p.nseg) { n.seg -= p.nseg; n.frame++; }
+        n.frame += p.step_frame;
+        return n;
+    };
 
-    // ---- tile staging: slot i = tid + l*NT of the chunk's 2 x CH x W4 float4 slots (constant over chunks)
-    int trow[NL], tlds[NL], txo[NL];
-    bool tpl[NL];
-#pragma unroll
-    for (int l = 0; l < NL; l++) {
+    // ---- tile staging: slot i = tid + l*NT of a chunk's 2 x CH x W4 float4 slots (plane, row, quad); recomputed where
+    // needed rather than kept in registers across the big phase
+    auto stage_slot = [&](int l, int &pl, int &row, int &q) __attribute__((always_inline)) {
         const int i = min(tid + l * NT, G::TILE4 - 1);
-        const int pl = i / (CH * W4), rem = i - pl * (CH * W4);
-        trow[l] = rem / W4;
-        const int q = rem - trow[l] * W4;
-        tlds[l] = (pl * CH + trow[l]) * P4 + q;
-        tpl[l] = pl != 0;
-        // VEC: every slot is one aligned float4 from an in-range address; slots hanging over the left/right image border
-        // fetch a neighbouring quad and are rewritten in LDS below.  !VEC: element loads with the reflection applied.
-        txo[l] = VEC ? min(max(x0 - HALO + 4 * q, 0), max(p.nx - 4, 0)) : x0 - HALO + 4 * q;
-    }
-    const bool x_inside = x0 - HALO >= 0 && x0 - HALO + G::W <= p.nx;
+        pl = i / (CH * W4);
+        const int rem = i - pl * (CH * W4);
+        row = rem / W4;
+        q = rem - row * W4;
+    };
     ft_v4f pre[NL];
-
-    auto prefetch = [&](int chunk) __attribute__((always_inline)) {
-        const int yc = ybase + chunk * CH;
+    // VEC: every slot is fetched as ONE aligned float4 from an in-range address (slots hanging over the left/right image
+    // border fetch a neighbouring quad and are rebuilt in LDS by patch_borders()): a straight-line sequence of loads, so
+    // they stay asynchronous and the waitcnt bookkeeping stays exact.  !VEC (unaligned planes, rows that are no whole
+    // quads): element loads with the reflection of gaussian.cpp:345-349 applied.
+    auto prefetch = [&](const TensorPos &t) __attribute__((always_inline)) {
+        const int yc = FT_Y0(t) - R + t.chunk * CH, tx0 = FT_X0(t);
+        const float *ixf = p.ix + (size_t)t.frame * p.frame_stride;
+        const float *iyf = p.iy + (size_t)t.frame * p.frame_stride;
 #pragma unroll
         for (int l = 0; l < NL; l++) {
             if ((l + 1) * NT <= G::TILE4 || tid + l * NT < G::TILE4) {
-                const int gy = fir_reflect(yc + trow[l], p.ny);
-                const float *rowp = (tpl[l] ? iyf : ixf) + (size_t)gy * p.nx;
+                int pl, row, q;
+                stage_slot(l, pl, row, q);
+                const int gy = fir_reflect(yc + row, p.ny);
+                const float *rowp = (pl ? iyf : ixf) + (size_t)gy * p.nx;
+                const int xo = tx0 - HALO + 4 * q;
                 if (VEC) {
-                    pre[l] = *reinterpret_cast<const ft_v4f *>(rowp + txo[l]);
+                    pre[l] = *reinterpret_cast<const ft_v4f *>(rowp + min(max(xo, 0), max(p.nx - 4, 0)));
                 } else {
                     float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = rowp[fir_reflect(txo[l] + e, p.nx)];
+                    for (int e = 0; e < 4; e++) v[e] = rowp[fir_reflect(xo + e, p.nx)];
                     pre[l] = ft_v4f{v[0], v[1], v[2], v[3]};
                 }
             }
@@ -200,21 +305,25 @@ __global__ void __launch_bounds__(3 * TW) FT_WAVES_PER_EU(TW) fir_tensor(TensorP
     auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int l = 0; l < NL; l++)
-            if ((l + 1) * NT <= G::TILE4 || tid + l * NT < G::TILE4) reinterpret_cast<ft_v4f *>(raw4)[tlds[l]] = pre[l];
-        if (VEC && !x_inside) {
-            // border strips only (workgroup-uniform): rebuild the reflected halo columns from the columns of the same
-            // LDS row.  left: x = -k -> k;  right: x = nx-1+k -> nx-k  (gaussian.cpp:345-349)
-            __syncthreads();
-            float *rawf = reinterpret_cast<float *>(raw4);
-            for (int i = tid; i < 2 * CH * 2 * HALO; i += NT) {
-                const int h = i % (2 * HALO), rr = i / (2 * HALO);  // rr = plane*CH + row
-                int c, x;
-                if (h < HALO) { c = h; x = x0 - HALO + c; if (x >= 0) continue; }
-                else { x = p.nx + (h - HALO); c = x - x0 + HALO; if (c >= G::W) continue; }
-                const int sc = fir_reflect(x, p.nx) - x0 + HALO;
-                if (sc < 0 || sc >= G::W) continue;
-                rawf[rr * P4 * 4 + c] = rawf[rr * P4 * 4 + sc];
+            if ((l + 1) * NT <= G::TILE4 || tid + l * NT < G::TILE4) {
+                int pl, row, q;
+                stage_slot(l, pl, row, q);
+                reinterpret_cast<ft_v4f *>(raw4)[(pl * CH + row) * P4 + q] = pre[l];
             }
+    };
+    // border strips only (workgroup-uniform): rebuild the reflected halo columns from the columns of the same LDS row.
+    // left: x = -k -> k;  right: x = nx-1+k -> nx-k  (gaussian.cpp:345-349)
+    auto patch_borders = [&](const TensorPos &t) __attribute__((always_inline)) {
+        float *rawf = reinterpret_cast<float *>(raw4);
+        const int tx0 = FT_X0(t);
+        for (int i = tid; i < 2 * CH * 2 * HALO; i += NT) {
+            const int h = i % (2 * HALO), rr_ = i / (2 * HALO);  // rr_ = plane*CH + row
+            int c, x;
+            if (h < HALO) { c = h; x = tx0 - HALO + c; if (x >= 0) continue; }
+            else { x = p.nx + (h - HALO); c = x - tx0 + HALO; if (c >= G::W) continue; }
+            const int sc = fir_reflect(x, p.nx) - tx0 + HALO;
+            if (sc < 0 || sc >= G::W) continue;
+            rawf[rr_ * P4 * 4 + c] = rawf[rr_ * P4 * 4 + sc];
         }
     };
 
@@ -230,105 +339,165 @@ __global__ void __launch_bounds__(3 * TW) FT_WAVES_PER_EU(TW) fir_tensor(TensorP
     const int rs = TW == 128 ? (lane & 7) : (lane >> 2);
     const int col = idx;                            // column pass: column of the strip
     const int scol = ft_ring_col(col);
-    const int gx = x0 + col;
-    float *outp = (plane == 0 ? p.out0 : plane == 1 ? p.out1 : p.out2) + (size_t)frame * p.frame_stride;
+    float *const outp = plane == 0 ? p.out0 : plane == 1 ? p.out1 : p.out2;
     float wo[2 * R];  // the column's last 2R row-filtered values of the previous chunk (kept as floats: 2R registers)
 #pragma unroll
     for (int i = 0; i < 2 * R; i++) wo[i] = 0.f;
+    float nv[CH];
+#pragma unroll
+    for (int i = 0; i < CH; i++) nv[i] = 0.f;
 
-    prefetch(0);
-    commit();
-    for (int chunk = 0; chunk < nchunks; chunk++) {
-        __syncthreads();  // raw tile of this chunk complete; ring free (column pass / output phase of the previous chunk done)
-
-        // ---- row pass
-        if (plane == 0) ft_row_task<R, TW, FMA, 0>(raw4, ring, rr, rs, p.B);
-        else if (plane == 1) ft_row_task<R, TW, FMA, 1>(raw4, ring, rr, rs, p.B);
-        else ft_row_task<R, TW, FMA, 2>(raw4, ring, rr, rs, p.B);
-        __syncthreads();
-        // the raw tile is free: fetch the next one into registers now (in flight during the column pass, written to LDS
-        // after it -- the loads precede the column pass's stores in the memory queue, so waiting for them does not wait
-        // for the stores).  Unconditional: past the last chunk it fetches clamped rows that are never used.
-        prefetch(chunk + 1);
-
-        // ---- column pass.  wn[2R + r] = this chunk's row r of the column, wn[0..2R) = the previous chunk's last 2R rows;
-        // output row oi_base + r is centred on wn[R + r]; all indices are compile-time constants.  The 16 reads, the
-        // conversions and the 16 tap chains carry no control flow, so the chains interleave (a chain alone is
-        // latency-bound: 2R+1 dependent f64 operations).
-        const float *rcol = ring + plane * CH * RP + scol;
-        const int oi_base = chunk * CH - 2 * R;
-        float nv[CH];
-#pragma unroll
-        for (int r = 0; r < CH; r++) nv[r] = rcol[r * RP];
-        double wn[CH + 2 * R];
-#pragma unroll
-        for (int i = 0; i < 2 * R; i++) wn[i] = (double)wo[i];
-#pragma unroll
-        for (int r = 0; r < CH; r++) wn[2 * R + r] = (double)nv[r];
-#pragma unroll
-        for (int i = 0; i < 2 * R; i++) wo[i] = nv[CH - 2 * R + i];
-        auto tap_chain = [&](int r) __attribute__((always_inline)) -> float {
-            const int c = R + r;
-            double sum = p.B[0] * wn[c];
-#pragma unroll
-            for (int j = 1; j <= R; j++) {
-                const double pair = wn[c - j] + wn[c + j];
-                if (FMA) sum = __builtin_fma(p.B[j], pair, sum);
-                else sum += p.B[j] * pair;
-            }
-            return (float)sum;
-        };
-        if (OUT == 0) {
-            if (gx < p.nx) {  // one exec region around the whole pass: no per-store branches between the chains
-                float *dst = outp + (unsigned)(y0 + oi_base) * (unsigned)p.nx + (unsigned)gx;  // one frame < 2^32 px; row oi_base may lie above the segment
-                if (oi_base >= 0 && oi_base + CH <= nrows) {  // workgroup-uniform: every row of the chunk is an output row
-#pragma unroll
-                    for (int r = 0; r < CH; r++) dst[(unsigned)r * (unsigned)p.nx] = tap_chain(r);
-                } else {
-                    float o[CH];
-#pragma unroll
-                    for (int r = 0; r < CH; r++) o[r] = tap_chain(r);
-#pragma unroll
-                    for (int r = 0; r < CH; r++)
-                        if (oi_base + r >= 0 && oi_base + r < nrows) outp[(unsigned)(y0 + oi_base + r) * (unsigned)p.nx + (unsigned)gx] = o[r];
-                }
+    // output phase (OUT 1/2): rows of the chunk at `t` from the output buffer to global memory as float4s
+    auto output_rows = [&](const TensorPos &t) __attribute__((always_inline)) {
+        const float4 *ob4 = reinterpret_cast<const float4 *>(obuf);
+        constexpr int ROW4 = TW / 4, RP4 = RP / 4;
+        const int oi_base = t.chunk * CH - 2 * R, tx0 = FT_X0(t), ty0 = FT_Y0(t), tnrows = FT_NROWS(t);
+        if (OUT == 2) {
+            for (int i = tid; i < CH * ROW4; i += NT) {
+                const int r = i / ROW4, q = i - r * ROW4;
+                const int oi = oi_base + r, x = tx0 + 4 * q;
+                if (oi < 0 || oi >= tnrows || x >= p.nx) continue;
+                const int sl = ft_ring_slot4(q >> 2, q & 3);
+                const float4 a = ob4[(0 * CH + r) * RP4 + sl], b = ob4[(1 * CH + r) * RP4 + sl], c = ob4[(2 * CH + r) * RP4 + sl];
+                const ft_v4f v = {harris_response_value<0>(a.x, b.x, c.x, p.k), harris_response_value<0>(a.y, b.y, c.y, p.k),
+                                  harris_response_value<0>(a.z, b.z, c.z, p.k), harris_response_value<0>(a.w, b.w, c.w, p.k)};
+                float *dst = p.out0 + (size_t)t.frame * p.frame_stride + (unsigned)(ty0 + oi) * (unsigned)p.nx + (unsigned)x;
+                *reinterpret_cast<ft_v4f *>(dst) = v;
             }
         } else {
-#pragma unroll
-            for (int r = 0; r < CH; r++) ring[(plane * CH + r) * RP + scol] = tap_chain(r);  // slot r was read by this very thread
-        }
-        if (OUT != 0) {
-            // ---- output phase: the chunk's smoothed A, B, C rows sit in the ring (slot r <-> output row oi_base + r)
-            __syncthreads();
-            const float4 *ring4 = reinterpret_cast<const float4 *>(ring);
-            constexpr int ROW4 = TW / 4, RP4 = RP / 4;
-            if (OUT == 2) {
-                for (int i = tid; i < CH * ROW4; i += NT) {
-                    const int r = i / ROW4, q = i - r * ROW4;
-                    const int oi = oi_base + r, x = x0 + 4 * q;
-                    if (oi < 0 || oi >= nrows || x >= p.nx) continue;
-                    const int sl = ft_ring_slot4(q >> 2, q & 3);
-                    const float4 a = ring4[(0 * CH + r) * RP4 + sl], b = ring4[(1 * CH + r) * RP4 + sl], c = ring4[(2 * CH + r) * RP4 + sl];
-                    const ft_v4f v = {harris_response_value<0>(a.x, b.x, c.x, p.k), harris_response_value<0>(a.y, b.y, c.y, p.k),
-                                      harris_response_value<0>(a.z, b.z, c.z, p.k), harris_response_value<0>(a.w, b.w, c.w, p.k)};
-                    float *dst = p.out0 + (size_t)frame * p.frame_stride + (unsigned)(y0 + oi) * (unsigned)p.nx + (unsigned)x;
-                    *reinterpret_cast<ft_v4f *>(dst) = v;
-                }
-            } else {
-                for (int i = tid; i < 3 * CH * ROW4; i += NT) {
-                    const int pl = i / (CH * ROW4), rem = i - pl * (CH * ROW4);
-                    const int r = rem / ROW4, q = rem - r * ROW4;
-                    const int oi = oi_base + r, x = x0 + 4 * q;
-                    if (oi < 0 || oi >= nrows || x >= p.nx) continue;
-                    const float4 a = ring4[(pl * CH + r) * RP4 + ft_ring_slot4(q >> 2, q & 3)];
-                    float *dst = (pl == 0 ? p.out0 : pl == 1 ? p.out1 : p.out2) + (size_t)frame * p.frame_stride +
-                                 (unsigned)(y0 + oi) * (unsigned)p.nx + (unsigned)x;
-                    *reinterpret_cast<ft_v4f *>(dst) = ft_v4f{a.x, a.y, a.z, a.w};
-                }
+            for (int i = tid; i < 3 * CH * ROW4; i += NT) {
+                const int pl = i / (CH * ROW4), rem = i - pl * (CH * ROW4);
+                const int r = rem / ROW4, q = rem - r * ROW4;
+                const int oi = oi_base + r, x = tx0 + 4 * q;
+                if (oi < 0 || oi >= tnrows || x >= p.nx) continue;
+                const float4 a = ob4[(pl * CH + r) * RP4 + ft_ring_slot4(q >> 2, q & 3)];
+                float *dst = (pl == 0 ? p.out0 : pl == 1 ? p.out1 : p.out2) + (size_t)t.frame * p.frame_stride +
+                             (unsigned)(ty0 + oi) * (unsigned)p.nx + (unsigned)x;
+                *reinterpret_cast<ft_v4f *>(dst) = ft_v4f{a.x, a.y, a.z, a.w};
             }
         }
-        commit();  // stage the next chunk's tile; the next row pass reads it (and writes the ring) after the barrier at the top
+    };
+
+    // The two passes of the big phase, in groups of ILP outputs whose tap chains advance together.
+    //   DO_COL: column pass of the chunk at `tp` (nv[] = its 16 rows of this thread's column, wo[] = the 2R rows before
+    //           them -> 16 output rows).  FULL (workgroup-uniform): every row of the chunk is an output row and the strip
+    //           lies inside the image, so the stores need no predicate; otherwise each store is guarded.
+    //   DO_ROW: row pass of the current chunk (this thread's 16+2R products pr[] -> 16 row-filtered floats in the ring).
+    // (Interleaving the groups of the two passes, so that the stores trickle out over the whole phase, was tried: the two
+    // windows together do not fit the 168-register budget -- spills, 116 us per frame.  So was pinning the order of the
+    // groups with scheduling fences: +10 %.)
+    auto big_phase = [&](auto do_row_tag, auto do_col_tag, auto full_tag, const TensorPos &tp, float (&pr)[G::NW])
+                         __attribute__((always_inline)) {
+        constexpr bool DO_ROW = decltype(do_row_tag)::value, DO_COL = decltype(do_col_tag)::value, FULL = decltype(full_tag)::value;
+        constexpr int ILP = FT_ILP, NG = CH / ILP;
+        float cw[CH + 2 * R];  // column window: the previous chunk's last 2R rows, then this chunk's 16
+        double dcw[CH + 2 * R], dpr[G::NW];
+        const int oi_base = tp.chunk * CH - 2 * R, tnrows = FT_NROWS(tp);
+        const int gx = FT_X0(tp) + col;
+        float *cdst = outp + (size_t)tp.frame * p.frame_stride + (unsigned)(FT_Y0(tp) + max(oi_base, 0)) * (unsigned)p.nx + (unsigned)gx;
+        if (oi_base < 0) cdst -= (size_t)(-oi_base) * p.nx;  // row oi_base lies above the segment: only guarded stores use it
+        if (DO_COL) {
+#pragma unroll
+            for (int i = 0; i < 2 * R; i++) cw[i] = wo[i];
+#pragma unroll
+            for (int r = 0; r < CH; r++) cw[2 * R + r] = nv[r];
+#pragma unroll
+            for (int i = 0; i < 2 * R; i++) wo[i] = nv[CH - 2 * R + i];
+        }
+        float4 *rdst = reinterpret_cast<float4 *>(ring + (plane * CH + rr) * RP);
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            if (DO_COL) {
+                float o[ILP];
+                ft_group<R, FMA, ILP, CH + 2 * R>(cw, dcw, ILP * g, p.B, o);
+#pragma unroll
+                for (int e = 0; e < ILP; e++) {
+                    const int r = ILP * g + e;
+                    if (OUT != 0) obuf[(plane * CH + r) * RP + scol] = o[e];
+                    else if (FULL) cdst[(unsigned)r * (unsigned)p.nx] = o[e];
+                    else if (gx < p.nx && oi_base + r >= 0 && oi_base + r < tnrows) cdst[(ptrdiff_t)r * p.nx] = o[e];
+                }
+            }
+            if (DO_ROW) {
+                float o[ILP];
+                ft_group<R, FMA, ILP, G::NW>(pr, dpr, ILP * g, p.B, o);
+#pragma unroll
+                for (int h = 0; h < ILP / 4; h++) rdst[ft_ring_slot4(rs, g * (ILP / 4) + h)] = make_float4(o[4 * h], o[4 * h + 1], o[4 * h + 2], o[4 * h + 3]);
+            }
+        }
+    };
+
+    TensorPos cur;  // chunk of the row pass in this step
+    cur.strip = worker % p.nstrips;
+    cur.seg = (worker / p.nstrips) % p.nseg;
+    cur.frame = worker / (p.nstrips * p.nseg);
+    cur.chunk = 0;
+    if (cur.frame >= p.n_frames) return;  // workgroup-uniform (the host launches min(workers, tiles) workgroups)
+    TensorPos prev = cur, prev2 = cur;    // chunk of the column pass / of the output phase in this step
+    bool have_cur = true, have_prev = false, have_prev2 = false;
+#ifdef FT_PROFILE
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_amdgcn_s_memtime();
+#endif
+    prefetch(cur);
+    while (have_cur || have_prev || (OUT != 0 && have_prev2)) {
+        FT_T(0);
+        __syncthreads();  // barrier 1: ring = row-filtered chunk `prev`, output buffer = chunk `prev2`, raw tile consumed
+        FT_T(1);
+        if (have_prev) {
+            const float *rcol = ring + plane * CH * RP + scol;
+#pragma unroll
+            for (int r = 0; r < CH; r++) nv[r] = rcol[r * RP];
+        }
+        if (have_cur) {
+            commit();
+            if (VEC && !(FT_X0(cur) - HALO >= 0 && FT_X0(cur) - HALO + G::W <= p.nx)) {
+                __syncthreads();
+                patch_borders(cur);
+            }
+        }
+        if (OUT != 0 && have_prev2) output_rows(prev2);
+        FT_T(2);
+        __syncthreads();  // barrier 2: ring and output buffer may be overwritten, raw tile of `cur` complete
+        // big phase.  Order: the fetch of the next tile first (it lands while the phase computes), then the column pass --
+        // its stores are then old by the time the next small phase waits for the fetched tile -- then the row pass.
+        FT_T(3);
+        TensorPos nxt = cur;
+        bool have_nxt = false;
+        if (have_cur) {
+            nxt = next_pos(cur);
+            have_nxt = nxt.frame < p.n_frames;
+        }
+        FT_T(4);
+        float pr[G::NW];
+        {
+            using T = std::true_type;
+            using F = std::false_type;
+            const int oib = prev.chunk * CH - 2 * R;
+            const bool full = OUT != 0 || (oib >= 0 && oib + CH <= FT_NROWS(prev) && FT_X0(prev) + TW <= p.nx);
+            // column pass first (its stores drain while the row pass computes), then the row pass
+            if (have_nxt) prefetch(nxt);  // lands while the phase computes; issued later it was not there in time (+5..9 %)
+            if (have_prev) {
+                if (full) big_phase(F(), T(), T(), prev, pr);
+                else big_phase(F(), T(), F(), prev, pr);
+            }
+            FT_T(5);
+            if (have_cur) {
+                if (plane == 0) ft_row_products<R, TW, 0>(raw4, rr, rs, pr);
+                else if (plane == 1) ft_row_products<R, TW, 1>(raw4, rr, rs, pr);
+                else ft_row_products<R, TW, 2>(raw4, rr, rs, pr);
+                big_phase(T(), F(), T(), prev, pr);
+            }
+        }
+        FT_T(6);
+        prev2 = prev; have_prev2 = have_prev;
+        prev = cur; have_prev = have_cur;
+        cur = nxt; have_cur = have_nxt;
     }
+#ifdef FT_PROFILE
+    if ((threadIdx.x & 63) == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&g_ft_prof[i], prof[i]);
+#endif
 }
 
 // ------------------------------------------------------------------ host side
@@ -339,14 +508,15 @@ static imgfd_status launch_tensor_r(imgfd_ctx *ctx, TensorParams &p, int n_frame
 {
     using G = TensorGeom<R, TW>;
     const int strips = ceil_div(p.nx, G::TW);
-    // Segment length: a workgroup walks (rows + 2R) rows in chunks of CH.  With `slots` workgroups resident on the chip,
-    // the pass takes ceil(workgroups / slots) rounds of (chunks per segment) steps: pick the segment count that
-    // minimises that product (ties: fewer, longer segments = less halo work).
+    const size_t lds = G::lds_bytes(OUT);
+    // Workers = the workgroups the chip holds at once (persistent: each walks its share of the tiles).  Segment length: a
+    // tile is (rows + 2R) rows in chunks of CH; the pass takes ceil(tiles / workers) tiles of (chunks per tile) steps per
+    // worker: pick the segment count that minimises that product (ties: fewer, longer segments = less halo work).
     static int per_cu = 0;
     if (!per_cu) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)fir_tensor<R, TW, true, true, OUT>, G::NT, G::LDS_BYTES) != hipSuccess || n < 1)
-            n = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)fir_tensor<R, TW, true, true, OUT>, G::NT, lds) != hipSuccess || n < 1)
+            n = 1;
         per_cu = n;
         if (const char *e = getenv("IMGFD_TENSOR_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
     }
@@ -357,16 +527,24 @@ static imgfd_status launch_tensor_r(imgfd_ctx *ctx, TensorParams &p, int n_frame
         int m = ceil_div(ceil_div(p.ny, nseg) + 2 * R, G::CH);
         if (m < 2) m = 2;
         const int sr = m * G::CH - 2 * R;  // (rows + 2R) fills whole chunks
-        const long wgs = (long)strips * ceil_div(p.ny, sr) * n_frames;
-        const long cost = ((wgs + slots - 1) / slots) * m;
+        const long tiles = (long)strips * ceil_div(p.ny, sr) * n_frames;
+        const long cost = ((tiles + slots - 1) / slots) * m;
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; seg = sr; }
     }
     p.seg_rows = seg;
     if (const char *e = getenv("IMGFD_TENSOR_SEG")) if (atoi(e) > 0) p.seg_rows = atoi(e);
-    dim3 grid(strips, ceil_div(p.ny, p.seg_rows), n_frames);
+    p.nstrips = strips;
+    p.nseg = ceil_div(p.ny, p.seg_rows);
+    p.n_frames = n_frames;
+    const long tiles = (long)p.nstrips * p.nseg * n_frames;
+    long workers = std::min<long>(tiles, slots);
+    if (const char *e = getenv("IMGFD_TENSOR_WORKERS")) if (atoi(e) > 0) workers = std::min<long>(tiles, atoi(e));  // tests: several tiles per worker on small images
+    p.step_strip = (int)(workers % p.nstrips);
+    p.step_seg = (int)((workers / p.nstrips) % p.nseg);
+    p.step_frame = (int)(workers / ((long)p.nstrips * p.nseg));
+    dim3 grid((unsigned)workers);
     static const char *env = getenv("IMGFD_XCD_REMAP");
     p.xcd_remap = env ? atoi(env) : 1;
-    const size_t lds = G::LDS_BYTES;
     auto go = [&](auto kern) -> imgfd_status {
         IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, grid, dim3(G::NT), lds, ctx->stream, p);
