@@ -448,12 +448,10 @@ __device__ __forceinline__ unsigned long long lane_below(unsigned long long v)
 #endif
 }
 
-#ifndef HY_WORDS
-#define HY_WORDS 4  // tile = 256 columns x 64 rows per wave; MI355X sweep (avg us of the 12 sweeps of a round): 1 -> 134, 2 -> 82, 4 -> 55, 8 -> 62
-#endif
-
-// One sweep.  flags[sweep] is raised when any tile changed; a sweep whose predecessor (same round) was
-// idle returns at once, so the host may queue a whole round of sweeps behind one read-back.  act[] holds one byte per
+#define HY_WORDS 4   // a wave's tile: 4 words (256 columns) x 64 rows (lane = row), iterated to a fixpoint in registers
+// One sweep over all tiles of all frames (a wave per tile, the tile iterated to its fixpoint in registers).  flags[sweep]
+// is raised when any tile changed; a sweep whose predecessor was idle returns at once, so the host queues a fixed number
+// of sweeps without ever reading a flag back.  act[] holds one byte per
 // tile and sweep parity: "this tile changed in that sweep"; a tile can only change if itself or one of its 8
 // neighbours changed in the previous sweep (its inputs are its own words and their halo), so all others leave at once.
 __global__ void __launch_bounds__(256) canny_hyst_bits(unsigned long long *__restrict__ S,
@@ -553,6 +551,219 @@ __global__ void __launch_bounds__(256) canny_hyst_bits(unsigned long long *__res
         if (lane == 0) atomicOr(&flags[sweep], 1u);
     }
     if (lane == 0) act_w[tile] = any ? 1 : 0;
+}
+
+
+#define HY_NT 512    // threads per region workgroup (8 waves)
+#define HY_MAXTILES 96
+
+// A REGION of the frame -- RW words x RH rows of both bit planes plus a one-pixel ring of S -- lives in LDS while one
+// workgroup drives it to its fixpoint: the waves take the region's tiles in turn (halo words / rows of a tile are read
+// from LDS, i.e. from what the neighbouring tiles' waves wrote last), rounds separated by __syncthreads, until a whole
+// round changed nothing.  Tiles whose 3x3 tile neighbourhood did not change in the previous round are skipped.
+// Afterwards the region's S goes back to global memory, and `border` says whether a pixel on the region's outline
+// changed: only those can make a neighbouring region change.
+struct HystGeom {
+    int wpr, ny;          // bit-plane words per row, rows
+    int RW, RH;           // region size in words / rows
+    int rx, ry;           // regions per frame
+    int pitch;            // LDS row pitch in words (odd: lane <-> row accesses of ds_read_b64 hit 32 distinct bank pairs)
+};
+
+__device__ __forceinline__ bool hyst_region(unsigned long long *__restrict__ Sf, const unsigned long long *__restrict__ Wf,
+                                            const HystGeom &g, int reg, unsigned long long *sS, unsigned long long *sW,
+                                            unsigned char *tact, unsigned *lflag)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwaves = HY_NT / 64;
+    const int rgx = reg % g.rx, rgy = reg / g.rx;
+    const int w0 = rgx * g.RW, y0 = rgy * g.RH;             // region origin in the plane
+    const int rw = min(g.RW, g.wpr - w0), rh = min(g.RH, g.ny - y0);
+    const int P = g.pitch;
+    // ---- load: S with its ring (LDS row r+1, word c+1 <-> plane row y0+r, word w0+c; outside the plane = 0), W interior
+    for (int i = tid; i < (rh + 2) * (rw + 2); i += HY_NT) {
+        const int r = i / (rw + 2) - 1, c = i - (r + 1) * (rw + 2) - 1;
+        const int y = y0 + r, wi = w0 + c;
+        const bool in = y >= 0 && y < g.ny && wi >= 0 && wi < g.wpr;
+        sS[(r + 1) * P + c + 1] = in ? Sf[(size_t)y * g.wpr + wi] : 0ull;
+        if (r >= 0 && r < rh && c >= 0 && c < rw) sW[r * P + c] = Wf[(size_t)y * g.wpr + wi];
+    }
+    const int tiles_x = (rw + HY_WORDS - 1) / HY_WORDS, tiles_y = (rh + 63) / 64, ntiles = tiles_x * tiles_y;
+    for (int i = tid; i < 2 * HY_MAXTILES; i += HY_NT) tact[i] = 1;  // round 0: every tile
+    if (tid < 4) lflag[tid] = 0;
+    __syncthreads();
+    bool region_changed = false;
+    for (int round = 0;; round++) {
+        unsigned char *act_w = tact + (round & 1) * HY_MAXTILES;
+        const unsigned char *act_r = tact + ((round + 1) & 1) * HY_MAXTILES;
+        bool wave_changed = false;
+        for (int tile = wv; tile < ntiles; tile += nwaves) {
+            const int tx = tile % tiles_x, ty = tile / tiles_x;
+            if (round > 0) {  // a tile can only change if itself or one of its 8 neighbours changed in the previous round
+                bool near = false;
+                if (lane < 9) {
+                    const int nx_ = tx + lane % 3 - 1, ny_ = ty + lane / 3 - 1;
+                    near = nx_ >= 0 && nx_ < tiles_x && ny_ >= 0 && ny_ < tiles_y && act_r[ny_ * tiles_x + nx_] != 0;
+                }
+                if (!__any(near)) { if (lane == 0) act_w[tile] = 0; continue; }
+            }
+            const int r = ty * 64 + lane;           // region row of this lane
+            const bool rowok = r < rh;              // r == rh: the ring row below the region (a source of S, never changed)
+            const int c0 = tx * HY_WORDS;
+            unsigned long long sv[HY_WORDS + 2], wvw[HY_WORDS];  // sv[0] / sv[HY_WORDS+1]: the words left / right of the tile
+            const unsigned long long *srow = sS + ((r <= rh ? r : 0) + 1) * P + c0;  // word c0-1 of the row (ring offset +1)
+#pragma unroll
+            for (int q = 0; q < HY_WORDS + 2; q++) sv[q] = (r <= rh && c0 - 1 + q <= rw) ? srow[q] : 0ull;
+            bool todo = false;
+#pragma unroll
+            for (int q = 0; q < HY_WORDS; q++) {
+                wvw[q] = (rowok && c0 + q < rw) ? sW[r * P + c0 + q] : 0ull;
+                todo = todo || (wvw[q] & ~sv[q + 1]) != 0ull;
+            }
+            if (!__any(todo)) { if (lane == 0) act_w[tile] = 0; continue; }  // no marked-but-not-strong pixel in the tile
+            // rows above / below the tile: lanes 0..5 fetch the six words, everybody gets them by shuffle
+            unsigned long long trow = 0ull, brow = 0ull;
+            if (lane < HY_WORDS + 2 && c0 - 1 + lane <= rw) {
+                trow = sS[(ty * 64) * P + c0 + lane];                                   // region row ty*64 - 1
+                if (ty * 64 + 64 <= rh) brow = sS[(ty * 64 + 65) * P + c0 + lane];      // region row ty*64 + 64 (<= rh: the ring)
+            }
+            unsigned long long top_d[HY_WORDS], bot_d[HY_WORDS];
+            {
+                unsigned long long t[HY_WORDS + 2], b[HY_WORDS + 2];
+#pragma unroll
+                for (int q = 0; q < HY_WORDS + 2; q++) { t[q] = __shfl(trow, q); b[q] = __shfl(brow, q); }
+#pragma unroll
+                for (int q = 0; q < HY_WORDS; q++) {
+                    top_d[q] = dilate_h(t[q + 1], t[q], t[q + 2]);
+                    bot_d[q] = dilate_h(b[q + 1], b[q], b[q + 2]);
+                }
+            }
+            bool any = false;
+            for (;;) {
+                bool ch = false;
+                unsigned long long d[HY_WORDS];
+#pragma unroll
+                for (int q = 0; q < HY_WORDS; q++) d[q] = dilate_h(sv[q + 1], sv[q], sv[q + 2]);
+#pragma unroll
+                for (int q = 0; q < HY_WORDS; q++) {
+                    unsigned long long up = lane_above(d[q]), dn = lane_below(d[q]);
+                    if (lane == 0) up = top_d[q];
+                    if (lane == 63) dn = bot_d[q];
+                    const unsigned long long cand = wvw[q] & ~sv[q + 1] & (d[q] | up | dn);
+                    if (cand) {
+                        sv[q + 1] |= flood_runs(wvw[q], cand);
+                        ch = true;
+                    }
+                }
+                if (!__any(ch)) break;
+                any = true;
+            }
+            if (any) {
+#pragma unroll
+                for (int q = 0; q < HY_WORDS; q++)
+                    if (rowok && c0 + q < rw) sS[(r + 1) * P + c0 + q + 1] = sv[q + 1];
+                wave_changed = true;
+            }
+            if (lane == 0) act_w[tile] = any ? 1 : 0;
+        }
+        if (wave_changed && lane == 0) lflag[round % 3] = 1;
+        __syncthreads();
+        const bool more = lflag[round % 3] != 0;
+        if (tid == 0) lflag[(round + 2) % 3] = 0;  // last read before this barrier, next written after the one that follows
+        if (!more) break;
+        region_changed = true;
+    }
+    // ---- write back, and tell whether the region's outline changed (compare with the plane, which still holds the old S)
+    bool border = false;
+    if (region_changed) {
+        const unsigned long long lastmask = 1ull << 63;  // a region ends on a word boundary or at the plane's last word: its last
+                                                         // column is bit 63 of its last word or lies on the image border
+        for (int i = tid; i < rh * rw; i += HY_NT) {
+            const int r = i / rw, c = i - r * rw;
+            const unsigned long long nv = sS[(r + 1) * P + c + 1];
+            unsigned long long *dst = Sf + (size_t)(y0 + r) * g.wpr + w0 + c;
+            const unsigned long long diff = nv & ~*dst;
+            if (diff) {
+                *dst = nv;
+                if (r == 0 || r == rh - 1) border = true;
+                else if ((c == 0 && (diff & 1ull)) || (c == rw - 1 && (diff & lastmask))) border = true;
+            }
+        }
+    }
+    if (border) lflag[3] = 1;
+    __syncthreads();
+    const bool any_border = lflag[3] != 0;
+    __syncthreads();  // everybody has read the verdict before the next region resets the flags
+    return any_border;
+}
+
+// did region `reg` or one of its 8 neighbours report a changed outline (flags of the previous round)?
+__device__ __forceinline__ bool hyst_region_due(const unsigned char *flags, const HystGeom &g, int reg)
+{
+    const int rgx = reg % g.rx, rgy = reg / g.rx;
+    for (int dy = -1; dy <= 1; dy++)
+        for (int dx = -1; dx <= 1; dx++) {
+            const int x = rgx + dx, y = rgy + dy;
+            if (x >= 0 && x < g.rx && y >= 0 && y < g.ry && flags[y * g.rx + x]) return true;
+        }
+    return false;
+}
+
+// one round: every region whose neighbourhood changed in the previous round (all of them in round 0) is driven to its
+// fixpoint by its own workgroup; rflag[parity][frame][region] = "the region's outline changed in this round"
+__global__ void __launch_bounds__(HY_NT) canny_hyst_regions(unsigned long long *__restrict__ S, const unsigned long long *__restrict__ Wm,
+                                                           HystGeom g, unsigned char *__restrict__ rflag, int round)
+{
+    HIP_DYNAMIC_SHARED(unsigned long long, hy_smem)
+    unsigned long long *sS = hy_smem, *sW = sS + (size_t)(g.RH + 2) * g.pitch;
+    unsigned *lflag = reinterpret_cast<unsigned *>(sW + (size_t)g.RH * g.pitch);
+    unsigned char *tact = reinterpret_cast<unsigned char *>(lflag + 4);
+    const int reg = blockIdx.x, frame = blockIdx.y, regions = g.rx * g.ry, nf = gridDim.y;
+    unsigned char *fl_w = rflag + ((size_t)(round & 1) * nf + frame) * regions;
+    const unsigned char *fl_r = rflag + ((size_t)((round + 1) & 1) * nf + frame) * regions;
+    if (round > 0 && !hyst_region_due(fl_r, g, reg)) {  // workgroup-uniform
+        if (threadIdx.x == 0) fl_w[reg] = 0;
+        return;
+    }
+    const size_t plane = (size_t)g.ny * g.wpr;
+    const bool border = hyst_region(S + frame * plane, Wm + frame * plane, g, reg, sS, sW, tact, lflag);
+    if (threadIdx.x == 0) fl_w[reg] = border ? 1 : 0;
+}
+
+// Termination on the device: after the queued rounds ONE workgroup per frame looks at the last round's flags.  Nothing
+// set (the case in practice): it leaves.  Otherwise it finishes the frame alone -- passes over the regions in turn, each
+// to its fixpoint, until a whole pass changed no outline -- which always terminates and needs no synchronisation between
+// workgroups (S only ever grows, and it is bounded by W).
+__global__ void __launch_bounds__(HY_NT) canny_hyst_finish(unsigned long long *__restrict__ S, const unsigned long long *__restrict__ Wm,
+                                                          HystGeom g, const unsigned char *__restrict__ rflag, int last_round,
+                                                          const unsigned *__restrict__ sweep_flag)
+{
+    if (sweep_flag && *sweep_flag == 0) return;  // the last queued sweep was idle: converged (the case in practice)
+    HIP_DYNAMIC_SHARED(unsigned long long, hy_smem)
+    unsigned long long *sS = hy_smem, *sW = sS + (size_t)(g.RH + 2) * g.pitch;
+    unsigned *lflag = reinterpret_cast<unsigned *>(sW + (size_t)g.RH * g.pitch);
+    unsigned char *tact = reinterpret_cast<unsigned char *>(lflag + 4);
+    unsigned char *fl = tact + 2 * HY_MAXTILES;  // [2][regions]
+    const int frame = blockIdx.x, regions = g.rx * g.ry, nf = gridDim.x;
+    const unsigned char *last = rflag + ((size_t)(last_round & 1) * nf + frame) * regions;
+    for (int i = threadIdx.x; i < regions; i += HY_NT) fl[i] = sweep_flag ? 1 : last[i];  // after sweeps: every region is due
+    __syncthreads();
+    const size_t plane = (size_t)g.ny * g.wpr;
+    for (int pass = 0;; pass++) {
+        unsigned char *cur = fl + (pass & 1) * regions, *nxt = fl + ((pass + 1) & 1) * regions;
+        bool any = false;
+        for (int i = 0; i < regions; i++) any = any || cur[i];
+        if (!any) break;
+        for (int reg = 0; reg < regions; reg++) {
+            bool border = false;
+            if (hyst_region_due(cur, g, reg)) {
+                border = hyst_region(S + frame * plane, Wm + frame * plane, g, reg, sS, sW, tact, lflag);
+                __threadfence();  // the next region reads this one's rows from global memory
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) nxt[reg] = border ? 1 : 0;
+        }
+        __syncthreads();
+    }
 }
 
 // edges = 255 where strong, else 0 (rcpp_canny.cpp:210-215); thread = 16 pixels
@@ -665,10 +876,44 @@ size_t canny_ws_bytes(int nx, int ny, int nf)
     const size_t n = (size_t)nx * ny * nf;
     const size_t words = (size_t)ceil_div(nx, 64) * ny * nf;
     return align_up(n * sizeof(double), 256) + align_up(n * sizeof(float), 256) + 2 * align_up(words * 8, 256) +
+           align_up(2 * (size_t)nf * ceil_div(nx, 64) * ceil_div(ny, 8), 256) +
            align_up(2 * (size_t)nf * ceil_div(ceil_div(nx, 64), 4) * ceil_div(ny, 64), 256) + 4096;
 }
 
-#define HY_ROUND 12  // sweeps queued per host read-back
+#define HY_SWEEPS 24  // sweeps queued per batch (the bench frames converge in 10-12); flags[] holds one word per sweep
+// Region geometry: as large as LDS allows (15 words x 540 rows: 147 KB for both planes and the ring) when the batch alone
+// fills the device, smaller regions (more workgroups, more rounds) for small batches.
+HystGeom hyst_geometry(int wpr, int ny, int nf, int num_cu)
+{
+    HystGeom g;
+    g.wpr = wpr; g.ny = ny;
+    g.RW = std::min(wpr, 15);
+    g.RH = std::min(ny, 540);
+    auto count = [&]() { return (long)ceil_div(wpr, g.RW) * ceil_div(ny, g.RH) * nf; };
+    if (const char *e = getenv("IMGFD_HYST_REGION")) {  // tests: "RWxRH"
+        int a = 0, b = 0;
+        if (sscanf(e, "%dx%d", &a, &b) == 2 && a >= 1 && a <= 15 && b >= 8 && b <= 540) { g.RW = std::min(wpr, a); g.RH = std::min(ny, b); }
+    } else {
+        while (count() < 2L * num_cu && (g.RH > 128 || g.RW > 4)) {
+            if (g.RH > 128 && g.RH / 64 >= g.RW / 4) g.RH = std::max(128, (g.RH / 2 + 63) / 64 * 64);
+            else if (g.RW > 4) g.RW = std::max(4, (g.RW / 2 + 3) / 4 * 4);
+            else break;
+        }
+    }
+    g.rx = ceil_div(wpr, g.RW);
+    g.ry = ceil_div(ny, g.RH);
+    g.pitch = (g.RW + 2) | 1;
+    return g;
+}
+size_t hyst_lds_bytes(const HystGeom &g) { return 8 * (size_t)g.pitch * ((g.RH + 2) + g.RH) + 16 + 2 * HY_MAXTILES; }
+// rounds queued before the finishing kernel: enough for a component to cross a few regions back and forth; what is left
+// after them (never seen on the test images) is finished by canny_hyst_finish
+int hyst_rounds(const HystGeom &g, int wpr, int ny)
+{
+    (void)wpr; (void)ny;
+    if (const char *e = getenv("IMGFD_HYST_ROUNDS")) if (atoi(e) >= 1) return atoi(e);
+    return std::min(16, 4 + 2 * std::max(g.rx, g.ry) / 2);
+}
 
 // all device work for nf frames; d_edges / d_counts are device buffers
 imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, size_t frame_stride, int nx, int ny,
@@ -690,9 +935,11 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
     unsigned long long *S = (unsigned long long *)ws_alloc(ctx, words * 8);
     unsigned long long *Wm = (unsigned long long *)ws_alloc(ctx, words * 8);
     unsigned *flags = (unsigned *)ws_alloc(ctx, 256);
-    const size_t act_bytes = 2 * (size_t)nf * ceil_div(wpr, HY_WORDS) * ceil_div(ny, 64);
+    const size_t act_bytes = 2 * (size_t)nf * ceil_div(wpr, HY_WORDS) * ceil_div(ny, 64);  // tile activity of the sweeps, two parities
     unsigned char *act = (unsigned char *)ws_alloc(ctx, act_bytes);
-    if ((!fast && !tmp) || !blur || !S || !Wm || !flags || !act) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    const size_t rflag_bytes = 2 * (size_t)nf * wpr * ceil_div(ny, 8);  // region flags, two parities (a region is at least 1 word x 8 rows)
+    unsigned char *rflag = (unsigned char *)ws_alloc(ctx, rflag_bytes);
+    if ((!fast && !tmp) || !blur || !S || !Wm || !flags || !act || !rflag) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
     if (fast) {
         BlurMarchParams p;
         memset(&p, 0, sizeof p);
@@ -719,19 +966,32 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
                        (int)high_thr, (int)(nx % 4 == 0 && (size_t)blur % 16 == 0));
     IMGFD_HIP(ctx, hipGetLastError());
     if (after_front) IMGFD_TRY((*after_front)());
-    // hysteresis: rounds of HY_ROUND sweeps; converged when the last sweep of a round was idle
-    const int tiles_x = ceil_div(wpr, HY_WORDS), tiles_y = ceil_div(ny, 64);
-    dim3 g3(ceil_div(tiles_x * tiles_y, 4), nf);
-    int gsweep = 0;
-    for (int round = 0; round < 100000; round++) {
-        IMGFD_HIP(ctx, hipMemsetAsync(flags, 0, sizeof(unsigned) * HY_ROUND, ctx->stream));
-        for (int i = 0; i < HY_ROUND; i++, gsweep++)
-            hipLaunchKernelGGL(canny_hyst_bits, g3, dim3(256), 0, ctx->stream, S, Wm, wpr, ny, tiles_x, tiles_y, flags, i,
-                               act, gsweep);
-        unsigned last = 0;
-        IMGFD_HIP(ctx, hipMemcpyAsync(&last, flags + HY_ROUND - 1, sizeof last, hipMemcpyDeviceToHost, ctx->stream));
-        IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (!last) break;
+    // Hysteresis, terminated on the device -- no host read-back anywhere.  A fixed number of sweeps is queued (a sweep whose
+    // predecessor changed nothing returns at once: an idle launch costs a few microseconds), then the finishing kernel,
+    // which leaves at once when the last sweep was idle and otherwise completes the frames region by region.
+    {
+        HystGeom g = hyst_geometry(wpr, ny, nf, ctx->num_cu);
+        const int regions = g.rx * g.ry;
+        const size_t lds = hyst_lds_bytes(g) + 2 * (size_t)regions;
+        IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)canny_hyst_regions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)canny_hyst_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const char *mode = getenv("IMGFD_HYST_MODE");  // experiment switch: "regions" = LDS-resident region rounds instead of sweeps
+        if (mode && !strcmp(mode, "regions")) {
+            const int rounds = hyst_rounds(g, wpr, ny);
+            for (int r = 0; r < rounds; r++)
+                hipLaunchKernelGGL(canny_hyst_regions, dim3(regions, nf), dim3(HY_NT), lds, ctx->stream, S, Wm, g, rflag, r);
+            hipLaunchKernelGGL(canny_hyst_finish, dim3(nf), dim3(HY_NT), lds, ctx->stream, S, Wm, g, rflag, rounds - 1, (const unsigned *)nullptr);
+        } else {
+            int sweeps = HY_SWEEPS;
+            if (const char *e = getenv("IMGFD_HYST_SWEEPS")) if (atoi(e) >= 1 && atoi(e) <= HY_SWEEPS) sweeps = atoi(e);  // tests: force the finishing kernel to work
+            const int tiles_x = ceil_div(wpr, HY_WORDS), tiles_y = ceil_div(ny, 64);
+            dim3 g3(ceil_div(tiles_x * tiles_y, 4), nf);
+            IMGFD_HIP(ctx, hipMemsetAsync(flags, 0, sizeof(unsigned) * HY_SWEEPS, ctx->stream));
+            for (int i = 0; i < sweeps; i++)
+                hipLaunchKernelGGL(canny_hyst_bits, g3, dim3(256), 0, ctx->stream, S, Wm, wpr, ny, tiles_x, tiles_y, flags, i, act, i);
+            hipLaunchKernelGGL(canny_hyst_finish, dim3(nf), dim3(HY_NT), lds, ctx->stream, S, Wm, g, rflag, 0, (const unsigned *)(flags + sweeps - 1));
+        }
+        IMGFD_HIP(ctx, hipGetLastError());
     }
     IMGFD_HIP(ctx, hipMemsetAsync(d_counts, 0, sizeof(int64_t) * nf, ctx->stream));
     hipLaunchKernelGGL(canny_expand_bits, dim3(ceil_div(ceil_div(nx, 16), 256), ny, nf), dim3(256), 0, ctx->stream, S, wpr,

@@ -62,13 +62,73 @@ def test_thresholds_are_int_truncated(be):
 
 
 def test_hysteresis_long_chain(be):
-    """a weak chain that snakes across many 64x64 tiles must light up from a single strong seed"""
-    img = np.full((200, 300), 60, np.uint8)
-    img[100:, :] = 66          # faint horizontal step -> weak edge along the whole row
-    img[100:, 5:9] = 140       # a short strong segment seeds it
-    edges, n = be.canny(img, s=1.0, low_thr=2, high_thr=40)
-    ref, rn = oracle.canny(img, s=1.0, low_thr=2, high_thr=40)
-    assert rn > 150 and mismatch(edges, ref) <= 2, (n, rn)
+    """a weak edge across many 64-pixel words must light up from its strong left end: the contrast of a (slightly
+    slanted) step decays smoothly along x -- one unbroken line whose left end alone is above the high threshold.  The step
+    has an intermediate row (a two-level step makes neighbouring rows tie exactly in the non-maximum test, and ties are
+    where the device's unit-vector form of atan2 -> cos/sin may legitimately flip a pixel)."""
+    yy, xx = np.mgrid[0:200, 0:300]
+    t = (100 + xx / 37.0).astype(int)
+    c = 6 + 90 * np.exp(-xx / 8.0)
+    img = np.round(60 + (yy > t) * c + (yy == t) * c * 0.3).astype(np.uint8)
+    edges, n = be.canny(img, **SERP_KW)
+    ref, rn, dbg = oracle.canny(img, debug=True, **SERP_KW)
+    assert np.count_nonzero(dbg["nms"] == 2) < 300 and rn > 1000        # ~200 strong pixels light ~1100
+    assert (ref > 0)[:, 150:290].any(axis=0).all() and not (dbg["nms"][:, 150:290] == 2).any()   # weak there, yet lit
+    assert mismatch(edges, ref) == 0 and n == rn
+
+
+def _serpentine(nx=640, ny=400):
+    """one weak edge that snakes up and down across the whole image, lit from its far left end only: the region enclosed
+    by the snake stands out from the background by a contrast that decays smoothly along x (strong for x < ~30, weak
+    beyond -- a junction with a separate strong blob would not do: NMS cuts the weak line next to it), with a rim at 30 %
+    of it (no exact ties, see above).  The hysteresis has to carry the seed through every part of the frame, upwards and
+    downwards."""
+    inside = np.zeros((ny, nx), bool)
+    x, up = 10, True
+    while x + 60 < nx:
+        inside[16:ny - 16, x:x + 14] = True
+        if up: inside[16:30, x:x + 54] = True
+        else: inside[ny - 30:ny - 16, x:x + 54] = True
+        up = not up
+        x += 40
+    core = inside.copy()
+    core[1:] &= inside[:-1]; core[:-1] &= inside[1:]; core[:, 1:] &= inside[:, :-1]; core[:, :-1] &= inside[:, 1:]
+    contrast = (7 + 90 * np.exp(-np.arange(nx) / 6.0))[None, :]
+    return np.round(60 + core * contrast + (inside & ~core) * 0.3 * contrast).astype(np.uint8)
+
+
+SERP_KW = dict(s=1.0, low_thr=5, high_thr=60)
+
+
+def test_serpentine_really_propagates():
+    img = _serpentine()
+    edges, n, dbg = oracle.canny(img, debug=True, **SERP_KW)
+    strong, marked = np.count_nonzero(dbg["nms"] == 2), np.count_nonzero(dbg["nms"] >= 1)
+    cols = np.nonzero(edges.any(axis=0))[0]
+    assert strong < 600 and n > 0.9 * marked > 8000 and cols.max() > 600   # a few hundred seeds light ~10 000 pixels
+
+
+@pytest.mark.parametrize("mode,region,rounds,nx,ny", [("sweeps", "15x540", "24", 384, 200), ("sweeps", "4x128", "3", 384, 200),
+                                                       ("sweeps", "2x64", "1", 320, 160), ("regions", "15x540", "8", 384, 200),
+                                                       ("regions", "2x64", "2", 320, 160), ("regions", "1x16", "1", 200, 100)])
+def test_hysteresis_device_side_termination(be, mode, region, rounds, nx, ny, monkeypatch):
+    """The hysteresis never reports to the host: a fixed number of sweeps (or of LDS-resident region rounds) is queued and a
+    finishing kernel completes whatever they left, region by region.  Few sweeps / rounds and small regions force the
+    finishing kernel to do most of the work, with components crossing many region outlines."""
+    monkeypatch.setenv("IMGFD_HYST_MODE", mode)
+    monkeypatch.setenv("IMGFD_HYST_REGION", region)
+    monkeypatch.setenv("IMGFD_HYST_ROUNDS" if mode == "regions" else "IMGFD_HYST_SWEEPS", rounds)
+    img = _serpentine(nx, ny)
+    kw = SERP_KW
+    ref, rn, dbg = oracle.canny(img, debug=True, **kw)
+    assert rn > 3 * np.count_nonzero(dbg["nms"] == 2)                     # most of what is lit was only marked
+    edges, n = be.canny(img, **kw)
+    assert n == rn and mismatch(edges, ref) == 0, (region, rounds, n, rn)
+    frames = np.stack([img, synth.frame(31, nx, ny), img[::-1].copy()])
+    e, c = be.canny_dev(frames, **kw)
+    for f in range(3):
+        r, k = oracle.canny(frames[f], **kw)
+        assert c[f] == k and mismatch(e[f], r) <= (0 if f != 1 else 3)
 
 
 def test_batch_dev(be):
