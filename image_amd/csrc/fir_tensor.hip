@@ -97,6 +97,26 @@ struct TensorGeom {
     static_assert(16 * (NS - 1) + 4 * NW4 <= W, "row-pass window reads stay inside the tile row");
 };
 
+// a float plane addressed as a hardware buffer: store(value) at byte offset lane_off (per lane) + row_off (wave-uniform)
+#ifdef HIPEMU
+struct FtBuffer { float *base; };
+__device__ __forceinline__ FtBuffer ft_make_buffer(float *base, unsigned) { return FtBuffer{base}; }
+__device__ __forceinline__ void ft_buffer_store(const FtBuffer &b, unsigned lane_off, unsigned row_off, float v)
+{
+    *reinterpret_cast<float *>(reinterpret_cast<char *>(b.base) + (size_t)(row_off + lane_off)) = v;
+}
+#else
+struct FtBuffer { __amdgpu_buffer_rsrc_t r; };
+__device__ __forceinline__ FtBuffer ft_make_buffer(float *base, unsigned bytes)
+{
+    return FtBuffer{__builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00027000)};  // raw buffer, 32-bit data format
+}
+__device__ __forceinline__ void ft_buffer_store(const FtBuffer &b, unsigned lane_off, unsigned row_off, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, (int)lane_off, (int)row_off, 0);
+}
+#endif
+
 // ring position of column c of a row: the four float4 slots of each 16-column strip are rotated by (strip / 2), so the
 // row pass's ds_write_b128 (8 lanes = 8 strips of one row) covers 8 distinct slots mod 8 and the column pass's
 // ds_read_b32 still reads 64 consecutive dwords per wave in some order
@@ -394,8 +414,10 @@ __global__ void __launch_bounds__(3 * TW) FT_WAVES_PER_EU(TW) fir_tensor(TensorP
         double dcw[CH + 2 * R], dpr[G::NW];
         const int oi_base = tp.chunk * CH - 2 * R, tnrows = FT_NROWS(tp);
         const int gx = FT_X0(tp) + col;
-        float *cdst = outp + (size_t)tp.frame * p.frame_stride + (unsigned)(FT_Y0(tp) + max(oi_base, 0)) * (unsigned)p.nx + (unsigned)gx;
-        if (oi_base < 0) cdst -= (size_t)(-oi_base) * p.nx;  // row oi_base lies above the segment: only guarded stores use it
+        // output stores: buffer addressing -- the frame's plane as the resource, the row as a SCALAR byte offset, the column
+        // as the lane's constant offset: no per-store 64-bit address arithmetic on the vector pipe (one frame < 2^32 bytes)
+        const FtBuffer cbuf = ft_make_buffer(outp + (size_t)tp.frame * p.frame_stride, (unsigned)p.nx * (unsigned)p.ny * 4u);
+        const unsigned crow0 = (unsigned)(FT_Y0(tp) + oi_base) * (unsigned)p.nx * 4u;  // wraps for rows above the segment: those stores are guarded
         if (DO_COL) {
 #pragma unroll
             for (int i = 0; i < 2 * R; i++) cw[i] = wo[i];
@@ -414,8 +436,9 @@ __global__ void __launch_bounds__(3 * TW) FT_WAVES_PER_EU(TW) fir_tensor(TensorP
                 for (int e = 0; e < ILP; e++) {
                     const int r = ILP * g + e;
                     if (OUT != 0) obuf[(plane * CH + r) * RP + scol] = o[e];
-                    else if (FULL) cdst[(unsigned)r * (unsigned)p.nx] = o[e];
-                    else if (gx < p.nx && oi_base + r >= 0 && oi_base + r < tnrows) cdst[(ptrdiff_t)r * p.nx] = o[e];
+                    else if (FULL) ft_buffer_store(cbuf, (unsigned)gx * 4u, crow0 + (unsigned)r * (unsigned)p.nx * 4u, o[e]);
+                    else if (gx < p.nx && oi_base + r >= 0 && oi_base + r < tnrows)
+                        ft_buffer_store(cbuf, (unsigned)gx * 4u, crow0 + (unsigned)r * (unsigned)p.nx * 4u, o[e]);
                 }
             }
             if (DO_ROW) {
