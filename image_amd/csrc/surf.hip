@@ -393,12 +393,172 @@ __global__ void __launch_bounds__(256) surf_nms_interp(const double *__restrict_
     if (k < q.cap) out[k] = rec;
 }
 
+
+// ---- ranking on the device (imgfd_surf_dev): get_surf_points, surf.h:268-285, without the host
+// One workgroup per tile.  Order of two records: higher score first; equal scores (exact ties of two determinants): the
+// point get_interest_points emitted first comes first (what a stable sort would do; the reference's std::sort over
+// reverse iterators leaves the order of exact ties to the library's introsort).  As a 128-bit value: (score bits, ~key),
+// larger = better (scores are non-negative doubles: their bit patterns order like the values; keys are unique).
+//   1. radix select, 16 passes of 8 bits from the top: the composite of the lim-th best record
+//   2. the <= lim records at or above it are collected, ranked among themselves (all pairs, composites staged through LDS)
+//   3. in rank order: drop the points whose 32*scale box leaves the image (:271-285), compact with a block scan, write
+//      x, y, scale for K19 and the head of the feature record (x, y, -, pyramid_scale, score, laplacian)
+// counts_out[0] = points kept (or -candidates when the record buffer overflowed: nothing is written then).
+#define SR_NT 1024
+struct SurfRankParams {
+    const SurfRecord *rec;
+    const unsigned long long *count;
+    unsigned long long cap;
+    unsigned lim;            // min(max_points, rows of the feature buffer)
+    int rows, cols;
+    unsigned *sel, *order;   // scratch, lim entries each
+    double *pts;             // lim x 3 for K19
+    double *feat;            // lim x 70 feature records of this tile
+    long long *count_out;    // d_counts[f]
+    unsigned *m_out;         // the same number for the K19 kernels
+};
+
+__device__ __forceinline__ unsigned long long surf_score_bits(double v)
+{
+    unsigned long long b;
+    memcpy(&b, &v, sizeof b);
+    return b;
+}
+__device__ __forceinline__ unsigned surf_comp_byte(const SurfRecord &r, int pass)  // pass 0 = most significant byte
+{
+    const unsigned long long hi = surf_score_bits(r.score), lo = ~r.key;
+    return pass < 8 ? (unsigned)(hi >> (8 * (7 - pass))) & 0xffu : (unsigned)(lo >> (8 * (15 - pass))) & 0xffu;
+}
+// a > b in the ranking order
+__device__ __forceinline__ bool surf_better(unsigned long long sa, unsigned long long ka, unsigned long long sb, unsigned long long kb)
+{
+    return sa > sb || (sa == sb && ka < kb);
+}
+
+__global__ void __launch_bounds__(SR_NT) surf_rank_select(SurfRankParams q)
+{
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long thr_hi, thr_lo;   // composite of the lim-th best record (prefix built pass by pass)
+    __shared__ unsigned want, nsel, scan[SR_NT], carry;
+    __shared__ unsigned long long st_s[SR_NT], st_k[SR_NT];
+    const int tid = threadIdx.x;
+    const unsigned long long cnt = *q.count;
+    if (cnt > q.cap) {  // more candidates than the record buffer holds: report, leave the feature rows alone
+        if (tid == 0) { *q.count_out = -(long long)cnt; *q.m_out = 0; }
+        return;
+    }
+    const unsigned n = (unsigned)cnt;
+    const unsigned lim = min(q.lim, n);
+    if (lim == 0) {
+        if (tid == 0) { *q.count_out = 0; *q.m_out = 0; }
+        return;
+    }
+    // ---- 1. threshold composite (only when something has to be cut)
+    if (tid == 0) { thr_hi = 0; thr_lo = 0; want = lim; nsel = 0; }
+    __syncthreads();
+    if (n > lim) {
+        for (int pass = 0; pass < 16; pass++) {
+            for (int i = tid; i < 256; i += SR_NT) hist[i] = 0;
+            __syncthreads();
+            const unsigned long long phi = thr_hi, plo = thr_lo;
+            for (unsigned i = tid; i < n; i += SR_NT) {
+                const SurfRecord &r = q.rec[i];
+                const unsigned long long hi = surf_score_bits(r.score), lo = ~r.key;
+                // records that match the prefix fixed so far (the top `pass` bytes)
+                bool match;
+                if (pass == 0) match = true;
+                else if (pass <= 8) match = (hi >> (8 * (8 - pass))) == (phi >> (8 * (8 - pass)));
+                else match = hi == phi && (lo >> (8 * (16 - pass))) == (plo >> (8 * (16 - pass)));
+                if (match) atomicAdd(&hist[surf_comp_byte(r, pass)], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {  // walk the bins from the top: the bin in which the `want`-th best record lies
+                unsigned w = want, b = 255;
+                for (;; b--) {
+                    if (hist[b] >= w) break;
+                    w -= hist[b];
+                    if (b == 0) break;
+                }
+                want = w;
+                if (pass < 8) thr_hi |= (unsigned long long)b << (8 * (7 - pass));
+                else thr_lo |= (unsigned long long)b << (8 * (15 - pass));
+            }
+            __syncthreads();
+        }
+    }
+    // ---- 2. collect (composite >= threshold; everything when nothing is cut), then rank among the collected
+    {
+        const unsigned long long thi = thr_hi, tlo = thr_lo;
+        for (unsigned i = tid; i < n; i += SR_NT) {
+            const SurfRecord &r = q.rec[i];
+            const unsigned long long hi = surf_score_bits(r.score), lo = ~r.key;
+            if (n <= lim || hi > thi || (hi == thi && lo >= tlo)) {
+                const unsigned k = atomicAdd(&nsel, 1u);
+                if (k < lim) q.sel[k] = i;
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned m = min(nsel, lim);  // == lim
+    for (unsigned base = 0; base < m; base += SR_NT) {
+        const unsigned i = base + tid;
+        unsigned long long si = 0, ki = 0;
+        if (i < m) { const SurfRecord &r = q.rec[q.sel[i]]; si = surf_score_bits(r.score); ki = r.key; }
+        unsigned rank = 0;
+        for (unsigned jb = 0; jb < m; jb += SR_NT) {
+            __syncthreads();
+            if (jb + tid < m) { const SurfRecord &r = q.rec[q.sel[jb + tid]]; st_s[tid] = surf_score_bits(r.score); st_k[tid] = r.key; }
+            __syncthreads();
+            const unsigned jn = min((unsigned)SR_NT, m - jb);
+            if (i < m)
+                for (unsigned j = 0; j < jn; j++) rank += surf_better(st_s[j], st_k[j], si, ki) ? 1u : 0u;
+        }
+        if (i < m) q.order[rank] = q.sel[i];
+    }
+    __syncthreads();
+    // ---- 3. box test, compaction in rank order, outputs
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (unsigned base = 0; base < m; base += SR_NT) {
+        const unsigned k = base + tid;
+        bool keep = false;
+        SurfRecord r;
+        if (k < m) {
+            r = q.rec[q.order[k]];
+            const unsigned long bs = (unsigned long)(32.0 * r.scale);
+            const long px = (long)floor(r.x + 0.5), py = (long)floor(r.y + 0.5);
+            const long l = px - (long)bs / 2, t = py - (long)bs / 2, rr = l + (long)bs - 1, b = t + (long)bs - 1;
+            keep = l >= 0 && t >= 0 && rr <= q.cols - 1 && b <= q.rows - 1;
+        }
+        scan[tid] = keep ? 1u : 0u;
+        __syncthreads();
+        for (int d = 1; d < SR_NT; d <<= 1) {  // inclusive Hillis-Steele scan
+            const unsigned v = tid >= d ? scan[tid - d] : 0u;
+            __syncthreads();
+            scan[tid] += v;
+            __syncthreads();
+        }
+        if (keep) {
+            const unsigned pos = carry + scan[tid] - 1;
+            q.pts[3 * pos] = r.x; q.pts[3 * pos + 1] = r.y; q.pts[3 * pos + 2] = r.scale;
+            double *h = q.feat + (size_t)pos * 70;
+            h[0] = r.x; h[1] = r.y; h[2] = 0.0; h[3] = r.scale; h[4] = r.score; h[5] = r.laplacian;
+        }
+        __syncthreads();
+        if (tid == SR_NT - 1) carry += scan[tid];
+        __syncthreads();
+    }
+    if (tid == 0) { *q.count_out = (long long)carry; *q.m_out = carry; }
+}
+
 // surf_host.cpp
 // surf_describe.hip
+// m_dev != nullptr: m is an upper bound (the grid); the number of points is read from *m_dev on the device
 imgfd_status launch_surf_orient(imgfd_ctx *ctx, const unsigned *d_I, int rows, int cols, const double *d_pts, int m,
-                                double *d_samples, double *d_trig);
+                                double *d_samples, double *d_trig, const unsigned *m_dev = nullptr);
 imgfd_status launch_surf_desc(imgfd_ctx *ctx, const unsigned *d_I, int rows, int cols, const double *d_pts,
-                              const double *d_trig, int m, double *d_des, int des_stride, double *d_angle);
+                              const double *d_trig, int m, double *d_des, int des_stride, double *d_angle,
+                              const unsigned *m_dev = nullptr);
 
 namespace {
 
@@ -667,59 +827,33 @@ try {
     const size_t total = surf_geometry(rows, cols, &g);
     const size_t n = (size_t)rows * cols;
     SurfDevice d;
-    d.cap = 1ull << 16;
-    std::vector<SurfRecord> pts;
-    std::vector<size_t> keep;
-    std::vector<int64_t> counts((size_t)n_frames, 0);
-    const long lim = (long)std::min<int64_t>((int64_t)max_points, cap);
-    for (int f = 0; f < n_frames;) {
-        IMGFD_TRY(ws_reserve(ctx, surf_ws_bytes(g, total, d.cap)));
-        (void)ws_alloc(ctx, 3 * n);  // the slot imgfd_surf uses for the uploaded image (same carving, same size function)
-        d.integral = (unsigned *)ws_alloc(ctx, 4 * n);
-        d.pyr = (double *)ws_alloc(ctx, 8 * std::max<size_t>(total, 1));
-        d.pyr_bytes = 8 * std::max<size_t>(total, 1);
-        d.rec = (SurfRecord *)ws_alloc(ctx, sizeof(SurfRecord) * d.cap);
-        d.count = (unsigned long long *)ws_alloc(ctx, 256);
-        if (!d.integral || !d.pyr || !d.rec || !d.count) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    d.cap = 1ull << 18;  // candidate records per tile (12 MB); a tile with more reports -candidates in d_counts
+    const unsigned lim = (unsigned)std::min<int64_t>(std::min<int64_t>((int64_t)max_points, cap), 1 << 24);
+    // one carving for all tiles: they go through the same buffers back to back on the context's stream, no host sync
+    IMGFD_TRY(ws_reserve(ctx, surf_ws_bytes(g, total, d.cap) + align_up(sizeof(unsigned) * 2 * (size_t)lim, 256) +
+                                  align_up(sizeof(double) * 8 * (size_t)lim, 256) + 1024));
+    (void)ws_alloc(ctx, 3 * n);  // the slot imgfd_surf uses for the uploaded image (same carving, same size function)
+    d.integral = (unsigned *)ws_alloc(ctx, 4 * n);
+    d.pyr = (double *)ws_alloc(ctx, 8 * std::max<size_t>(total, 1));
+    d.pyr_bytes = 8 * std::max<size_t>(total, 1);
+    d.rec = (SurfRecord *)ws_alloc(ctx, sizeof(SurfRecord) * d.cap);
+    d.count = (unsigned long long *)ws_alloc(ctx, 256);
+    unsigned *sel = (unsigned *)ws_alloc(ctx, sizeof(unsigned) * 2 * (size_t)lim);
+    double *k19 = (double *)ws_alloc(ctx, sizeof(double) * 8 * (size_t)lim);  // x, y, scale | angle, sin, cos, sin(-), cos(-)
+    if (!d.integral || !d.pyr || !d.rec || !d.count || !sel || !k19) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    unsigned *m_dev = reinterpret_cast<unsigned *>(d.count) + 8;  // inside the 256-byte counter slot
+    double *d_pts = k19, *d_trig = k19 + 3 * (size_t)lim;
+    for (int f = 0; f < n_frames; f++) {
         IMGFD_TRY(surf_device_stages(ctx, d_rgb + (size_t)f * frame_stride_bytes, g, detection_threshold, d));
-        unsigned long long cnt = 0;
-        IMGFD_HIP(ctx, hipMemcpyAsync(&cnt, d.count, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
-        IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (cnt > d.cap) { d.cap = cnt + 1024; continue; }  // redo the frame with a larger record buffer
-        pts.resize((size_t)cnt);
-        if (cnt) {
-            IMGFD_HIP(ctx, hipMemcpyAsync(pts.data(), d.rec, sizeof(SurfRecord) * cnt, hipMemcpyDeviceToHost, ctx->stream));
-            IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        }
-        std::sort(pts.begin(), pts.end(), [](const SurfRecord &a, const SurfRecord &b) { return a.key < b.key; });
-        keep.clear();
-        if (cnt) surf_select(pts, lim, rows, cols, keep);
-        const size_t m = keep.size();
-        counts[(size_t)f] = (int64_t)m;
-        if (m) {
-            SurfK19 k;
-            IMGFD_TRY(surf_k19_carve(ctx, m, &k));
-            double *feat = d_features + (size_t)f * (size_t)cap * 70;
-            // head of every record: x, y, (angle), pyramid_scale, score, laplacian -- staged in the pinned des area
-            double *h_head = k.h_des;
-            for (size_t j = 0; j < m; j++) {
-                const SurfRecord &p = pts[keep[j]];
-                k.h_pts[3 * j] = p.x; k.h_pts[3 * j + 1] = p.y; k.h_pts[3 * j + 2] = p.scale;
-                double *h = h_head + 6 * j;
-                h[0] = p.x; h[1] = p.y; h[2] = 0.0; h[3] = p.scale; h[4] = p.score; h[5] = p.laplacian;
-            }
-            IMGFD_HIP(ctx, hipMemcpyAsync(k.d_pts, k.h_pts, sizeof(double) * 3 * m, hipMemcpyHostToDevice, ctx->stream));
-            IMGFD_HIP(ctx, hipMemcpy2DAsync(feat, 70 * sizeof(double), h_head, 6 * sizeof(double), 6 * sizeof(double), m,
-                                            hipMemcpyHostToDevice, ctx->stream));
-            IMGFD_TRY(launch_surf_orient(ctx, d.integral, rows, cols, k.d_pts, (int)m, nullptr, k.d_trig));
-            IMGFD_TRY(launch_surf_desc(ctx, d.integral, rows, cols, k.d_pts, k.d_trig, (int)m, feat + 6, 70, feat + 2));
-            // the pinned staging is reused by the next frame
-            IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        }
-        f++;
+        double *feat = d_features + (size_t)f * (size_t)cap * 70;
+        SurfRankParams q;
+        q.rec = d.rec; q.count = d.count; q.cap = d.cap; q.lim = lim; q.rows = rows; q.cols = cols; q.sel = sel; q.order = sel + lim;
+        q.pts = d_pts; q.feat = feat; q.count_out = reinterpret_cast<long long *>(d_counts) + f; q.m_out = m_dev;
+        hipLaunchKernelGGL(surf_rank_select, dim3(1), dim3(SR_NT), 0, ctx->stream, q);
+        IMGFD_TRY(launch_surf_orient(ctx, d.integral, rows, cols, d_pts, (int)lim, nullptr, d_trig, m_dev));
+        IMGFD_TRY(launch_surf_desc(ctx, d.integral, rows, cols, d_pts, d_trig, (int)lim, feat + 6, 70, feat + 2, m_dev));
     }
-    IMGFD_HIP(ctx, hipMemcpyAsync(d_counts, counts.data(), sizeof(int64_t) * (size_t)n_frames, hipMemcpyHostToDevice, ctx->stream));
-    IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 } catch (const std::bad_alloc &) {
     return imgfd_fail(ctx, IMGFD_ERR_OOM, "imgfd_surf_dev: out of host memory");

@@ -64,8 +64,10 @@ __device__ __forceinline__ long surf_to_long(double v) { return (long)floor(v + 
 // trig != nullptr: write angle, sin, cos, sin(-), cos(-) per point (device mode).
 __global__ void __launch_bounds__(128) surf_orient(const unsigned *__restrict__ I, int rows, int cols,
                                                    const double *__restrict__ pts, SurfOrientTable T,
-                                                   double *__restrict__ samples, double *__restrict__ trig)
+                                                   double *__restrict__ samples, double *__restrict__ trig,
+                                                   const unsigned *__restrict__ m_dev)
 {
+    if (m_dev && blockIdx.x >= *m_dev) return;  // the grid covers the upper bound; the number of points lives on the device
     __shared__ double sx[SURF_NSAMP], sy[SURF_NSAMP], sa[SURF_NSAMP];
     __shared__ double wx[45], wy[45];
     const size_t p = blockIdx.x;
@@ -121,8 +123,10 @@ __global__ void __launch_bounds__(128) surf_orient(const unsigned *__restrict__ 
 // angle_out, its angle to angle_out[p*des_stride]
 __global__ void __launch_bounds__(64) surf_desc(const unsigned *__restrict__ I, int rows, int cols,
                                                 const double *__restrict__ pts, const double *__restrict__ trig,
-                                                double *__restrict__ des, int des_stride, double *__restrict__ angle_out)
+                                                double *__restrict__ des, int des_stride, double *__restrict__ angle_out,
+                                                const unsigned *__restrict__ m_dev)
 {
+    if (m_dev && blockIdx.x >= *m_dev) return;
     __shared__ int hx[400], hy[400];
     __shared__ double rx[16 * 49], ry[16 * 49];
     __shared__ double d[64];
@@ -198,21 +202,21 @@ void surf_orient_table(SurfOrientTable *T)
 }
 
 imgfd_status launch_surf_orient(imgfd_ctx *ctx, const unsigned *d_I, int rows, int cols, const double *d_pts, int m,
-                                double *d_samples, double *d_trig)
+                                double *d_samples, double *d_trig, const unsigned *m_dev)
 {
     if (m < 1) return IMGFD_OK;
     SurfOrientTable T;
     surf_orient_table(&T);
-    hipLaunchKernelGGL(surf_orient, dim3(m), dim3(128), 0, ctx->stream, d_I, rows, cols, d_pts, T, d_samples, d_trig);
+    hipLaunchKernelGGL(surf_orient, dim3(m), dim3(128), 0, ctx->stream, d_I, rows, cols, d_pts, T, d_samples, d_trig, m_dev);
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }
 
 imgfd_status launch_surf_desc(imgfd_ctx *ctx, const unsigned *d_I, int rows, int cols, const double *d_pts,
-                              const double *d_trig, int m, double *d_des, int des_stride, double *d_angle)
+                              const double *d_trig, int m, double *d_des, int des_stride, double *d_angle, const unsigned *m_dev)
 {
     if (m < 1) return IMGFD_OK;
-    hipLaunchKernelGGL(surf_desc, dim3(m), dim3(64), 0, ctx->stream, d_I, rows, cols, d_pts, d_trig, d_des, des_stride, d_angle);
+    hipLaunchKernelGGL(surf_desc, dim3(m), dim3(64), 0, ctx->stream, d_I, rows, cols, d_pts, d_trig, d_des, des_stride, d_angle, m_dev);
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }

@@ -88,6 +88,47 @@ def test_batch_surf_dev_descriptors_on_the_device(be):
     assert len(few["x"]) <= 7 and np.array_equal(few["score"], np.sort(few["score"])[::-1])
 
 
+@pytest.mark.parametrize("max_points", [1, 9, 25])
+def test_surf_dev_ranks_and_cuts_on_the_device(be, max_points):
+    """imgfd_surf_dev orders the candidates on the device (radix select of the max_points best, rank, box test, compaction):
+    with fewer slots than candidates the strongest survive, in the reference's order"""
+    frames = np.stack([blobs(140 + f, 384, 256) for f in range(2)])
+    got = be.surf_dev(frames, max_points=max_points, threshold=5.0)
+    for f in range(2):
+        allp = oracle.surf_interest_points(frames[f], 5.0)
+        assert len(allp) > max_points                           # the cut really cuts
+        ref = oracle.surf(frames[f], max_points, 5.0)
+        assert np.array_equal(got[f]["score"], ref["score"])    # the same scores in the same (descending) order
+        sc = np.sort(allp[:, 3])[::-1]
+        if sc[max_points - 1] != sc[max_points]:                # no exact tie across the cut: the same points (ties inside may swap)
+            key = lambda d: sorted(zip(d["score"], d["x"], d["y"], d["pyramid_scale"], d["laplacian"]))
+            assert key(got[f]) == key(ref)
+        untied = np.ones(len(ref["score"]), bool)
+        untied[1:] &= ref["score"][1:] != ref["score"][:-1]; untied[:-1] &= ref["score"][:-1] != ref["score"][1:]
+        for k in ("x", "y", "pyramid_scale", "laplacian"):
+            assert np.array_equal(got[f][k][untied], ref[k][untied]), (k, max_points)
+        if untied.any():
+            assert np.abs(got[f]["surf"][untied] - ref["surf"][untied]).max() <= 1e-9
+
+
+def test_surf_dev_exact_score_ties_keep_emission_order(be):
+    """two identical blobs give pairs of exactly equal scores: the device breaks the tie by emission order (what a stable
+    sort would do); the set of points is the reference's either way"""
+    one = blobs(150, 192, 160)
+    img = np.concatenate([one, one], axis=1)                    # the same content twice, side by side
+    got = be.surf_dev(img[None], max_points=400, threshold=5.0)[0]
+    ref = oracle.surf(img, 400, 5.0)
+    assert len(got["x"]) == len(ref["x"]) > 4
+    assert np.array_equal(got["score"], ref["score"])           # same multiset, same (descending) order of scores
+    key = lambda d: sorted(zip(d["score"], d["x"], d["y"]))
+    assert key(got) == key(ref)
+    s = got["score"]
+    tied = np.nonzero(s[1:] == s[:-1])[0]
+    assert len(tied) > 0
+    # emission order within a tie: octave/interval first (equal here), then row, then column -> the left copy first
+    assert all(got["x"][i] < got["x"][i + 1] or got["y"][i] < got["y"][i + 1] for i in tied)
+
+
 def test_golden_dlib(be, golden):
     """vectors written by dlib's own get_surf_points on the reference's example image"""
     g = golden("surf_cruise_boat")
