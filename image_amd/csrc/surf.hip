@@ -461,15 +461,27 @@ __global__ void __launch_bounds__(SR_NT) surf_rank_select(SurfRankParams q)
             for (int i = tid; i < 256; i += SR_NT) hist[i] = 0;
             __syncthreads();
             const unsigned long long phi = thr_hi, plo = thr_lo;
-            for (unsigned i = tid; i < n; i += SR_NT) {
-                const SurfRecord &r = q.rec[i];
+            for (unsigned i0 = 0; i0 < n; i0 += SR_NT) {  // every lane makes every trip (wave intrinsics inside)
+                const unsigned i = i0 + tid;
+                const SurfRecord &r = q.rec[min(i, n - 1)];
                 const unsigned long long hi = surf_score_bits(r.score), lo = ~r.key;
                 // records that match the prefix fixed so far (the top `pass` bytes)
                 bool match;
-                if (pass == 0) match = true;
+                if (i >= n) match = false;
+                else if (pass == 0) match = true;
                 else if (pass <= 8) match = (hi >> (8 * (8 - pass))) == (phi >> (8 * (8 - pass)));
                 else match = hi == phi && (lo >> (8 * (16 - pass))) == (plo >> (8 * (16 - pass)));
-                if (match) atomicAdd(&hist[surf_comp_byte(r, pass)], 1u);
+                // histogram increment, aggregated per wave: the top bytes of the scores (sign, exponent) are the same for
+                // almost every record, and thousands of atomics on one LDS word serialise
+                int b = match ? (int)surf_comp_byte(r, pass) : -1;
+                while (__any(b >= 0)) {
+                    const int lead = __shfl(b, __ffsll((long long)__ballot(b >= 0)) - 1);
+                    const unsigned long long same = __ballot(b == lead);
+                    if (b == lead) {
+                        if (((int)__lane_id()) == __ffsll((long long)same) - 1) atomicAdd(&hist[lead], (unsigned)__popcll(same));
+                        b = -1;
+                    }
+                }
             }
             __syncthreads();
             if (tid == 0) {  // walk the bins from the top: the bin in which the `want`-th best record lies
@@ -826,32 +838,64 @@ try {
     SurfGeom g;
     const size_t total = surf_geometry(rows, cols, &g);
     const size_t n = (size_t)rows * cols;
-    SurfDevice d;
-    d.cap = 1ull << 18;  // candidate records per tile (12 MB); a tile with more reports -candidates in d_counts
+    const unsigned long long rec_cap = 1ull << 18;  // candidate records per tile (12 MB); a tile with more reports -candidates in d_counts
     const unsigned lim = (unsigned)std::min<int64_t>(std::min<int64_t>((int64_t)max_points, cap), 1 << 24);
-    // one carving for all tiles: they go through the same buffers back to back on the context's stream, no host sync
-    IMGFD_TRY(ws_reserve(ctx, surf_ws_bytes(g, total, d.cap) + align_up(sizeof(unsigned) * 2 * (size_t)lim, 256) +
-                                  align_up(sizeof(double) * 8 * (size_t)lim, 256) + 1024));
-    (void)ws_alloc(ctx, 3 * n);  // the slot imgfd_surf uses for the uploaded image (same carving, same size function)
-    d.integral = (unsigned *)ws_alloc(ctx, 4 * n);
-    d.pyr = (double *)ws_alloc(ctx, 8 * std::max<size_t>(total, 1));
-    d.pyr_bytes = 8 * std::max<size_t>(total, 1);
-    d.rec = (SurfRecord *)ws_alloc(ctx, sizeof(SurfRecord) * d.cap);
-    d.count = (unsigned long long *)ws_alloc(ctx, 256);
-    unsigned *sel = (unsigned *)ws_alloc(ctx, sizeof(unsigned) * 2 * (size_t)lim);
-    double *k19 = (double *)ws_alloc(ctx, sizeof(double) * 8 * (size_t)lim);  // x, y, scale | angle, sin, cos, sin(-), cos(-)
-    if (!d.integral || !d.pyr || !d.rec || !d.count || !sel || !k19) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
-    unsigned *m_dev = reinterpret_cast<unsigned *>(d.count) + 8;  // inside the 256-byte counter slot
-    double *d_pts = k19, *d_trig = k19 + 3 * (size_t)lim;
+    // Two lanes: even tiles on the context's stream, odd tiles on its companion stream, each lane with its own buffers.
+    // A tile is a chain of a dozen kernels, several of them small (the ranking runs in ONE workgroup, the descriptor grids
+    // are a few hundred workgroups): with two tiles in flight those fill the gaps of the other tile's pyramid kernels.
+    // Within a lane the tiles go through the same buffers back to back; no host synchronisation anywhere.
+    struct Lane { imgfd_ctx *c; SurfDevice d; unsigned *sel; double *k19; unsigned *m_dev; };
+    Lane lanes[2];
+    int nlanes = n_frames > 1 ? 2 : 1;
+    if (const char *e = getenv("IMGFD_SURF_LANES")) if (atoi(e) == 1) nlanes = 1;
+    lanes[0].c = ctx;
+    if (nlanes == 2) {
+        imgfd_ctx *side = nullptr;
+        IMGFD_TRY(ctx_side(ctx, &side));
+        lanes[1].c = side;
+        IMGFD_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));          // the tiles (and whatever produced them) come first
+        IMGFD_HIP(ctx, hipStreamWaitEvent(side->stream, ctx->ev_fork, 0));
+    }
+    for (int l = 0; l < nlanes; l++) {
+        Lane &L = lanes[l];
+        imgfd_ctx *c = L.c;
+        const imgfd_status st = ws_reserve(c, surf_ws_bytes(g, total, rec_cap) + align_up(sizeof(unsigned) * 2 * (size_t)lim, 256) +
+                                                  align_up(sizeof(double) * 8 * (size_t)lim, 256) + 1024);
+        if (st != IMGFD_OK) return imgfd_fail(ctx, st, "imgfd_surf_dev: workspace allocation failed");
+        (void)ws_alloc(c, 3 * n);  // the slot imgfd_surf uses for the uploaded image (same carving, same size function)
+        L.d.cap = rec_cap;
+        L.d.integral = (unsigned *)ws_alloc(c, 4 * n);
+        L.d.pyr = (double *)ws_alloc(c, 8 * std::max<size_t>(total, 1));
+        L.d.pyr_bytes = 8 * std::max<size_t>(total, 1);
+        L.d.rec = (SurfRecord *)ws_alloc(c, sizeof(SurfRecord) * rec_cap);
+        L.d.count = (unsigned long long *)ws_alloc(c, 256);
+        L.sel = (unsigned *)ws_alloc(c, sizeof(unsigned) * 2 * (size_t)lim);
+        L.k19 = (double *)ws_alloc(c, sizeof(double) * 8 * (size_t)lim);  // x, y, scale | angle, sin, cos, sin(-), cos(-)
+        if (!L.d.integral || !L.d.pyr || !L.d.rec || !L.d.count || !L.sel || !L.k19) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+        L.m_dev = reinterpret_cast<unsigned *>(L.d.count) + 8;  // inside the 256-byte counter slot
+    }
     for (int f = 0; f < n_frames; f++) {
-        IMGFD_TRY(surf_device_stages(ctx, d_rgb + (size_t)f * frame_stride_bytes, g, detection_threshold, d));
+        Lane &L = lanes[f % nlanes];
+        imgfd_ctx *c = L.c;
+        double *d_pts = L.k19, *d_trig = L.k19 + 3 * (size_t)lim;
+        imgfd_status st = surf_device_stages(c, d_rgb + (size_t)f * frame_stride_bytes, g, detection_threshold, L.d);
         double *feat = d_features + (size_t)f * (size_t)cap * 70;
         SurfRankParams q;
-        q.rec = d.rec; q.count = d.count; q.cap = d.cap; q.lim = lim; q.rows = rows; q.cols = cols; q.sel = sel; q.order = sel + lim;
-        q.pts = d_pts; q.feat = feat; q.count_out = reinterpret_cast<long long *>(d_counts) + f; q.m_out = m_dev;
-        hipLaunchKernelGGL(surf_rank_select, dim3(1), dim3(SR_NT), 0, ctx->stream, q);
-        IMGFD_TRY(launch_surf_orient(ctx, d.integral, rows, cols, d_pts, (int)lim, nullptr, d_trig, m_dev));
-        IMGFD_TRY(launch_surf_desc(ctx, d.integral, rows, cols, d_pts, d_trig, (int)lim, feat + 6, 70, feat + 2, m_dev));
+        q.rec = L.d.rec; q.count = L.d.count; q.cap = L.d.cap; q.lim = lim; q.rows = rows; q.cols = cols; q.sel = L.sel; q.order = L.sel + lim;
+        q.pts = d_pts; q.feat = feat; q.count_out = reinterpret_cast<long long *>(d_counts) + f; q.m_out = L.m_dev;
+        if (st == IMGFD_OK) {
+            hipLaunchKernelGGL(surf_rank_select, dim3(1), dim3(SR_NT), 0, c->stream, q);
+            st = launch_surf_orient(c, L.d.integral, rows, cols, d_pts, (int)lim, nullptr, d_trig, L.m_dev);
+        }
+        if (st == IMGFD_OK) st = launch_surf_desc(c, L.d.integral, rows, cols, d_pts, d_trig, (int)lim, feat + 6, 70, feat + 2, L.m_dev);
+        if (st != IMGFD_OK) {
+            if (c != ctx) ctx->err = c->err;
+            return st;
+        }
+    }
+    if (nlanes == 2) {  // whoever waits for the context's stream waits for the odd tiles too
+        IMGFD_HIP(ctx, hipEventRecord(ctx->ev_join, lanes[1].c->stream));
+        IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     }
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;

@@ -177,8 +177,12 @@ IMGFD_API imgfd_status imgfd_surf_points_dev(imgfd_ctx *ctx, const uint8_t *d_rg
  * pyramid_scale, score, laplacian, surf[64]: the columns dlib_surf_points returns (rcpp_surf.cpp:31-52) -- strongest
  * first as get_surf_points orders them (surf.h:268-285); d_counts[f] = records of frame f (<= min(max_points, cap)).
  * atan2/sin/cos come from the device libm here, so angles and descriptors agree with imgfd_surf to ~1e-12 rather than
- * bit for bit (SURVEY.md 8d asks for 1e-6); the interest points themselves are identical.  The call synchronises the
- * context's stream once per frame (the point list is ranked on the host). */
+ * bit for bit (SURVEY.md 8d asks for 1e-6); the interest points themselves are identical.  Everything runs on the
+ * context's stream without host synchronisation: the candidates of a tile are ranked on the device (the max_points
+ * strongest, strongest first; two candidates with exactly equal scores keep the order get_interest_points emitted them
+ * in -- the reference leaves that order to std::sort) and the descriptor kernels read the point count on the device.
+ * d_counts[f] < 0: tile f produced -d_counts[f] candidates, more than the library buffers (262144); its feature rows are
+ * left untouched -- use imgfd_surf for such a tile. */
 IMGFD_API imgfd_status imgfd_surf_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, int rows, int cols,
                                       size_t frame_stride_bytes, long max_points, double detection_threshold,
                                       double *d_features, int64_t cap, int64_t *d_counts);
