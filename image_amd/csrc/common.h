@@ -23,11 +23,11 @@ struct imgfd_ctx {
     int fir_mode = 1;  // 1 = fused accumulate, 0 = strict
     int num_cu = 256;
     std::string err;
-    // grow-only device workspace arena (bump-allocated per call, reset at call entry)
+    // grow-only device workspace arena (bump-allocated per call, reset at call entry; when it has to grow, the stream is
+    // drained and the old arena freed on the spot)
     char *ws = nullptr;
     size_t ws_size = 0;
     size_t ws_used = 0;
-    std::vector<void *> ws_old;  // superseded arenas, freed at destroy/sync points
     // pinned host staging
     char *pin = nullptr;
     size_t pin_size = 0;

@@ -15,7 +15,8 @@ static imgfd_status ctx_init(int device, void *stream, bool own, imgfd_ctx **out
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return IMGFD_ERR_NO_DEVICE;
     if (device < 0 || device >= count) return IMGFD_ERR_INVALID;
     if (hipSetDevice(device) != hipSuccess) return IMGFD_ERR_NO_DEVICE;
-    imgfd_ctx *ctx = new imgfd_ctx();
+    imgfd_ctx *ctx = new (std::nothrow) imgfd_ctx();
+    if (!ctx) return IMGFD_ERR_OOM;
     ctx->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -54,7 +55,6 @@ void imgfd_ctx_destroy(imgfd_ctx *ctx)
     for (hipEvent_t e : {ctx->ev_fork, ctx->ev_gate, ctx->ev_join})
         if (e) (void)hipEventDestroy(e);
     (void)hipStreamSynchronize(ctx->stream);
-    for (void *p : ctx->ws_old) (void)hipFree(p);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->aux) (void)hipFree(ctx->aux);
@@ -76,8 +76,6 @@ imgfd_status imgfd_ctx_sync(imgfd_ctx *ctx)
         if (st != IMGFD_OK) { ctx->err = ctx->side->err; return st; }
     }
     IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (void *p : ctx->ws_old) (void)hipFree(p);
-    ctx->ws_old.clear();
     return IMGFD_OK;
 }
 
@@ -133,8 +131,13 @@ imgfd_status ws_reserve(imgfd_ctx *ctx, size_t bytes)
 {
     ctx->ws_used = 0;
     if (bytes <= ctx->ws_size) return IMGFD_OK;
-    // kernels of earlier calls may still be using the old arena: retire it, free at the next sync
-    if (ctx->ws) ctx->ws_old.push_back(ctx->ws);
+    // Kernels of earlier calls may still be using the old arena: wait for the stream, then free it here.  (Growth is rare --
+    // the arena only ever grows -- and parking the old arena until the next imgfd_ctx_sync kept it alive for as long as a
+    // caller of the host entry points, which synchronise on their own, never called that function.)
+    if (ctx->ws) {
+        IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->ws);
+    }
     ctx->ws = nullptr;
     ctx->ws_size = 0;
     bytes = align_up(bytes + bytes / 8, (size_t)1 << 20);
@@ -163,10 +166,17 @@ imgfd_status ctx_side(imgfd_ctx *ctx, imgfd_ctx **side)
         const imgfd_status st = imgfd_ctx_create(ctx->device, &s);
         if (st != IMGFD_OK) return imgfd_fail(ctx, st, "could not create the companion context");
         s->fir_mode = ctx->fir_mode;
+        // the three events first; the companion is published only when everything it needs exists
+        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+        for (int i = 0; i < 3; i++) {
+            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) {
+                for (int j = 0; j < i; j++) (void)hipEventDestroy(ev[j]);
+                imgfd_ctx_destroy(s);
+                return imgfd_fail(ctx, IMGFD_ERR_HIP, "could not create the companion context's events");
+            }
+        }
+        ctx->ev_fork = ev[0]; ctx->ev_gate = ev[1]; ctx->ev_join = ev[2];
         ctx->side = s;
-        IMGFD_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        IMGFD_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_gate, hipEventDisableTiming));
-        IMGFD_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     }
     *side = ctx->side;
     return IMGFD_OK;

@@ -65,9 +65,15 @@ imgfd_status imgfd_fast9_dev(imgfd_ctx *ctx, const imgfd_frames *fr, uint8_t thr
 {
     if (!ctx || !fr || !fr->d_frames || (!d_points && cap > 0) || !d_counts || cap < 0 || fr->n_frames < 0 || fr->dtype != 0)
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_fast9_dev: bad argument (frames must be u8)");
+    if (fr->nx < 1 || fr->ny < 1 || fr->row_stride_bytes < fr->nx)
+        return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_fast9_dev: bad frame geometry");
     if (fr->n_frames == 0) return IMGFD_OK;
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
     const int w = fr->nx, h = fr->ny;
+    if (w < 7 || h < 7) {  // empty search domain (f9.cpp:2959-2960), as the host entry point answers
+        IMGFD_HIP(ctx, hipMemsetAsync(d_counts, 0, sizeof(int64_t) * fr->n_frames, ctx->stream));
+        return IMGFD_OK;
+    }
     const size_t per_frame = compact_bytes(w, h, 1);
     int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)fr->n_frames, ((size_t)1 << 30) / per_frame));
     IMGFD_TRY(ws_reserve(ctx, compact_bytes(w, h, chunk) + 4096));

@@ -482,7 +482,8 @@ imgfd_status imgfd_k_nms(imgfd_ctx *ctx, const float *d_R, int nx, int ny, float
     CompactBuffers cb;
     IMGFD_TRY(compact_carve(ctx, nx, ny, 1, &cb));
     IMGFD_TRY(compact_clear(ctx, cb, ny, 1));
-    IMGFD_TRY(launch_harris_nms(ctx, d_R, nx, ny, 1, Th, radius, cb));
+    // the tiled kernel of the batch path (radius <= 6; it falls back to the per-pixel kernel beyond)
+    IMGFD_TRY(launch_harris_nms_tiled(ctx, d_R, nx, ny, 1, Th, radius, cb));
     return compact_emit(ctx, cb, nx, ny, 1, 0, d_R, d_corners, cap, d_count);
 }
 

@@ -14,6 +14,18 @@
 #include "common.h"
 #include "harris_device.h"
 
+// The reference walks a row from column `radius` and first skips "the downhill at the beginning": every j with
+// R[j] < Th or R[j-1] >= R[j] (harris.cpp:177).  A pixel inside that initial run is never a candidate, although the window
+// rule would accept it when its left neighbour ties it exactly (left neighbours only have to be <=).  Callers test this
+// for window maxima whose left neighbour is EQUAL (anything else already fails one of the two rules): true = the whole
+// stretch radius..x belongs to the initial run, the reference emits nothing here.
+__device__ __forceinline__ bool harris_row_start_blocks(const float *row, int x, int radius, float Th)
+{
+    for (int j = x; j >= radius; j--)
+        if (!(row[j] < Th) && !(row[j - 1] >= row[j])) return false;  // the scan line would have stopped skipping at j
+    return true;
+}
+
 __global__ void __launch_bounds__(256) harris_nms_kernel(const float *__restrict__ R, int nx, int ny, float Th,
                                                          int radius, unsigned long long *__restrict__ mask,
                                                          unsigned *__restrict__ rowcount, int words_per_row)
@@ -44,6 +56,8 @@ __global__ void __launch_bounds__(256) harris_nms_kernel(const float *__restrict
                     }
                 }
             }
+            // the scan line's start-of-row rule (harris.cpp:177): see harris_row_start_blocks
+            if (ok && c[-1] == v) ok = !harris_row_start_blocks(Rf + (size_t)y * nx, x, radius, Th);
             corner = ok;
         }
     }
@@ -199,7 +213,18 @@ __global__ void __launch_bounds__(256) harris_resp_nms_kernel(const float *__res
                 fail = fail || (strict[j] ? (q >= v) : (q > v));
             }
         }
-        if (!__any(fail) && lane == 0) atomicOr(&rowmask[r], 1ull << c);
+        if (!__any(fail) && lane == 0) {
+            // start-of-row rule of the scan line (harris_row_start_blocks): only for an exact tie with the left neighbour
+            bool blocked = false;
+            if (R_at(r, c - 1) == v) {
+                blocked = true;
+                for (int j = x0 + c; j >= radius && blocked; j--) {
+                    const float rj = R_at(r, j - x0), rl = R_at(r, j - 1 - x0);
+                    if (!(rj < Th) && !(rl >= rj)) blocked = false;
+                }
+            }
+            if (!blocked) atomicOr(&rowmask[r], 1ull << c);
+        }
     }
     __syncthreads();
     // (4) mask words

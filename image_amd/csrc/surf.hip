@@ -738,10 +738,16 @@ imgfd_status surf_describe_assisted(imgfd_ctx *ctx, const unsigned *d_I, int row
         work(0, m);
     } else {
         std::vector<std::thread> pool;
+        pool.reserve(nthr);  // no reallocation (and no exception) while threads are running
         const size_t per = (m + nthr - 1) / nthr;
         for (unsigned t = 0; t < nthr; t++) {
             const size_t j0 = std::min(m, t * per), j1 = std::min(m, j0 + per);
-            if (j0 < j1) pool.emplace_back(work, j0, j1);
+            if (j0 >= j1) continue;
+            try {
+                pool.emplace_back(work, j0, j1);
+            } catch (...) {  // no thread to be had: this share runs here (a joinable std::thread must never be unwound)
+                work(j0, j1);
+            }
         }
         for (auto &th : pool) th.join();
     }

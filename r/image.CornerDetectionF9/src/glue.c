@@ -32,3 +32,9 @@ void R_init_image_CornerDetectionF9(DllInfo *dll)
     R_registerRoutines(dll, NULL, CallEntries, NULL, NULL);
     R_useDynamicSymbols(dll, FALSE);
 }
+
+void R_unload_image_CornerDetectionF9(DllInfo *dll)
+{
+    (void)dll;
+    imgfd_glue_unload();
+}

@@ -51,3 +51,9 @@ void R_init_image_CornerDetectionHarris(DllInfo *dll) /* RcppExports.cpp:35-43 *
     R_registerRoutines(dll, NULL, CallEntries, NULL, NULL);
     R_useDynamicSymbols(dll, FALSE);
 }
+
+void R_unload_image_CornerDetectionHarris(DllInfo *dll)
+{
+    (void)dll;
+    imgfd_glue_unload();
+}

@@ -7,11 +7,20 @@
 #include <stdint.h>
 #include "imgfd.h"
 
+static imgfd_ctx *imgfd_glue_ctx_slot = NULL; /* one context per package DLL, created on first use */
 static imgfd_ctx *imgfd_glue_ctx(void)
 {
-    static imgfd_ctx *c = NULL;
-    if (!c && imgfd_ctx_create(0, &c) != IMGFD_OK) Rf_error("imgfd: no MI355X device / HIP runtime");
-    return c;
+    if (!imgfd_glue_ctx_slot && imgfd_ctx_create(0, &imgfd_glue_ctx_slot) != IMGFD_OK) {
+        imgfd_glue_ctx_slot = NULL;
+        Rf_error("imgfd: no MI355X device / HIP runtime");
+    }
+    return imgfd_glue_ctx_slot;
+}
+/* R_unload_<pkg>: give the stream, the device workspace and the pinned buffers back when the package's DLL is unloaded */
+static void imgfd_glue_unload(void)
+{
+    if (imgfd_glue_ctx_slot) imgfd_ctx_destroy(imgfd_glue_ctx_slot);
+    imgfd_glue_ctx_slot = NULL;
 }
 static void imgfd_glue_check(imgfd_status s)
 {

@@ -60,6 +60,35 @@ def fhog_golden():
     print("fhog_cruise_boat", {k: v.shape for k, v in out.items()})
 
 
+def fhog_dlib_kat():
+    """dlib's OWN known-answer vectors for extract_fhog_features: the `face.dng` image and the serialized feature arrays
+    embedded in dlib/test/fhog.cpp:156-214 (RGB at two cell sizes, grayscale), dumped by oracle/_ref/dlib_kat (built from
+    that test source where it lies, `make -C oracle dlib_kat`).  dlib's criterion for them is max |diff| < 1e-6 (:33-52)."""
+    import struct
+    import subprocess
+    import tempfile
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "dlib_kat"])
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "kat.bin")
+        subprocess.check_call([os.path.join(ROOT, "oracle", "_ref", "dlib_kat"), path])   # exits non-zero if dlib itself misses its vectors
+        b = open(path, "rb").read()
+    rows, cols = struct.unpack_from("<ii", b, 0)
+    off = 8
+    out = {"rgb": np.frombuffer(b, np.uint8, rows * cols * 3, off).reshape(rows, cols, 3).copy()}
+    off += rows * cols * 3
+    out["gray"] = np.frombuffer(b, np.uint8, rows * cols, off).reshape(rows, cols).copy()
+    off += rows * cols
+    for name in ("rgb_a", "rgb_b", "gray_a"):
+        sbin, nr, nc = struct.unpack_from("<iii", b, off)
+        off += 12
+        out["cell_" + name] = np.array(sbin)
+        out["hog_" + name] = np.frombuffer(b, np.float32, nr * nc * 31, off).reshape(nr, nc, 31).copy()
+        off += nr * nc * 31 * 4
+    assert off == len(b)
+    np.savez_compressed(os.path.join(OUT, "fhog_dlib_kat"), **out)
+    print("fhog_dlib_kat", {k: (v.shape if v.ndim else int(v)) for k, v in out.items()})
+
+
 def surf_golden():
     """dlib's own get_surf_points (max_points 1000, threshold 30: the R defaults) on the reference's example image."""
     from PIL import Image
@@ -112,6 +141,7 @@ def main():
     # R hands Canny the column-major memory of grey[row, col], i.e. the transposed raster
     canny_golden("canny_chairs", np.ascontiguousarray(chairs.T))
     canny_golden("canny_synth_320x240_seed7", synth.frame(7, 320, 240, n_rect=20), tuple(CANNY_CASES))
+    fhog_dlib_kat()
 
 
 if __name__ == "__main__":

@@ -37,6 +37,24 @@ def test_fast9_bad_arguments(be):
     assert be.lib.imgfd_fast9(be.ctx, img.ctypes.data_as(C.c_void_p), 6, 6, 16, 20, 0, C.byref(out)) == OK and out.n == 0  # empty domain
 
 
+def test_fast9_dev_degenerate_frames(be):
+    """the batch entry point validates its frame geometry: zero or negative sizes are refused (a zero-row frame used to
+    divide by zero), frames too small for a ring answer zero corners like the host entry point"""
+    d = be.to_dev(np.zeros((2, 16, 16), np.uint8))
+    cnt = be.empty((2,), np.int64)
+    pts = be.empty((2, 8, 2), np.int32)
+    for nx, ny in ((16, 0), (0, 16), (-3, 16), (16, -1)):
+        fr = _binding.Frames(be.ptr(d), 2, nx, ny, 256, 16, 0)
+        assert be.lib.imgfd_fast9_dev(be.ctx, C.byref(fr), 20, 0, be.ptr(pts), 8, be.ptr(cnt)) == INVALID, (nx, ny)
+    fr = _binding.Frames(be.ptr(d), 2, 16, 16, 256, 8, 0)   # row stride < width
+    assert be.lib.imgfd_fast9_dev(be.ctx, C.byref(fr), 20, 0, be.ptr(pts), 8, be.ptr(cnt)) == INVALID
+    cnt2 = be.to_dev(np.full((2,), 77, np.int64))
+    fr = _binding.Frames(be.ptr(d), 2, 6, 16, 256, 16, 0)   # narrower than a ring: empty search domain
+    assert be.lib.imgfd_fast9_dev(be.ctx, C.byref(fr), 20, 0, be.ptr(pts), 8, be.ptr(cnt2)) == OK
+    be.sync()
+    assert be.to_host(cnt2).tolist() == [0, 0]
+
+
 def test_canny_bad_arguments(be):
     img = np.zeros((16, 16), np.uint8)
     edges = np.zeros((16, 16), np.uint8)

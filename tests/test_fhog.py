@@ -58,6 +58,20 @@ def test_golden_dlib(be, golden):
     assert np.max(np.abs(be.fhog(g["image"], 8, 3, 3) - ref)) <= TOL
 
 
+def test_dlib_known_answer_vectors(be, golden):
+    """dlib's OWN known-answer test for extract_fhog_features, dlib/test/fhog.cpp:156-214: the `face.dng` image embedded in
+    that file and the serialized features it must reproduce -- RGB at two cell sizes and grayscale -- to within 1e-6
+    (:33-52).  tests/golden/fhog_dlib_kat.npz holds them as dumped by oracle/dlib_kat.cpp (scripts/make_golden.py).  The
+    grayscale vector is fed as R = G = B: all three channels then give dlib's single-channel gradient."""
+    g = golden("fhog_dlib_kat")
+    gray3 = np.stack([g["gray"]] * 3, -1)
+    for img, name in ((g["rgb"], "rgb_a"), (g["rgb"], "rgb_b"), (gray3, "gray_a")):
+        cell, ref = int(g["cell_" + name]), g["hog_" + name]
+        for what, got in (("oracle", oracle.fhog(img, cell, 1, 1)), ("device", be.fhog(img, cell, 1, 1))):
+            assert got.shape == ref.shape, (what, name, got.shape, ref.shape)
+            assert np.max(np.abs(got - ref)) < TOL, (what, name, float(np.max(np.abs(got - ref))))
+
+
 def test_batch_dev(be):
     frames = np.stack([synth.frame_rgb(70 + f, 96, 80) for f in range(3)])
     got = be.fhog_dev(frames, 8, 1, 1)

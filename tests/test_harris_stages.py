@@ -184,6 +184,30 @@ def test_nms_window_rule_matches_scanline(be, radius, Th):
     assert np.array_equal(bits(got), bits(ref))
 
 
+def test_nms_start_of_row_rule_on_exact_ties(be):
+    """harris.cpp:177 skips 'the downhill at the beginning' of every row: a window maximum whose left neighbour TIES it and
+    that lies in the initial non-increasing run (from column `radius`) is never emitted, although the window rule accepts
+    it.  Planes with exact plateaus at the start of rows, in the middle of rows (where the tie does not block) and below
+    the threshold."""
+    rng = np.random.default_rng(5)
+    radius, Th = 3, 100.0
+    R = (rng.random((40, 200)) * 50).astype(np.float32)           # background below the threshold
+    R[10, 2:9] = 500.0                                              # plateau from column radius-1: initial run, blocked
+    R[14, 3:6] = 400.0                                              # plateau starting at column radius itself
+    R[18, 0:5] = 300.0; R[18, 5] = 350.0                            # a rise after the plateau: column 5 is a proper peak
+    R[22, 60:64] = 450.0                                            # the same tie in mid-row, after the scan line got going
+    R[26, 3:40] = np.linspace(900, 200, 37).astype(np.float32)      # a long downhill from the start, then ...
+    R[26, 50:53] = 600.0                                            # ... a tie plateau further along the row
+    R[30, 2] = 120.0; R[30, 3] = 120.0                              # tie exactly at column radius with column radius-1
+    got = be.k_nms(R, Th, radius)
+    ref = oracle.harris_stage("nms", R, Th=Th, radius=radius)
+    assert len(ref) >= 2 and got.shape == ref.shape and np.array_equal(bits(got), bits(ref)), (got, ref)
+    Rt = np.ascontiguousarray(np.tile(R, (3, 3)))                   # larger plane: several 64x64 tiles of the fused kernel
+    ref = oracle.harris_stage("nms", Rt, Th=Th, radius=radius)
+    got = be.k_nms(Rt, Th, radius)
+    assert got.shape == ref.shape and np.array_equal(bits(got), bits(ref))
+
+
 def test_nms_small_image_is_empty(be):
     R = np.random.default_rng(0).random((11, 40)).astype(np.float32) * 1000
     assert be.k_nms(R, 0.0, 5).shape[0] == 0
