@@ -1063,7 +1063,7 @@ try {
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
     const int nx = fr->nx, ny = fr->ny;
     const size_t per_frame = canny_ws_bytes(nx, ny, 1);
-    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)fr->n_frames, ((size_t)12 << 30) / per_frame));
+    const int chunk = sub_batch_frames(fr->n_frames, per_frame, (size_t)12 << 30);
     IMGFD_TRY(ws_reserve(ctx, canny_ws_bytes(nx, ny, chunk) + 512));
     for (int f0 = 0; f0 < fr->n_frames; f0 += chunk) {
         const int nf = std::min(chunk, fr->n_frames - f0);

@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <functional>
@@ -84,6 +85,19 @@ static inline imgfd_status imgfd_guard(imgfd_ctx *ctx, F &&body) noexcept
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+// frames per sub-batch of a *_dev entry point: as many as fit `budget` bytes of stage planes, at least one.
+// IMGFD_MAX_CHUNK_FRAMES (tests) lowers it so that small batches cross sub-batch boundaries too.
+static inline int sub_batch_frames(int n_frames, size_t per_frame_bytes, size_t budget)
+{
+    size_t c = budget / (per_frame_bytes ? per_frame_bytes : 1);
+    if (c > (size_t)n_frames) c = (size_t)n_frames;
+    if (c < 1) c = 1;
+    if (const char *e = getenv("IMGFD_MAX_CHUNK_FRAMES")) {
+        const int m = atoi(e);
+        if (m >= 1 && (size_t)m < c) c = (size_t)m;
+    }
+    return (int)c;
+}
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // workspace: all allocations of one API call are carved from one arena; ws_reserve() guarantees

@@ -419,9 +419,9 @@ imgfd_status imgfd_harris_dev(imgfd_ctx *ctx, const imgfd_frames *fr, float k, f
     const int esz = fr->dtype == 0 ? 1 : 4;
     if (fr->row_stride_bytes % esz || fr->frame_stride_bytes % esz)
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_harris_dev: strides must be multiples of the element size");
-    // sub-batches bounded by ~3 GiB of stage planes
+    // sub-batches bounded by 12 GiB of stage planes
     const size_t per_frame = 8 * sizeof(float) * (size_t)nx * ny;
-    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)fr->n_frames, ((size_t)12 << 30) / per_frame));
+    const int chunk = sub_batch_frames(fr->n_frames, per_frame, (size_t)12 << 30);
     const size_t tmp_floats = harris_tmp_floats(nx, ny, sigma_d, sigma_i, gaussian);
     IMGFD_TRY(ws_reserve(ctx, harris_ws_bytes(nx, ny, chunk, 0, tmp_floats)));
     HarrisPlanes hp;
