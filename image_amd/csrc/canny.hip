@@ -890,17 +890,20 @@ size_t canny_ws_bytes(int nx, int ny, int nf)
 #define HY_SWEEPS 24  // sweeps queued per batch (the bench frames converge in 10-12); flags[] holds one word per sweep
 // Region geometry: as large as LDS allows (15 words x 540 rows: 147 KB for both planes and the ring) when the batch alone
 // fills the device, smaller regions (more workgroups, more rounds) for small batches.
-HystGeom hyst_geometry(int wpr, int ny, int nf, int num_cu)
+HystGeom hyst_geometry(int wpr, int ny, int nf, int num_cu, bool small)
 {
     HystGeom g;
     g.wpr = wpr; g.ny = ny;
-    g.RW = std::min(wpr, 15);
-    g.RH = std::min(ny, 540);
+    // small: the finishing kernel behind the sweeps -- 8 words x 128 rows = 23 KB of LDS, so that its one workgroup per
+    // frame finds room beside whatever else occupies the CUs (the structure-tensor workgroups hold 135 KB each for the whole
+    // of their kernel: a 147 KB workgroup had to wait for all of them, 460 us in the two-stream schedule)
+    g.RW = std::min(wpr, small ? 8 : 15);
+    g.RH = std::min(ny, small ? 128 : 540);
     auto count = [&]() { return (long)ceil_div(wpr, g.RW) * ceil_div(ny, g.RH) * nf; };
     if (const char *e = getenv("IMGFD_HYST_REGION")) {  // tests: "RWxRH"
         int a = 0, b = 0;
         if (sscanf(e, "%dx%d", &a, &b) == 2 && a >= 1 && a <= 15 && b >= 8 && b <= 540) { g.RW = std::min(wpr, a); g.RH = std::min(ny, b); }
-    } else {
+    } else if (!small) {
         while (count() < 2L * num_cu && (g.RH > 128 || g.RW > 4)) {
             if (g.RH > 128 && g.RH / 64 >= g.RW / 4) g.RH = std::max(128, (g.RH / 2 + 63) / 64 * 64);
             else if (g.RW > 4) g.RW = std::max(4, (g.RW / 2 + 3) / 4 * 4);
@@ -977,13 +980,14 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
     // predecessor changed nothing returns at once: an idle launch costs a few microseconds), then the finishing kernel,
     // which leaves at once when the last sweep was idle and otherwise completes the frames region by region.
     {
-        HystGeom g = hyst_geometry(wpr, ny, nf, ctx->num_cu);
+        const char *mode = getenv("IMGFD_HYST_MODE");  // experiment switch: "regions" = LDS-resident region rounds instead of sweeps
+        const bool region_mode = mode && !strcmp(mode, "regions");
+        HystGeom g = hyst_geometry(wpr, ny, nf, ctx->num_cu, !region_mode);
         const int regions = g.rx * g.ry;
         const size_t lds = hyst_lds_bytes(g) + 2 * (size_t)regions;
         IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)canny_hyst_regions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)canny_hyst_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const char *mode = getenv("IMGFD_HYST_MODE");  // experiment switch: "regions" = LDS-resident region rounds instead of sweeps
-        if (mode && !strcmp(mode, "regions")) {
+        if (region_mode) {
             const int rounds = hyst_rounds(g, wpr, ny);
             for (int r = 0; r < rounds; r++)
                 hipLaunchKernelGGL(canny_hyst_regions, dim3(regions, nf), dim3(HY_NT), lds, ctx->stream, S, Wm, g, rflag, r);
