@@ -36,9 +36,11 @@ struct SurfLevel {
     int step, border_px, lobe, off;  // hessian_pyramid.h:119-128
     double area_inv;
     size_t plane;                    // offset (doubles) of the level inside the pyramid buffer
+    size_t mask;                     // offset (64-bit words) of the level's threshold mask: nr rows of ceil(nc/64) words
 };
 struct SurfGeom {
     int rows, cols;
+    size_t mask_words;               // 64-bit words of all threshold masks
     int nr[SURF_OCT], nc[SURF_OCT];
     SurfLevel lev[SURF_OCT * SURF_INT];
 };
@@ -49,7 +51,7 @@ static long surf_step_of(long o) { return 2 * (long)(pow(2.0, (double)o) + 0.5);
 static size_t surf_geometry(int rows, int cols, SurfGeom *g)
 {
     g->rows = rows; g->cols = cols;
-    size_t total = 0;
+    size_t total = 0, mask_words = 0;
     for (int o = 0; o < SURF_OCT; o++) {
         const long step = surf_step_of(o);
         g->nr[o] = (int)(rows / step); g->nc[o] = (int)(cols / step);
@@ -62,8 +64,11 @@ static size_t surf_geometry(int rows, int cols, SurfGeom *g)
             L.area_inv = 1.0 / pow(3.0 * L.lobe, 2.0);
             L.plane = total;
             total += (size_t)g->nr[o] * g->nc[o];
+            L.mask = mask_words;
+            mask_words += (size_t)g->nr[o] * ((g->nc[o] + 63) / 64);
         }
     }
+    g->mask_words = mask_words;
     return total;
 }
 
@@ -239,7 +244,8 @@ __device__ __forceinline__ double surf_lds_interval(const unsigned *__restrict__
 }
 
 template <int O>
-__global__ void __launch_bounds__(256) surf_pyramid_lds(const unsigned *__restrict__ I, double *__restrict__ pyr, SurfGeom g)
+__global__ void __launch_bounds__(256) surf_pyramid_lds(const unsigned *__restrict__ I, double *__restrict__ pyr, SurfGeom g,
+                                                        unsigned long long *__restrict__ mask, double thr)
 {
     using G = SurfPyrLds<O>;
     HIP_DYNAMIC_SHARED(unsigned, win)  // [G::H][G::P]
@@ -267,14 +273,25 @@ __global__ void __launch_bounds__(256) surf_pyramid_lds(const unsigned *__restri
         const int e = tid + 256 * k;  // level pixel of the block: row-major, LX per row
         const int lr = lr0 + e / G::LX, lc = lc0 + e % G::LX;
         const int r = lr * G::STEP, c = lc * G::STEP;
-        if (lr >= g.nr[O] || lc >= g.nc[O]) continue;
+        // a wave = 64 consecutive level pixels of one row (LX = 64, lc0 a multiple of 64): its ballot is one word of the
+        // level's threshold mask (|det| >= thr: the only pixels surf_nms_interp has to look at); every lane votes
+        const bool inside = lr < g.nr[O] && lc < g.nc[O];
         const unsigned *ctr = win + (r - y0) * G::P + (c - x0) / G::STEP;  // (c - x0) is a multiple of STEP: residue plane 0
         double *dst = pyr + (size_t)lr * g.nc[O] + lc;
 #define SPL_DO(IT)                                                                                        \
         {                                                                                                  \
             const SurfLevel &L = g.lev[O * SURF_INT + IT];                                                 \
             const int bp = L.border_px;                                                                    \
-            if (!(r < bp || r >= rows - bp || c < bp || c >= cols - bp)) dst[L.plane] = surf_lds_interval<O, IT>(ctr, L.area_inv); \
+            bool hot = false;                                                                              \
+            if (inside && !(r < bp || r >= rows - bp || c < bp || c >= cols - bp)) {                       \
+                const double v = surf_lds_interval<O, IT>(ctr, L.area_inv);                                \
+                dst[L.plane] = v;                                                                          \
+                hot = fabs(v) >= thr;                                                                      \
+            }                                                                                              \
+            if (mask) {                                                                                    \
+                const unsigned long long word = __ballot(hot);                                             \
+                if ((tid & 63) == 0 && lr < g.nr[O] && lc < g.nc[O]) mask[L.mask + (size_t)lr * ((g.nc[O] + 63) / 64) + (lc >> 6)] = word; \
+            }                                                                                              \
         }
         SPL_DO(0) SPL_DO(1) SPL_DO(2) SPL_DO(3) SPL_DO(4) SPL_DO(5)
 #undef SPL_DO
@@ -282,44 +299,106 @@ __global__ void __launch_bounds__(256) surf_pyramid_lds(const unsigned *__restri
 }
 
 template <int O>
-static imgfd_status launch_surf_pyramid_lds(imgfd_ctx *ctx, const unsigned *d_I, double *d_pyr, const SurfGeom &g)
+static imgfd_status launch_surf_pyramid_lds(imgfd_ctx *ctx, const unsigned *d_I, double *d_pyr, const SurfGeom &g,
+                                            unsigned long long *d_mask, double thr)
 {
+    static_assert(SurfPyrLds<O>::LX == 64, "a wave's ballot is one mask word");
     using G = SurfPyrLds<O>;
     const size_t lds = sizeof(unsigned) * (size_t)G::H * G::P;
     IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)surf_pyramid_lds<O>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(surf_pyramid_lds<O>, dim3(ceil_div(g.nc[O], G::LX), ceil_div(g.nr[O], G::LY)), dim3(256), lds, ctx->stream, d_I, d_pyr, g);
+    hipLaunchKernelGGL(surf_pyramid_lds<O>, dim3(ceil_div(g.nc[O], G::LX), ceil_div(g.nr[O], G::LY)), dim3(256), lds, ctx->stream, d_I, d_pyr, g, d_mask, thr);
     return IMGFD_OK;
 }
 
-// ---- K17: one launch per octave, blockIdx.z = interval
-__global__ void __launch_bounds__(256) surf_pyramid(const unsigned *__restrict__ I, double *__restrict__ pyr, SurfGeom g, int o)
+// ---- the integral image re-laid by column residue: J[row][x % 16][x / 16] = I[row][x] (cols a multiple of 16).  A wave
+// of surf_pyramid evaluates 64 consecutive level pixels, i.e. image columns step*lane + const: in I that is one word out of
+// every `step` (4, 8, 16: 25 / 12 / 6 % of each cache line used, 32 look-ups per pixel); in J the lanes of a look-up read
+// 16 / step runs of consecutive words.  One pass over the table (67 MB at 4096^2) serves octaves 1-3.
+// A workgroup moves 4096 columns of one row through LDS (word x at 17 * (x / 16) + x % 16: the transposed reads of 64 lanes
+// fall into 64 different banks), so that both the loads and the stores are runs of consecutive words.
+#define RL_COLS 4096
+__global__ void __launch_bounds__(256) surf_residue_layout(const unsigned *__restrict__ I, unsigned *__restrict__ J, int cols)
 {
-    const int lc = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int lr = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const SurfLevel L = g.lev[o * SURF_INT + blockIdx.z];
-    const int r = lr * L.step, c = lc * L.step;
-    if (lr >= g.nr[o] || lc >= g.nc[o]) return;
-    if (r < L.border_px || r >= g.rows - L.border_px || c < L.border_px || c >= g.cols - L.border_px) return;
-    const int lobe = L.lobe, off = L.off, cols = g.cols;
-    // A centre at least border_px = ceil(3(2i+3)/2) * step inside the image keeps every box corner inside it in every
-    // octave (3*lobe/2 + 1 < border_px), so the border cases of integral_image.h:64-96 cannot occur: the 32 look-ups
-    // are issued without branches in between (one memory round trip instead of sixteen).
+    __shared__ unsigned t[RL_COLS / 16 * 17];
+    const size_t row = blockIdx.y;
+    const int x0 = blockIdx.x * RL_COLS, per = cols >> 4, tid = threadIdx.x;
+    const unsigned *src = I + row * cols + x0;
+#pragma unroll
+    for (int j = 0; j < RL_COLS / 1024; j++) {
+        const int x = (j * 256 + tid) * 4;  // cols % 16 == 0: a quad is inside the row or outside it
+        if (x0 + x < cols) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(src + x);
+            unsigned *d = t + 17 * (x >> 4) + (x & 15);
+            d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+        }
+    }
+    __syncthreads();
+    const int k = (x0 >> 4) + tid;
+    if (k < per) {
+        unsigned *dst = J + row * cols + k;
+#pragma unroll
+        for (int m = 0; m < 16; m++) dst[(size_t)m * per] = t[17 * tid + m];
+    }
+}
+
+// ---- K17, gather form: one launch per octave, a thread evaluates all six intervals of one level pixel (the six filters
+// look at the same neighbourhood of the table: one pass over it instead of six).  Workgroup ids are dealt round-robin to the
+// 8 XCDs, each with its own L2: the ids are remapped so that an XCD owns a contiguous band of level rows and streams one
+// eighth of the table instead of all of it.  RES: look-ups go to the residue layout J.
+template <bool RES>
+__global__ void __launch_bounds__(256) surf_pyramid(const unsigned *__restrict__ I, double *__restrict__ pyr, SurfGeom g, int o,
+                                                    unsigned long long *__restrict__ mask, double thr)
+{
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int total = gridDim.x * gridDim.y, id = bx + gridDim.x * by;
+        const int qd = total >> 3, rem = total & 7, xcd = id & 7, local = id >> 3;
+        const int nid = xcd * qd + min(xcd, rem) + local;
+        bx = nid % (int)gridDim.x;
+        by = nid / (int)gridDim.x;
+    }
+    const int lc = bx * 64 + (threadIdx.x & 63);
+    const int lr = by * 4 + (threadIdx.x >> 6);
+    const int step = g.lev[o * SURF_INT].step, cols = g.cols, per = cols >> 4;
+    const int r = lr * step, c = lc * step;
+    const bool in_level = lr < g.nr[o] && lc < g.nc[o];
     const unsigned *ctr = I + (size_t)r * cols + c;
-    auto box = [&](int cx, int cy, int w, int h) __attribute__((always_inline)) -> int {  // centered_rect relative to the centre
-        const int l = cx - w / 2, t = cy - h / 2, rr = l + w - 1, b = t + h - 1;
-        const long rowb = (long)b * cols, rowt = (long)(t - 1) * cols;
-        return (int)(ctr[rowb + rr] - ctr[rowb + l - 1] - ctr[rowt + rr] + ctr[rowt + l - 1]);
-    };
-    double Dxx = box(0, 0, lobe * 3, 2 * lobe - 1) - box(0, 0, lobe, 2 * lobe - 1) * 3.0;       // :141-142
-    double Dyy = box(0, 0, 2 * lobe - 1, lobe * 3) - box(0, 0, 2 * lobe - 1, lobe) * 3.0;       // :144-145
-    double Dxy = (int)((unsigned)box(-off, off, lobe, lobe) + (unsigned)box(off, -off, lobe, lobe) -
-                       (unsigned)box(-off, -off, lobe, lobe) - (unsigned)box(off, off, lobe, lobe));  // :147-150
-    Dxx *= L.area_inv; Dyy *= L.area_inv; Dxy *= L.area_inv;
-    double sign = +1;
-    if (Dxx + Dyy < 0) sign = -1;
-    double det = Dxx * Dyy - 0.81 * Dxy * Dxy;
-    if (det < 0) det = 0;
-    pyr[L.plane + (size_t)lr * g.nc[o] + lc] = sign * det;
+#pragma unroll 1
+    for (int it = 0; it < SURF_INT; it++) {
+        const SurfLevel &L = g.lev[o * SURF_INT + it];
+        const bool inside = in_level && !(r < L.border_px || r >= g.rows - L.border_px || c < L.border_px || c >= cols - L.border_px);
+        bool hot = false;
+        if (inside) {
+            const int lobe = L.lobe, off = L.off;
+            // A centre at least border_px = ceil(3(2i+3)/2) * step inside the image keeps every box corner inside it in
+            // every octave (3*lobe/2 + 1 < border_px), so the border cases of integral_image.h:64-96 cannot occur: the 32
+            // look-ups are issued without branches in between (one memory round trip instead of sixteen).
+            auto at = [&](int dy, int dx) __attribute__((always_inline)) -> unsigned {
+                if (!RES) return ctr[(long)dy * cols + dx];
+                const int x = c + dx;
+                return I[(size_t)(r + dy) * cols + (x & 15) * per + (x >> 4)];
+            };
+            auto box = [&](int cx, int cy, int w, int h) __attribute__((always_inline)) -> int {  // centered_rect relative to the centre
+                const int l = cx - w / 2, t = cy - h / 2, rr = l + w - 1, b = t + h - 1;
+                return (int)(at(b, rr) - at(b, l - 1) - at(t - 1, rr) + at(t - 1, l - 1));
+            };
+            double Dxx = box(0, 0, lobe * 3, 2 * lobe - 1) - box(0, 0, lobe, 2 * lobe - 1) * 3.0;       // :141-142
+            double Dyy = box(0, 0, 2 * lobe - 1, lobe * 3) - box(0, 0, 2 * lobe - 1, lobe) * 3.0;       // :144-145
+            double Dxy = (int)((unsigned)box(-off, off, lobe, lobe) + (unsigned)box(off, -off, lobe, lobe) -
+                               (unsigned)box(-off, -off, lobe, lobe) - (unsigned)box(off, off, lobe, lobe));  // :147-150
+            Dxx *= L.area_inv; Dyy *= L.area_inv; Dxy *= L.area_inv;
+            double sign = +1;
+            if (Dxx + Dyy < 0) sign = -1;
+            double det = Dxx * Dyy - 0.81 * Dxy * Dxy;
+            if (det < 0) det = 0;
+            pyr[L.plane + (size_t)lr * g.nc[o] + lc] = sign * det;
+            hot = det >= thr;
+        }
+        if (mask) {  // one wave = 64 consecutive level pixels of a row = one word of the level's threshold mask
+            const unsigned long long word = __ballot(hot);
+            if ((threadIdx.x & 63) == 0 && in_level) mask[L.mask + (size_t)lr * ((g.nc[o] + 63) / 64) + (lc >> 6)] = word;
+        }
+    }
 }
 
 struct SurfRecord {
@@ -336,36 +415,50 @@ struct SurfNmsParams {
     unsigned long long cap;
 };
 
-// ---- K18: one launch per octave, blockIdx.z + 1 = interval (1..4)
-__global__ void __launch_bounds__(256) surf_nms_interp(const double *__restrict__ pyr, SurfGeom g, SurfNmsParams q,
-                                                       SurfRecord *__restrict__ out, unsigned long long *__restrict__ count)
+// ---- K18: 3x3x3 maximum test + interpolation of one level pixel (octave q.o, interval i, row r, column c)
+__device__ __forceinline__ void surf_nms_pixel(const double *__restrict__ pyr, const SurfGeom &g, const SurfNmsParams &q, int i, int r, int c,
+                                               SurfRecord *__restrict__ out, unsigned long long *__restrict__ count)
 {
-    const int o = q.o, i = blockIdx.z + 1;
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int o = q.o;
     const int nr = g.nr[o], nc = g.nc[o], b = q.border_next[i];
     if (r < b + 1 || r >= nr - b - 1 || c < b + 1 || c >= nc - b - 1) return;  // :474-476
-    const double *P0 = pyr + g.lev[o * SURF_INT + i - 1].plane;
-    const double *P1 = pyr + g.lev[o * SURF_INT + i].plane;
-    const double *P2 = pyr + g.lev[o * SURF_INT + i + 1].plane;
-#define V(P, rr, cc) fabs((P)[(size_t)(rr) * nc + (cc)])
-    const double raw = P1[(size_t)r * nc + c];
+    // the 3x3x3 block around the pixel in one memory round trip: 27 loads issued back to back, no branch in between (the
+    // early exits of a neighbour-by-neighbour scan made every pixel that survives a few comparisons pay one round trip each)
+    double v[3][3][3];  // [interval][row][column], absolute values
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const double *P = pyr + g.lev[o * SURF_INT + i - 1 + s].plane + (size_t)(r - 1) * nc + (c - 1);
+#pragma unroll
+        for (int y = 0; y < 3; y++)
+#pragma unroll
+            for (int x = 0; x < 3; x++) v[s][y][x] = P[(size_t)y * nc + x];
+    }
+    const double raw = v[1][1][1];
     const double val = fabs(raw);
     if (!(val >= q.thr)) return;
     // is_maximum_in_region :324-356: rejected by any strictly larger value in the 3x3x3 block
-    for (int rr = r - 1; rr <= r + 1; rr++)
-        for (int cc = c - 1; cc <= c + 1; cc++)
-            if (V(P0, rr, cc) > val || V(P1, rr, cc) > val || V(P2, rr, cc) > val) return;
+    bool larger = false;
+#pragma unroll
+    for (int s = 0; s < 3; s++)
+#pragma unroll
+        for (int y = 0; y < 3; y++)
+#pragma unroll
+            for (int x = 0; x < 3; x++) {
+                v[s][y][x] = fabs(v[s][y][x]);
+                larger |= v[s][y][x] > val;
+            }
+    if (larger) return;
     // interpolate_point :411-446
-    const double g0 = (V(P1, r, c + 1) - V(P1, r, c - 1)) / 2.0;
-    const double g1 = (V(P1, r + 1, c) - V(P1, r - 1, c)) / 2.0;
-    const double g2 = (V(P2, r, c) - V(P0, r, c)) / 2.0;
-    const double Dxx = (V(P1, r, c + 1) + V(P1, r, c - 1)) - 2 * val;
-    const double Dyy = (V(P1, r + 1, c) + V(P1, r - 1, c)) - 2 * val;
-    const double Dss = (V(P2, r, c) + V(P0, r, c)) - 2 * val;
-    const double Dxy = (V(P1, r + 1, c + 1) + V(P1, r - 1, c - 1) - V(P1, r - 1, c + 1) - V(P1, r + 1, c - 1)) / 4.0;
-    const double Dxs = (V(P2, r, c + 1) + V(P0, r, c - 1) - V(P0, r, c + 1) - V(P2, r, c - 1)) / 4.0;
-    const double Dys = (V(P2, r + 1, c) + V(P0, r - 1, c) - V(P0, r + 1, c) - V(P2, r - 1, c)) / 4.0;
+#define V(s, dy, dx) v[s][1 + (dy)][1 + (dx)]
+    const double g0 = (V(1, 0, 1) - V(1, 0, -1)) / 2.0;
+    const double g1 = (V(1, 1, 0) - V(1, -1, 0)) / 2.0;
+    const double g2 = (V(2, 0, 0) - V(0, 0, 0)) / 2.0;
+    const double Dxx = (V(1, 0, 1) + V(1, 0, -1)) - 2 * val;
+    const double Dyy = (V(1, 1, 0) + V(1, -1, 0)) - 2 * val;
+    const double Dss = (V(2, 0, 0) + V(0, 0, 0)) - 2 * val;
+    const double Dxy = (V(1, 1, 1) + V(1, -1, -1) - V(1, -1, 1) - V(1, 1, -1)) / 4.0;
+    const double Dxs = (V(2, 0, 1) + V(0, 0, -1) - V(0, 0, 1) - V(2, 0, -1)) / 4.0;
+    const double Dys = (V(2, 1, 0) + V(0, -1, 0) - V(0, 1, 0) - V(2, -1, 0)) / 4.0;
 #undef V
     // inv() of the symmetric 3x3 [a b c; d e f; g h i], matrix_la.h:922-962 with det :1576-1590
     const double ma = Dxx, mb = Dxy, mc = Dxs, md = Dxy, me = Dyy, mf = Dys, mg = Dxs, mh = Dys, mi = Dss;
@@ -393,6 +486,36 @@ __global__ void __launch_bounds__(256) surf_nms_interp(const double *__restrict_
     if (k < q.cap) out[k] = rec;
 }
 
+// dense form (no threshold masks): one launch per octave, a thread per level pixel, blockIdx.z + 1 = interval (1..4)
+__global__ void __launch_bounds__(256) surf_nms_interp(const double *__restrict__ pyr, SurfGeom g, SurfNmsParams q,
+                                                       SurfRecord *__restrict__ out, unsigned long long *__restrict__ count)
+{
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (r >= g.nr[q.o] || c >= g.nc[q.o]) return;
+    surf_nms_pixel(pyr, g, q, blockIdx.z + 1, r, c, out, count);
+}
+
+// masked form: the pyramid kernels published which level pixels reach the threshold, one bit each.  A wave takes NMS_ROWS
+// consecutive rows of one 64-pixel column of words of interval blockIdx.z + 1: one mask word per row tells whether any of
+// its 64 pixels (a lane each) has to look at its determinant at all -- almost none does.  (A launch of one thread per
+// pixel spent its time dispatching tens of thousands of workgroups that read one word and left; one thread per word
+// serialised up to 64 pixels per thread in the dense upper octaves.)
+#define NMS_ROWS 4
+__global__ void __launch_bounds__(256) surf_nms_masked(const double *__restrict__ pyr, SurfGeom g, SurfNmsParams q,
+                                                       SurfRecord *__restrict__ out, unsigned long long *__restrict__ count,
+                                                       const unsigned long long *__restrict__ mask)
+{
+    const int o = q.o, i = blockIdx.z + 1;
+    const int wpr = (g.nc[o] + 63) / 64, lane = threadIdx.x & 63;
+    const int wx = blockIdx.x, r0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * NMS_ROWS;
+    if (wx >= wpr) return;
+    const unsigned long long *m = mask + g.lev[o * SURF_INT + i].mask + wx;
+    for (int r = r0; r < min(r0 + NMS_ROWS, g.nr[o]); r++) {
+        const unsigned long long word = m[(size_t)r * wpr];  // the same address in every lane: one broadcast load
+        if ((word >> lane) & 1ull) surf_nms_pixel(pyr, g, q, i, r, wx * 64 + lane, out, count);
+    }
+}
 
 // ---- ranking on the device (imgfd_surf_dev): get_surf_points, surf.h:268-285, without the host
 // One workgroup per tile.  Order of two records: higher score first; equal scores (exact ties of two determinants): the
@@ -494,8 +617,12 @@ __global__ void __launch_bounds__(SR_NT) surf_rank_select(SurfRankParams q)
                 want = w;
                 if (pass < 8) thr_hi |= (unsigned long long)b << (8 * (7 - pass));
                 else thr_lo |= (unsigned long long)b << (8 * (15 - pass));
+                // after the 8 score bytes: hist[b] records share the threshold score and `want` of them are needed.  If that
+                // is all of them no tie straddles the cut: the key passes are not needed (thr_lo = 0 takes every key)
+                if (pass == 7 && hist[b] == w) want = 0;
             }
             __syncthreads();
+            if (pass >= 7 && want == 0) break;  // uniform: `want` was written before the barrier
         }
     }
     // ---- 2. collect (composite >= threshold; everything when nothing is cut), then rank among the collected
@@ -576,6 +703,8 @@ namespace {
 
 struct SurfDevice {
     unsigned *integral = nullptr;
+    unsigned *residue = nullptr;          // optional: the integral image re-laid by column residue (surf_residue_layout)
+    unsigned long long *mask = nullptr;   // optional: threshold masks of all pyramid levels (SurfGeom::mask_words words)
     double *pyr = nullptr;
     size_t pyr_bytes = 0;
     SurfRecord *rec = nullptr;
@@ -586,7 +715,8 @@ struct SurfDevice {
 size_t surf_ws_bytes(const SurfGeom &g, size_t pyr_total, unsigned long long cap)
 {
     const size_t n = (size_t)g.rows * g.cols;
-    return align_up(3 * n, 256) + align_up(4 * n, 256) + align_up(8 * pyr_total, 256) + align_up(sizeof(SurfRecord) * cap, 256) + 4096;
+    return align_up(3 * n, 256) + 2 * align_up(4 * n, 256) + align_up(8 * pyr_total, 256) + align_up(8 * g.mask_words, 256) +
+           align_up(sizeof(SurfRecord) * cap, 256) + 4096;
 }
 
 // K16-K18 for one image already in device memory; leaves the records (unordered) + count on the device
@@ -613,25 +743,40 @@ imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const Surf
     // the pyramid buffer is idle until the integral image is complete: it lends the column scan its scratch
     launch_surf_integral(ctx, d_rgb, d.integral, g.rows, g.cols, d.pyr, d.pyr_bytes);
     IMGFD_HIP(ctx, hipMemsetAsync(d.count, 0, sizeof(unsigned long long), ctx->stream));
+    bool residue_ready = false;
     for (int o = 0; o < SURF_OCT; o++) {
         if (g.nr[o] < 1 || g.nc[o] < 1) continue;
         static_assert(SURF_INT == 6, "surf_pyramid_lds unrolls six intervals");
         // the LDS kernels assume dlib's level geometry (lobe = step*(i+1) + 1); anything else takes the gather kernel
         const bool std_geom = g.lev[o * SURF_INT].step == (2 << o) && g.lev[o * SURF_INT].lobe == (2 << o) + 1 &&
                               g.lev[o * SURF_INT + SURF_INT - 1].lobe == (2 << o) * SURF_INT + 1 && (size_t)d.integral % 16 == 0;
-        if (o == 0 && std_geom) { IMGFD_TRY(launch_surf_pyramid_lds<0>(ctx, d.integral, d.pyr, g)); continue; }
+        if (o == 0 && std_geom) { IMGFD_TRY(launch_surf_pyramid_lds<0>(ctx, d.integral, d.pyr, g, d.mask, thr)); continue; }
         // (octave 1 through the same kernel -- an 86 KB window, one workgroup per CU -- measured 219 us against 164 us for
         // the gather kernel on a 4096^2 tile: not used)
-        dim3 grid(ceil_div(g.nc[o], 64), ceil_div(g.nr[o], 4), SURF_INT);
-        hipLaunchKernelGGL(surf_pyramid, grid, dim3(256), 0, ctx->stream, d.integral, d.pyr, g, o);
+        dim3 grid(ceil_div(g.nc[o], 64), ceil_div(g.nr[o], 4));
+        static const char *res_env = getenv("IMGFD_SURF_RESIDUE");  // experiment switch: 0 = gather from the plain table
+        if (o >= 1 && d.residue && g.cols % 16 == 0 && !(res_env && atoi(res_env) == 0)) {
+            if (!residue_ready) {  // once per image, after the integral image is complete
+                hipLaunchKernelGGL(surf_residue_layout, dim3(ceil_div(g.cols, RL_COLS), g.rows), dim3(256), 0, ctx->stream, d.integral, d.residue, g.cols);
+                residue_ready = true;
+            }
+            hipLaunchKernelGGL(surf_pyramid<true>, grid, dim3(256), 0, ctx->stream, d.residue, d.pyr, g, o, d.mask, thr);
+        } else {
+            hipLaunchKernelGGL(surf_pyramid<false>, grid, dim3(256), 0, ctx->stream, d.integral, d.pyr, g, o, d.mask, thr);
+        }
     }
     for (int o = 0; o < SURF_OCT; o++) {
         if (g.nr[o] < 1 || g.nc[o] < 1) continue;
         SurfNmsParams q;
         q.o = o; q.thr = thr; q.pow2_o1 = pow(2.0, o + 1.0); q.step = (double)surf_step_of(o); q.cap = d.cap;
         for (int i = 0; i < SURF_INT; i++) q.border_next[i] = (int)surf_border_of(std::min(i + 1, SURF_INT - 1));
-        dim3 grid(ceil_div(g.nc[o], 64), ceil_div(g.nr[o], 4), SURF_INT - 2);
-        hipLaunchKernelGGL(surf_nms_interp, grid, dim3(256), 0, ctx->stream, d.pyr, g, q, d.rec, d.count);
+        if (d.mask) {
+            dim3 grid(ceil_div(g.nc[o], 64), ceil_div(g.nr[o], 4 * NMS_ROWS), SURF_INT - 2);
+            hipLaunchKernelGGL(surf_nms_masked, grid, dim3(256), 0, ctx->stream, d.pyr, g, q, d.rec, d.count, (const unsigned long long *)d.mask);
+        } else {
+            dim3 grid(ceil_div(g.nc[o], 64), ceil_div(g.nr[o], 4), SURF_INT - 2);
+            hipLaunchKernelGGL(surf_nms_interp, grid, dim3(256), 0, ctx->stream, d.pyr, g, q, d.rec, d.count);
+        }
     }
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
@@ -655,6 +800,8 @@ imgfd_status surf_points_host(imgfd_ctx *ctx, const void *rgb, int kind, int row
         ctx->ws_used = 0;
         uint8_t *d_rgb = (uint8_t *)ws_alloc(ctx, 3 * n);
         d.integral = (unsigned *)ws_alloc(ctx, 4 * n);
+        d.residue = (unsigned *)ws_alloc(ctx, 4 * n);
+        d.mask = (unsigned long long *)ws_alloc(ctx, 8 * std::max<size_t>(g.mask_words, 1));
         d.pyr = (double *)ws_alloc(ctx, 8 * std::max<size_t>(total, 1));
         d.pyr_bytes = 8 * std::max<size_t>(total, 1);
         d.rec = (SurfRecord *)ws_alloc(ctx, sizeof(SurfRecord) * d.cap);
@@ -817,9 +964,11 @@ imgfd_status imgfd_surf_points_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_f
     SurfGeom g;
     const size_t total = surf_geometry(rows, cols, &g);
     const size_t n = (size_t)rows * cols;
-    IMGFD_TRY(ws_reserve(ctx, align_up(4 * n, 256) + align_up(8 * std::max<size_t>(total, 1), 256) + 4096));
+    IMGFD_TRY(ws_reserve(ctx, 2 * align_up(4 * n, 256) + align_up(8 * std::max<size_t>(g.mask_words, 1), 256) + align_up(8 * std::max<size_t>(total, 1), 256) + 4096));
     SurfDevice d;
     d.integral = (unsigned *)ws_alloc(ctx, 4 * n);
+    d.residue = (unsigned *)ws_alloc(ctx, 4 * n);
+    d.mask = (unsigned long long *)ws_alloc(ctx, 8 * std::max<size_t>(g.mask_words, 1));
     d.pyr = (double *)ws_alloc(ctx, 8 * std::max<size_t>(total, 1));
     d.pyr_bytes = 8 * std::max<size_t>(total, 1);
     if (!d.integral || !d.pyr) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
@@ -871,6 +1020,8 @@ try {
         (void)ws_alloc(c, 3 * n);  // the slot imgfd_surf uses for the uploaded image (same carving, same size function)
         L.d.cap = rec_cap;
         L.d.integral = (unsigned *)ws_alloc(c, 4 * n);
+        L.d.residue = (unsigned *)ws_alloc(c, 4 * n);
+        L.d.mask = (unsigned long long *)ws_alloc(c, 8 * std::max<size_t>(g.mask_words, 1));
         L.d.pyr = (double *)ws_alloc(c, 8 * std::max<size_t>(total, 1));
         L.d.pyr_bytes = 8 * std::max<size_t>(total, 1);
         L.d.rec = (SurfRecord *)ws_alloc(c, sizeof(SurfRecord) * rec_cap);
