@@ -310,56 +310,74 @@ static imgfd_status launch_surf_pyramid_lds(imgfd_ctx *ctx, const unsigned *d_I,
     return IMGFD_OK;
 }
 
-// ---- the integral image re-laid by column residue: J[row][x % 16][x / 16] = I[row][x] (cols a multiple of 16).  A wave
-// of surf_pyramid evaluates 64 consecutive level pixels, i.e. image columns step*lane + const: in I that is one word out of
-// every `step` (4, 8, 16: 25 / 12 / 6 % of each cache line used, 32 look-ups per pixel); in J the lanes of a look-up read
-// 16 / step runs of consecutive words.  One pass over the table (67 MB at 4096^2) serves octaves 1-3.
-// A workgroup moves 4096 columns of one row through LDS (word x at 17 * (x / 16) + x % 16: the transposed reads of 64 lanes
-// fall into 64 different banks), so that both the loads and the stores are runs of consecutive words.
+// ---- the integral image re-laid by column residue: J[row][x % M][x / M] = I[row][x] (M = 1 << LM, cols a multiple of 16).
+// A wave of surf_pyramid evaluates 64 consecutive level pixels, i.e. image columns step*lane + const: in I that is one
+// word out of every `step` (4, 8, 16: 25 / 12 / 6 % of each cache line used, 32 look-ups per pixel).  In J with M = 4 the
+// lanes of an octave-1 look-up read 64 consecutive words (octave 2: every second word, octave 3: every fourth); M = 16 gives
+// runs of 16 / 8 / 4 words to octaves 1 / 2 / 3.  One pass over the table (67 MB at 4096^2) serves octaves 1-3.
+// A workgroup moves 4096 columns of one row through LDS (word x at (M + 1) * (x / M) + x % M: the transposed reads of 64
+// lanes fall into 64 different banks), so that both the loads and the stores are runs of consecutive words.
 #define RL_COLS 4096
+template <int LM>
 __global__ void __launch_bounds__(256) surf_residue_layout(const unsigned *__restrict__ I, unsigned *__restrict__ J, int cols)
 {
-    __shared__ unsigned t[RL_COLS / 16 * 17];
+    constexpr int M = 1 << LM, RUN = RL_COLS / M;
+    __shared__ unsigned t[RUN * (M + 1)];
     const size_t row = blockIdx.y;
-    const int x0 = blockIdx.x * RL_COLS, per = cols >> 4, tid = threadIdx.x;
+    const int x0 = blockIdx.x * RL_COLS, per = cols >> LM, tid = threadIdx.x;
     const unsigned *src = I + row * cols + x0;
 #pragma unroll
     for (int j = 0; j < RL_COLS / 1024; j++) {
         const int x = (j * 256 + tid) * 4;  // cols % 16 == 0: a quad is inside the row or outside it
         if (x0 + x < cols) {
             const uint4 q = *reinterpret_cast<const uint4 *>(src + x);
-            unsigned *d = t + 17 * (x >> 4) + (x & 15);
+            unsigned *d = t + (M + 1) * (x >> LM) + (x & (M - 1));
             d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
         }
     }
     __syncthreads();
-    const int k = (x0 >> 4) + tid;
-    if (k < per) {
-        unsigned *dst = J + row * cols + k;
+    unsigned *dst = J + row * cols + (x0 >> LM);
 #pragma unroll
-        for (int m = 0; m < 16; m++) dst[(size_t)m * per] = t[17 * tid + m];
+    for (int j = 0; j < RL_COLS / 256; j++) {
+        const int idx = j * 256 + tid, m = idx / RUN, k = idx % RUN;
+        if ((x0 >> LM) + k < per) dst[(size_t)m * per + k] = t[(M + 1) * k + m];
     }
 }
 
-// ---- K17, gather form: one launch per octave, a thread evaluates all six intervals of one level pixel (the six filters
+// ---- K17, gather form: one launch for the octaves it serves, a thread evaluates all six intervals of one level pixel (the six filters
 // look at the same neighbourhood of the table: one pass over it instead of six).  Workgroup ids are dealt round-robin to the
 // 8 XCDs, each with its own L2: the ids are remapped so that an XCD owns a contiguous band of level rows and streams one
 // eighth of the table instead of all of it.  RES: look-ups go to the residue layout J.
-template <bool RES>
-__global__ void __launch_bounds__(256) surf_pyramid(const unsigned *__restrict__ I, double *__restrict__ pyr, SurfGeom g, int o,
+struct SurfBlocks {
+    unsigned first[SURF_OCT + 1];  // first workgroup id of each octave in a launch that covers several (empty ranges allowed)
+};
+__device__ __forceinline__ int surf_octave_of_block(const SurfBlocks &b, unsigned bid)
+{
+    int o = 0;
+#pragma unroll
+    for (int k = 1; k < SURF_OCT; k++) o += bid >= b.first[k] ? 1 : 0;
+    return o;
+}
+
+template <int LM>  // 0: the plain table; else the residue layout with M = 1 << LM
+__global__ void __launch_bounds__(256) surf_pyramid(const unsigned *__restrict__ I, double *__restrict__ pyr, SurfGeom g, SurfBlocks blocks,
                                                     unsigned long long *__restrict__ mask, double thr)
 {
-    int bx = blockIdx.x, by = blockIdx.y;
+    // the octaves of one launch follow each other in the grid, each padded to a multiple of 8 workgroups so that
+    // id % 8 (the XCD) is the same thing inside an octave's range as in the whole grid
+    const int o = surf_octave_of_block(blocks, blockIdx.x);
+    const int gx = (g.nc[o] + 63) / 64, gy = (g.nr[o] + 3) / 4;
+    int bx, by;
     {
-        const int total = gridDim.x * gridDim.y, id = bx + gridDim.x * by;
-        const int qd = total >> 3, rem = total & 7, xcd = id & 7, local = id >> 3;
-        const int nid = xcd * qd + min(xcd, rem) + local;
-        bx = nid % (int)gridDim.x;
-        by = nid / (int)gridDim.x;
+        const int id = blockIdx.x - blocks.first[o], padded = blocks.first[o + 1] - blocks.first[o];
+        const int nid = (id & 7) * (padded >> 3) + (id >> 3);
+        if (nid >= gx * gy) return;
+        bx = nid % gx;
+        by = nid / gx;
     }
     const int lc = bx * 64 + (threadIdx.x & 63);
     const int lr = by * 4 + (threadIdx.x >> 6);
-    const int step = g.lev[o * SURF_INT].step, cols = g.cols, per = cols >> 4;
+    const int step = g.lev[o * SURF_INT].step, cols = g.cols, per = cols >> LM;
     const int r = lr * step, c = lc * step;
     const bool in_level = lr < g.nr[o] && lc < g.nc[o];
     const unsigned *ctr = I + (size_t)r * cols + c;
@@ -374,9 +392,9 @@ __global__ void __launch_bounds__(256) surf_pyramid(const unsigned *__restrict__
             // every octave (3*lobe/2 + 1 < border_px), so the border cases of integral_image.h:64-96 cannot occur: the 32
             // look-ups are issued without branches in between (one memory round trip instead of sixteen).
             auto at = [&](int dy, int dx) __attribute__((always_inline)) -> unsigned {
-                if (!RES) return ctr[(long)dy * cols + dx];
+                if (LM == 0) return ctr[(long)dy * cols + dx];
                 const int x = c + dx;
-                return I[(size_t)(r + dy) * cols + (x & 15) * per + (x >> 4)];
+                return I[(size_t)(r + dy) * cols + (x & ((1 << LM) - 1)) * per + (x >> LM)];
             };
             auto box = [&](int cx, int cy, int w, int h) __attribute__((always_inline)) -> int {  // centered_rect relative to the centre
                 const int l = cx - w / 2, t = cy - h / 2, rr = l + w - 1, b = t + h - 1;
@@ -407,31 +425,32 @@ struct SurfRecord {
 };
 
 struct SurfNmsParams {
-    int o;
     int border_next[SURF_INT];  // get_border_size(i+1) for the interval handled (level coordinates)
     double thr;
-    double pow2_o1;             // std::pow(2.0, o+1.0)
-    double step;                // get_step_size(o)
+    double pow2_o1[SURF_OCT];   // std::pow(2.0, o+1.0)
+    double step[SURF_OCT];      // get_step_size(o)
     unsigned long long cap;
+    SurfBlocks blocks;          // masked form: all octaves in one launch
 };
 
-// ---- K18: 3x3x3 maximum test + interpolation of one level pixel (octave q.o, interval i, row r, column c)
-__device__ __forceinline__ void surf_nms_pixel(const double *__restrict__ pyr, const SurfGeom &g, const SurfNmsParams &q, int i, int r, int c,
+// ---- K18: 3x3x3 maximum test + interpolation of one level pixel (octave o, interval i, row r, column c)
+__device__ __forceinline__ void surf_nms_pixel(const double *__restrict__ pyr, const SurfGeom &g, const SurfNmsParams &q, int o, int i, int r, int c,
                                                SurfRecord *__restrict__ out, unsigned long long *__restrict__ count)
 {
-    const int o = q.o;
     const int nr = g.nr[o], nc = g.nc[o], b = q.border_next[i];
     if (r < b + 1 || r >= nr - b - 1 || c < b + 1 || c >= nc - b - 1) return;  // :474-476
-    // the 3x3x3 block around the pixel in one memory round trip: 27 loads issued back to back, no branch in between (the
-    // early exits of a neighbour-by-neighbour scan made every pixel that survives a few comparisons pay one round trip each)
+    // the 3x3x3 block around the pixel in two memory round trips, loads issued back to back with no branch in between:
+    // the pixel's own interval first (most pixels above the threshold are not the largest of their own 3x3), then the
+    // two neighbouring intervals.  (Neighbour-by-neighbour early exits cost a round trip per comparison; all 27 values
+    // at once fetched three times the cache lines for pixels the first nine reject.)
     double v[3][3][3];  // [interval][row][column], absolute values
-#pragma unroll
-    for (int s = 0; s < 3; s++) {
-        const double *P = pyr + g.lev[o * SURF_INT + i - 1 + s].plane + (size_t)(r - 1) * nc + (c - 1);
+    const size_t at = (size_t)(r - 1) * nc + (c - 1);
+    {
+        const double *P = pyr + g.lev[o * SURF_INT + i].plane + at;
 #pragma unroll
         for (int y = 0; y < 3; y++)
 #pragma unroll
-            for (int x = 0; x < 3; x++) v[s][y][x] = P[(size_t)y * nc + x];
+            for (int x = 0; x < 3; x++) v[1][y][x] = P[(size_t)y * nc + x];
     }
     const double raw = v[1][1][1];
     const double val = fabs(raw);
@@ -439,7 +458,23 @@ __device__ __forceinline__ void surf_nms_pixel(const double *__restrict__ pyr, c
     // is_maximum_in_region :324-356: rejected by any strictly larger value in the 3x3x3 block
     bool larger = false;
 #pragma unroll
-    for (int s = 0; s < 3; s++)
+    for (int y = 0; y < 3; y++)
+#pragma unroll
+        for (int x = 0; x < 3; x++) {
+            v[1][y][x] = fabs(v[1][y][x]);
+            larger |= v[1][y][x] > val;
+        }
+    if (larger) return;
+#pragma unroll
+    for (int s = 0; s < 3; s += 2) {
+        const double *P = pyr + g.lev[o * SURF_INT + i - 1 + s].plane + at;
+#pragma unroll
+        for (int y = 0; y < 3; y++)
+#pragma unroll
+            for (int x = 0; x < 3; x++) v[s][y][x] = P[(size_t)y * nc + x];
+    }
+#pragma unroll
+    for (int s = 0; s < 3; s += 2)
 #pragma unroll
         for (int y = 0; y < 3; y++)
 #pragma unroll
@@ -476,9 +511,9 @@ __device__ __forceinline__ void surf_nms_pixel(const double *__restrict__ pyr, c
     if (!(fmax(fabs(ix), fmax(fabs(iy), fabs(iz))) < 0.5)) return;
     SurfRecord rec;
     rec.key = ((unsigned long long)(o * 8 + i) << 40) | ((unsigned long long)r << 20) | (unsigned long long)c;
-    rec.x = (c + ix) * q.step;
-    rec.y = (r + iy) * q.step;
-    const double lobe = q.pow2_o1 * (i + iz + 1) + 1;
+    rec.x = (c + ix) * q.step[o];
+    rec.y = (r + iy) * q.step[o];
+    const double lobe = q.pow2_o1[o] * (i + iz + 1) + 1;
     rec.scale = 1.2 / 9.0 * (3 * lobe);
     rec.score = val;
     rec.laplacian = raw > 0 ? +1.0 : -1.0;  // get_laplacian :294-297
@@ -487,33 +522,67 @@ __device__ __forceinline__ void surf_nms_pixel(const double *__restrict__ pyr, c
 }
 
 // dense form (no threshold masks): one launch per octave, a thread per level pixel, blockIdx.z + 1 = interval (1..4)
-__global__ void __launch_bounds__(256) surf_nms_interp(const double *__restrict__ pyr, SurfGeom g, SurfNmsParams q,
+__global__ void __launch_bounds__(256) surf_nms_interp(const double *__restrict__ pyr, SurfGeom g, SurfNmsParams q, int o,
                                                        SurfRecord *__restrict__ out, unsigned long long *__restrict__ count)
 {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (r >= g.nr[q.o] || c >= g.nc[q.o]) return;
-    surf_nms_pixel(pyr, g, q, blockIdx.z + 1, r, c, out, count);
+    if (r >= g.nr[o] || c >= g.nc[o]) return;
+    surf_nms_pixel(pyr, g, q, o, blockIdx.z + 1, r, c, out, count);
 }
 
-// masked form: the pyramid kernels published which level pixels reach the threshold, one bit each.  A wave takes NMS_ROWS
-// consecutive rows of one 64-pixel column of words of interval blockIdx.z + 1: one mask word per row tells whether any of
-// its 64 pixels (a lane each) has to look at its determinant at all -- almost none does.  (A launch of one thread per
-// pixel spent its time dispatching tens of thousands of workgroups that read one word and left; one thread per word
-// serialised up to 64 pixels per thread in the dense upper octaves.)
-#define NMS_ROWS 4
-__global__ void __launch_bounds__(256) surf_nms_masked(const double *__restrict__ pyr, SurfGeom g, SurfNmsParams q,
-                                                       SurfRecord *__restrict__ out, unsigned long long *__restrict__ count,
-                                                       const unsigned long long *__restrict__ mask)
+// masked form: the pyramid kernels published which level pixels reach the threshold, one bit each -- a fraction of a
+// percent in octave 0, a few percent above (measured on the bench tiles).  One launch for all octaves (q.blocks).  A
+// workgroup takes up to 256 consecutive mask words of one interval, a thread each, and turns their set bits into a dense list
+// in LDS (popcount, block scan, one entry per bit: thread << 6 | bit); the threads then share the listed pixels evenly,
+// so that the 27-value neighbourhood test runs on full waves in one memory round trip.  (A thread per level pixel spent
+// its time dispatching workgroups that read one word and left; a wave per word waited on four dependent rows.)
+#define NMS_WORDS 256
+// words per workgroup: the masks get denser with the octave (and the levels smaller): 256, 128, 64, 32 keeps the listed
+// pixels per workgroup near one per thread and the number of workgroups per octave within a factor of two of each other
+__host__ __device__ inline int surf_nms_words(int o) { return NMS_WORDS >> (o < 3 ? o : 3); }
+__host__ __device__ inline unsigned surf_nms_blocks(int nr, int nc, int o)
 {
-    const int o = q.o, i = blockIdx.z + 1;
-    const int wpr = (g.nc[o] + 63) / 64, lane = threadIdx.x & 63;
-    const int wx = blockIdx.x, r0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * NMS_ROWS;
-    if (wx >= wpr) return;
-    const unsigned long long *m = mask + g.lev[o * SURF_INT + i].mask + wx;
-    for (int r = r0; r < min(r0 + NMS_ROWS, g.nr[o]); r++) {
-        const unsigned long long word = m[(size_t)r * wpr];  // the same address in every lane: one broadcast load
-        if ((word >> lane) & 1ull) surf_nms_pixel(pyr, g, q, i, r, wx * 64 + lane, out, count);
+    return (unsigned)(((size_t)nr * ((nc + 63) / 64) + surf_nms_words(o) - 1) / surf_nms_words(o));
+}
+__global__ void __launch_bounds__(NMS_WORDS) surf_nms_masked(const double *__restrict__ pyr, SurfGeom g, SurfNmsParams q,
+                                                             SurfRecord *__restrict__ out, unsigned long long *__restrict__ count,
+                                                             const unsigned long long *__restrict__ mask)
+{
+    __shared__ unsigned short list[NMS_WORDS * 64];
+    __shared__ unsigned wave_sum[NMS_WORDS / 64];
+    const int o = surf_octave_of_block(q.blocks, blockIdx.x), tid = threadIdx.x, lane = tid & 63;
+    const int wpr = (g.nc[o] + 63) / 64;
+    const size_t words = (size_t)g.nr[o] * wpr;
+    const unsigned per = surf_nms_blocks(g.nr[o], g.nc[o], o), id = blockIdx.x - q.blocks.first[o];
+    const int i = (int)(id / per) + 1;
+    const size_t w0 = (size_t)(id % per) * surf_nms_words(o);
+    unsigned long long word = tid < surf_nms_words(o) && w0 + tid < words ? mask[g.lev[o * SURF_INT + i].mask + w0 + tid] : 0ull;
+    const unsigned cnt = (unsigned)__popcll(word);
+    unsigned incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wave_sum[tid >> 6] = incl;
+    __syncthreads();
+    unsigned pos = incl - cnt, total = 0;
+#pragma unroll
+    for (int k = 0; k < NMS_WORDS / 64; k++) {
+        if (k < (tid >> 6)) pos += wave_sum[k];
+        total += wave_sum[k];
+    }
+    while (word) {
+        const int bit = __ffsll((long long)word) - 1;
+        word &= word - 1;
+        list[pos++] = (unsigned short)(tid << 6 | bit);
+    }
+    __syncthreads();
+    for (unsigned k = tid; k < total; k += NMS_WORDS) {
+        const unsigned e = list[k];
+        const size_t w = w0 + (e >> 6);
+        surf_nms_pixel(pyr, g, q, o, i, (int)(w / wpr), (int)(w % wpr) * 64 + (int)(e & 63), out, count);
     }
 }
 
@@ -743,7 +812,6 @@ imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const Surf
     // the pyramid buffer is idle until the integral image is complete: it lends the column scan its scratch
     launch_surf_integral(ctx, d_rgb, d.integral, g.rows, g.cols, d.pyr, d.pyr_bytes);
     IMGFD_HIP(ctx, hipMemsetAsync(d.count, 0, sizeof(unsigned long long), ctx->stream));
-    bool residue_ready = false;
     for (int o = 0; o < SURF_OCT; o++) {
         if (g.nr[o] < 1 || g.nc[o] < 1) continue;
         static_assert(SURF_INT == 6, "surf_pyramid_lds unrolls six intervals");
@@ -753,29 +821,47 @@ imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const Surf
         if (o == 0 && std_geom) { IMGFD_TRY(launch_surf_pyramid_lds<0>(ctx, d.integral, d.pyr, g, d.mask, thr)); continue; }
         // (octave 1 through the same kernel -- an 86 KB window, one workgroup per CU -- measured 219 us against 164 us for
         // the gather kernel on a 4096^2 tile: not used)
-        dim3 grid(ceil_div(g.nc[o], 64), ceil_div(g.nr[o], 4));
-        static const char *res_env = getenv("IMGFD_SURF_RESIDUE");  // experiment switch: 0 = gather from the plain table
-        if (o >= 1 && d.residue && g.cols % 16 == 0 && !(res_env && atoi(res_env) == 0)) {
-            if (!residue_ready) {  // once per image, after the integral image is complete
-                hipLaunchKernelGGL(surf_residue_layout, dim3(ceil_div(g.cols, RL_COLS), g.rows), dim3(256), 0, ctx->stream, d.integral, d.residue, g.cols);
-                residue_ready = true;
-            }
-            hipLaunchKernelGGL(surf_pyramid<true>, grid, dim3(256), 0, ctx->stream, d.residue, d.pyr, g, o, d.mask, thr);
-        } else {
-            hipLaunchKernelGGL(surf_pyramid<false>, grid, dim3(256), 0, ctx->stream, d.integral, d.pyr, g, o, d.mask, thr);
+        // the gather kernel: this octave and everything above it in one launch
+        SurfBlocks blocks;
+        unsigned nb = 0;
+        for (int k = 0; k < SURF_OCT; k++) {
+            blocks.first[k] = nb;
+            if (k >= o && g.nr[k] >= 1 && g.nc[k] >= 1) nb += (unsigned)align_up((size_t)ceil_div(g.nc[k], 64) * ceil_div(g.nr[k], 4), (size_t)8);
         }
-    }
-    for (int o = 0; o < SURF_OCT; o++) {
-        if (g.nr[o] < 1 || g.nc[o] < 1) continue;
-        SurfNmsParams q;
-        q.o = o; q.thr = thr; q.pow2_o1 = pow(2.0, o + 1.0); q.step = (double)surf_step_of(o); q.cap = d.cap;
-        for (int i = 0; i < SURF_INT; i++) q.border_next[i] = (int)surf_border_of(std::min(i + 1, SURF_INT - 1));
-        if (d.mask) {
-            dim3 grid(ceil_div(g.nc[o], 64), ceil_div(g.nr[o], 4 * NMS_ROWS), SURF_INT - 2);
-            hipLaunchKernelGGL(surf_nms_masked, grid, dim3(256), 0, ctx->stream, d.pyr, g, q, d.rec, d.count, (const unsigned long long *)d.mask);
+        blocks.first[SURF_OCT] = nb;
+        if (!nb) break;
+        static const char *res_env = getenv("IMGFD_SURF_RESIDUE");  // experiment switch: 0 = the plain table, 4 | 16 = modulus
+        const int modulus = res_env ? atoi(res_env) : 4;
+        const dim3 lgrid(ceil_div(g.cols, RL_COLS), g.rows);
+        if (o >= 1 && d.residue && g.cols % 16 == 0 && modulus == 4) {
+            hipLaunchKernelGGL(surf_residue_layout<2>, lgrid, dim3(256), 0, ctx->stream, d.integral, d.residue, g.cols);
+            hipLaunchKernelGGL(surf_pyramid<2>, dim3(nb), dim3(256), 0, ctx->stream, d.residue, d.pyr, g, blocks, d.mask, thr);
+        } else if (o >= 1 && d.residue && g.cols % 16 == 0 && modulus == 16) {
+            hipLaunchKernelGGL(surf_residue_layout<4>, lgrid, dim3(256), 0, ctx->stream, d.integral, d.residue, g.cols);
+            hipLaunchKernelGGL(surf_pyramid<4>, dim3(nb), dim3(256), 0, ctx->stream, d.residue, d.pyr, g, blocks, d.mask, thr);
         } else {
+            hipLaunchKernelGGL(surf_pyramid<0>, dim3(nb), dim3(256), 0, ctx->stream, d.integral, d.pyr, g, blocks, d.mask, thr);
+        }
+        break;
+    }
+    SurfNmsParams q;
+    q.thr = thr; q.cap = d.cap;
+    for (int i = 0; i < SURF_INT; i++) q.border_next[i] = (int)surf_border_of(std::min(i + 1, SURF_INT - 1));
+    unsigned nb = 0;
+    for (int o = 0; o < SURF_OCT; o++) {
+        q.pow2_o1[o] = pow(2.0, o + 1.0);
+        q.step[o] = (double)surf_step_of(o);
+        q.blocks.first[o] = nb;
+        if (g.nr[o] >= 1 && g.nc[o] >= 1) nb += surf_nms_blocks(g.nr[o], g.nc[o], o) * (SURF_INT - 2);
+    }
+    q.blocks.first[SURF_OCT] = nb;
+    if (d.mask) {
+        if (nb) hipLaunchKernelGGL(surf_nms_masked, dim3(nb), dim3(NMS_WORDS), 0, ctx->stream, d.pyr, g, q, d.rec, d.count, (const unsigned long long *)d.mask);
+    } else {
+        for (int o = 0; o < SURF_OCT; o++) {
+            if (g.nr[o] < 1 || g.nc[o] < 1) continue;
             dim3 grid(ceil_div(g.nc[o], 64), ceil_div(g.nr[o], 4), SURF_INT - 2);
-            hipLaunchKernelGGL(surf_nms_interp, grid, dim3(256), 0, ctx->stream, d.pyr, g, q, d.rec, d.count);
+            hipLaunchKernelGGL(surf_nms_interp, grid, dim3(256), 0, ctx->stream, d.pyr, g, q, o, d.rec, d.count);
         }
     }
     IMGFD_HIP(ctx, hipGetLastError());
