@@ -434,11 +434,12 @@ struct SurfNmsParams {
 };
 
 // ---- K18: 3x3x3 maximum test + interpolation of one level pixel (octave o, interval i, row r, column c)
-__device__ __forceinline__ void surf_nms_pixel(const double *__restrict__ pyr, const SurfGeom &g, const SurfNmsParams &q, int o, int i, int r, int c,
-                                               SurfRecord *__restrict__ out, unsigned long long *__restrict__ count)
+// true: `rec` is an interest point
+__device__ __forceinline__ bool surf_nms_pixel(const double *__restrict__ pyr, const SurfGeom &g, const SurfNmsParams &q, int o, int i, int r, int c,
+                                               SurfRecord &rec)
 {
     const int nr = g.nr[o], nc = g.nc[o], b = q.border_next[i];
-    if (r < b + 1 || r >= nr - b - 1 || c < b + 1 || c >= nc - b - 1) return;  // :474-476
+    if (r < b + 1 || r >= nr - b - 1 || c < b + 1 || c >= nc - b - 1) return false;  // :474-476
     // the 3x3x3 block around the pixel in two memory round trips, loads issued back to back with no branch in between:
     // the pixel's own interval first (most pixels above the threshold are not the largest of their own 3x3), then the
     // two neighbouring intervals.  (Neighbour-by-neighbour early exits cost a round trip per comparison; all 27 values
@@ -454,7 +455,7 @@ __device__ __forceinline__ void surf_nms_pixel(const double *__restrict__ pyr, c
     }
     const double raw = v[1][1][1];
     const double val = fabs(raw);
-    if (!(val >= q.thr)) return;
+    if (!(val >= q.thr)) return false;
     // is_maximum_in_region :324-356: rejected by any strictly larger value in the 3x3x3 block
     bool larger = false;
 #pragma unroll
@@ -464,7 +465,7 @@ __device__ __forceinline__ void surf_nms_pixel(const double *__restrict__ pyr, c
             v[1][y][x] = fabs(v[1][y][x]);
             larger |= v[1][y][x] > val;
         }
-    if (larger) return;
+    if (larger) return false;
 #pragma unroll
     for (int s = 0; s < 3; s += 2) {
         const double *P = pyr + g.lev[o * SURF_INT + i - 1 + s].plane + at;
@@ -482,7 +483,7 @@ __device__ __forceinline__ void surf_nms_pixel(const double *__restrict__ pyr, c
                 v[s][y][x] = fabs(v[s][y][x]);
                 larger |= v[s][y][x] > val;
             }
-    if (larger) return;
+    if (larger) return false;
     // interpolate_point :411-446
 #define V(s, dy, dx) v[s][1 + (dy)][1 + (dx)]
     const double g0 = (V(1, 0, 1) - V(1, 0, -1)) / 2.0;
@@ -508,8 +509,7 @@ __device__ __forceinline__ void surf_nms_pixel(const double *__restrict__ pyr, c
     const double ix = -(v00 * g0 + v01 * g1 + v02 * g2);
     const double iy = -(v10 * g0 + v11 * g1 + v12 * g2);
     const double iz = -(v20 * g0 + v21 * g1 + v22 * g2);
-    if (!(fmax(fabs(ix), fmax(fabs(iy), fabs(iz))) < 0.5)) return;
-    SurfRecord rec;
+    if (!(fmax(fabs(ix), fmax(fabs(iy), fabs(iz))) < 0.5)) return false;
     rec.key = ((unsigned long long)(o * 8 + i) << 40) | ((unsigned long long)r << 20) | (unsigned long long)c;
     rec.x = (c + ix) * q.step[o];
     rec.y = (r + iy) * q.step[o];
@@ -517,8 +517,7 @@ __device__ __forceinline__ void surf_nms_pixel(const double *__restrict__ pyr, c
     rec.scale = 1.2 / 9.0 * (3 * lobe);
     rec.score = val;
     rec.laplacian = raw > 0 ? +1.0 : -1.0;  // get_laplacian :294-297
-    const unsigned long long k = atomicAdd(count, 1ull);
-    if (k < q.cap) out[k] = rec;
+    return true;
 }
 
 // dense form (no threshold masks): one launch per octave, a thread per level pixel, blockIdx.z + 1 = interval (1..4)
@@ -528,7 +527,11 @@ __global__ void __launch_bounds__(256) surf_nms_interp(const double *__restrict_
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (r >= g.nr[o] || c >= g.nc[o]) return;
-    surf_nms_pixel(pyr, g, q, o, blockIdx.z + 1, r, c, out, count);
+    SurfRecord rec;
+    if (surf_nms_pixel(pyr, g, q, o, blockIdx.z + 1, r, c, rec)) {
+        const unsigned long long k = atomicAdd(count, 1ull);
+        if (k < q.cap) out[k] = rec;
+    }
 }
 
 // masked form: the pyramid kernels published which level pixels reach the threshold, one bit each -- a fraction of a
@@ -579,10 +582,26 @@ __global__ void __launch_bounds__(NMS_WORDS) surf_nms_masked(const double *__res
         list[pos++] = (unsigned short)(tid << 6 | bit);
     }
     __syncthreads();
-    for (unsigned k = tid; k < total; k += NMS_WORDS) {
-        const unsigned e = list[k];
-        const size_t w = w0 + (e >> 6);
-        surf_nms_pixel(pyr, g, q, o, i, (int)(w / wpr), (int)(w % wpr) * 64 + (int)(e & 63), out, count);
+    // the records of a trip are counted in LDS and get their places in the record buffer with one atomic on the global
+    // counter per workgroup (ten thousand returning atomics on one address, one per record, were most of this kernel's time)
+    __shared__ unsigned found;
+    __shared__ unsigned long long base;
+    for (unsigned k0 = 0; k0 < total; k0 += NMS_WORDS) {  // uniform trip count: barriers inside
+        if (tid == 0) found = 0;
+        __syncthreads();
+        SurfRecord rec;
+        bool hit = false;
+        unsigned slot = 0;
+        if (k0 + tid < total) {
+            const unsigned e = list[k0 + tid];
+            const size_t w = w0 + (e >> 6);
+            hit = surf_nms_pixel(pyr, g, q, o, i, (int)(w / wpr), (int)(w % wpr) * 64 + (int)(e & 63), rec);
+            if (hit) slot = atomicAdd(&found, 1u);
+        }
+        __syncthreads();
+        if (tid == 0 && found) base = atomicAdd(count, (unsigned long long)found);
+        __syncthreads();
+        if (hit && base + slot < q.cap) out[base + slot] = rec;
     }
 }
 
