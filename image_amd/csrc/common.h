@@ -100,6 +100,27 @@ static inline int sub_batch_frames(int n_frames, size_t per_frame_bytes, size_t 
 }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// ---- tile runs: the 2-D tile kernels over u8 frames (fast9_tile, gauss_grad_tile) walk `run` consecutive tiles of one
+// band of rows per workgroup instead of one tile.  A 64-pixel tile row with its halo straddles two 128-byte lines; with
+// one tile per workgroup the x-neighbour (another workgroup, dealt to another XCD with its own L2) fetched both lines
+// again: 4-5 times the algorithmic bytes came from HBM.  Inside a run the shared lines are re-read within microseconds
+// by the same CU and mostly hit its L2.
+struct TileRuns {
+    int tiles_x, bands, frames, run, runs_per_band;
+    unsigned total;  // runs_per_band * bands * frames
+};
+static inline TileRuns tile_runs(int tiles_x, int bands, int frames, int run)
+{
+    TileRuns t;
+    t.tiles_x = tiles_x; t.bands = bands; t.frames = frames;
+    t.run = run < 1 ? 1 : (run > tiles_x ? tiles_x : run);
+    t.runs_per_band = (tiles_x + t.run - 1) / t.run;
+    t.total = (unsigned)t.runs_per_band * (unsigned)bands * (unsigned)frames;
+    return t;
+}
+// run length for a frame batch (env IMGFD_TILE_RUN overrides: experiments)
+int tile_run_length(int tiles_x, int bands, int frames, int num_cu);
+
 // workspace: all allocations of one API call are carved from one arena; ws_reserve() guarantees
 // capacity up front so no pointer handed out earlier in the call is invalidated.
 imgfd_status ws_reserve(imgfd_ctx *ctx, size_t bytes);

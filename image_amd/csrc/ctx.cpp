@@ -127,6 +127,18 @@ imgfd_status prof_mark(imgfd_ctx *ctx)
     return IMGFD_OK;
 }
 
+int tile_run_length(int tiles_x, int bands, int frames, int num_cu)
+{
+    static const char *env = getenv("IMGFD_TILE_RUN");
+    if (env && atoi(env) > 0) return atoi(env);
+    // Measured on 32 x 4K frames (scripts/gpu_u8.sh, profiles/r02/u8_runs.txt): runs of 4 cut the fetched bytes by a third
+    // at the same or a slightly better duration; longer runs fetch less still but serialise too much of a workgroup's
+    // latency (staging -> phases -> barriers) and run slower, as does a grid of resident workgroups walking the runs
+    // round-robin instead of one workgroup per run.  A small batch keeps one tile per workgroup: it needs the parallelism.
+    const long tiles = (long)tiles_x * bands * frames;
+    return tiles >= 64L * num_cu ? 4 : 1;
+}
+
 imgfd_status ws_reserve(imgfd_ctx *ctx, size_t bytes)
 {
     ctx->ws_used = 0;

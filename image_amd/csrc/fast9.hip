@@ -13,6 +13,8 @@
 // compaction mask.
 #include "common.h"
 
+#include <algorithm>
+
 // ring offsets in the order of makeOffsets(): (dx,dy)
 #define F9_RING(X)                                                                                  \
     X(0, 0, 3) X(1, 1, 3) X(2, 2, 2) X(3, 3, 1) X(4, 3, 0) X(5, 3, -1) X(6, 2, -2) X(7, 1, -3)       \
@@ -116,7 +118,7 @@ template <int NONMAX>
 __global__ void __launch_bounds__(256) fast9_tile(const unsigned char *__restrict__ img, int w, int h, int stride,
                                                   size_t frame_stride, int b, int aligned4, int aligned16,
                                                   unsigned long long *__restrict__ mask,
-                                                  unsigned *__restrict__ rowcount, int words_per_row)
+                                                  unsigned *__restrict__ rowcount, int words_per_row, TileRuns runs)
 {
     // LDS tile: rows y0-4 .. y0+TY+3; columns x0-16 .. x0+79 (the left margin of 16 keeps the first column 16-byte
     // aligned in the frame, so interior tiles are staged with 16-byte loads; only x0-4 .. x0+67 are ever looked at)
@@ -131,8 +133,14 @@ __global__ void __launch_bounds__(256) fast9_tile(const unsigned char *__restric
     unsigned char(*tile)[LW] = reinterpret_cast<unsigned char(*)[LW]>(tile32);
     unsigned char(*sc)[SCW] = reinterpret_cast<unsigned char(*)[SCW]>(sc32);
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * F9_TX, y0 = blockIdx.y * F9_TY;
-    const unsigned char *fr = img + (size_t)blockIdx.z * frame_stride;
+    {  // one run of tiles per workgroup (TileRuns, common.h)
+    const unsigned run_id = blockIdx.x;
+    const int frame = (int)(run_id / (unsigned)(runs.runs_per_band * runs.bands));
+    const int in_frame = (int)(run_id - (unsigned)frame * (unsigned)(runs.runs_per_band * runs.bands));
+    const int band = in_frame / runs.runs_per_band, tile0 = (in_frame - band * runs.runs_per_band) * runs.run;
+    for (int tile_x = tile0; tile_x < min(tile0 + runs.run, runs.tiles_x); tile_x++) {
+    const int x0 = tile_x * F9_TX, y0 = band * F9_TY;
+    const unsigned char *fr = img + (size_t)frame * frame_stride;
     // ---- stage the tile; out-of-image positions repeat the border pixel (they are never tested, only loaded)
     if (aligned16 && x0 - XL >= 0 && x0 - XL + LW <= w) {  // workgroup-uniform
         for (int i = tid; i < LH * (LW / 16); i += 256) {
@@ -235,23 +243,28 @@ __global__ void __launch_bounds__(256) fast9_tile(const unsigned char *__restric
         const int gy = y0 + r;
         if (gy >= h) continue;
         const unsigned long long word = rowmask[r];
-        mask[((size_t)blockIdx.z * h + gy) * words_per_row + blockIdx.x] = word;
-        if (word) atomicAdd(&rowcount[(size_t)blockIdx.z * h + gy], (unsigned)__popcll(word));
+        mask[((size_t)frame * h + gy) * words_per_row + tile_x] = word;
+        if (word) atomicAdd(&rowcount[(size_t)frame * h + gy], (unsigned)__popcll(word));
+    }
+    __syncthreads();  // the next tile's staging clears rowmask and the score tile
+    }
     }
 }
 
 imgfd_status launch_fast9(imgfd_ctx *ctx, const uint8_t *d_img, int w, int h, int stride,
                           size_t frame_stride, int n_frames, int threshold, int nonmax, const CompactBuffers &cb)
 {
-    dim3 grid(cb.words_per_row, ceil_div(h, F9_TY), n_frames);
+    const int bands = ceil_div(h, F9_TY);
+    const TileRuns runs = tile_runs(cb.words_per_row, bands, n_frames, tile_run_length(cb.words_per_row, bands, n_frames, ctx->num_cu));
+    dim3 grid(runs.total);
     const int aligned4 = ((size_t)d_img % 4 == 0) && stride % 4 == 0 && frame_stride % 4 == 0;
     const int aligned16 = ((size_t)d_img % 16 == 0) && stride % 16 == 0 && frame_stride % 16 == 0;
     if (!nonmax)
         hipLaunchKernelGGL(fast9_tile<0>, grid, dim3(256), 0, ctx->stream, d_img, w, h, stride, frame_stride, threshold,
-                           aligned4, aligned16, cb.mask, cb.rowcount, cb.words_per_row);
+                           aligned4, aligned16, cb.mask, cb.rowcount, cb.words_per_row, runs);
     else
         hipLaunchKernelGGL(fast9_tile<1>, grid, dim3(256), 0, ctx->stream, d_img, w, h, stride, frame_stride, threshold,
-                           aligned4, aligned16, cb.mask, cb.rowcount, cb.words_per_row);
+                           aligned4, aligned16, cb.mask, cb.rowcount, cb.words_per_row, runs);
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }

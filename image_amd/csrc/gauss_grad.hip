@@ -12,6 +12,7 @@
 #include "common.h"
 #include "fir_device.h"
 
+#include <algorithm>
 #include <type_traits>
 
 #define GG_TX 64
@@ -30,6 +31,7 @@ struct GaussGradParams {
     int vec16; // ... aligned 16-pixel loads (u8 frames)
     long in_frame_stride;
     double B[8];
+    TileRuns runs;
 };
 
 template <int R, int GRAD, bool U8, bool FMA>
@@ -51,8 +53,16 @@ __global__ void __launch_bounds__(256) gauss_grad_tile(GaussGradParams p)
     __shared__ float rowf[RH][SW + 1];
     __shared__ float is[SH][SW + 1];
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * GG_TX, y0 = blockIdx.y * GG_TY;
-    const size_t fin = (size_t)blockIdx.z * p.in_frame_stride;
+    // TileRuns, common.h.  No barrier is needed between two tiles: each of the three LDS arrays is next written one
+    // barrier after its last readers
+    {
+    const unsigned run_id = blockIdx.x;  // one run of tiles per workgroup
+    const int frame = (int)(run_id / (unsigned)(p.runs.runs_per_band * p.runs.bands));
+    const int in_frame = (int)(run_id - (unsigned)frame * (unsigned)(p.runs.runs_per_band * p.runs.bands));
+    const int band = in_frame / p.runs.runs_per_band, tile0 = (in_frame - band * p.runs.runs_per_band) * p.runs.run;
+    for (int tile_x = tile0; tile_x < min(tile0 + p.runs.run, p.runs.tiles_x); tile_x++) {
+    const int x0 = tile_x * GG_TX, y0 = band * GG_TY;
+    const size_t fin = (size_t)frame * p.in_frame_stride;
     // ---- input tile; logical index outside the image -> the reference's reflection (gaussian.cpp:345-349, 376-380)
     if (U8 && p.vec16 && x0 - XO >= 0 && x0 - XO + RW <= p.nx) {  // workgroup-uniform: no column reflection in this tile
         for (int i = tid; i < RH * (RW / 16); i += 256) {
@@ -126,7 +136,7 @@ __global__ void __launch_bounds__(256) gauss_grad_tile(GaussGradParams p)
     __syncthreads();
     // ---- gradient: lane = column (coalesced 256-byte row segments)
     const int lane = tid & 63;
-    float *Ix = p.Ix + (size_t)blockIdx.z * p.nx * p.ny, *Iy = p.Iy + (size_t)blockIdx.z * p.nx * p.ny;
+    float *Ix = p.Ix + (size_t)frame * p.nx * p.ny, *Iy = p.Iy + (size_t)frame * p.nx * p.ny;
     for (int r = tid >> 6; r < GG_TY; r += 4) {
         const int x = x0 + lane, y = y0 + r;
         if (x >= p.nx || y >= p.ny) continue;
@@ -144,6 +154,8 @@ __global__ void __launch_bounds__(256) gauss_grad_tile(GaussGradParams p)
         }
         Ix[(size_t)y * p.nx + x] = gx;
         Iy[(size_t)y * p.nx + x] = gy;
+    }
+    }
     }
 }
 
@@ -164,9 +176,10 @@ imgfd_status launch_gauss_grad_fused(imgfd_ctx *ctx, const void *d_in, int in_is
     const size_t esz = in_is_u8 ? 1 : 4;
     p.vec4 = ((size_t)d_in % (4 * esz) == 0) && in_pitch % 4 == 0 && in_frame_stride % 4 == 0 && nx % 4 == 0;
     p.vec16 = in_is_u8 && ((size_t)d_in % 16 == 0) && in_pitch % 16 == 0 && in_frame_stride % 16 == 0 && nx % 16 == 0;
-    dim3 grid(ceil_div(nx, GG_TX), ceil_div(ny, GG_TY), n_frames);
     const bool sobel = grad_type == IMGFD_SOBEL_OPERATOR;
-#define GG_LAUNCH(G, U, F) hipLaunchKernelGGL((gauss_grad_tile<3, G, U, F>), grid, dim3(256), 0, ctx->stream, p)
+    const int tiles_x = ceil_div(nx, GG_TX), bands = ceil_div(ny, GG_TY);
+    p.runs = tile_runs(tiles_x, bands, n_frames, tile_run_length(tiles_x, bands, n_frames, ctx->num_cu));
+#define GG_LAUNCH(G, U, F) hipLaunchKernelGGL((gauss_grad_tile<3, G, U, F>), dim3(p.runs.total), dim3(256), 0, ctx->stream, p)
     if (ctx->fir_mode) {
         if (in_is_u8) { if (sobel) GG_LAUNCH(1, true, true); else GG_LAUNCH(0, true, true); }
         else { if (sobel) GG_LAUNCH(1, false, true); else GG_LAUNCH(0, false, true); }
