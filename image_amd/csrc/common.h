@@ -100,6 +100,13 @@ static inline int sub_batch_frames(int n_frames, size_t per_frame_bytes, size_t 
 }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// streaming (non-temporal) store: data the kernel itself will not read again
+#ifdef HIPEMU
+#define IMGFD_STREAM_STORE(value, ptr) (*(ptr) = (value))
+#else
+#define IMGFD_STREAM_STORE(value, ptr) __builtin_nontemporal_store((value), (ptr))
+#endif
+
 // ---- tile runs: the 2-D tile kernels over u8 frames (fast9_tile, gauss_grad_tile) walk `run` consecutive tiles of one
 // band of rows per workgroup instead of one tile.  A 64-pixel tile row with its halo straddles two 128-byte lines; with
 // one tile per workgroup the x-neighbour (another workgroup, dealt to another XCD with its own L2) fetched both lines

@@ -83,8 +83,7 @@ __device__ __forceinline__ int fir_swz4(int q) { return q + (q >> 4); }
 // PX = consecutive outputs per thread and pass (4 or 8), NT = threads per workgroup (CH * TW / PX)
 template <int R, int MODE, int TW, int CH, int FIR_PX = 8, int FIR_NT = 256>
 struct FirGeom {
-    static constexpr int NI = MODE == 2 ? 2 : 1;
-    static constexpr int NP = MODE == 2 ? 3 : 1;
+    static constexpr int NI = 1, NP = 1;  // input / output planes (the two-in three-out structure tensor lives in fir_tensor.hip)
     static constexpr int HALO = (R + 3) / 4 * 4;  // tile halo in whole float4 slots: x0-HALO is 16-byte aligned
     static constexpr int W = TW + 2 * HALO;
     static constexpr int W4 = W / 4;
@@ -99,7 +98,7 @@ struct FirGeom {
     static constexpr size_t LDS_BYTES = sizeof(float) * ((size_t)NI * CH * RPITCH + (size_t)NP * RING * TW);
 };
 
-// MODE 0: one f32 plane in -> one plane out;  MODE 1: one u8 plane in;  MODE 2: Ix,Iy in -> A,B,C out
+// MODE 0: one f32 plane in -> one plane out;  MODE 1: one u8 plane in
 template <int R, int MODE, int TW, int CH, bool FMA, int FIR_PX, int FIR_NT, bool VEC>
 #ifdef HIPEMU
 #define FIR_WAVES_PER_EU(n)
@@ -139,11 +138,8 @@ __global__ void __launch_bounds__(FIR_NT) FIR_WAVES_PER_EU(FIR_NT == 192 ? 3 : F
     const int ybase = y0 - R;
 
     const float *in0f = reinterpret_cast<const float *>(p.in0) + (size_t)frame * p.in_frame_stride;
-    const float *in1f = reinterpret_cast<const float *>(p.in1) + (size_t)frame * p.in_frame_stride;
     const unsigned char *in0b = reinterpret_cast<const unsigned char *>(p.in0) + (size_t)frame * p.in_frame_stride;
-    float *outp[3] = {p.out0 + (size_t)frame * p.out_frame_stride,
-                      NP == 3 ? p.out1 + (size_t)frame * p.out_frame_stride : nullptr,
-                      NP == 3 ? p.out2 + (size_t)frame * p.out_frame_stride : nullptr};
+    float *outp[1] = {p.out0 + (size_t)frame * p.out_frame_stride};
 
     // tile slot owned by this thread in load round l: row tr[l], float4 slot tq[l] (constant over chunks)
     int tr[NL4], tq[NL4];
@@ -159,10 +155,10 @@ __global__ void __launch_bounds__(FIR_NT) FIR_WAVES_PER_EU(FIR_NT == 192 ? 3 : F
     }
     const bool x_inside = x0 - HALO >= 0 && x0 - HALO + G::W <= p.nx;
 
-    fir_v4f pre0[NL4], pre1[NL4];
+    fir_v4f pre0[NL4];
 
     // ---- issue the global loads of one chunk into registers.  One straight-line sequence of loads: no
-    // control-flow merge may touch pre0/pre1 before commit(), or the loads stop being asynchronous.
+    // control-flow merge may touch pre0 before commit(), or the loads stop being asynchronous.
     auto prefetch = [&](int chunk) __attribute__((always_inline)) {
         const int yc = ybase + chunk * CH;
 #pragma unroll
@@ -172,19 +168,16 @@ __global__ void __launch_bounds__(FIR_NT) FIR_WAVES_PER_EU(FIR_NT == 192 ? 3 : F
                 if (VEC) {
                     const unsigned off = (unsigned)gy * (unsigned)p.in_pitch + xoff[l];
                     pre0[l] = *reinterpret_cast<const fir_v4f *>(in0f + off);
-                    if (MODE == 2) pre1[l] = *reinterpret_cast<const fir_v4f *>(in1f + off);
                 } else {
-                    float v0[4], v1[4];
+                    float v0[4];
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         const int gx = fir_reflect(x0 - HALO + 4 * tq[l] + e, p.nx);
                         const size_t off = (size_t)gy * p.in_pitch + gx;
                         if (MODE == 1) v0[e] = (float)in0b[off];
                         else v0[e] = in0f[off];
-                        v1[e] = MODE == 2 ? in1f[off] : 0.f;
                     }
                     pre0[l] = fir_v4f{v0[0], v0[1], v0[2], v0[3]};
-                    if (MODE == 2) pre1[l] = fir_v4f{v1[0], v1[1], v1[2], v1[3]};
                 }
             }
         }
@@ -194,7 +187,6 @@ __global__ void __launch_bounds__(FIR_NT) FIR_WAVES_PER_EU(FIR_NT == 192 ? 3 : F
         for (int l = 0; l < NL4; l++) {
             if (l < NL4 - 1 || tid + l * FIR_NT < CH * W4) {
                 reinterpret_cast<fir_v4f *>(raw4)[(0 * CH + tr[l]) * G::RP4 + fir_swz4(tq[l])] = pre0[l];
-                if (MODE == 2) reinterpret_cast<fir_v4f *>(raw4)[(1 * CH + tr[l]) * G::RP4 + fir_swz4(tq[l])] = pre1[l];
             }
         }
         if (VEC && !x_inside) {
@@ -232,17 +224,12 @@ __global__ void __launch_bounds__(FIR_NT) FIR_WAVES_PER_EU(FIR_NT == 192 ? 3 : F
         // ---- row pass: raw tile -> ring of row-filtered rows
         for (int item = tid; item < CH * STRIPS; item += FIR_NT) {
             const int r = item / STRIPS, s = item - r * STRIPS;
-            float wx[NW4 * 4], wy[NW4 * 4];
+            float wx[NW4 * 4];
             const float4 *rx = raw4 + (0 * CH + r) * G::RP4;
-            const float4 *ry = raw4 + (1 * CH + r) * G::RP4;
 #pragma unroll
             for (int q = 0; q < NW4; q++) {
                 const float4 v = rx[fir_swz4((FIR_PX / 4) * s + S0 + q)];
                 wx[4 * q] = v.x; wx[4 * q + 1] = v.y; wx[4 * q + 2] = v.z; wx[4 * q + 3] = v.w;
-                if (MODE == 2) {
-                    const float4 u = ry[fir_swz4((FIR_PX / 4) * s + S0 + q)];
-                    wy[4 * q] = u.x; wy[4 * q + 1] = u.y; wy[4 * q + 2] = u.z; wy[4 * q + 3] = u.w;
-                }
             }
             const int slot = (chunk * CH + r) & (RING - 1);
 #pragma unroll
@@ -250,12 +237,7 @@ __global__ void __launch_bounds__(FIR_NT) FIR_WAVES_PER_EU(FIR_NT == 192 ? 3 : F
                 double d[NW];
 #pragma unroll
                 for (int k = 0; k < NW; k++) {
-                    float v;
-                    if (MODE != 2) v = wx[OFF + k];
-                    else if (pl == 0) v = wx[OFF + k] * wx[OFF + k];  // harris.cpp:59
-                    else if (pl == 1) v = wx[OFF + k] * wy[OFF + k];  // harris.cpp:60
-                    else v = wy[OFF + k] * wy[OFF + k];               // harris.cpp:61
-                    d[k] = (double)v;
+                    d[k] = (double)wx[OFF + k];
                 }
                 float o[FIR_PX];
                 fir_window8<R, FMA, FIR_PX>(d, p.B, o);
@@ -446,12 +428,6 @@ static imgfd_status launch_generic(imgfd_ctx *ctx, const float *in, float *tmp, 
     return IMGFD_OK;
 }
 
-static bool fir_has_fast_path(int R, int mode)
-{
-    if (mode == 2) return R == 7 || R == 3 || R == 1;
-    return R == 3;
-}
-
 size_t gaussian_tmp_bytes(int nx, int ny, int n_frames, float sigma, int type, int planes)
 {
     (void)planes;
@@ -560,22 +536,9 @@ imgfd_status launch_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const fl
     const int R = size - 1;
     p.in0 = d_Ix; p.in1 = d_Iy; p.out0 = d_A; p.out1 = d_B; p.out2 = d_C; p.nx = nx; p.ny = ny;
     p.in_pitch = nx; p.in_frame_stride = (long)nx * ny; p.out_frame_stride = (long)nx * ny;
-    static const char *impl = getenv("IMGFD_TENSOR_IMPL");  // experiment switch: "old" = the round-1 kernel, "wide" = float4 row stores
-    if (tensor_fast_path(R) && !(impl && !strcmp(impl, "old"))) {
-        const imgfd_status st = launch_tensor_march(ctx, d_Ix, d_Iy, d_A, d_B, d_C, nx, ny, n_frames, R, p.B, 0.f,
-                                                    impl && !strcmp(impl, "wide") ? 1 : 0);
+    if (tensor_fast_path(R)) {  // radius 7, 3, 1: the marching structure-tensor kernel of fir_tensor.hip (any shape and alignment)
+        const imgfd_status st = launch_tensor_march(ctx, d_Ix, d_Iy, d_A, d_B, d_C, nx, ny, n_frames, R, p.B, 0.f, 0);
         if (st != IMGFD_ERR_UNSUPPORTED) return st;
-        if (impl && !strcmp(impl, "wide")) {
-            const imgfd_status st0 = launch_tensor_march(ctx, d_Ix, d_Iy, d_A, d_B, d_C, nx, ny, n_frames, R, p.B, 0.f, 0);
-            if (st0 != IMGFD_ERR_UNSUPPORTED) return st0;
-        }
-    }
-    if (fir_has_fast_path(R, 2)) {
-        switch (R) {
-            case 7: return launch_march<7, 2, 128, 16>(ctx, p, n_frames);
-            case 3: return launch_march<3, 2, 128, 16>(ctx, p, n_frames);
-            case 1: return launch_march<1, 2, 128, 16>(ctx, p, n_frames);
-        }
     }
     if (!d_tmp) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "generic structure tensor needs a scratch plane");
     IMGFD_TRY(products());

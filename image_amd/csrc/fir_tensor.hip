@@ -582,7 +582,8 @@ static imgfd_status launch_tensor_r(imgfd_ctx *ctx, TensorParams &p, int n_frame
     return go(fir_tensor<R, TW, false, true, OUT>);
 }
 
-// out_mode 0: A, B, C (direct stores), 1: A, B, C (float4 rows through LDS), 2: Harris response only (d_A receives R).
+// out_mode 0: A, B, C (direct stores), 2: Harris response only (d_A receives R).  (OUT 1 of the kernel -- A, B, C as float4
+// rows through LDS -- measured no faster than the direct stores and is not instantiated.)
 // Returns IMGFD_ERR_UNSUPPORTED when no specialised kernel serves the radius / alignment (the caller falls back).
 imgfd_status launch_tensor_march(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_A, float *d_B, float *d_C,
                                  int nx, int ny, int n_frames, int R, const double *B, float k, int out_mode)
@@ -597,6 +598,7 @@ imgfd_status launch_tensor_march(imgfd_ctx *ctx, const float *d_Ix, const float 
     // float4 tile loads / row stores need 16-byte aligned planes and whole quads per row (frames are nx*ny floats apart)
     const bool vec = nx % 4 == 0 && nx >= 4 && (size_t)d_Ix % 16 == 0 && (size_t)d_Iy % 16 == 0 && (size_t)d_A % 16 == 0 &&
                      (out_mode == 2 || ((size_t)d_B % 16 == 0 && (size_t)d_C % 16 == 0));
+    if (out_mode != 0 && out_mode != 2) return IMGFD_ERR_UNSUPPORTED;
     if (out_mode != 0 && !vec) return IMGFD_ERR_UNSUPPORTED;
     // 256-column strips (12 waves: every SIMD carries three) unless the image is narrow
     static const char *twe = getenv("IMGFD_TENSOR_TW");
@@ -605,11 +607,9 @@ imgfd_status launch_tensor_march(imgfd_ctx *ctx, const float *d_Ix, const float 
     case RR:                                                                                               \
         if (tw == 256) {                                                                                   \
             if (out_mode == 2) return launch_tensor_r<RR, 256, 2>(ctx, p, n_frames, vec);                  \
-            if (out_mode == 1) return launch_tensor_r<RR, 256, 1>(ctx, p, n_frames, vec);                  \
             return launch_tensor_r<RR, 256, 0>(ctx, p, n_frames, vec);                                     \
         }                                                                                                  \
         if (out_mode == 2) return launch_tensor_r<RR, 128, 2>(ctx, p, n_frames, vec);                      \
-        if (out_mode == 1) return launch_tensor_r<RR, 128, 1>(ctx, p, n_frames, vec);                      \
         return launch_tensor_r<RR, 128, 0>(ctx, p, n_frames, vec);
     switch (R) {
         FT_GO(7)

@@ -152,8 +152,10 @@ __global__ void __launch_bounds__(256) gauss_grad_tile(GaussGradParams p)
             gx = (float)(0.5 * (is[i][j + 1] - is[i][j - 1]));
             gy = (float)(0.5 * (is[i + 1][j] - is[i - 1][j]));
         }
-        Ix[(size_t)y * p.nx + x] = gx;
-        Iy[(size_t)y * p.nx + x] = gy;
+        // streaming stores: the 8 B/px written here would otherwise push the u8 lines a run of tiles shares out of the L2
+        // before the next tile of the run reads them again
+        IMGFD_STREAM_STORE(gx, &Ix[(size_t)y * p.nx + x]);
+        IMGFD_STREAM_STORE(gy, &Iy[(size_t)y * p.nx + x]);
     }
     }
     }

@@ -5,8 +5,7 @@ cd "$GRAFT_REPO_ROOT"; R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/k3"; mkdir -p "$O"
 export TMPDIR=/tmp
 ( timeout 900 python -m pytest tests/test_harris_stages.py -m gpu -x -q 2>&1 | tail -5 ) > "$O/pytest.txt" 2>&1
 {
-  echo "--- default (new kernel)";           timeout 300 python scripts/k3_variants.py
-  echo "--- old (round-1 kernel)";           IMGFD_TENSOR_IMPL=old BATCHES=32 timeout 300 python scripts/k3_variants.py
+  echo "--- default"; timeout 300 python scripts/k3_variants.py
   for v in ${VARIANTS:-}; do echo "--- $v"; env $v timeout 300 python scripts/k3_variants.py; done
 } > "$O/k3_variants.txt" 2>&1
 [ "${PMC:-1}" = "0" ] && exit 0

@@ -29,5 +29,5 @@ done
 cd "$R"
 bash scripts/gpu_pmc_k3.sh > /dev/null 2>&1
 cp gpurun_out/k3/k3_pmc.txt "$O/k3_pmc_summary.txt"; cp gpurun_out/k3/k3_traffic.json "$O/k3_traffic.json"
-{ BATCHES=1,8,32 python scripts/k3_variants.py; IMGFD_TENSOR_IMPL=old BATCHES=1,8,32 python scripts/k3_variants.py; } 2>/dev/null | grep kernel > "$O/k3_new_vs_round1_kernel.txt"
+BATCHES=1,8,32 python scripts/k3_variants.py 2>/dev/null | grep kernel > "$O/k3_doorway.txt"
 exit 0

@@ -7,7 +7,7 @@ cd /tmp
 for run in $RUNS; do
   E=""; [ "$run" != default ] && E="IMGFD_TILE_RUN=${run%f}"; [ "${run%f}" != "$run" ] && E="$E IMGFD_TILE_GRID=full"
   rm -rf /tmp/pu8
-  env $E timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/pu8/t -o p -- python $R/bench.py --no-cpu --steps 3 --warmup 1 --inner 1 --no-overlap > /dev/null 2>&1
+  env $E timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/pu8/t -o p -- python $R/bench.py --no-cpu --steps 8 --warmup 2 --inner 1 --no-overlap > /dev/null 2>&1
   env $E timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pu8/c -o p -- python $R/bench.py --no-cpu --steps 1 --warmup 1 --inner 1 --no-overlap > /dev/null 2>&1
   python - "$run" "$FILT" <<'PY'
 import csv, sys, glob, collections, re
@@ -24,6 +24,7 @@ for fn in glob.glob('/tmp/pu8/c/**/*counter_collection.csv', recursive=True):
 alg = 32 * 3840 * 2160
 for k in t:
     fs = f.get(k, [0]); fb = 2 * 1024 * sum(fs) / len(fs)
-    print(f"run {run:>7s}  {k:42s} n {len(t[k]):3d} avg_us {sum(t[k])/len(t[k]):8.1f}   FETCHx2 {fb/1e9:6.3f} GB = {fb/alg:5.2f} B/px")
+    v = sorted(t[k])
+    print(f"run {run:>7s}  {k:42s} n {len(v):3d} min_us {v[0]:8.1f} median_us {v[len(v)//2]:8.1f}   FETCHx2 {fb/1e9:6.3f} GB = {fb/alg:5.2f} B/px")
 PY
 done | tee -a "$O/u8_runs.txt"

@@ -1,6 +1,6 @@
 """Time the 20 B/px structure-tensor kernel on 4K frames for the batch sizes in BATCHES (default 1,8,32): HIP events
 around back-to-back launches (imgfd_time_structure_tensor_batch).  The variant under test is chosen by the
-environment (IMGFD_TENSOR_IMPL=old|wide, IMGFD_XCD_REMAP, IMGFD_TENSOR_SEG, IMGFD_TENSOR_PER_CU), read once per process.
+environment (IMGFD_XCD_REMAP, IMGFD_TENSOR_SEG, IMGFD_TENSOR_PER_CU), read once per process.
 Prints one JSON line per batch size."""
 import json
 import os
@@ -24,7 +24,7 @@ ix = torch.empty((bmax, NY, NX), dtype=torch.float32, device="cuda")
 iy = torch.empty_like(ix)
 for f in range(bmax):
     det.gradients_of(frames[f], ix[f], iy[f])
-tag = {k: os.environ[k] for k in ("VARIANT_LIB", "IMGFD_TENSOR_IMPL", "IMGFD_XCD_REMAP", "IMGFD_TENSOR_SEG", "IMGFD_TENSOR_PER_CU", "FIR_MODE") if k in os.environ}
+tag = {k: os.environ[k] for k in ("VARIANT_LIB", "IMGFD_XCD_REMAP", "IMGFD_TENSOR_SEG", "IMGFD_TENSOR_PER_CU", "FIR_MODE") if k in os.environ}
 for b in batches:
     us = det.time_structure_tensor_batch(ix[:b], iy[:b], warmup=int(os.environ.get("WARMUP", "3")), iters=int(os.environ.get("ITERS", "30")))
     gbs = 20 * NX * NY * b / (us * 1e-6) / 1e9
