@@ -337,18 +337,54 @@ __device__ __forceinline__ void canny_grad_nms_tile(double (*sb)[GN_TX + 2 * GN_
         }
     }
     __syncthreads();
-    // gradient magnitude: the thread's own 4 pixels (lane = column, rows wv, wv+4, ...) keep h, v in registers;
-    // the one-pixel ring around the tile is shared out over the first threads.  A ring position outside the image
-    // stands for the clamped pixel, whose own neighbourhood is clamped again: evaluate at clamped coordinates.
-    const int c = tid & 63, wv = tid >> 6;
-    CannyGrad own[GN_TY / 4];
-    double own_rcp[GN_TY / 4];
+    // gradient magnitude: a thread owns one column of NQ consecutive tile rows (lane = column, wave wv = rows NQ*wv ..) and
+    // keeps h, v and 1/|g| in registers; the one-pixel ring around the tile is shared out over the first threads.  A ring
+    // position outside the image stands for the clamped pixel, whose own neighbourhood is clamped again: evaluate at
+    // clamped coordinates.
+    constexpr int NQ = GN_TY / 4;
+    // the wave index as a scalar: row numbers, LDS row offsets and the mask-word addresses stay in SGPRs
+    const int c = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), R0 = NQ * wv;
+    CannyGrad own[NQ];
+    double own_rcp[NQ];
+    if (INSIDE) {
+        // consecutive rows share their row terms: d(y) = b(y,x+1) - b(y,x-1) and e(y) = b(y,x-1) + 2 b(y,x) + b(y,x+1) give
+        // h = 2 d(y) + d(y+1) + d(y-1), v = e(y+1) - e(y-1) (rcpp_canny.cpp:157-163).  The blurred values are floats a few
+        // binades apart, every partial sum is exact in f64: the regrouping has the bits of the reference's left-to-right sum.
+        const int xc = c + GN_XO;
+        double d[NQ + 2], e[NQ + 2];
+        if (accGrad) {  // workgroup-uniform: a branch, not selects
 #pragma unroll
-    for (int q = 0; q < GN_TY / 4; q++) {
-        const int r = wv + 4 * q;
-        own[q] = canny_gradient<INSIDE>(sb, INSIDE ? x0 + c : min(x0 + c, nx - 1), INSIDE ? y0 + r : min(y0 + r, ny - 1), x0, y0,
-                                        nx, ny, accGrad);
-        sg[r + 1][c + 1] = canny_mag_rcp(own[q], &own_rcp[q]);
+            for (int j = 0; j < NQ + 2; j++) {
+                const double a = sb[R0 + 1 + j][xc - 1], b = sb[R0 + 1 + j][xc], cc = sb[R0 + 1 + j][xc + 1];
+                d[j] = cc - a;
+                e[j] = (a + cc) + 2 * b;
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                own[q].h = 2 * d[q + 1] + d[q + 2] + d[q];  // :157-159
+                own[q].v = e[q + 2] - e[q];                 // :160-163
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NQ + 2; j++) {
+                d[j] = sb[R0 + 1 + j][xc + 1] - sb[R0 + 1 + j][xc - 1];
+                e[j] = sb[R0 + 1 + j][xc];
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                own[q].h = d[q + 1];         // :167
+                own[q].v = e[q + 2] - e[q];  // :168-169
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) sg[R0 + q + 1][c + 1] = canny_mag_rcp(own[q], &own_rcp[q]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int r = R0 + q;
+            own[q] = canny_gradient<false>(sb, min(x0 + c, nx - 1), min(y0 + r, ny - 1), x0, y0, nx, ny, accGrad);
+            sg[r + 1][c + 1] = canny_mag_rcp(own[q], &own_rcp[q]);
+        }
     }
     constexpr int RING = 2 * (GN_TX + 2) + 2 * GN_TY;
     if (tid < RING) {
@@ -362,15 +398,16 @@ __device__ __forceinline__ void canny_grad_nms_tile(double (*sb)[GN_TX + 2 * GN_
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < GN_TY / 4; q++) {  // one wave per tile row: the ballot is the mask word
-        const int r = wv + 4 * q;
+    for (int q = 0; q < NQ; q++) {  // one wave per tile row: the ballot is the mask word
+        const int r = R0 + q;
         const int gx = x0 + c, gy = y0 + r;
         int o = 0;
         if (INSIDE || (gx < nx && gy < ny)) {
             const double now = sg[r + 1][c + 1];
             // unit direction (cos t, sin t) with t = atan2(v,h) (:69-70,173); atan2(0,0) = 0 -> (1,0)
-            double ux = 1.0, uy = 0.0;
-            if (now > 0) { const double rn = own_rcp[q]; ux = own[q].h * rn; uy = own[q].v * rn; }
+            // (a zero gradient has own_rcp = 0: the direction comes out as (0,0) instead of (1,0), both taps then read the
+            // pixel itself and 0 <= 0 rejects it -- as atan2(0,0)'s direction does, since no magnitude is negative)
+            const double ux = own[q].h * own_rcp[q], uy = own[q].v * own_rcp[q];
             // bilin(), :65-85, at (c,r) -/+ (ux,uy): x1 = floor(xt) is -1 or 0 (for xt == 1 exactly the far tap has weight
             // 0, so x1 = 0 gives the same sum), hence the weights (x2 - xt, xt - x1) are (1 - |xt|, |xt|) for xt >= 0 and
             // (|xt|, 1 - |xt|) for xt < 0 -- the same two numbers for both taps: the pixel's own column/row always
