@@ -288,8 +288,10 @@ __device__ __forceinline__ double canny_mag(const CannyGrad &g) { return sqrt(__
 // to within an ulp: the same size of perturbation as dropping atan2/cos/sin already is (only exact ties can flip).
 __device__ __forceinline__ double canny_mag_rcp(const CannyGrad &g, double *rcp)
 {
-    const double s = __builtin_fma(g.h, g.h, g.v * g.v);
-    if (!(s > 0)) { *rcp = 0.0; return 0.0; }
+    // a zero gradient is given the magnitude 1e-150 (s raised to the smallest value that keeps every step below in the
+    // normal range) instead of branching around the iteration: it is below every threshold, adds nothing to a neighbour's
+    // interpolation (x + 1e-150 == x for every other magnitude a float image can produce) and h * rcp = v * rcp = 0
+    const double s = fmax(__builtin_fma(g.h, g.h, g.v * g.v), 1e-300);
 #ifdef HIPEMU
     const double y0 = 1.0 / sqrt(s);
 #else
@@ -397,6 +399,9 @@ __device__ __forceinline__ void canny_grad_nms_tile(double (*sb)[GN_TX + 2 * GN_
         sg[r][cc] = canny_mag_rcp(canny_gradient<INSIDE>(sb, gx, gy, x0, y0, nx, ny, accGrad), &unused);
     }
     __syncthreads();
+    // a zero gradient carries the magnitude 1e-150 (canny_mag_rcp): never a maximum, whatever the threshold -- like the
+    // reference's 0 <= prev.  (A nonzero gradient of a float image is above 1e-45.)
+    const double low = fmax((double)low_thr, 1e-100);
 #pragma unroll
     for (int q = 0; q < NQ; q++) {  // one wave per tile row: the ballot is the mask word
         const int r = R0 + q;
@@ -415,17 +420,23 @@ __device__ __forceinline__ void canny_grad_nms_tile(double (*sb)[GN_TX + 2 * GN_
             // is one of bilin()'s own (at most with its two terms swapped), so the value has bilin()'s bits for this
             // (ux, uy) -- with 19 instead of 26 double operations for the two taps.
             const double ax = fabs(ux), ay = fabs(uy), bx = 1.0 - ax, by = 1.0 - ay;
+            // the tap at +(ux,uy) looks towards sign(ux), sign(uy); the tap at -(ux,uy) the other way.  (For a zero
+            // component bilin() takes the +1 side in both taps; its weight is 0 there and every magnitude is finite,
+            // so reading the opposite neighbour instead adds the same +0.)
+            constexpr int SGP = GN_TX + 2 + 1;  // row pitch of sg
+            const double *ctr = &sg[r + 1][c + 1];
+            const int sx = ux < 0 ? -1 : 1, sy = uy < 0 ? -SGP : SGP;
+            const double own_term = bx * now;
             double val[2];
 #pragma unroll
             for (int d = 0; d < 2; d++) {
-                const double xt = d ? ux : -ux, yt = d ? uy : -uy;
-                const int cxn = c + 1 + (xt < 0 ? -1 : 1), cyn = r + 1 + (yt < 0 ? -1 : 1);
-                const double g_own = bx * sg[r + 1][c + 1] + ax * sg[r + 1][cxn];
-                const double g_nb = bx * sg[cyn][c + 1] + ax * sg[cyn][cxn];
+                const int ox = d ? sx : -sx, oy = d ? sy : -sy;
+                const double g_own = own_term + ax * ctr[ox];
+                const double g_nb = bx * ctr[oy] + ax * ctr[oy + ox];
                 val[d] = by * g_own + ay * g_nb;
             }
             const double prev = val[0], next = val[1];
-            if ((now <= prev) || (now <= next) || (now <= (double)low_thr)) o = 0;  // maxima(), :88-106
+            if ((now <= prev) || (now <= next) || (now <= low)) o = 0;  // maxima(), :88-106
             else if (now >= (double)high_thr) o = 2;
             else o = 1;
         }
