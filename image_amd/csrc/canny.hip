@@ -196,19 +196,29 @@ __global__ void __launch_bounds__(BM_NT) canny_blur_march(BlurMarchParams p)
             // independent chains of R+1 dependent operations (integer pair sum -> v_cvt_f64_u32 -> f64 fma): groups of
             // 4 advance together, tap by tap (one chain at a time was latency-bound: 15 cycles per dependent f64 op).
             double *dst = ring + ((chunk * BM_CH + r) & (RING - 1)) * BM_TW + BM_PX * s;
-            auto byte_at = [&](int k) __attribute__((always_inline)) -> unsigned { return (dw[k >> 2] >> (8 * (k & 3))) & 0xffu; };
+            // every byte of the window becomes a double once (v_cvt_f32_ubyteN + v_cvt_f64_f32, both exact); the pair sums
+            // byte[o-j] + byte[o+j] are then f64 adds of two integers <= 255 -- exact, the value an integer add followed by a
+            // conversion gives, for 16 instead of 24 instructions per output
+            double wd[NQ * 4];
+#pragma unroll
+            for (int k = 0; k < NQ * 4; k++) {
+                wd[k] = (double)(float)((dw[k >> 2] >> (8 * (k & 3))) & 0xffu);
+#ifndef HIPEMU
+                asm volatile("" : "+v"(wd[k]));  // or the compiler folds the f64 adds back into integer adds + one conversion per pair
+#endif
+            }
 #pragma unroll
             for (int o0 = 0; o0 < BM_PX; o0 += 4) {
                 double acc[4];
 #pragma unroll
-                for (int g = 0; g < 4; g++) acc[g] = p.wx[0] * (double)byte_at(HL + o0 + g);
+                for (int g = 0; g < 4; g++) acc[g] = p.wx[0] * wd[HL + o0 + g];
 #pragma unroll
                 for (int j = 1; j <= R; j++) {
-                    unsigned pair[4];
+                    double pair[4];
 #pragma unroll
-                    for (int g = 0; g < 4; g++) pair[g] = byte_at(HL + o0 + g - j) + byte_at(HL + o0 + g + j);
+                    for (int g = 0; g < 4; g++) pair[g] = wd[HL + o0 + g - j] + wd[HL + o0 + g + j];
 #pragma unroll
-                    for (int g = 0; g < 4; g++) acc[g] = __builtin_fma(p.wx[j], (double)pair[g], acc[g]);
+                    for (int g = 0; g < 4; g++) acc[g] = __builtin_fma(p.wx[j], pair[g], acc[g]);
                 }
 #pragma unroll
                 for (int g = 0; g < 4; g++) dst[o0 + g] = acc[g];

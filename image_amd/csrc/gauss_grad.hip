@@ -50,8 +50,9 @@ __global__ void __launch_bounds__(256) gauss_grad_tile(GaussGradParams p)
     constexpr int RP = U8 ? RW + 16 : RW + 4;  // row pitch in elements (u8: rows stay 16-byte aligned for ds_write_b128)
     using raw_t = typename std::conditional<U8, unsigned char, float>::type;
     __shared__ __attribute__((aligned(16))) raw_t raw[RH][RP];
-    __shared__ float rowf[RH][SW + 1];
-    __shared__ float is[SH][SW + 1];
+    constexpr int SWP = (SW + GG_PX - 1) / GG_PX * GG_PX, SHP = (SH + GG_PX - 1) / GG_PX * GG_PX;  // whole groups of GG_PX
+    __shared__ float rowf[SHP + 2 * R][SWP + 1];  // rows RH .. are padding: read by the last row group, never written
+    __shared__ float is[SHP][SWP + 1];
     const int tid = threadIdx.x;
     // TileRuns, common.h.  No barrier is needed between two tiles: each of the three LDS arrays is next written one
     // barrier after its last readers
@@ -115,9 +116,10 @@ __global__ void __launch_bounds__(256) gauss_grad_tile(GaussGradParams p)
         }
         float o[GG_PX];
         fir_window8<R, FMA, GG_PX>(d, p.B, o);
+        // the row is padded to whole groups (SWP): the last group writes its surplus outputs into the pad unconditionally
+        // (a test per output costs an exec-mask branch each)
 #pragma unroll
-        for (int k = 0; k < GG_PX; k++)
-            if (c0 + k < SW) rowf[r][c0 + k] = o[k];
+        for (int k = 0; k < GG_PX; k++) rowf[r][c0 + k] = o[k];
     }
     __syncthreads();
     // ---- column pass: is[r][c] for r < SH, c < SW; a thread takes GG_PX consecutive rows of one column
@@ -126,12 +128,11 @@ __global__ void __launch_bounds__(256) gauss_grad_tile(GaussGradParams p)
         const int g = i / SW, c = i - g * SW, r0 = g * GG_PX;
         double d[GG_PX + 2 * R];
 #pragma unroll
-        for (int k = 0; k < GG_PX + 2 * R; k++) d[k] = (double)rowf[min(r0 + k, RH - 1)][c];
+        for (int k = 0; k < GG_PX + 2 * R; k++) d[k] = (double)rowf[r0 + k][c];
         float o[GG_PX];
         fir_window8<R, FMA, GG_PX>(d, p.B, o);
 #pragma unroll
-        for (int k = 0; k < GG_PX; k++)
-            if (r0 + k < SH) is[r0 + k][c] = o[k];
+        for (int k = 0; k < GG_PX; k++) is[r0 + k][c] = o[k];  // rows SH .. SHP-1 are padding
     }
     __syncthreads();
     // ---- gradient: lane = column (coalesced 256-byte row segments)
