@@ -495,20 +495,23 @@ __device__ __forceinline__ unsigned long long dilate_h(unsigned long long s, uns
 __device__ __forceinline__ unsigned long long lane_above(unsigned long long v)
 {
 #ifdef HIPEMU
-    return __shfl_up(v, 1);
+    const unsigned long long r = __shfl_up(v, 1);
+    return (threadIdx.x & 63) == 0 ? 0ull : r;  // like the DPP form: no source lane -> 0
 #else
-    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(v >> 32), 0x138, 0xf, 0xf, false);
+    // bound_ctrl: a lane without a source reads 0 -- no "old" value has to be put into the destination first
+    const unsigned lo = __builtin_amdgcn_mov_dpp((unsigned)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+    const unsigned hi = __builtin_amdgcn_mov_dpp((unsigned)(v >> 32), 0x138, 0xf, 0xf, true);
     return ((unsigned long long)hi << 32) | lo;
 #endif
 }
 __device__ __forceinline__ unsigned long long lane_below(unsigned long long v)
 {
 #ifdef HIPEMU
-    return __shfl_down(v, 1);
+    const unsigned long long r = __shfl_down(v, 1);
+    return (threadIdx.x & 63) == 63 ? 0ull : r;
 #else
-    const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-    const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(v >> 32), 0x130, 0xf, 0xf, false);
+    const unsigned lo = __builtin_amdgcn_mov_dpp((unsigned)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+    const unsigned hi = __builtin_amdgcn_mov_dpp((unsigned)(v >> 32), 0x130, 0xf, 0xf, true);
     return ((unsigned long long)hi << 32) | lo;
 #endif
 }
@@ -587,6 +590,9 @@ __global__ void __launch_bounds__(256) canny_hyst_bits(unsigned long long *__res
             bot_d[q] = dilate_h(b[q + 1], b[q], b[q + 2]);
         }
     }
+    unsigned long long halo_d[HY_WORDS];  // the dilated halo row a border lane sees: row above for lane 0, row below for lane 63
+#pragma unroll
+    for (int q = 0; q < HY_WORDS; q++) halo_d[q] = (lane == 0 ? top_d[q] : 0ull) | (lane == 63 ? bot_d[q] : 0ull);
     bool any = false;
     for (;;) {
         bool ch = false;
@@ -595,10 +601,8 @@ __global__ void __launch_bounds__(256) canny_hyst_bits(unsigned long long *__res
         for (int q = 0; q < HY_WORDS; q++) d[q] = dilate_h(s[q + 1], s[q], s[q + 2]);
 #pragma unroll
         for (int q = 0; q < HY_WORDS; q++) {
-            unsigned long long up = lane_above(d[q]), dn = lane_below(d[q]);
-            if (lane == 0) up = top_d[q];
-            if (lane == 63) dn = bot_d[q];
-            const unsigned long long cand = w[q] & ~s[q + 1] & (d[q] | up | dn);
+            // lane_above / lane_below give 0 to lanes 0 / 63: their neighbours are the halo rows, OR-ed in (halo_d)
+            const unsigned long long cand = w[q] & ~s[q + 1] & (d[q] | lane_above(d[q]) | lane_below(d[q]) | halo_d[q]);
             if (cand) {
                 s[q + 1] |= flood_runs(w[q], cand);
                 ch = true;
