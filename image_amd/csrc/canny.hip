@@ -1012,6 +1012,11 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
     const size_t rflag_bytes = 2 * (size_t)nf * wpr * ceil_div(ny, 8);  // region flags, two parities (a region is at least 1 word x 8 rows)
     unsigned char *rflag = (unsigned char *)ws_alloc(ctx, rflag_bytes);
     if ((!fast && !tmp) || !blur || !S || !Wm || !flags || !act || !rflag) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    // where the caller's hook (imgfd_detect_dev: FAST-9 and the Harris chain on the other stream) is released: before the
+    // blur by default; env IMGFD_GATE=1 | 2 releases it after the blur | after the gradient/NMS kernel (experiments)
+    static const char *gate_env = getenv("IMGFD_GATE");
+    const int gate_at = gate_env ? atoi(gate_env) : 0;
+    if (after_front && gate_at == 0) IMGFD_TRY((*after_front)());
     if (fast) {
         BlurMarchParams p;
         memset(&p, 0, sizeof p);
@@ -1033,11 +1038,12 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
         hipLaunchKernelGGL(canny_blur_rows, g1, dim3(256), 0, ctx->stream, d_in, row_stride, frame_stride, tmp, nx, ny, tx);
         hipLaunchKernelGGL(canny_blur_cols, g1, dim3(256), 0, ctx->stream, tmp, blur, nx, ny, ty);
     }
+    if (after_front && gate_at == 1) IMGFD_TRY((*after_front)());
     dim3 g2(wpr, ceil_div(ny, GN_TY), nf);
     hipLaunchKernelGGL(canny_grad_nms, g2, dim3(256), 0, ctx->stream, blur, S, Wm, nx, ny, wpr, accGrad, (int)low_thr,
                        (int)high_thr, (int)(nx % 4 == 0 && (size_t)blur % 16 == 0));
     IMGFD_HIP(ctx, hipGetLastError());
-    if (after_front) IMGFD_TRY((*after_front)());
+    if (after_front && gate_at != 0 && gate_at != 1) IMGFD_TRY((*after_front)());
     // Hysteresis, terminated on the device -- no host read-back anywhere.  A fixed number of sweeps is queued (a sweep whose
     // predecessor changed nothing returns at once: an idle launch costs a few microseconds), then the finishing kernel,
     // which leaves at once when the last sweep was idle and otherwise completes the frames region by region.

@@ -1,15 +1,15 @@
 // image_amd/csrc/detect.hip -- Harris + FAST-9 + Canny on one device-resident batch, overlapped on two HIP streams.
 //
 // Host-side scheduling only; the kernels are those of imgfd_harris_dev / imgfd_fast9_dev / imgfd_canny_dev and every
-// result is what those calls return.  Why overlap: Canny's hysteresis (rcpp_canny.cpp:184-215) is a fixpoint iteration
-// whose later sweeps touch a handful of tiles -- a few waves on a 256-CU device -- and whose convergence the host has to
-// read back.  The batch's Canny front (blur, gradient + NMS: f64 issue-bound, they want the device to themselves) runs
-// on the context's companion stream; the context's own stream is gated on it and then receives FAST-9 and the Harris
-// chain, which fill the machine while the hysteresis rounds trickle along on the companion stream.  FAST-9 goes first:
-// it needs few wave slots and so suffers least from the heavy first two sweeps.
+// result is what those calls return.  Why overlap: every large kernel of the three chains is bound by VALU issue and
+// sustains 0.66-0.88 of it on its own (profiles/r02/*pmc_all_kernels.txt); Canny's hysteresis (rcpp_canny.cpp:184-215) is
+// a fixpoint iteration whose later sweeps touch a handful of tiles -- a few waves on a 256-CU device.  Two kernels side by
+// side fill each other's issue gaps.  Canny runs on the context's companion stream, FAST-9 and the Harris chain on the
+// context's own stream, both from the start of the batch (measured on 32 x 4K frames, scripts/gpu_gate.sh: 61.0 Gpixel/s;
+// releasing the second stream only after Canny's blur + gradient/NMS: 59.1; Harris before FAST-9: 57.3).
 //
-//      companion stream :  blur | grad+NMS | hysteresis sweeps ................... | expand, count |
-//      context stream   :                  | FAST-9 | gauss+grad | structure tensor | response+NMS | compaction |
+//      companion stream :  blur | grad+NMS | hysteresis sweeps ...... | expand, count |
+//      context stream   :  FAST-9 | gauss+grad | structure tensor + response | NMS | compaction |
 #include "common.h"
 
 extern "C" {
@@ -45,7 +45,7 @@ try {
     const std::function<imgfd_status()> gate = [&]() -> imgfd_status {
         IMGFD_HIP(ctx, hipEventRecord(ctx->ev_gate, side->stream));
         IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gate, 0));
-        IMGFD_TRY(fast9());  // light on wave slots: it takes the heavy first hysteresis sweeps as neighbours, not Gaussian+gradient
+        IMGFD_TRY(fast9());
         return harris();
     };
     const imgfd_status st = canny_dev_hooked(side, fr, p->s, p->low_thr, p->high_thr, p->accGrad, d_edges, d_counts + 2 * B, &gate);
