@@ -214,7 +214,7 @@ imgfd_status launch_harris_nms_tiled(imgfd_ctx *ctx, const float *d_R, int nx, i
 // fast9.hip
 imgfd_status launch_fast9(imgfd_ctx *ctx, const uint8_t *d_img, int w, int h, int stride,
                           size_t frame_stride, int n_frames, int threshold, int nonmax, const CompactBuffers &cb);
-// canny.hip: imgfd_canny_dev with a hook that runs on the host right after the blur and gradient/NMS kernels of the
-// (first chunk of the) batch have been queued, i.e. before the hysteresis rounds block the host
+// canny.hip: imgfd_canny_dev with a hook that runs on the host while the (first chunk of the) batch is being queued --
+// before the blur kernel by default (IMGFD_GATE, canny_device); imgfd_detect_dev queues the other detectors from it
 imgfd_status canny_dev_hooked(imgfd_ctx *ctx, const imgfd_frames *fr, double s, double low_thr, double high_thr, int accGrad,
                               uint8_t *d_edges, int64_t *d_counts, const std::function<imgfd_status()> *after_front);
