@@ -30,4 +30,7 @@ cd "$R"
 bash scripts/gpu_pmc_k3.sh > /dev/null 2>&1
 cp gpurun_out/k3/k3_pmc.txt "$O/k3_pmc_summary.txt"; cp gpurun_out/k3/k3_traffic.json "$O/k3_traffic.json"
 BATCHES=1,8,32 python scripts/k3_variants.py 2>/dev/null | grep kernel > "$O/k3_doorway.txt"
+bash scripts/gpu_pmc_all.sh "$O" > /dev/null 2>&1
+bash scripts/gpu_surf.sh > "$O/surf_kernels.txt" 2>&1
+bash scripts/gpu_hyst.sh > "$O/canny_launches.txt" 2>&1
 exit 0

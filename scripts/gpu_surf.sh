@@ -5,7 +5,7 @@ timeout 600 python -m pytest tests/test_surf.py -m gpu -x -q 2>&1 | tail -2
 timeout 900 python bench.py --config 4 --no-cpu --steps 3 --warmup 1 --batch 64 2>/dev/null | python -c "
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); print('2 lanes:', d['value'], 'fhog ms/tile', d['roofline']['fhog_ms_per_tile'], 'surf ms/tile', d['roofline']['surf']['ms_per_tile'], d['parity']['parity_sample'])"
-for env in "" "IMGFD_SURF_RESIDUE=16"; do
+for env in "" "IMGFD_SURF_RESIDUE=0"; do
 cd /tmp; rm -rf /tmp/prof4
 env IMGFD_SURF_LANES=1 $env timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof4 -o p -- python $R/bench.py --config 4 --batch 8 --no-cpu --steps 2 --warmup 1 > /dev/null 2>&1
 f=$(find /tmp/prof4 -name '*kernel_trace.csv' | head -1)
