@@ -79,22 +79,27 @@ __device__ __forceinline__ unsigned f9_pk_min(unsigned a, unsigned b)
     return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(f9_u16x2, a), __builtin_bit_cast(f9_u16x2, b)));
 }
 #endif
-// two pixels at a time (16-bit lanes): non-zero lane <=> at least two of the four compass values exceed the centre by
-// more than b, i.e. the second largest of max(n_i - p, 0) is > b
-__device__ __forceinline__ unsigned f9_two_above(unsigned p, unsigned n0, unsigned n1, unsigned n2, unsigned n3, unsigned bb)
+// bytes 1 and 3 of a dword in the low bytes of its two 16-bit lanes (v_perm_b32: one instruction for shift + mask)
+__device__ __forceinline__ unsigned f9_odd_bytes(unsigned v)
 {
-    const unsigned t0 = f9_pk_subs(n0, p), t1 = f9_pk_subs(n1, p), t2 = f9_pk_subs(n2, p), t3 = f9_pk_subs(n3, p);
-    const unsigned m1 = f9_pk_max(t0, t1), m2 = f9_pk_max(t2, t3), l1 = f9_pk_min(t0, t1), l2 = f9_pk_min(t2, t3);
-    const unsigned second = f9_pk_max(f9_pk_min(m1, m2), f9_pk_max(l1, l2));
-    return f9_pk_subs(second, bb);
+#ifdef HIPEMU
+    return (v >> 8) & 0x00ff00ffu;
+#else
+    return __builtin_amdgcn_perm(0u, v, 0x0c030c01u);
+#endif
 }
-// ... or at least two are below it by more than b
-__device__ __forceinline__ unsigned f9_two_below(unsigned p, unsigned n0, unsigned n1, unsigned n2, unsigned n3, unsigned bb)
+
+// Compass pre-test, two pixels at a time (16-bit lanes).  A contiguous arc of 9 of the 16 ring pixels leaves out 7
+// consecutive ones, which cannot hold two opposite ring pixels (8 apart): the arc contains the north or the south pixel,
+// and the east or the west pixel.  So a corner needs max(N,S) and max(E,W) above p + b, or min(N,S) and min(E,W) below
+// p - b (f9.cpp:2962-2963: cb = min(255, p + b), c_b = max(0, p - b); a ring pixel is never above 255 or below 0, so the
+// unsaturated sum and the saturating difference decide the same).  Non-zero lane <=> the pixel passes.  11 packed
+// instructions per pair of pixels (the "two of the four compass pixels" form of this test took 23 and let more through).
+__device__ __forceinline__ unsigned f9_compass(unsigned p, unsigned n, unsigned e, unsigned s, unsigned w, unsigned bb)
 {
-    const unsigned t0 = f9_pk_subs(p, n0), t1 = f9_pk_subs(p, n1), t2 = f9_pk_subs(p, n2), t3 = f9_pk_subs(p, n3);
-    const unsigned m1 = f9_pk_max(t0, t1), m2 = f9_pk_max(t2, t3), l1 = f9_pk_min(t0, t1), l2 = f9_pk_min(t2, t3);
-    const unsigned second = f9_pk_max(f9_pk_min(m1, m2), f9_pk_max(l1, l2));
-    return f9_pk_subs(second, bb);
+    const unsigned hi = f9_pk_min(f9_pk_max(n, s), f9_pk_max(e, w));
+    const unsigned lo = f9_pk_max(f9_pk_min(n, s), f9_pk_min(e, w));
+    return f9_pk_subs(hi, p + bb) | f9_pk_subs(f9_pk_subs(p, bb), lo);
 }
 
 #define F9_TX 64   // tile width = one __ballot word
@@ -106,10 +111,9 @@ __device__ __forceinline__ unsigned f9_two_below(unsigned p, unsigned n0, unsign
 // One workgroup per 64 x F9_TY tile.  The u8 tile (+4 halo) is staged in LDS once (HBM traffic = the algorithmic
 // 1 B/px + halo).  Three phases:
 //   1. compass pre-test on packed dwords: a thread takes 4 consecutive pixels (5 LDS dword reads instead of 20 byte
-//      reads) and evaluates them two at a time in the 16-bit lanes of packed instructions; any 9 contiguous ring
-//      pixels contain at least two of the four compass points, so a pixel with fewer than two brighter and fewer than
-//      two darker compass points cannot be a corner ("at least two above" = the second largest difference is above).  Survivors (a few percent of a
-//      natural frame) are appended to a candidate list in LDS.
+//      reads) and evaluates them two at a time in the 16-bit lanes of packed instructions (f9_compass: a 9-arc
+//      holds one pixel of each opposite compass pair).  Survivors (a few percent of a natural frame) are appended to a
+//      candidate list in LDS.
 //   2. the full ring test (+ score) runs over the candidate list with all lanes busy and writes the score tile
 //      (+1 halo for the 3x3 test) in LDS.
 //   3. the 3x3 non-max test reads the score tile, again for the candidates only; survivors set their bit in the
@@ -169,31 +173,33 @@ __global__ void __launch_bounds__(256) fast9_tile(const unsigned char *__restric
     for (int i = tid; i < F9_TY; i += 256) rowmask[i] = 0ull;
     if (tid == 0) ncand = 0u;
     __syncthreads();
-    // ---- phase 1: compass pre-test; score-tile row r <-> tile row r + 3, score column cx <-> tile column cx + 3
-    for (int i = tid; i < SR * NQ; i += 256) {
-        const int r = i / NQ, q = QL + i - r * NQ;
+    // ---- phase 1: compass pre-test; score-tile row r <-> tile row r + 3, score column cx <-> tile column cx + 3.
+    // A thread keeps its dword column q and walks down the rows, P1_ROWS at a time: what depends on the column alone
+    // (the mask of tested pixels) is worked out once per tile, and no item index has to be divided into row and column.
+    constexpr int P1_ROWS = 256 / NQ;
+    const int p1_row = tid / NQ, q = QL + tid - p1_row * NQ;
+    unsigned colmask;  // pixels of this dword inside the tested range: tile columns [lo, hi) and image columns [3, w - 3)
+    {
+        const int lo = max(NONMAX ? XL - 1 : XL, 3 - (x0 - XL)), hi = min(NONMAX ? XL + F9_TX + 1 : XL + F9_TX, w - 3 - (x0 - XL));
+        const int a = lo - 4 * q, e_end = hi - 4 * q;  // valid e in [a, e_end)
+        const unsigned vlo = a <= 0 ? 0xfu : (a >= 4 ? 0u : (0xfu << a) & 0xfu);
+        const unsigned vhi = e_end >= 4 ? 0xfu : (e_end <= 0 ? 0u : (1u << e_end) - 1u);
+        colmask = p1_row < P1_ROWS ? vlo & vhi : 0u;
+    }
+    // rows with a tested pixel: image rows [3, h - 3); without non-max suppression only the tile's own rows
+    const int r_first = max(NONMAX ? 0 : 1, 3 - (y0 - 1)), r_last = min(NONMAX ? SR - 1 : F9_TY, h - 4 - (y0 - 1));
+    for (int r = r_first + p1_row; r <= r_last && colmask; r += P1_ROWS) {
         const int ty = r + F9_HALO - 1;
-        const int gy = y0 + r - 1;
         const unsigned cur = tile32[ty][q], prev = tile32[ty][q - 1], next = tile32[ty][q + 1];
         const unsigned up = tile32[ty - 3][q], dn = tile32[ty + 3][q];
         const unsigned lf = (prev >> 8) | (cur << 24);  // byte e = pixel (4q + e) - 3
         const unsigned rt = (cur >> 24) | (next << 8);  // byte e = pixel (4q + e) + 3
-        unsigned pass = 0;
-        if (gy >= 3 && gy < h - 3 && (NONMAX || (r >= 1 && r <= F9_TY))) {
-            // pixels 0, 2 of the dword in the 16-bit lanes of the "even" words, pixels 1, 3 in the "odd" ones
-            const unsigned M = 0x00ff00ffu, bb = (unsigned)b * 0x00010001u;
-            const unsigned pe = cur & M, po = (cur >> 8) & M;
-            const unsigned fe = f9_two_above(pe, dn & M, rt & M, up & M, lf & M, bb) | f9_two_below(pe, dn & M, rt & M, up & M, lf & M, bb);
-            const unsigned fo = f9_two_above(po, (dn >> 8) & M, (rt >> 8) & M, (up >> 8) & M, (lf >> 8) & M, bb) |
-                                f9_two_below(po, (dn >> 8) & M, (rt >> 8) & M, (up >> 8) & M, (lf >> 8) & M, bb);
-            pass = ((fe & 0xffffu) ? 1u : 0u) | ((fo & 0xffffu) ? 2u : 0u) | ((fe >> 16) ? 4u : 0u) | ((fo >> 16) ? 8u : 0u);
-            // pixels of this dword inside the tested range: tile columns [lo, hi) and image columns [3, w - 3)
-            const int lo = max(NONMAX ? XL - 1 : XL, 3 - (x0 - XL)), hi = min(NONMAX ? XL + F9_TX + 1 : XL + F9_TX, w - 3 - (x0 - XL));
-            const int a = lo - 4 * q, e_end = hi - 4 * q;  // valid e in [a, e_end)
-            const unsigned vlo = a <= 0 ? 0xfu : (a >= 4 ? 0u : (0xfu << a) & 0xfu);
-            const unsigned vhi = e_end >= 4 ? 0xfu : (e_end <= 0 ? 0u : (1u << e_end) - 1u);
-            pass &= vlo & vhi;
-        }
+        // pixels 0, 2 of the dword in the 16-bit lanes of the "even" words, pixels 1, 3 in the "odd" ones
+        const unsigned M = 0x00ff00ffu, bb = (unsigned)b * 0x00010001u;
+        const unsigned pe = cur & M, po = f9_odd_bytes(cur);
+        const unsigned fe = f9_compass(pe, up & M, rt & M, dn & M, lf & M, bb);
+        const unsigned fo = f9_compass(po, f9_odd_bytes(up), f9_odd_bytes(rt), f9_odd_bytes(dn), f9_odd_bytes(lf), bb);
+        const unsigned pass = (((fe & 0xffffu) ? 1u : 0u) | ((fo & 0xffffu) ? 2u : 0u) | ((fe >> 16) ? 4u : 0u) | ((fo >> 16) ? 8u : 0u)) & colmask;
         // append the survivors (order inside the list is irrelevant: every candidate writes its own score cell); only
         // a few percent of the threads get here, so a returning LDS atomic is cheaper than a wave-wide prefix sum
         if (pass) {
