@@ -137,6 +137,8 @@ __global__ void __launch_bounds__(256) fast9_tile(const unsigned char *__restric
     unsigned char(*tile)[LW] = reinterpret_cast<unsigned char(*)[LW]>(tile32);
     unsigned char(*sc)[SCW] = reinterpret_cast<unsigned char(*)[SCW]>(sc32);
     const int tid = threadIdx.x;
+    // the score tile is cleared once; every tile puts back to 0 the cells its candidates wrote (far fewer than the tile)
+    for (int i = tid; i < SR * (SCW / 4); i += 256) (&sc32[0][0])[i] = 0u;
     {  // one run of tiles per workgroup (TileRuns, common.h)
     const unsigned run_id = blockIdx.x;
     const int frame = (int)(run_id / (unsigned)(runs.runs_per_band * runs.bands));
@@ -169,7 +171,6 @@ __global__ void __launch_bounds__(256) fast9_tile(const unsigned char *__restric
             tile32[r][q] = v;
         }
     }
-    for (int i = tid; i < SR * (SCW / 4); i += 256) (&sc32[0][0])[i] = 0u;
     for (int i = tid; i < F9_TY; i += 256) rowmask[i] = 0ull;
     if (tid == 0) ncand = 0u;
     __syncthreads();
@@ -199,10 +200,11 @@ __global__ void __launch_bounds__(256) fast9_tile(const unsigned char *__restric
         const unsigned pe = cur & M, po = f9_odd_bytes(cur);
         const unsigned fe = f9_compass(pe, up & M, rt & M, dn & M, lf & M, bb);
         const unsigned fo = f9_compass(po, f9_odd_bytes(up), f9_odd_bytes(rt), f9_odd_bytes(dn), f9_odd_bytes(lf), bb);
-        const unsigned pass = (((fe & 0xffffu) ? 1u : 0u) | ((fo & 0xffffu) ? 2u : 0u) | ((fe >> 16) ? 4u : 0u) | ((fo >> 16) ? 8u : 0u)) & colmask;
         // append the survivors (order inside the list is irrelevant: every candidate writes its own score cell); only
-        // a few percent of the threads get here, so a returning LDS atomic is cheaper than a wave-wide prefix sum
-        if (pass) {
+        // a few percent of the threads get here, so a returning LDS atomic is cheaper than a wave-wide prefix sum -- and
+        // the four lane tests are only made for a dword that has a survivor at all
+        if (fe | fo) {
+            const unsigned pass = (((fe & 0xffffu) ? 1u : 0u) | ((fo & 0xffffu) ? 2u : 0u) | ((fe >> 16) ? 4u : 0u) | ((fo >> 16) ? 8u : 0u)) & colmask;
             unsigned at = atomicAdd(&ncand, (unsigned)__popc(pass));
 #pragma unroll
             for (int e = 0; e < 4; e++)
@@ -252,7 +254,12 @@ __global__ void __launch_bounds__(256) fast9_tile(const unsigned char *__restric
         mask[((size_t)frame * h + gy) * words_per_row + tile_x] = word;
         if (word) atomicAdd(&rowcount[(size_t)frame * h + gy], (unsigned)__popcll(word));
     }
-    __syncthreads();  // the next tile's staging clears rowmask and the score tile
+    for (unsigned i = tid; i < nc; i += 256) {  // phase 3 is over (barrier above): the score cells go back to 0
+        const int pos = cand[i];
+        const int r = pos / LW;
+        sc[r][pos - r * LW - (XL - 1)] = 0;
+    }
+    __syncthreads();  // the next tile's staging clears rowmask; its phases write the candidate list and the score tile
     }
     }
 }
