@@ -87,6 +87,12 @@ __global__ void __launch_bounds__(256) canny_blur_cols(const double *__restrict_
 //            (crealf, tools.c:129) happens at the 256-byte coalesced store.
 // HBM traffic is the algorithmic 1 B read + 4 B written per pixel (+ halo, served by L2).
 #define BM_TW 64
+// Ring row = BM_TW doubles stored transposed by 8 (column c at (c % 8) * 8 + c / 8) and BM_RP apart.  The row pass hands
+// each thread 8 adjacent columns (strip s, output o -> position o * 8 + s): the 8 strips of a row write 8 consecutive
+// doubles per ds_write_b64 and, 72 = 8 mod 16, the two rows of a 16-lane group fall into the other half of the banks --
+// no conflicts (straight [row][column] storage put all 64 lanes of a write on two bank pairs).  The column pass gives
+// lane l the position l (consecutive doubles) and works out which column that is.
+#define BM_RP (BM_TW + 8)
 #define BM_CH 32
 #define BM_NT 256
 #define BM_PX 8
@@ -118,7 +124,7 @@ struct BlurGeom {
     static constexpr int NQ = (HL - R + BM_PX + 2 * R + 3) / 4;  // dwords of one thread's byte window
     static constexpr int RING = (BM_CH + 2 * R) <= 64 ? 64 : 128;
     static constexpr int NLD = (BM_CH * WD + BM_NT - 1) / BM_NT;
-    static constexpr size_t LDS_BYTES = sizeof(unsigned) * BM_CH * PITCH + sizeof(double) * RING * BM_TW;
+    static constexpr size_t LDS_BYTES = sizeof(unsigned) * BM_CH * PITCH + sizeof(double) * RING * BM_RP;
 };
 
 template <int R>
@@ -127,8 +133,8 @@ __global__ void __launch_bounds__(BM_NT) canny_blur_march(BlurMarchParams p)
     using G = BlurGeom<R>;
     constexpr int HL = G::HL, WD = G::WD, PITCH = G::PITCH, NQ = G::NQ, RING = G::RING, NLD = G::NLD;
     HIP_DYNAMIC_SHARED(double, smem_d)
-    double *ring = smem_d;                                               // [RING][BM_TW]
-    unsigned *raw = reinterpret_cast<unsigned *>(smem_d + RING * BM_TW);  // [BM_CH][PITCH]
+    double *ring = smem_d;                                               // [RING][BM_RP], columns transposed by 8
+    unsigned *raw = reinterpret_cast<unsigned *>(smem_d + RING * BM_RP);  // [BM_CH][PITCH]
 
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * BM_TW;
@@ -195,7 +201,7 @@ __global__ void __launch_bounds__(BM_NT) canny_blur_march(BlurMarchParams p)
             // byte k of the window = column x0 - HL + 8s + k; output o is centred on byte HL + o.  The 8 outputs are
             // independent chains of R+1 dependent operations (integer pair sum -> v_cvt_f64_u32 -> f64 fma): groups of
             // 4 advance together, tap by tap (one chain at a time was latency-bound: 15 cycles per dependent f64 op).
-            double *dst = ring + ((chunk * BM_CH + r) & (RING - 1)) * BM_TW + BM_PX * s;
+            double *dst = ring + ((chunk * BM_CH + r) & (RING - 1)) * BM_RP + s;  // output o of the strip at dst[8 * o]
             // every byte of the window becomes a double once (v_cvt_f32_ubyteN + v_cvt_f64_f32, both exact); the pair sums
             // byte[o-j] + byte[o+j] are then f64 adds of two integers <= 255 -- exact, the value an integer add followed by a
             // conversion gives, for 16 instead of 24 instructions per output
@@ -221,14 +227,15 @@ __global__ void __launch_bounds__(BM_NT) canny_blur_march(BlurMarchParams p)
                     for (int g = 0; g < 4; g++) acc[g] = __builtin_fma(p.wx[j], pair[g], acc[g]);
                 }
 #pragma unroll
-                for (int g = 0; g < 4; g++) dst[o0 + g] = acc[g];
+                for (int g = 0; g < 4; g++) dst[8 * (o0 + g)] = acc[g];
             }
         }
         __syncthreads();
 
         // ---- column pass: thread = (8-row group g, column col)
         {
-            const int g = __builtin_amdgcn_readfirstlane(tid >> 6), col = tid & 63;  // the wave index: ring rows in SGPRs
+            const int g = __builtin_amdgcn_readfirstlane(tid >> 6), pos = tid & 63;  // the wave index: ring rows in SGPRs
+            const int col = (pos & 7) * 8 + (pos >> 3);  // the column stored at ring position `pos`
             const int oi0 = chunk * BM_CH - 2 * R + BM_PX * g;  // first output row of the group, relative to y0
             if (oi0 + BM_PX > 0 && oi0 < nrows) {
                 double acc[BM_PX];
@@ -236,7 +243,7 @@ __global__ void __launch_bounds__(BM_NT) canny_blur_march(BlurMarchParams p)
                 for (int o = 0; o < BM_PX; o++) acc[o] = 0.0;
 #pragma unroll
                 for (int k = 0; k < BM_PX + 2 * R; k++) {
-                    const double v = ring[((oi0 + k) & (RING - 1)) * BM_TW + col];
+                    const double v = ring[((oi0 + k) & (RING - 1)) * BM_RP + pos];
 #pragma unroll
                     for (int o = 0; o < BM_PX; o++) {
                         const int j = k - R - o;
