@@ -163,11 +163,12 @@ imgfd_status launch_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const fl
 // when no specialised instance serves the radius / alignment: the caller falls back.
 bool tensor_fast_path(int R);
 imgfd_status launch_tensor_march(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_A, float *d_B, float *d_C,
-                                 int nx, int ny, int n_frames, int R, const double *B, float k, int out_mode);
+                                 int nx, int ny, int n_frames, int R, const double *B, float k, int out_mode,
+                                 unsigned char *d_tq = nullptr, float Th = 0.f);
 // structure tensor + Harris response in one kernel (R plane only); false when that path does not apply
 bool tensor_response_supported(int nx, int ny, float sigma, int gauss, int measure, const float *d_Ix, const float *d_Iy, const float *d_R);
 imgfd_status launch_tensor_response(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_R, int nx, int ny,
-                                    int n_frames, float sigma, float k);
+                                    int n_frames, float sigma, float k, unsigned char *d_tq = nullptr, float Th = 0.f);
 // scratch (bytes) launch_gaussian / launch_structure_tensor need in d_tmp for `n_frames` frames
 size_t gaussian_tmp_bytes(int nx, int ny, int n_frames, float sigma, int type, int planes);
 // sii.hip
@@ -208,7 +209,10 @@ imgfd_status launch_harris_resp_nms(imgfd_ctx *ctx, const float *d_A, const floa
                                     int n_frames, int measure, float k, float Th, int radius, const CompactBuffers &cb);
 imgfd_status launch_harris_nms(imgfd_ctx *ctx, const float *d_R, int nx, int ny, int n_frames, float Th,
                                int radius, const CompactBuffers &cb);
-// the tiled NMS of launch_harris_resp_nms on a materialised R plane (the batch path after launch_tensor_response)
+// NMS from the R plane and the threshold quads launch_tensor_response left in d_tq (the batch path; nx % 4 == 0)
+imgfd_status launch_harris_nms_sparse(imgfd_ctx *ctx, const float *d_R, const unsigned char *d_tq, int nx, int ny, int n_frames,
+                                      float Th, int radius, const CompactBuffers &cb);
+// the tiled NMS of launch_harris_resp_nms on a materialised R plane (stage doorway; radius up to the LDS halo)
 imgfd_status launch_harris_nms_tiled(imgfd_ctx *ctx, const float *d_R, int nx, int ny, int n_frames, float Th, int radius,
                                      const CompactBuffers &cb);
 // fast9.hip

@@ -496,13 +496,15 @@ bool tensor_response_supported(int nx, int ny, float sigma, int gauss, int measu
     return nx % 4 == 0 && nx >= 4 && (size_t)d_Ix % 16 == 0 && (size_t)d_Iy % 16 == 0 && (size_t)d_R % 16 == 0;
 }
 
+// d_tq (optional, nx * ny * n_frames / 4 bytes): the kernel also publishes "R is not below Th", a byte per quad of pixels --
+// the input of launch_harris_nms_sparse
 imgfd_status launch_tensor_response(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_R, int nx, int ny,
-                                    int n_frames, float sigma, float k)
+                                    int n_frames, float sigma, float k, unsigned char *d_tq, float Th)
 {
     double B[IMGFD_MAX_TAPS];
     const int size = fir_coeffs(sigma, 3, B);
     if (size < 0) return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "gaussian sigma too large (more than 64 taps)");
-    const imgfd_status st = launch_tensor_march(ctx, d_Ix, d_Iy, d_R, nullptr, nullptr, nx, ny, n_frames, size - 1, B, k, 2);
+    const imgfd_status st = launch_tensor_march(ctx, d_Ix, d_Iy, d_R, nullptr, nullptr, nx, ny, n_frames, size - 1, B, k, 2, d_tq, Th);
     if (st == IMGFD_ERR_UNSUPPORTED) return imgfd_fail(ctx, st, "fused structure tensor + response: unsupported shape");
     return st;
 }

@@ -75,6 +75,12 @@ struct TensorParams {
     int step_strip, step_seg, step_frame;  // the number of workers as (strips, segments, frames) digits: a worker's next tile
     int xcd_remap;
     float k;            // Harris constant (OUT = 2)
+    // OUT = 2, optional: one byte per quad of pixels, bit e = "the response of pixel x + e is not below the threshold
+    // (harris.cpp:160-162: skip = R < Th) nor beaten by a neighbour inside the quad", quad (frame, y, x / 4) at tq[(frame * ny + y) * (nx / 4) + x / 4]: what the
+    // sparse NMS kernel starts from.  (A byte per lane: no cross-lane traffic in the output phase, which every wave of the
+    // workgroup waits for.  Assembling 64-bit mask words here -- four ballots and a bit spread per row -- cost 14 %.)
+    unsigned char *tq;
+    float Th;
     double B[8];        // taps B[0..R], R <= 7
 };
 
@@ -381,8 +387,17 @@ __global__ void __launch_bounds__(3 * TW) FT_WAVES_PER_EU(TW) fir_tensor(TensorP
                 const float4 a = ob4[(0 * CH + r) * RP4 + sl], b = ob4[(1 * CH + r) * RP4 + sl], c = ob4[(2 * CH + r) * RP4 + sl];
                 const ft_v4f v = {harris_response_value<0>(a.x, b.x, c.x, p.k), harris_response_value<0>(a.y, b.y, c.y, p.k),
                                   harris_response_value<0>(a.z, b.z, c.z, p.k), harris_response_value<0>(a.w, b.w, c.w, p.k)};
-                float *dst = p.out0 + (size_t)t.frame * p.frame_stride + (unsigned)(ty0 + oi) * (unsigned)p.nx + (unsigned)x;
-                *reinterpret_cast<ft_v4f *>(dst) = v;
+                const size_t px = (size_t)t.frame * p.frame_stride + (unsigned)(ty0 + oi) * (unsigned)p.nx + (unsigned)x;
+                *reinterpret_cast<ft_v4f *>(p.out0 + px) = v;
+                if (p.tq) {  // kernel-uniform
+                    // ... and is not beaten by a horizontal neighbour inside the quad: the two comparisons of the window rule's
+                    // 3x3 pre-test (nms.hip) that can be made here -- a blob above the threshold shrinks to its ridge
+                    const bool t0 = !(v[0] < p.Th) && !(v[1] >= v[0]);
+                    const bool t1 = !(v[1] < p.Th) && !(v[2] >= v[1]) && !(v[0] > v[1]);
+                    const bool t2 = !(v[2] < p.Th) && !(v[3] >= v[2]) && !(v[1] > v[2]);
+                    const bool t3 = !(v[3] < p.Th) && !(v[2] > v[3]);
+                    p.tq[px >> 2] = (unsigned char)((t0 ? 1u : 0u) | (t1 ? 2u : 0u) | (t2 ? 4u : 0u) | (t3 ? 8u : 0u));
+                }
             }
         } else {
             for (int i = tid; i < 3 * CH * ROW4; i += NT) {
@@ -586,7 +601,8 @@ static imgfd_status launch_tensor_r(imgfd_ctx *ctx, TensorParams &p, int n_frame
 // rows through LDS -- measured no faster than the direct stores and is not instantiated.)
 // Returns IMGFD_ERR_UNSUPPORTED when no specialised kernel serves the radius / alignment (the caller falls back).
 imgfd_status launch_tensor_march(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_A, float *d_B, float *d_C,
-                                 int nx, int ny, int n_frames, int R, const double *B, float k, int out_mode)
+                                 int nx, int ny, int n_frames, int R, const double *B, float k, int out_mode,
+                                 unsigned char *d_tq, float Th)
 {
     if (!tensor_fast_path(R)) return IMGFD_ERR_UNSUPPORTED;
     TensorParams p;
@@ -594,6 +610,7 @@ imgfd_status launch_tensor_march(imgfd_ctx *ctx, const float *d_Ix, const float 
     p.ix = d_Ix; p.iy = d_Iy; p.out0 = d_A; p.out1 = d_B; p.out2 = d_C; p.nx = nx; p.ny = ny;
     p.frame_stride = (long)nx * ny;
     p.k = k;
+    p.tq = out_mode == 2 ? d_tq : nullptr; p.Th = Th;
     memcpy(p.B, B, sizeof(double) * (R + 1));
     // float4 tile loads / row stores need 16-byte aligned planes and whole quads per row (frames are nx*ny floats apart)
     const bool vec = nx % 4 == 0 && nx >= 4 && (size_t)d_Ix % 16 == 0 && (size_t)d_Iy % 16 == 0 && (size_t)d_A % 16 == 0 &&

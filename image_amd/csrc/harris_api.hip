@@ -228,9 +228,13 @@ imgfd_status harris_device_stages(imgfd_ctx *ctx, const void *d_in, int in_is_u8
         // the default path: the structure tensor never leaves the CU -- its kernel's epilogue evaluates the corner
         // response (harris.cpp:78-133) and only R is stored; NMS then reads 4 B/px instead of 12
         IMGFD_TRY(prof_mark(ctx));
-        IMGFD_TRY(launch_tensor_response(ctx, hp.Ix, hp.Iy, hp.R, nx, ny, n_frames, a.sigma_i, a.k));
+        static const char *nms_env = getenv("IMGFD_NMS");  // experiment switch: "tiled" = the round-2a kernel that streams R through LDS
+        const bool sparse = !(nms_env && nms_env[0] == 't');
+        unsigned char *tq = reinterpret_cast<unsigned char *>(hp.A);  // the A plane is idle on this path: it holds the threshold quads
+        IMGFD_TRY(launch_tensor_response(ctx, hp.Ix, hp.Iy, hp.R, nx, ny, n_frames, a.sigma_i, a.k, sparse ? tq : nullptr, a.Th));
         IMGFD_TRY(prof_mark(ctx));
-        IMGFD_TRY(launch_harris_nms_tiled(ctx, hp.R, nx, ny, n_frames, a.Th, radius, hp.cb));
+        if (sparse) IMGFD_TRY(launch_harris_nms_sparse(ctx, hp.R, tq, nx, ny, n_frames, a.Th, radius, hp.cb));
+        else IMGFD_TRY(launch_harris_nms_tiled(ctx, hp.R, nx, ny, n_frames, a.Th, radius, hp.cb));
         IMGFD_TRY(compact_emit(ctx, hp.cb, nx, ny, n_frames, 0, hp.R, d_corners, cap, d_counts));
         return IMGFD_OK;
     }

@@ -267,6 +267,167 @@ imgfd_status launch_harris_resp_nms(imgfd_ctx *ctx, const float *d_A, const floa
     return IMGFD_OK;
 }
 
+// ---- NMS from threshold bits.  fir_tensor's response epilogue leaves, next to R, one bit per pixel "R is not below Th"
+// (harris.cpp:160-162; a byte per quad of pixels, tq; the quad's own horizontal comparisons already applied): only those pixels -- corners and their
+// surroundings, a fraction of a percent of a frame -- are ever candidates, and a neighbour below the threshold never beats
+// one, so nothing of R is read but the 3x3 and (2r+1)^2 neighbourhoods of the candidates.  (The tiled kernel above streams
+// the whole plane through LDS: 4 B/px and 25 VALU instructions per pixel to find them.)
+//   a workgroup takes SN_WORDS consecutive mask words, a thread each (16 quad bytes -> 64 bits): bits outside the search
+//   domain are dropped, the rest
+//   become a dense list in LDS (popcount, block scan);
+//   (2) the window rule's 3x3 pre-test, a thread per listed pixel; survivors move to the front of the list;
+//   (3) the full window, a wave per survivor, window positions over the lanes; the scan line's start-of-row rule;
+//   (4) the surviving bits go to `mask`, their popcounts to `rowcount`.
+// The comparisons are those of harris_resp_nms_kernel, term by term.
+#define SN_WORDS 256
+template <int HC>
+__global__ void __launch_bounds__(SN_WORDS) harris_nms_sparse(const float *__restrict__ Rp, const unsigned char *__restrict__ tq,
+                                                            int nx, int ny, float Th, int radius_rt,
+                                                            unsigned long long *__restrict__ mask, unsigned *__restrict__ rowcount,
+                                                            int wpr, size_t nwords)
+{
+    __shared__ unsigned short list[SN_WORDS * 64];  // (thread << 6) | bit
+    __shared__ unsigned long long res[SN_WORDS];
+    __shared__ unsigned wave_sum[SN_WORDS / 64], nsurv;
+    const int radius = HC > 0 ? HC : radius_rt;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t w0 = (size_t)blockIdx.x * SN_WORDS, w = w0 + tid;
+    // word w = (row, wx): row = frame * ny + y
+    const size_t row = w / (size_t)wpr;
+    const int wx = (int)(w - row * (size_t)wpr), y = (int)(row % (size_t)ny);
+    unsigned long long word = 0ull;
+    {   // the search domain keeps `radius` away from the border (harris.cpp:170-176)
+        const int lo = radius - 64 * wx, hi = nx - radius - 64 * wx;  // valid bits: [lo, hi)
+        if (w < nwords && !(y < radius || y >= ny - radius || hi <= 0 || lo >= 64)) {
+            // the 16 quad bytes of the word (fewer at the end of a row), low nibbles packed into 64 bits
+            const int qpr = nx >> 2, q0 = 16 * wx;
+            const unsigned char *src = tq + row * (size_t)qpr + q0;
+            unsigned d[4] = {0u, 0u, 0u, 0u};
+            if (q0 + 16 <= qpr && ((size_t)src & 3) == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) d[k] = reinterpret_cast<const unsigned *>(src)[k];
+            } else {
+                for (int k = 0; k < 16 && q0 + k < qpr; k++) d[k >> 2] |= (unsigned)src[k] << (8 * (k & 3));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                unsigned z = d[k] & 0x0f0f0f0fu;
+                z = (z | (z >> 4)) & 0x00ff00ffu;
+                z = (z | (z >> 8)) & 0x0000ffffu;
+                word |= (unsigned long long)z << (16 * k);
+            }
+            if (lo > 0) word &= ~0ull << lo;
+            if (hi < 64) word &= ~(~0ull << hi);
+        }
+    }
+    res[tid] = 0ull;
+    if (tid == 0) nsurv = 0u;
+    const unsigned cnt = (unsigned)__popcll(word);
+    unsigned incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wave_sum[wv] = incl;
+    __syncthreads();
+    unsigned pos = incl - cnt, total = 0;
+#pragma unroll
+    for (int k = 0; k < SN_WORDS / 64; k++) {
+        if (k < wv) pos += wave_sum[k];
+        total += wave_sum[k];
+    }
+    while (word) {
+        const int bit = __ffsll((long long)word) - 1;
+        word &= word - 1;
+        list[pos++] = (unsigned short)(tid << 6 | bit);
+    }
+    __syncthreads();
+    // pixel of a list entry: plane pointer of its frame, coordinates
+    auto locate = [&](unsigned e, const float *&Rf, int &x, int &yy) __attribute__((always_inline)) {
+        const size_t we = w0 + (e >> 6), rw = we / (size_t)wpr;
+        const size_t frame = rw / (size_t)ny;
+        yy = (int)(rw - frame * (size_t)ny);
+        x = (int)(we - rw * (size_t)wpr) * 64 + (int)(e & 63u);
+        Rf = Rp + frame * (size_t)nx * ny;
+    };
+    // ---- (2) threshold (already in the bits) + 3x3 pre-test with the window rule's own comparisons
+    for (unsigned k0 = 0; k0 < total; k0 += SN_WORDS) {  // uniform trip count: barriers inside
+        const unsigned k = k0 + tid;
+        unsigned e = 0;
+        bool ok = false;
+        if (k < total) {
+            e = list[k];
+            const float *Rf; int x, yy;
+            locate(e, Rf, x, yy);
+            const float *c = Rf + (size_t)yy * nx + x;
+            const float v = c[0];
+            ok = !(c[-nx - 1] >= v) && !(c[-nx] >= v) && !(c[-nx + 1] >= v) && !(c[1] >= v) && !(c[-1] > v) &&
+                 !(c[nx - 1] > v) && !(c[nx] > v) && !(c[nx + 1] > v);
+        }
+        __syncthreads();  // every entry of this trip has been read: survivors may overwrite the front of the list
+        if (ok) list[atomicAdd(&nsurv, 1u)] = (unsigned short)e;
+        __syncthreads();
+    }
+    // ---- (3) full window, one survivor per wave at a time, window positions spread over the lanes
+    const int n = (int)nsurv;
+    const int side = 2 * radius + 1, npos = side * side;
+    for (int ci = wv; ci < n; ci += SN_WORDS / 64) {
+        const unsigned e = list[ci];
+        const float *Rf; int x, yy;
+        locate(e, Rf, x, yy);
+        const float *c = Rf + (size_t)yy * nx + x;
+        const float v = c[0];
+        bool fail = false;
+        for (int pidx = lane; pidx < npos; pidx += 64) {
+            const int dy = pidx / side - radius, dx = pidx % side - radius;
+            if (dy == 0 && dx == 0) continue;
+            const float q = c[(long)dy * nx + dx];
+            const bool strict = dy < 0 || (dy == 0 && dx > 0);  // above, or to the right on the same row: must be <
+            fail = fail || (strict ? (q >= v) : (q > v));
+        }
+        if (!__any(fail) && lane == 0) {
+            // start-of-row rule of the scan line (harris_row_start_blocks): only for an exact tie with the left neighbour
+            bool blocked = false;
+            if (c[-1] == v) {
+                blocked = true;
+                const float *rowp = Rf + (size_t)yy * nx;
+                for (int j = x; j >= radius && blocked; j--) {
+                    const float rj = rowp[j], rl = rowp[j - 1];
+                    if (!(rj < Th) && !(rl >= rj)) blocked = false;
+                }
+            }
+            if (!blocked) atomicOr(&res[e >> 6], 1ull << (e & 63u));
+        }
+    }
+    __syncthreads();
+    // ---- (4)
+    if (w < nwords) {
+        const unsigned long long out = res[tid];
+        mask[w] = out;
+        if (out) atomicAdd(&rowcount[row], (unsigned)__popcll(out));
+    }
+}
+
+// NMS on the R plane and the threshold quads of fir_tensor's response epilogue (launch_tensor_response); nx % 4 == 0
+imgfd_status launch_harris_nms_sparse(imgfd_ctx *ctx, const float *d_R, const unsigned char *d_tq, int nx, int ny, int n_frames,
+                                      float Th, int radius, const CompactBuffers &cb)
+{
+    const size_t nwords = (size_t)cb.words_per_row * ny * n_frames;
+    if (ny <= 2 * radius + 1 || nx <= 2 * radius + 1) {  // harris.cpp:151-152: nothing is detected on images not larger than the window
+        IMGFD_HIP(ctx, hipMemsetAsync(cb.mask, 0, sizeof(unsigned long long) * nwords, ctx->stream));
+        return IMGFD_OK;
+    }
+    if (radius < 1) radius = 1;
+    const dim3 grid((unsigned)((nwords + SN_WORDS - 1) / SN_WORDS));
+    if (radius == 5)
+        hipLaunchKernelGGL(harris_nms_sparse<5>, grid, dim3(SN_WORDS), 0, ctx->stream, d_R, d_tq, nx, ny, Th, radius, cb.mask, cb.rowcount, cb.words_per_row, nwords);
+    else
+        hipLaunchKernelGGL(harris_nms_sparse<0>, grid, dim3(SN_WORDS), 0, ctx->stream, d_R, d_tq, nx, ny, Th, radius, cb.mask, cb.rowcount, cb.words_per_row, nwords);
+    IMGFD_HIP(ctx, hipGetLastError());
+    return IMGFD_OK;
+}
+
 imgfd_status launch_harris_nms_tiled(imgfd_ctx *ctx, const float *d_R, int nx, int ny, int n_frames, float Th, int radius,
                                      const CompactBuffers &cb)
 {
