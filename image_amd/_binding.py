@@ -104,6 +104,8 @@ SIGNATURES = {
                                    C.c_int, C.c_float]),
     "imgfd_k_nms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int64,
                               C.c_void_p]),
+    "imgfd_k_nms_quads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int64,
+                                    C.c_void_p]),
     "imgfd_time_structure_tensor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
                                               C.POINTER(C.c_double)]),

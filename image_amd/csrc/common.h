@@ -209,6 +209,8 @@ imgfd_status launch_harris_resp_nms(imgfd_ctx *ctx, const float *d_A, const floa
                                     int n_frames, int measure, float k, float Th, int radius, const CompactBuffers &cb);
 imgfd_status launch_harris_nms(imgfd_ctx *ctx, const float *d_R, int nx, int ny, int n_frames, float Th,
                                int radius, const CompactBuffers &cb);
+// the threshold quads of an R plane that is already in memory (stage doorway; nx % 4 == 0, d_tq: nx / 4 * ny * n_frames bytes)
+imgfd_status launch_harris_threshold_quads(imgfd_ctx *ctx, const float *d_R, unsigned char *d_tq, int nx, int ny, int n_frames, float Th);
 // NMS from the R plane and the threshold quads launch_tensor_response left in d_tq (the batch path; nx % 4 == 0)
 imgfd_status launch_harris_nms_sparse(imgfd_ctx *ctx, const float *d_R, const unsigned char *d_tq, int nx, int ny, int n_frames,
                                       float Th, int radius, const CompactBuffers &cb);

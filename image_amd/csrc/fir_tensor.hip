@@ -389,15 +389,7 @@ __global__ void __launch_bounds__(3 * TW) FT_WAVES_PER_EU(TW) fir_tensor(TensorP
                                   harris_response_value<0>(a.z, b.z, c.z, p.k), harris_response_value<0>(a.w, b.w, c.w, p.k)};
                 const size_t px = (size_t)t.frame * p.frame_stride + (unsigned)(ty0 + oi) * (unsigned)p.nx + (unsigned)x;
                 *reinterpret_cast<ft_v4f *>(p.out0 + px) = v;
-                if (p.tq) {  // kernel-uniform
-                    // ... and is not beaten by a horizontal neighbour inside the quad: the two comparisons of the window rule's
-                    // 3x3 pre-test (nms.hip) that can be made here -- a blob above the threshold shrinks to its ridge
-                    const bool t0 = !(v[0] < p.Th) && !(v[1] >= v[0]);
-                    const bool t1 = !(v[1] < p.Th) && !(v[2] >= v[1]) && !(v[0] > v[1]);
-                    const bool t2 = !(v[2] < p.Th) && !(v[3] >= v[2]) && !(v[1] > v[2]);
-                    const bool t3 = !(v[3] < p.Th) && !(v[2] > v[3]);
-                    p.tq[px >> 2] = (unsigned char)((t0 ? 1u : 0u) | (t1 ? 2u : 0u) | (t2 ? 4u : 0u) | (t3 ? 8u : 0u));
-                }
+                if (p.tq) p.tq[px >> 2] = (unsigned char)harris_quad_bits(v[0], v[1], v[2], v[3], p.Th);  // kernel-uniform
             }
         } else {
             for (int i = tid; i < 3 * CH * ROW4; i += NT) {

@@ -491,6 +491,24 @@ imgfd_status imgfd_k_nms(imgfd_ctx *ctx, const float *d_R, int nx, int ny, float
     return compact_emit(ctx, cb, nx, ny, 1, 0, d_R, d_corners, cap, d_count);
 }
 
+imgfd_status imgfd_k_nms_quads(imgfd_ctx *ctx, const float *d_R, int nx, int ny, float Th, int radius,
+                               imgfd_corner *d_corners, int64_t cap, int64_t *d_count)
+{
+    if (!ctx || !d_R || !d_corners || !d_count || nx < 4 || nx % 4 != 0 || ny < 1 || cap < 0)
+        return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_k_nms_quads: bad argument (rows of whole quads)");
+    const size_t quads = (size_t)(nx / 4) * ny;
+    IMGFD_TRY(ws_reserve(ctx, compact_bytes(nx, ny, 1) + quads + 8192));
+    CompactBuffers cb;
+    IMGFD_TRY(compact_carve(ctx, nx, ny, 1, &cb));
+    unsigned char *tq = (unsigned char *)ws_alloc(ctx, quads);
+    if (!tq) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    IMGFD_TRY(compact_clear(ctx, cb, ny, 1));
+    // the batch path's pair: threshold quads (there: written by the structure-tensor kernel's epilogue), then the sparse kernel
+    IMGFD_TRY(launch_harris_threshold_quads(ctx, d_R, tq, nx, ny, 1, Th));
+    IMGFD_TRY(launch_harris_nms_sparse(ctx, d_R, tq, nx, ny, 1, Th, radius, cb));
+    return compact_emit(ctx, cb, nx, ny, 1, 0, d_R, d_corners, cap, d_count);
+}
+
 imgfd_status imgfd_k_tensor_response(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_R, int nx, int ny,
                                      float sigma, float k)
 {

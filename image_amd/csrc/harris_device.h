@@ -24,3 +24,16 @@ __device__ __forceinline__ float harris_response_value(float a, float b, float c
         return detA - k * traceA * traceA;
     }
 }
+
+// The threshold quad of four horizontally adjacent responses: bit e = "v[e] is not below the threshold (skip = R < Th,
+// harris.cpp:160-162) and not beaten by its neighbour inside the quad" -- the two comparisons of the window rule's 3x3
+// pre-test (nms.hip) that need no pixel outside the quad.  Written by fir_tensor's response epilogue, read by
+// harris_nms_sparse.
+__device__ __forceinline__ unsigned harris_quad_bits(float v0, float v1, float v2, float v3, float Th)
+{
+    const bool t0 = !(v0 < Th) && !(v1 >= v0);
+    const bool t1 = !(v1 < Th) && !(v2 >= v1) && !(v0 > v1);
+    const bool t2 = !(v2 < Th) && !(v3 >= v2) && !(v1 > v2);
+    const bool t3 = !(v3 < Th) && !(v2 > v3);
+    return (t0 ? 1u : 0u) | (t1 ? 2u : 0u) | (t2 ? 4u : 0u) | (t3 ? 8u : 0u);
+}

@@ -409,6 +409,23 @@ __global__ void __launch_bounds__(SN_WORDS) harris_nms_sparse(const float *__res
     }
 }
 
+// threshold quads of a materialised R plane (what fir_tensor's response epilogue writes on the way): the stage doorway's
+// way into harris_nms_sparse.  n_quads = nx / 4 * ny * n_frames
+__global__ void __launch_bounds__(256) harris_threshold_quads(const float *__restrict__ R, unsigned char *__restrict__ tq, float Th, size_t n_quads)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_quads) return;
+    const float *v = R + 4 * i;
+    tq[i] = (unsigned char)harris_quad_bits(v[0], v[1], v[2], v[3], Th);
+}
+imgfd_status launch_harris_threshold_quads(imgfd_ctx *ctx, const float *d_R, unsigned char *d_tq, int nx, int ny, int n_frames, float Th)
+{
+    const size_t n_quads = (size_t)(nx / 4) * ny * n_frames;
+    hipLaunchKernelGGL(harris_threshold_quads, dim3((unsigned)((n_quads + 255) / 256)), dim3(256), 0, ctx->stream, d_R, d_tq, Th, n_quads);
+    IMGFD_HIP(ctx, hipGetLastError());
+    return IMGFD_OK;
+}
+
 // NMS on the R plane and the threshold quads of fir_tensor's response epilogue (launch_tensor_response); nx % 4 == 0
 imgfd_status launch_harris_nms_sparse(imgfd_ctx *ctx, const float *d_R, const unsigned char *d_tq, int nx, int ny, int n_frames,
                                       float Th, int radius, const CompactBuffers &cb)

@@ -280,6 +280,12 @@ IMGFD_API imgfd_status imgfd_k_response(imgfd_ctx *ctx, const float *d_A, const 
 IMGFD_API imgfd_status imgfd_k_nms(imgfd_ctx *ctx, const float *d_R, int nx, int ny, float Th, int radius,
                          imgfd_corner *d_corners, int64_t cap, int64_t *d_count);
 
+/* K5 as the batch path runs it: the threshold test of harris.cpp:160-162 as a byte per quad of pixels (there: written by
+ * the structure-tensor kernel's epilogue), then non_maximum_suppression harris.cpp:141-255 reading R only around the
+ * pixels that pass + raster-ordered compaction.  nx % 4 == 0; any radius. */
+IMGFD_API imgfd_status imgfd_k_nms_quads(imgfd_ctx *ctx, const float *d_R, int nx, int ny, float Th, int radius,
+                                         imgfd_corner *d_corners, int64_t cap, int64_t *d_count);
+
 /* Time `iters` back-to-back launches of the structure-tensor kernel with HIP events on the context's
  * stream (after `warmup` untimed launches); *avg_us = mean microseconds per launch. */
 IMGFD_API imgfd_status imgfd_time_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy,

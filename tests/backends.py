@@ -72,12 +72,14 @@ class _Base:
                                              nx, ny, measure, k), "k_response")
         return self.to_host(R)
 
-    def k_nms(self, R, Th, radius):
+    def k_nms(self, R, Th, radius, quads=False):
+        """quads=True: the batch path's kernels (threshold quads + sparse NMS) instead of the tiled one."""
         ny, nx = R.shape
         d = self.to_dev(np.ascontiguousarray(R, np.float32))
         cap = nx * ny // 4 + 16
         out = self.empty((cap, 3), np.float32); cnt = self.empty((1,), np.int64)
-        self.check(self.lib.imgfd_k_nms(self.ctx, self.ptr(d), nx, ny, Th, radius, self.ptr(out), cap, self.ptr(cnt)), "k_nms")
+        fn = self.lib.imgfd_k_nms_quads if quads else self.lib.imgfd_k_nms
+        self.check(fn(self.ctx, self.ptr(d), nx, ny, Th, radius, self.ptr(out), cap, self.ptr(cnt)), "k_nms")
         n = int(self.to_host(cnt)[0])
         return self.to_host(out)[:n]
 

@@ -173,18 +173,20 @@ def test_response_bit_exact(be, measure):
     assert_bits_equal(got, oracle.harris_stage("response", A, B, Cc, measure=measure, k=0.06), f"response {measure}")
 
 
+@pytest.mark.parametrize("quads", [False, True], ids=["tiled", "quads"])
 @pytest.mark.parametrize("radius,Th", [(5, 130.0), (1, 10.0), (3, 1000.0), (8, 0.5)])
-def test_nms_window_rule_matches_scanline(be, radius, Th):
+def test_nms_window_rule_matches_scanline(be, radius, Th, quads):
     ix, iy = _gradients(19, 320, 240)
     A, B, Cc = oracle.harris_stage("autocorrelation", ix, iy, sigma=2.5, gauss=0)
     R = oracle.harris_stage("response", A, B, Cc, measure=0, k=0.06)
-    got = be.k_nms(R, Th, radius)
+    got = be.k_nms(R, Th, radius, quads=quads)
     ref = oracle.harris_stage("nms", R, Th=Th, radius=radius)
     assert got.shape == ref.shape, (got.shape, ref.shape)
     assert np.array_equal(bits(got), bits(ref))
 
 
-def test_nms_start_of_row_rule_on_exact_ties(be):
+@pytest.mark.parametrize("quads", [False, True], ids=["tiled", "quads"])
+def test_nms_start_of_row_rule_on_exact_ties(be, quads):
     """harris.cpp:177 skips 'the downhill at the beginning' of every row: a window maximum whose left neighbour TIES it and
     that lies in the initial non-increasing run (from column `radius`) is never emitted, although the window rule accepts
     it.  Planes with exact plateaus at the start of rows, in the middle of rows (where the tie does not block) and below
@@ -199,15 +201,34 @@ def test_nms_start_of_row_rule_on_exact_ties(be):
     R[26, 3:40] = np.linspace(900, 200, 37).astype(np.float32)      # a long downhill from the start, then ...
     R[26, 50:53] = 600.0                                            # ... a tie plateau further along the row
     R[30, 2] = 120.0; R[30, 3] = 120.0                              # tie exactly at column radius with column radius-1
-    got = be.k_nms(R, Th, radius)
+    got = be.k_nms(R, Th, radius, quads=quads)
     ref = oracle.harris_stage("nms", R, Th=Th, radius=radius)
     assert len(ref) >= 2 and got.shape == ref.shape and np.array_equal(bits(got), bits(ref)), (got, ref)
     Rt = np.ascontiguousarray(np.tile(R, (3, 3)))                   # larger plane: several 64x64 tiles of the fused kernel
     ref = oracle.harris_stage("nms", Rt, Th=Th, radius=radius)
-    got = be.k_nms(Rt, Th, radius)
+    got = be.k_nms(Rt, Th, radius, quads=quads)
     assert got.shape == ref.shape and np.array_equal(bits(got), bits(ref))
 
 
 def test_nms_small_image_is_empty(be):
     R = np.random.default_rng(0).random((11, 40)).astype(np.float32) * 1000
     assert be.k_nms(R, 0.0, 5).shape[0] == 0
+    assert be.k_nms(R, 0.0, 5, quads=True).shape[0] == 0
+
+
+def test_nms_quads_plateaus(be):
+    """The quad byte drops a pixel that a neighbour inside its quad beats; plateaus (ties inside a quad and across two) and
+    peaks on every column residue must come out as the scan line has them.  (Plateaus that tie a plateau in the row above
+    are left out: the scan line's skip marks of earlier rows, which then reach into the start-of-row rule, are not modelled
+    by either NMS kernel -- DESIGN.md section 4.)"""
+    rng = np.random.default_rng(11)
+    R = (rng.random((64, 132)) * 90).astype(np.float32)
+    for i, c in enumerate(range(8, 120, 7)):          # isolated peaks on columns of every residue mod 4
+        R[6 + (i * 5) % 50, c] = 500.0 + i
+    R[40, 20:24] = 700.0; R[57, 98:103] = 720.0       # plateaus inside one quad and across two
+    R[50, 65:67] = 650.0; R[54, 63:65] = 640.0         # two-pixel ties in a quad's middle and across a quad (and word) border
+    for radius in (1, 2, 5):
+        ref = oracle.harris_stage("nms", R, Th=100.0, radius=radius)
+        for quads in (False, True):
+            got = be.k_nms(R, 100.0, radius, quads=quads)
+            assert got.shape == ref.shape and np.array_equal(bits(got), bits(ref)), (radius, quads, len(got), len(ref))
