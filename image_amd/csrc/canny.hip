@@ -209,9 +209,7 @@ __global__ void __launch_bounds__(BM_NT) canny_blur_march(BlurMarchParams p)
 #pragma unroll
             for (int k = 0; k < NQ * 4; k++) {
                 wd[k] = (double)(float)((dw[k >> 2] >> (8 * (k & 3))) & 0xffu);
-#ifndef HIPEMU
-                asm volatile("" : "+v"(wd[k]));  // or the compiler folds the f64 adds back into integer adds + one conversion per pair
-#endif
+                IMGFD_OPAQUE(wd[k]);  // or the compiler folds the f64 adds back into integer adds + one conversion per pair
             }
 #pragma unroll
             for (int o0 = 0; o0 < BM_PX; o0 += 4) {
@@ -309,11 +307,7 @@ __device__ __forceinline__ double canny_mag_rcp(const CannyGrad &g, double *rcp)
     // normal range) instead of branching around the iteration: it is below every threshold, adds nothing to a neighbour's
     // interpolation (x + 1e-150 == x for every other magnitude a float image can produce) and h * rcp = v * rcp = 0
     const double s = fmax(__builtin_fma(g.h, g.h, g.v * g.v), 1e-300);
-#ifdef HIPEMU
-    const double y0 = 1.0 / sqrt(s);
-#else
     const double y0 = __builtin_amdgcn_rsq(s);
-#endif
     double gq = s * y0, hq = 0.5 * y0;
     double r = __builtin_fma(-hq, gq, 0.5);
     gq = __builtin_fma(gq, r, gq);
@@ -501,29 +495,22 @@ __device__ __forceinline__ unsigned long long dilate_h(unsigned long long s, uns
 // round trip like ds_bpermute); lanes 0 / 63 receive 0 and are overridden with the halo rows by the caller
 __device__ __forceinline__ unsigned long long lane_above(unsigned long long v)
 {
-#ifdef HIPEMU
-    const unsigned long long r = __shfl_up(v, 1);
-    return (threadIdx.x & 63) == 0 ? 0ull : r;  // like the DPP form: no source lane -> 0
-#else
     // bound_ctrl: a lane without a source reads 0 -- no "old" value has to be put into the destination first
     const unsigned lo = __builtin_amdgcn_mov_dpp((unsigned)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
     const unsigned hi = __builtin_amdgcn_mov_dpp((unsigned)(v >> 32), 0x138, 0xf, 0xf, true);
     return ((unsigned long long)hi << 32) | lo;
-#endif
 }
 __device__ __forceinline__ unsigned long long lane_below(unsigned long long v)
 {
-#ifdef HIPEMU
-    const unsigned long long r = __shfl_down(v, 1);
-    return (threadIdx.x & 63) == 63 ? 0ull : r;
-#else
     const unsigned lo = __builtin_amdgcn_mov_dpp((unsigned)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
     const unsigned hi = __builtin_amdgcn_mov_dpp((unsigned)(v >> 32), 0x130, 0xf, 0xf, true);
     return ((unsigned long long)hi << 32) | lo;
-#endif
 }
 
-#define HY_WORDS 4   // a wave's tile: 4 words (256 columns) x 64 rows (lane = row), iterated to a fixpoint in registers
+#ifndef HY_WORDS
+#define HY_WORDS 4
+#endif
+// HY_WORDS: a wave's tile: 4 words (256 columns) x 64 rows (lane = row), iterated to a fixpoint in registers
 // One sweep over all tiles of all frames (a wave per tile, the tile iterated to its fixpoint in registers).  flags[sweep]
 // is raised when any tile changed; a sweep whose predecessor was idle returns at once, so the host queues a fixed number
 // of sweeps without ever reading a flag back.  act[] holds one byte per

@@ -101,10 +101,21 @@ static inline int sub_batch_frames(int n_frames, size_t per_frame_bytes, size_t 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // streaming (non-temporal) store: data the kernel itself will not read again
-#ifdef HIPEMU
-#define IMGFD_STREAM_STORE(value, ptr) (*(ptr) = (value))
-#else
 #define IMGFD_STREAM_STORE(value, ptr) __builtin_nontemporal_store((value), (ptr))
+// The one place where the device build and the host-side emulator build of the tests (HIPEMU, tests/hipemu: the same
+// sources compiled by g++) part over compiler-specific syntax; gfx950 builtins are emulated in tests/hipemu/hip/hip_runtime.h.
+#ifdef HIPEMU
+#define IMGFD_OPAQUE(x) ((void)0)
+#define IMGFD_WAVES_PER_EU(lo, hi)
+#define IMGFD_LDS_SPACE
+typedef hipemu_u16x2 imgfd_u16x2;
+#else
+typedef unsigned short imgfd_u16x2 __attribute__((ext_vector_type(2)));  // two 16-bit lanes of a dword (packed instructions)
+#define IMGFD_LDS_SPACE __attribute__((address_space(3)))  // a pointer that is known to address LDS
+#define IMGFD_OPAQUE(x) asm volatile("" : "+v"(x))  // keeps the optimiser from rewriting the expression that produced x
+// LDS (not registers) fixes the residency of the marching kernels: tell the register allocator so, or it trades VGPRs
+// for an occupancy the LDS footprint can never reach (and spills)
+#define IMGFD_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
 #endif
 
 // ---- tile runs: the 2-D tile kernels over u8 frames (fast9_tile, gauss_grad_tile) walk `run` consecutive tiles of one

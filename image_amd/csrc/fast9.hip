@@ -50,44 +50,20 @@ __device__ __forceinline__ int f9_score(const int (&v)[16], int p)
 }
 
 // packed arithmetic on two unsigned 16-bit lanes of a dword (v_pk_sub_u16 clamp / v_pk_max_u16 / v_pk_min_u16)
-#ifdef HIPEMU
 __device__ __forceinline__ unsigned f9_pk_subs(unsigned a, unsigned b)
 {
-    const unsigned al = a & 0xffffu, bl = b & 0xffffu, ah = a >> 16, bh = b >> 16;
-    return (al > bl ? al - bl : 0u) | ((ah > bh ? ah - bh : 0u) << 16);
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(imgfd_u16x2, a), __builtin_bit_cast(imgfd_u16x2, b)));
 }
 __device__ __forceinline__ unsigned f9_pk_max(unsigned a, unsigned b)
 {
-    return max(a & 0xffffu, b & 0xffffu) | (max(a >> 16, b >> 16) << 16);
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(imgfd_u16x2, a), __builtin_bit_cast(imgfd_u16x2, b)));
 }
 __device__ __forceinline__ unsigned f9_pk_min(unsigned a, unsigned b)
 {
-    return min(a & 0xffffu, b & 0xffffu) | (min(a >> 16, b >> 16) << 16);
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(imgfd_u16x2, a), __builtin_bit_cast(imgfd_u16x2, b)));
 }
-#else
-typedef unsigned short f9_u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned f9_pk_subs(unsigned a, unsigned b)
-{
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(f9_u16x2, a), __builtin_bit_cast(f9_u16x2, b)));
-}
-__device__ __forceinline__ unsigned f9_pk_max(unsigned a, unsigned b)
-{
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(f9_u16x2, a), __builtin_bit_cast(f9_u16x2, b)));
-}
-__device__ __forceinline__ unsigned f9_pk_min(unsigned a, unsigned b)
-{
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(f9_u16x2, a), __builtin_bit_cast(f9_u16x2, b)));
-}
-#endif
 // bytes 1 and 3 of a dword in the low bytes of its two 16-bit lanes (v_perm_b32: one instruction for shift + mask)
-__device__ __forceinline__ unsigned f9_odd_bytes(unsigned v)
-{
-#ifdef HIPEMU
-    return (v >> 8) & 0x00ff00ffu;
-#else
-    return __builtin_amdgcn_perm(0u, v, 0x0c030c01u);
-#endif
-}
+__device__ __forceinline__ unsigned f9_odd_bytes(unsigned v) { return __builtin_amdgcn_perm(0u, v, 0x0c030c01u); }
 
 // Compass pre-test, two pixels at a time (16-bit lanes).  A contiguous arc of 9 of the 16 ring pixels leaves out 7
 // consecutive ones, which cannot hold two opposite ring pixels (8 apart): the arc contains the north or the south pixel,

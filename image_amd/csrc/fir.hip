@@ -100,14 +100,8 @@ struct FirGeom {
 
 // MODE 0: one f32 plane in -> one plane out;  MODE 1: one u8 plane in
 template <int R, int MODE, int TW, int CH, bool FMA, int FIR_PX, int FIR_NT, bool VEC>
-#ifdef HIPEMU
-#define FIR_WAVES_PER_EU(n)
-#else
-// LDS (not registers) fixes the residency of this kernel at two workgroups per CU: tell the register allocator so,
-// or it trades VGPRs for an occupancy the LDS footprint can never reach (and spills)
-#define FIR_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n)))
-#endif
-__global__ void __launch_bounds__(FIR_NT) FIR_WAVES_PER_EU(FIR_NT == 192 ? 3 : FIR_NT / 128) fir_march(FirParams p)
+// LDS fixes the residency of this kernel at two workgroups per CU (IMGFD_WAVES_PER_EU, common.h)
+__global__ void __launch_bounds__(FIR_NT) IMGFD_WAVES_PER_EU(FIR_NT == 192 ? 3 : FIR_NT / 128, FIR_NT == 192 ? 3 : FIR_NT / 128) fir_march(FirParams p)
 {
     using G = FirGeom<R, MODE, TW, CH, FIR_PX, FIR_NT>;
     constexpr int NI = G::NI, NP = G::NP, W4 = G::W4, RPITCH = G::RPITCH, RING = G::RING, HALO = G::HALO;

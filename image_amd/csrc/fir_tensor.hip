@@ -57,12 +57,8 @@ extern "C" __attribute__((visibility("default"))) int imgfd_debug_ft_profile(uns
 #endif
 
 typedef float ft_v4f __attribute__((vector_size(16)));  // native vector: always promoted to registers
-#ifdef HIPEMU
-typedef volatile ft_v4f ft_lds_v4f;
-#else
 // a volatile 16-byte read that is known to address LDS (a volatile access through a generic pointer becomes a flat load)
-typedef volatile __attribute__((address_space(3))) ft_v4f ft_lds_v4f;
-#endif
+typedef volatile IMGFD_LDS_SPACE ft_v4f ft_lds_v4f;
 
 struct TensorParams {
     const float *ix;
@@ -104,14 +100,6 @@ struct TensorGeom {
 };
 
 // a float plane addressed as a hardware buffer: store(value) at byte offset lane_off (per lane) + row_off (wave-uniform)
-#ifdef HIPEMU
-struct FtBuffer { float *base; };
-__device__ __forceinline__ FtBuffer ft_make_buffer(float *base, unsigned) { return FtBuffer{base}; }
-__device__ __forceinline__ void ft_buffer_store(const FtBuffer &b, unsigned lane_off, unsigned row_off, float v)
-{
-    *reinterpret_cast<float *>(reinterpret_cast<char *>(b.base) + (size_t)(row_off + lane_off)) = v;
-}
-#else
 struct FtBuffer { __amdgpu_buffer_rsrc_t r; };
 __device__ __forceinline__ FtBuffer ft_make_buffer(float *base, unsigned bytes)
 {
@@ -121,7 +109,6 @@ __device__ __forceinline__ void ft_buffer_store(const FtBuffer &b, unsigned lane
 {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, (int)lane_off, (int)row_off, 0);
 }
-#endif
 
 // ring position of column c of a row: the four float4 slots of each 16-column strip are rotated by (strip / 2), so the
 // row pass's ds_write_b128 (8 lanes = 8 strips of one row) covers 8 distinct slots mod 8 and the column pass's
@@ -218,9 +205,6 @@ __device__ __forceinline__ void ft_group(const float (&w)[NWIN], double (&dw)[NW
     for (int g = 0; g < ILP; g++) out[g] = (float)sum[g];
 }
 
-#ifdef HIPEMU
-#define FT_WAVES_PER_EU(tw)
-#else
 // Register budget = what the wave placement needs, not what the occupancy API answers.  A workgroup's waves are dealt to
 // the CU's four SIMDs in turn, so only multiples of 4 waves load the SIMDs evenly:
 //   TW 256: 12 waves = 3 per SIMD, one workgroup per CU (85 / 135 KB of LDS): up to 168 VGPRs.
@@ -228,8 +212,7 @@ __device__ __forceinline__ void ft_group(const float (&w)[NWIN], double (&dw)[NW
 //           barriers, 75 % of the f64 rate at best (measured: 48 us per 4K frame against 44); with 128 VGPRs two such
 //           workgroups share a CU but the allocator spills, with 160 the hardware admits ONE per CU whatever the
 //           occupancy API answers (1.4 resident waves per SIMD measured).  Same 168-register budget, no spills.
-#define FT_WAVES_PER_EU(tw) __attribute__((amdgpu_waves_per_eu(3, 3)))
-#endif
+#define FT_WAVES_PER_EU(tw) IMGFD_WAVES_PER_EU(3, 3)
 // OUT 0: A, B, C stored straight from the column pass (one dword per lane and row, 256 B per wave)
 // OUT 1: A, B, C staged through LDS and stored as float4 rows
 // OUT 2: corner response (Harris measure) computed from the staged A, B, C; only R is stored (float4 rows)

@@ -313,6 +313,53 @@ static inline double max(double a, double b) { return fmax(a, b); }
 // wave-uniform values are what kernels pass here: every emulated lane already holds the same value
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 
+// ---- gfx950 builtins the product sources use unconditionally (emulated here, so that the kernels carry no test branches)
+static inline double __builtin_amdgcn_rsq(double x) { return 1.0 / sqrt(x); }  // v_rsq_f64: a seed, refined by the caller
+// v_perm_b32: byte k of the result is picked by selector byte k: 0..3 = bytes of b, 4..7 = bytes of a, 0x0c = 0x00
+static inline unsigned __builtin_amdgcn_perm(unsigned a, unsigned b, unsigned sel) {
+    unsigned r = 0;
+    for (int k = 0; k < 4; k++) {
+        const unsigned c = (sel >> (8 * k)) & 0xffu;
+        unsigned byte = 0;
+        if (c < 4) byte = (b >> (8 * c)) & 0xffu;
+        else if (c < 8) byte = (a >> (8 * (c - 4))) & 0xffu;
+        else if (c != 0x0c) { fprintf(stderr, "hipemu: v_perm_b32 selector 0x%02x not emulated\n", c); abort(); }
+        r |= byte << (8 * k);
+    }
+    return r;
+}
+// v_mov_b32_dpp with bound_ctrl: wave_shr:1 (0x138: lane i reads lane i-1) and wave_shl:1 (0x130: lane i reads lane i+1);
+// a lane without a source reads 0
+static inline unsigned __builtin_amdgcn_mov_dpp(unsigned v, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    if ((ctrl != 0x138 && ctrl != 0x130) || row_mask != 0xf || bank_mask != 0xf || !bound_ctrl) {
+        fprintf(stderr, "hipemu: DPP control 0x%x not emulated\n", ctrl);
+        abort();
+    }
+    const int lane = (int)__lane_id();
+    const unsigned r = ctrl == 0x138 ? __shfl_up(v, 1) : __shfl_down(v, 1);
+    return (ctrl == 0x138 ? lane == 0 : lane == 63) ? 0u : r;
+}
+// streaming store hint
+#define __builtin_nontemporal_store(value, ptr) (*(ptr) = (value))
+// two unsigned 16-bit lanes in a dword (the device build's `unsigned short ext_vector_type(2)`) with the element-wise
+// builtins the kernels use on it (v_pk_sub_u16 clamp, v_pk_max_u16, v_pk_min_u16)
+struct hipemu_u16x2 { unsigned short x, y; };
+static inline hipemu_u16x2 __builtin_elementwise_sub_sat(hipemu_u16x2 a, hipemu_u16x2 b) {
+    return hipemu_u16x2{(unsigned short)(a.x > b.x ? a.x - b.x : 0), (unsigned short)(a.y > b.y ? a.y - b.y : 0)};
+}
+static inline hipemu_u16x2 __builtin_elementwise_max(hipemu_u16x2 a, hipemu_u16x2 b) {
+    return hipemu_u16x2{a.x > b.x ? a.x : b.x, a.y > b.y ? a.y : b.y};
+}
+static inline hipemu_u16x2 __builtin_elementwise_min(hipemu_u16x2 a, hipemu_u16x2 b) {
+    return hipemu_u16x2{a.x < b.x ? a.x : b.x, a.y < b.y ? a.y : b.y};
+}
+// raw buffer addressing: resource = base pointer (+ size, flags: ignored), store at base + voffset + soffset
+struct __amdgpu_buffer_rsrc_t { char *base; };
+static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void *base, short, int, int) { return __amdgpu_buffer_rsrc_t{(char *)base}; }
+static inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned data, __amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
+    memcpy(r.base + (size_t)(unsigned)voffset + (size_t)(unsigned)soffset, &data, 4);
+}
+
 // ------------------------------------------------------------------ host API
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100 };
