@@ -457,6 +457,15 @@ imgfd_status imgfd_k_gradient(imgfd_ctx *ctx, const float *d_I, float *d_Ix, flo
     return launch_gradient(ctx, d_I, d_Ix, d_Iy, nx, ny, 1, type);
 }
 
+imgfd_status imgfd_k_gauss_grad_u8(imgfd_ctx *ctx, const uint8_t *d_u8, float *d_Ix, float *d_Iy, int nx, int ny, float sigma_d,
+                                   int grad_type)
+{
+    if (!ctx || !d_u8 || !d_Ix || !d_Iy || nx < 3 || ny < 3) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_k_gauss_grad_u8: bad argument");
+    if (!gauss_grad_fused_supported(nx, ny, sigma_d, IMGFD_STD_GAUSSIAN))
+        return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "imgfd_k_gauss_grad_u8: the fused kernel serves radius 3 (sigma_d in [1, 4/3)) only");
+    return launch_gauss_grad_fused(ctx, d_u8, 1, nx, (size_t)nx * ny, d_Ix, d_Iy, nx, ny, 1, sigma_d, grad_type);
+}
+
 imgfd_status imgfd_k_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_A,
                                       float *d_B, float *d_C, int nx, int ny, float sigma, int gauss)
 {

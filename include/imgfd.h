@@ -264,6 +264,11 @@ IMGFD_API imgfd_status imgfd_k_gaussian(imgfd_ctx *ctx, const float *d_in, float
 /* K2: central differences / Sobel, gradient.cpp:115-128 */
 IMGFD_API imgfd_status imgfd_k_gradient(imgfd_ctx *ctx, const float *d_I, float *d_Ix, float *d_Iy, int nx,
                               int ny, int type);
+/* K1 + K2 as the batch path runs them on u8 frames: discrete Gaussian of radius 3 (sigma_d in [1, 4/3)) and the gradient of
+ * the smoothed frame in one kernel (gaussian.cpp:289-395 + gradient.cpp:17-106); the smoothed plane is not written.
+ * d_u8: ny rows of nx bytes (pitch nx).  IMGFD_ERR_UNSUPPORTED for another radius. */
+IMGFD_API imgfd_status imgfd_k_gauss_grad_u8(imgfd_ctx *ctx, const uint8_t *d_u8, float *d_Ix, float *d_Iy, int nx, int ny,
+                                             float sigma_d, int grad_type);
 /* K3: the structure-tensor pass, compute_autocorrelation_matrix harris.cpp:44-70:
  * reads Ix,Iy (8 B/px), writes the smoothed A,B,C (12 B/px) */
 IMGFD_API imgfd_status imgfd_k_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_A,

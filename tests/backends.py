@@ -49,6 +49,13 @@ class _Base:
         self.check(self.lib.imgfd_k_gradient(self.ctx, self.ptr(d_in), self.ptr(ix), self.ptr(iy), nx, ny, type), "k_gradient")
         return self.to_host(ix), self.to_host(iy)
 
+    def k_gauss_grad_u8(self, img_u8, sigma_d=1.0, type=0):
+        ny, nx = img_u8.shape
+        d_in = self.to_dev(np.ascontiguousarray(img_u8, np.uint8))
+        ix = self.empty((ny, nx), np.float32); iy = self.empty((ny, nx), np.float32)
+        self.check(self.lib.imgfd_k_gauss_grad_u8(self.ctx, self.ptr(d_in), self.ptr(ix), self.ptr(iy), nx, ny, sigma_d, type), "k_gauss_grad_u8")
+        return self.to_host(ix), self.to_host(iy)
+
     def k_structure_tensor(self, ix, iy, sigma, gauss=0):
         ny, nx = ix.shape
         dx = self.to_dev(np.ascontiguousarray(ix, np.float32)); dy = self.to_dev(np.ascontiguousarray(iy, np.float32))

@@ -73,6 +73,20 @@ def test_gradient_bit_exact(be, nx, ny, type):
     assert_bits_equal(iy, ry, "Iy")
 
 
+@pytest.mark.parametrize("type", [0, 1])
+@pytest.mark.parametrize("nx,ny", SIZES + [(4, 5), (5, 70), (64, 61), (67, 130), (129, 16), (260, 200)])
+def test_fused_gauss_grad_u8_strict_bit_exact(be, nx, ny, type):
+    """The kernel the batch path runs on u8 frames (marching strips: segments of rows, 15-row steps, border strips, strips
+    that start on the last column) against the two reference stages, bit for bit in strict mode."""
+    be.set_fir_mode(0)
+    img = synth.frame(23, nx, ny)
+    ix, iy = be.k_gauss_grad_u8(img, 1.0, type)
+    sm = oracle.harris_stage("gaussian", img.astype(np.float32), sigma=1.0, type=0)
+    rx, ry = oracle.harris_stage("gradient", sm, type=type)
+    assert_bits_equal(ix, rx, f"Ix {nx}x{ny}")
+    assert_bits_equal(iy, ry, f"Iy {nx}x{ny}")
+
+
 def _gradients(seed, nx, ny):
     img = oracle.harris_stage("gaussian", synth.frame(seed, nx, ny).astype(np.float32), sigma=1.0, type=0)
     return oracle.harris_stage("gradient", img, type=0)
