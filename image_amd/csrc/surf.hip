@@ -8,9 +8,13 @@
 //                        surf_gray_rowscan4 (one workgroup per row, 16-byte stores) + surf_colscan_sums/_apply (columns
 //                        cut into row segments); surf_gray_rowscan / surf_colscan serve unaligned or small images.
 //   K17 Hessian pyramid  hessian_pyramid::build_pyramid(img, 4, 6, 2), dlib/image_keypoint/hessian_pyramid.h:87-178:
-//                        24 levels of box-filter determinants in f64, one thread per level pixel, 32 integral-image
-//                        look-ups each (the 67 MB table of a 4096^2 tile lives in the Infinity Cache).
-//   K18 interest points  get_interest_points :453-506: 3x3x3 maximum test (:324-356) + quadratic interpolation with
+//                        24 levels of box-filter determinants in f64, 32 integral-image look-ups per level pixel:
+//                        surf_pyramid_lds<0> (first octave: the table window of a block of level pixels in LDS, all six
+//                        intervals from it), surf_pyramid<LM> (octaves 1-3 in one launch, gathering from a copy of the
+//                        table re-laid by column residue, surf_residue_layout).  Both publish one threshold bit per
+//                        level pixel (|det| >= threshold).
+//   K18 interest points  get_interest_points :453-506: surf_nms_masked turns the threshold bits into dense lists and runs
+//                        the 3x3x3 maximum test (:324-356) + quadratic interpolation with
 //                        the closed-form 3x3 inverse (:411-446, dlib/matrix/matrix_la.h:922-962), in f64 with the
 //                        reference's operation order (no contraction).  Survivors are appended with a sort key
 //                        (octave, interval, row, column); the host orders them by that key = the order in which the
