@@ -279,7 +279,9 @@ imgfd_status launch_harris_resp_nms(imgfd_ctx *ctx, const float *d_A, const floa
 //   (3) the full window, a wave per survivor, window positions over the lanes; the scan line's start-of-row rule;
 //   (4) the surviving bits go to `mask`, their popcounts to `rowcount`.
 // The comparisons are those of harris_resp_nms_kernel, term by term.
+#ifndef SN_WORDS
 #define SN_WORDS 256
+#endif
 template <int HC>
 __global__ void __launch_bounds__(SN_WORDS) harris_nms_sparse(const float *__restrict__ Rp, const unsigned char *__restrict__ tq,
                                                             int nx, int ny, float Th, int radius_rt,
