@@ -1055,7 +1055,9 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
                 hipLaunchKernelGGL(canny_hyst_regions, dim3(regions, nf), dim3(HY_NT), lds, ctx->stream, S, Wm, g, rflag, r);
             hipLaunchKernelGGL(canny_hyst_finish, dim3(nf), dim3(HY_NT), lds, ctx->stream, S, Wm, g, rflag, rounds - 1, (const unsigned *)nullptr);
         } else {
-            int sweeps = HY_SWEEPS;
+            // a small batch has nothing to hide idle launches behind (a single 4K frame: 24 launches were 184 of its 438 us):
+            // fewer sweeps are queued, the finishing kernel completes whatever an unusually long chain of weak pixels leaves
+            int sweeps = nf >= 8 ? HY_SWEEPS : 14;
             if (const char *e = getenv("IMGFD_HYST_SWEEPS")) if (atoi(e) >= 1 && atoi(e) <= HY_SWEEPS) sweeps = atoi(e);  // tests: force the finishing kernel to work
             const int tiles_x = ceil_div(wpr, HY_WORDS), tiles_y = ceil_div(ny, 64);
             dim3 g3(ceil_div(tiles_x * tiles_y, 4), nf);
