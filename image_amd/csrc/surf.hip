@@ -200,10 +200,13 @@ __global__ void __launch_bounds__(256) surf_colscan_apply(unsigned *__restrict__
 // it loses to the gather kernel): the integral-image window of a block of level
 // pixels, with the widest filter's reach around it, is staged in LDS once and serves all six intervals (6 x 32 look-ups
 // per level pixel from LDS instead of scattered global loads).  Same arithmetic as surf_pyramid below.
+#ifndef SURF_LDS_LY
+#define SURF_LDS_LY 16  // level rows per workgroup of the first octave's LDS kernel (imgfd_surf_dev per tile: 8 -> 0.453, 16 -> 0.441-0.455, 32 -> 0.472 ms)
+#endif
 template <int O>
 struct SurfPyrLds {
     static constexpr int STEP = 2 << O;
-    static constexpr int LX = O == 0 ? 64 : 32, LY = O == 0 ? 16 : 8;  // level pixels per workgroup
+    static constexpr int LX = O == 0 ? 64 : 32, LY = O == 0 ? SURF_LDS_LY : 8;  // level pixels per workgroup
     static constexpr int LOBE_MAX = STEP * SURF_INT + 1;               // hessian_pyramid.h:119-128: lobe = step*(i+1) + 1
     static constexpr int REACH = (3 * LOBE_MAX) / 2;                   // half of the widest box; "+1" for the l-1 / t-1 corner
     static constexpr int HL = (REACH + 1 + 3) / 4 * 4;                 // left / top margin: a multiple of 4 (16-byte loads) and of STEP
