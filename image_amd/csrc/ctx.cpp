@@ -3,6 +3,19 @@
 
 #include <stdlib.h>
 
+namespace {
+struct TuneKey { const char *name, *env; int imgfd_ctx::Tune::*field; };
+const std::vector<TuneKey> &tune_keys()
+{
+    static const std::vector<TuneKey> keys = {
+        {"fhog_fused", "IMGFD_FHOG_FUSED", &imgfd_ctx::Tune::fhog_fused},
+        {"fhog_bands", "IMGFD_FHOG_BANDS", &imgfd_ctx::Tune::fhog_bands},
+        {"fhog_sqrt", "IMGFD_FHOG_SQRT", &imgfd_ctx::Tune::fhog_sqrt},
+    };
+    return keys;
+}
+}  // namespace
+
 extern "C" {
 
 int imgfd_version(void) { return IMGFD_VERSION; }
@@ -36,6 +49,8 @@ static imgfd_status ctx_init(int device, void *stream, bool own, imgfd_ctx **out
     }
     const char *m = getenv("IMGFD_FIR_MODE");
     if (m) ctx->fir_mode = atoi(m) ? 1 : 0;
+    for (const TuneKey &k : tune_keys())
+        if (const char *e = getenv(k.env)) ctx->tune.*(k.field) = atoi(e);
     *out = ctx;
     return IMGFD_OK;
 }
@@ -58,6 +73,7 @@ void imgfd_ctx_destroy(imgfd_ctx *ctx)
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->aux) (void)hipFree(ctx->aux);
+    if (ctx->fhog_olut) (void)hipFree(ctx->fhog_olut);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -86,6 +102,18 @@ imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode)
     if (!ctx || (mode != 0 && mode != 1)) return IMGFD_ERR_INVALID;
     ctx->fir_mode = mode;
     return IMGFD_OK;
+}
+
+imgfd_status imgfd_set_tuning(imgfd_ctx *ctx, const char *name, int value)
+{
+    if (!ctx || !name) return IMGFD_ERR_INVALID;
+    for (const TuneKey &k : tune_keys())
+        if (!strcmp(k.name, name)) {
+            ctx->tune.*(k.field) = value;
+            if (ctx->side) ctx->side->tune.*(k.field) = value;
+            return IMGFD_OK;
+        }
+    return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_set_tuning: unknown switch");
 }
 
 imgfd_status imgfd_profile_k3(imgfd_ctx *ctx, int enable)
@@ -178,6 +206,7 @@ imgfd_status ctx_side(imgfd_ctx *ctx, imgfd_ctx **side)
         const imgfd_status st = imgfd_ctx_create(ctx->device, &s);
         if (st != IMGFD_OK) return imgfd_fail(ctx, st, "could not create the companion context");
         s->fir_mode = ctx->fir_mode;
+        s->tune = ctx->tune;
         // the three events first; the companion is published only when everything it needs exists
         hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
         for (int i = 0; i < 3; i++) {

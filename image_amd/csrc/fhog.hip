@@ -17,22 +17,13 @@
 // The reference handles columns in groups of 8 with float "SIMD" arithmetic and the remainder with a scalar
 // tail whose rounding order and colour tie-break differ (:828-918 vs :920-955); both are reproduced, keyed on
 // the pixel's column (fhog_is_body).  Library build flag -ffp-contract=off keeps a*b+c unfused like x86-64 -O2.
-#include "common.h"
+#include "fhog_device.h"
 
 #include <math.h>
 #include <stdlib.h>
 
 #include <algorithm>
 
-struct FhogGeom {
-    int rows, cols, cs;
-    int cells_nr, cells_nc;    // fhog.h:780-781
-    int visible_nr, visible_nc;  // :817-818
-    int body_end;              // columns 1 .. body_end-1 take the 8-wide path, the rest the scalar tail
-    int hog_nr, hog_nc;        // interior cells (:806-807)
-    int out_nr, out_nc;        // with filter padding (init_hog :455)
-    int off_r, off_c;          // :813-814
-};
 
 static bool fhog_geometry(int rows, int cols, int cs, int pad_r, int pad_c, FhogGeom *g)
 {
@@ -68,9 +59,6 @@ static bool fhog_geometry(int rows, int cols, int cs, int pad_r, int pad_c, Fhog
     return true;
 }
 
-__constant__ float FHOG_DIRS[9][2] = {{1.0000f, 0.0000f}, {0.9397f, 0.3420f}, {0.7660f, 0.6428f}, {0.500f, 0.8660f},
-                                      {0.1736f, 0.9848f}, {-0.1736f, 0.9848f}, {-0.5000f, 0.8660f},
-                                      {-0.7660f, 0.6428f}, {-0.9397f, 0.3420f}};
 
 // K13: packed[y*cols + x] = (len << 5) | best_o for 1 <= y < visible_nr, 1 <= x < visible_nc; 0 elsewhere
 // (a zero-length gradient votes +0.0f, which leaves every sum unchanged)
@@ -101,16 +89,7 @@ __global__ void __launch_bounds__(256) fhog_grad_orient(const unsigned char *__r
             if (len[1] > tl) { tl = len[1]; tx = gx[1]; ty = gy[1]; }
             if (len[2] > tl) { tl = len[2]; tx = gx[2]; ty = gy[2]; }
         }
-        const float fx = (float)tx, fy = (float)ty;
-        float best_dot = 0;
-        int best_o = 0;
-#pragma unroll
-        for (int o = 0; o < 9; o++) {  // :846-859 and :929-943 decide identically
-            const float dot = fx * FHOG_DIRS[o][0] + fy * FHOG_DIRS[o][1];
-            if (dot > best_dot) { best_dot = dot; best_o = o; }
-            else if (-dot > best_dot) { best_dot = -dot; best_o = o + 9; }
-        }
-        out = ((unsigned)tl << 5) | (unsigned)best_o;
+        out = ((unsigned)tl << 5) | (unsigned)fhog_best_orientation(tx, ty);  // :846-859 and :929-943 decide identically
     }
     packed[((size_t)blockIdx.z * g.rows + y) * g.cols + x] = out;
 }
@@ -135,16 +114,7 @@ __device__ __forceinline__ unsigned fhog_pack(const int (&l)[3], const int (&r)[
         if (len[1] > tl) { tl = len[1]; tx = gx[1]; ty = gy[1]; }
         if (len[2] > tl) { tl = len[2]; tx = gx[2]; ty = gy[2]; }
     }
-    const float fx = (float)tx, fy = (float)ty;
-    float best_dot = 0;
-    int best_o = 0;
-#pragma unroll
-    for (int o = 0; o < 9; o++) {
-        const float dot = fx * FHOG_DIRS[o][0] + fy * FHOG_DIRS[o][1];
-        if (dot > best_dot) { best_dot = dot; best_o = o; }
-        else if (-dot > best_dot) { best_dot = -dot; best_o = o + 9; }
-    }
-    return ((unsigned)tl << 5) | (unsigned)best_o;
+    return ((unsigned)tl << 5) | (unsigned)fhog_best_orientation(tx, ty);
 }
 
 // K13, fast form: one thread per 4 consecutive pixels (12 bytes = 3 aligned dwords per row when cols % 4 == 0 and the
@@ -420,10 +390,10 @@ __global__ void __launch_bounds__(256) fhog_features_cs1(const unsigned *__restr
 
 namespace {
 
-size_t fhog_ws_bytes(const FhogGeom &g, int nf)
+size_t fhog_ws_bytes(const FhogGeom &g, int nf, bool fused)
 {
     if (g.cs == 1) return align_up(sizeof(unsigned) * (size_t)g.rows * g.cols * nf, 256) + 4096;  // no histograms
-    return align_up(sizeof(unsigned) * (size_t)g.rows * g.cols * nf, 256) +
+    return (fused ? 0 : align_up(sizeof(unsigned) * (size_t)g.rows * g.cols * nf, 256)) +  // fhog_hist8 needs no pixel plane
            align_up(sizeof(float) * (size_t)(g.cells_nr + 2) * (g.cells_nc + 2) * 18 * nf, 256) +
            align_up(sizeof(float) * (size_t)g.cells_nr * g.cells_nc * nf, 256) + 4096;
 }
@@ -431,13 +401,21 @@ size_t fhog_ws_bytes(const FhogGeom &g, int nf)
 // d_rgb: nf interlaced RGB frames; d_out: nf * 31 * out_nc * out_nr floats
 imgfd_status fhog_device(imgfd_ctx *ctx, const uint8_t *d_rgb, size_t frame_stride, const FhogGeom &g, int nf, float *d_out)
 {
-    unsigned *packed = (unsigned *)ws_alloc(ctx, sizeof(unsigned) * (size_t)g.rows * g.cols * nf);
+    const bool fused = ctx->tune.fhog_fused && fhog_fused_supported(g, d_rgb, frame_stride);
+    unsigned *packed = fused ? nullptr : (unsigned *)ws_alloc(ctx, sizeof(unsigned) * (size_t)g.rows * g.cols * nf);
     float *hist = g.cs == 1 ? nullptr : (float *)ws_alloc(ctx, sizeof(float) * (size_t)(g.cells_nr + 2) * (g.cells_nc + 2) * 18 * nf);
     float *norm = g.cs == 1 ? nullptr : (float *)ws_alloc(ctx, sizeof(float) * (size_t)g.cells_nr * g.cells_nc * nf);
-    if (!packed || (g.cs != 1 && (!hist || !norm))) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    if ((!fused && !packed) || (g.cs != 1 && (!hist || !norm))) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
     const size_t out_n = (size_t)31 * g.out_nr * g.out_nc * nf;
     if (g.out_nr != g.hog_nr || g.out_nc != g.hog_nc)  // init_hog: zero border of the padded output
         IMGFD_HIP(ctx, hipMemsetAsync(d_out, 0, out_n * sizeof(float), ctx->stream));
+    if (fused) {  // K13 + K14 in one kernel: no per-pixel plane between them
+        IMGFD_TRY(fhog_fused_hist(ctx, d_rgb, frame_stride, g, nf, hist, norm));
+        hipLaunchKernelGGL(fhog_features, dim3(ceil_div(g.hog_nr, 64), ceil_div(g.hog_nc, 4), nf), dim3(256), 0, ctx->stream,
+                           hist, norm, d_out, g);
+        IMGFD_HIP(ctx, hipGetLastError());
+        return IMGFD_OK;
+    }
     if (g.cols % 4 == 0 && (size_t)d_rgb % 4 == 0 && frame_stride % 4 == 0 && (size_t)packed % 16 == 0)
         hipLaunchKernelGGL(fhog_grad_orient4, dim3(ceil_div(g.cols / 4, 256), g.rows, nf), dim3(256), 0, ctx->stream, d_rgb,
                            frame_stride, packed, g);
@@ -484,7 +462,7 @@ static imgfd_status fhog_host(imgfd_ctx *ctx, const void *rgb, int kind, int row
     if (!fhog_geometry(rows, cols, cell_size, filter_rows_padding, filter_cols_padding, &g)) return IMGFD_OK;  // hog.clear()
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
     const size_t in_bytes = (size_t)3 * rows * cols, out_n = (size_t)31 * g.out_nr * g.out_nc;
-    IMGFD_TRY(ws_reserve(ctx, fhog_ws_bytes(g, 1) + align_up(in_bytes, 256) + align_up(out_n * sizeof(float), 256) +
+    IMGFD_TRY(ws_reserve(ctx, fhog_ws_bytes(g, 1, false) + align_up(in_bytes, 256) + align_up(out_n * sizeof(float), 256) +
                               upload_stage_bytes(kind, in_bytes)));
     uint8_t *d_in = (uint8_t *)ws_alloc(ctx, in_bytes);
     float *d_out = (float *)ws_alloc(ctx, out_n * sizeof(float));
@@ -520,9 +498,10 @@ imgfd_status imgfd_fhog_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, 
     FhogGeom g;
     if (!n_frames || !fhog_geometry(rows, cols, cell_size, filter_rows_padding, filter_cols_padding, &g)) return IMGFD_OK;
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t per_frame = fhog_ws_bytes(g, 1);
+    const bool fused = ctx->tune.fhog_fused && fhog_fused_supported(g, d_rgb, frame_stride_bytes);
+    const size_t per_frame = fhog_ws_bytes(g, 1, fused);
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_frames, ((size_t)2 << 30) / per_frame));
-    IMGFD_TRY(ws_reserve(ctx, fhog_ws_bytes(g, chunk)));
+    IMGFD_TRY(ws_reserve(ctx, fhog_ws_bytes(g, chunk, fused)));
     const size_t out_n = (size_t)31 * g.out_nr * g.out_nc;
     for (int f0 = 0; f0 < n_frames; f0 += chunk) {
         const int nf = std::min(chunk, n_frames - f0);

@@ -79,6 +79,13 @@ IMGFD_API int imgfd_version(void);
  *       f32 stages (products, response) never contract.  Results differ from strict only when the
  *       f64 sum sits within ~1e-16 relative of a float rounding boundary. */
 IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
+/* Lab switches.  None changes a result; the defaults are the measured best.  Each can also be given through the
+ * environment variable in brackets, which is read ONCE, when the context is created.
+ *   "fhog_fused" [IMGFD_FHOG_FUSED]  1 (default): cell_size 8 runs the fused gradient + histogram kernel; 0: stage kernels
+ *   "fhog_bands" [IMGFD_FHOG_BANDS]  bands of 8 cell rows one workgroup of that kernel marches through (0: from the batch)
+ *   "fhog_sqrt"  [IMGFD_FHOG_SQRT]   0 (default): rsq + Newton step; 1: the compiler's sqrtf (both correctly rounded)
+ * Unknown names give IMGFD_ERR_INVALID. */
+IMGFD_API imgfd_status imgfd_set_tuning(imgfd_ctx *ctx, const char *name, int value);
 
 /* ------------------------------------------------------------------ Harris */
 typedef struct {
@@ -267,6 +274,8 @@ IMGFD_API imgfd_status imgfd_k_gradient(imgfd_ctx *ctx, const float *d_I, float 
 /* K1 + K2 as the batch path runs them on u8 frames: discrete Gaussian of radius 3 (sigma_d in [1, 4/3)) and the gradient of
  * the smoothed frame in one kernel (gaussian.cpp:289-395 + gradient.cpp:17-106); the smoothed plane is not written.
  * d_u8: ny rows of nx bytes (pitch nx).  IMGFD_ERR_UNSUPPORTED for another radius. */
+/* the square root of the fused fHOG kernel for every argument 0 .. n-1 (n <= 2*255^2 + 1); variant as "fhog_sqrt" */
+IMGFD_API imgfd_status imgfd_k_fhog_sqrt(imgfd_ctx *ctx, float *d_out, int n, int variant);
 IMGFD_API imgfd_status imgfd_k_gauss_grad_u8(imgfd_ctx *ctx, const uint8_t *d_u8, float *d_Ix, float *d_Iy, int nx, int ny,
                                              float sigma_d, int grad_type);
 /* K3: the structure-tensor pass, compute_autocorrelation_matrix harris.cpp:44-70:

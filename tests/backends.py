@@ -31,6 +31,14 @@ class _Base:
     def set_fir_mode(self, mode):
         self.check(self.lib.imgfd_set_fir_mode(self.ctx, mode))
 
+    def set_tuning(self, name, value):
+        self.check(self.lib.imgfd_set_tuning(self.ctx, name.encode(), int(value)), "imgfd_set_tuning")
+
+    def k_fhog_sqrt(self, n, variant=0):
+        out = self.empty((n,), np.float32)
+        self.check(self.lib.imgfd_k_fhog_sqrt(self.ctx, self.ptr(out), n, variant), "k_fhog_sqrt")
+        return self.to_host(out)
+
     def frames(self, dev, n, nx, ny, dtype):
         esz = 1 if dtype == 0 else 4
         return _binding.Frames(self.ptr(dev), n, nx, ny, nx * ny * esz, nx * esz, dtype)

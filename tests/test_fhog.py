@@ -72,6 +72,38 @@ def test_dlib_known_answer_vectors(be, golden):
             assert np.max(np.abs(got - ref)) < TOL, (what, name, float(np.max(np.abs(got - ref))))
 
 
+def test_fused_sqrt_exhaustive(be):
+    """the square root of the fused cell-size-8 kernel (fhog_fused.hip: one v_rsq_f32 + a Newton step) is the correctly
+    rounded one for every squared gradient length that can occur, 0 .. 2 * 255^2"""
+    n = 2 * 255 * 255 + 1
+    ref = np.sqrt(np.arange(n, dtype=np.float32))
+    for variant in (0, 1):
+        got = be.k_fhog_sqrt(n, variant)
+        bad = np.flatnonzero(got.view(np.uint32) != ref.view(np.uint32))
+        assert bad.size == 0, (variant, bad[:8], got[bad[:8]], ref[bad[:8]])
+
+
+@pytest.mark.parametrize("bands,sq", [(1, 0), (2, 0), (3, 1), (0, 0)])
+@pytest.mark.parametrize("w,h", [(264, 200), (1032, 520), (136, 72), (264, 1100), (252, 131)])
+def test_fused_kernel_shapes(be, w, h, bands, sq):
+    """fhog_hist8 (cell_size 8, width % 4 == 0): border / interior / tail-column workgroups, partial tiles, workgroups that
+    march through several bands -- on noise (every orientation, colour ties, large gradients) as well as the synthetic
+    frame; the stage kernels (fhog_fused 0) give the same bits"""
+    rng = np.random.default_rng(w * 7 + h)
+    noise = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    noise[:, ::7] = noise[:, 1::7][:, :noise[:, ::7].shape[1]]  # equal neighbours: colour-channel ties
+    try:
+        be.set_tuning("fhog_bands", bands); be.set_tuning("fhog_sqrt", sq)
+        for rgb in (noise, synth.frame_rgb(5, w, h)):
+            ref = oracle.fhog(rgb)
+            check(be.fhog(rgb), ref)
+            be.set_tuning("fhog_fused", 0)
+            check(be.fhog(rgb), ref)
+            be.set_tuning("fhog_fused", 1)
+    finally:
+        be.set_tuning("fhog_bands", 0); be.set_tuning("fhog_sqrt", 0); be.set_tuning("fhog_fused", 1)
+
+
 def test_batch_dev(be):
     frames = np.stack([synth.frame_rgb(70 + f, 96, 80) for f in range(3)])
     got = be.fhog_dev(frames, 8, 1, 1)
