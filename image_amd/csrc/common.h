@@ -39,14 +39,14 @@ struct imgfd_ctx {
     // second context (own stream and workspace) for work that overlaps this context's stream (imgfd_detect_dev)
     imgfd_ctx *side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_gate = nullptr, ev_join = nullptr;
-    // fHOG: orientation of every integer gradient (fhog_fused.hip), built on first use
-    unsigned char *fhog_olut = nullptr;
+    // fHOG: magnitude + orientation of every integer gradient (fhog_fused.hip), built on first use
+    unsigned *fhog_lut = nullptr;
     // lab switches (imgfd_set_tuning / IMGFD_* environment variables read ONCE at context creation; include/imgfd.h
     // lists them).  Defaults are the measured best; none changes a result.
     struct Tune {
         int fhog_fused = 1;  // 1: cell_size 8 through fhog_hist8; 0: the three stage kernels
         int fhog_bands = 0;  // bands a workgroup of fhog_hist8 marches through (0: chosen from the batch size)
-        int fhog_sqrt = 0;   // 0: rsq + Newton step, 1: compiler sqrtf
+        int fhog_threads = 256;  // workgroup size of fhog_hist8 (256 | 512)
     } tune;
     // in-pipeline K3 timing (imgfd_profile_k3)
     bool prof_on = false;

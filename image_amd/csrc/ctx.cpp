@@ -10,7 +10,7 @@ const std::vector<TuneKey> &tune_keys()
     static const std::vector<TuneKey> keys = {
         {"fhog_fused", "IMGFD_FHOG_FUSED", &imgfd_ctx::Tune::fhog_fused},
         {"fhog_bands", "IMGFD_FHOG_BANDS", &imgfd_ctx::Tune::fhog_bands},
-        {"fhog_sqrt", "IMGFD_FHOG_SQRT", &imgfd_ctx::Tune::fhog_sqrt},
+        {"fhog_threads", "IMGFD_FHOG_THREADS", &imgfd_ctx::Tune::fhog_threads},
     };
     return keys;
 }
@@ -73,7 +73,7 @@ void imgfd_ctx_destroy(imgfd_ctx *ctx)
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->aux) (void)hipFree(ctx->aux);
-    if (ctx->fhog_olut) (void)hipFree(ctx->fhog_olut);
+    if (ctx->fhog_lut) (void)hipFree(ctx->fhog_lut);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

@@ -35,9 +35,9 @@ __device__ __forceinline__ int fhog_best_orientation(int tx, int ty)
     return best_o;
 }
 
-// fhog_fused.hip.  The orientation of every possible gradient (tx, ty in -255..255) as a table of 511 x 512 bytes,
-// filled on the device with fhog_best_orientation: olut[(ty + 255) * 512 + tx + 255].
-#define FHOG_OLUT_BYTES (511 * 512)
+// fhog_fused.hip.  Magnitude and orientation of every possible gradient (tx, ty in -255..255) as a table of 511 x 512 packed
+// words, filled on the device: lut[(ty + 255) * 512 + tx + 255].
+#define FHOG_LUT_BYTES (511 * 512 * 4)
 bool fhog_fused_supported(const FhogGeom &g, const uint8_t *d_rgb, size_t frame_stride);
 imgfd_status fhog_fused_hist(imgfd_ctx *ctx, const uint8_t *d_rgb, size_t frame_stride, const FhogGeom &g, int nf, float *hist,
                              float *norm);

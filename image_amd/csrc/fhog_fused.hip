@@ -9,14 +9,17 @@
 //   phase 1  a workgroup stages the (v, o) of a window of 72 x 136 pixels in LDS: v = sqrt of the squared gradient length
 //            of the strongest colour channel, o = its orientation bin.  A thread owns 4 consecutive pixels (12 bytes =
 //            3 dwords) of a run of rows and slides a 3-row register window down the run: 5 dword loads per 4 pixels.
-//            The orientation is a table look-up -- the bin is a pure function of the integer gradient (tx, ty), 511 x 511
-//            possibilities, tabulated once per context by the reference's own float chain (fhog_best_orientation) --
-//            instead of nine dot products per pixel.
+//            Both are ONE table look-up: the packed (v, o) word is a pure function of the integer gradient (tx, ty), 511 x 511
+//            possibilities, tabulated once per context by the reference's own float chain (fhog_best_orientation) and a
+//            correctly rounded sqrtf -- instead of nine dot products and a square root per pixel.  Gradients of at most
+//            16 grey levels per axis -- most pixels of a photograph -- are answered from a 4 KB copy of the table's centre
+//            in LDS; the others gather from the 1 MB table in L2 (the gathers, not arithmetic, bound phase 1).
 //   phase 2  one thread per histogram cell (8 x 16 cells) walks the 16 x 16 pixels that vote into it in raster order
-//            and adds wy * (wx * v) into bin o of its private LDS histogram with ds_add_f32.  LDS operations of one wave
-//            execute in order and no other thread touches the cell, so the bin receives the reference's summands in the
-//            reference's order; there is no read-modify-write round trip to wait for.  With cell_size 8 the bilinear
-//            weights are the dyadic constants (k + 0.5) / 8, exact in float, so they are compile-time literals.
+//            and adds wy * (wx * v) into bin o of its private LDS histogram, four votes per LDS round trip (the bins of a
+//            batch are read together; a vote whose bin an earlier vote of the batch touched continues from that sum).  LDS
+//            operations of one wave execute in order and no other thread touches the cell, so every bin receives the
+//            reference's summands in the reference's order.  With cell_size 8 the bilinear weights are the dyadic
+//            constants (k + 0.5) / 8, exact in float, so they are compile-time literals.
 //   A workgroup marches down `bands` bands of 8 cell rows: the last 8 pixel rows of a band's window are the first 8 of
 //   the next one and stay in the LDS ring.
 //
@@ -40,28 +43,22 @@ constexpr int FH_PV = FH_WX;                  // dwords per row of V
 // of 16-byte slots apart and the ds_read_b128 lane groups of phase 2 see 16 distinct slots (lane <-> cell mapping below)
 constexpr int FH_VGROUP = 8 * FH_PV + 4;
 constexpr int FH_VDW = (FH_RING / 8) * FH_VGROUP;
-constexpr int FH_PO = 144;                    // u16 per row of O (288 bytes: 8 rows = a whole number of 256-byte bank rows)
 constexpr int FH_NCELL = FH_CR * FH_CC;       // 128 cells = 128 phase-2 threads
-constexpr int FH_THREADS = 256;
-constexpr size_t FH_LDS = (size_t)FH_VDW * 4 + (size_t)FH_RING * FH_PO * 2 + (size_t)18 * FH_NCELL * 4;
+constexpr size_t FH_LDS = (size_t)FH_VDW * 4;  // dynamic part (39 KB); + 9 KB of histograms + 4 KB of table: three workgroups per CU
 
 // bilinear weight of window row / column k (0..15) of a cell: fhog.h:823-826, :838-841 with cell_size 8
 __host__ __device__ constexpr float fh_weight(int k) { return k < 8 ? (k + 0.5f) / 8 : (15.5f - k) / 8; }
 
-// sqrt of an integer 0 .. 2 * 255^2, correctly rounded.  SQ 0: one v_rsq_f32 and a Newton step whose residual is an exact
-// fma (verified against sqrtf for every possible argument: tests/test_fhog.py::test_fused_sqrt_exhaustive);
-// SQ 1: the compiler's correctly rounded sqrtf.
-template <int SQ>
-__device__ __forceinline__ float fh_sqrt(int tl)
-{
-    const float f = (float)tl;
-    if (SQ == 1) return sqrtf(f);
-    const float r = __builtin_amdgcn_rsqf(fmaxf(f, 1.0f));
-    const float y0 = f * r;
-    const float h = 0.5f * r;
-    const float e = __builtin_fmaf(-y0, y0, f);
-    return __builtin_fmaf(e, h, y0);
-}
+// A window pixel is ONE dword in LDS: v is 0 or lies in [1, 361), so its sign bit and the four high exponent bits are
+// free: the word is v's float with the exponent field lowered by 126 (bits 23..26 hold 1..9; 0 for v = 0) and the
+// orientation bin in bits 27..31.  Masked with FH_VMASK it reads as the float v * 2^-126 (a normal number, or +0);
+// phase 2 multiplies it by column weights that carry the 2^126 -- a power of two moves no significand bit, so every
+// product and sum is the reference's.  (6 bytes per pixel in two arrays allowed two workgroups per CU; the kernel is
+// bound by how many cells a CU holds, profiles/r03.)
+constexpr unsigned FH_VMASK = 0x07ffffffu, FH_EXP_SHIFT = 126u << 23;
+constexpr float FH_2P126 = 0x1p126f;
+constexpr int FH_CEN = 16;  // the LDS copy of the table covers gradients -16 .. 15 per axis (32 x 32 words)
+__device__ __forceinline__ unsigned fh_pack(float v, unsigned o) { return (max(__float_as_uint(v), FH_EXP_SHIFT) - FH_EXP_SHIFT) | (o << 27); }
 
 struct FhRows {
     int x;      // image column of the group's first pixel (multiple of 4, may lie outside the image)
@@ -69,13 +66,14 @@ struct FhRows {
     int y;      // first image row
     int wr;     // its window row (ring slot = wr mod FH_RING)
     int nrows;
+    bool live;   // false: a lane that only keeps its wave whole (wave-wide vote below); it stores nothing
 };
 
 // phase 1 for one thread: `nrows` rows of one group of 4 pixels.  EDGE: loads clamped into the image, pixels outside
 // [1, visible) vote 0, tail columns use the scalar colour rule.
-template <bool EDGE, int SQ>
-__device__ __forceinline__ void fh_phase1(const unsigned *__restrict__ img, const unsigned char *__restrict__ olut, float *V,
-                                          unsigned short *O, const FhogGeom &g, int rd, const FhRows it)
+template <bool EDGE>
+__device__ __forceinline__ void fh_phase1(const unsigned *__restrict__ img, const unsigned *__restrict__ lut, const unsigned *lut_c,
+                                          unsigned *V, const FhogGeom &g, int rd, const FhRows it)
 {
     const int d0 = 3 * (it.x / 4);  // dword of the group's first byte in its row
     int di[5];
@@ -99,29 +97,20 @@ __device__ __forceinline__ void fh_phase1(const unsigned *__restrict__ img, cons
     };
     auto byte_of = [](const unsigned(&w)[5], int b) -> int { return (int)((w[b >> 2] >> (8 * (b & 3))) & 0xffu); };
 
-    unsigned up[5], cen[5], dn[5];
-    load(it.y - 1, up);
-    load(it.y, cen);
-    load(it.y + 1, dn);
     int slot = it.wr % FH_RING;
-    // the orientation bytes of a row are consumed one row later: the look-ups stay in flight behind the next row's
-    // arithmetic
-    float pv[4] = {0.f, 0.f, 0.f, 0.f};
-    unsigned po[4] = {0u, 0u, 0u, 0u};
+    // the words of a row are stored one row later: the look-ups stay in flight behind the next row's arithmetic
+    unsigned pw[4] = {0u, 0u, 0u, 0u};
     int pslot = -1;
     auto flush = [&]() {
-        float *vdst = V + (pslot >> 3) * FH_VGROUP + (pslot & 7) * FH_PV + it.col;
-        *reinterpret_cast<float4 *>(vdst) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-        unsigned short *odst = O + pslot * FH_PO + it.col;
-        *reinterpret_cast<uint2 *>(odst) = make_uint2((po[0] << 9) | (po[1] << 25), (po[2] << 9) | (po[3] << 25));
+        unsigned *vdst = V + (pslot >> 3) * FH_VGROUP + (pslot & 7) * FH_PV + it.col;
+        if (it.live) *reinterpret_cast<uint4 *>(vdst) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
     };
-#pragma unroll 1
-    for (int r = 0; r < it.nrows; r++) {
-        unsigned nxt[5] = {0u, 0u, 0u, 0u, 0u};
-        if (r + 1 < it.nrows) load(it.y + r + 2, nxt);
-        const bool rowvalid = !EDGE || (it.y + r >= 1 && it.y + r < g.visible_nr);
-        int tl[4];
-        unsigned no[4];
+    // one row of 4 pixels from the rows above / at / below it
+    auto row = [&](const unsigned(&up)[5], const unsigned(&cen)[5], const unsigned(&dn)[5], int y) {
+        const bool rowvalid = !EDGE || (y >= 1 && y < g.visible_nr);
+        unsigned nw[4];
+        int txs[4], tys[4];
+        unsigned span = 0;
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             // simd8 get_gradient (:265-274) keeps the LATER channel on ties, the scalar one (:24-59) the EARLIER:
@@ -137,32 +126,99 @@ __device__ __forceinline__ void fh_phase1(const unsigned *__restrict__ img, cons
                 const bool take = ch == 0 || len > t - b;
                 tx = take ? gx : tx; ty = take ? gy : ty; t = take ? len : t;
             }
-            if (EDGE && !(rowvalid && ((colvalid >> p) & 1u))) t = 0;  // a zero vote leaves every sum unchanged
-            tl[p] = t;
-            no[p] = olut[(unsigned)((ty + 255) * 512 + (tx + 255))];
+            txs[p] = tx + FH_CEN; tys[p] = ty + FH_CEN;
+            span |= (unsigned)txs[p] | (unsigned)tys[p];
+        }
+        // the whole wave inside the table's centre: 4 LDS reads; otherwise 4 gathers from the table in L2 (wave-uniform)
+        if (__all(span < 2u * FH_CEN || !it.live)) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) nw[p] = lut_c[tys[p] * (2 * FH_CEN) + txs[p]];
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; p++) nw[p] = lut[(unsigned)((tys[p] + 255 - FH_CEN) * 512 + (txs[p] + 255 - FH_CEN))];
+        }
+        if (EDGE) {
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+                if (!(rowvalid && ((colvalid >> p) & 1u))) nw[p] = 0u;  // a zero vote leaves every sum unchanged
         }
         if (pslot >= 0) flush();
 #pragma unroll
-        for (int p = 0; p < 4; p++) { pv[p] = fh_sqrt<SQ>(tl[p]); po[p] = no[p]; }
+        for (int p = 0; p < 4; p++) pw[p] = nw[p];
         pslot = slot;
         slot = slot + 1 == FH_RING ? 0 : slot + 1;
+    };
+    // Four row buffers used cyclically: while row r is worked on (rows r-1, r, r+1), row r+3 is fetched into the buffer
+    // row r-1 leaves -- two rows of arithmetic between a fetch and its first use, no register moves, no conditional fetch
+    // (a fetch the compiler cannot count forces s_waitcnt vmcnt(0) on every row).  Fetches past the run re-read its last row.
+    const int ylast = it.y + it.nrows;  // the row below the run's last row
+    unsigned b0[5], b1[5], b2[5], b3[5];
+    load(it.y - 1, b0);
+    load(it.y, b1);
+    load(it.y + 1, b2);
+    load(min(it.y + 2, ylast), b3);
+    int r = 0;
+#pragma unroll 1
+    for (; r + 4 <= it.nrows; r += 4) {
+        row(b0, b1, b2, it.y + r);     load(min(it.y + r + 3, ylast), b0);
+        row(b1, b2, b3, it.y + r + 1); load(min(it.y + r + 4, ylast), b1);
+        row(b2, b3, b0, it.y + r + 2); load(min(it.y + r + 5, ylast), b2);
+        row(b3, b0, b1, it.y + r + 3); load(min(it.y + r + 6, ylast), b3);
+    }
+#pragma unroll 1
+    for (; r < it.nrows; r++) {
+        row(b0, b1, b2, it.y + r);
 #pragma unroll
-        for (int k = 0; k < 5; k++) { up[k] = cen[k]; cen[k] = dn[k]; dn[k] = nxt[k]; }
+        for (int k = 0; k < 5; k++) { b0[k] = b1[k]; b1[k] = b2[k]; b2[k] = b3[k]; }
+        load(min(it.y + r + 3, ylast), b3);
     }
     flush();
 }
 
+// The 16 votes of one window row of a cell, in batches of 4.  A bin update is a read-modify-write of LDS (ds_add_f32 keeps
+// the order too, but runs at ~3 cycles per LANE: 367 us per tile, profiles/r03): the four bins of a batch are read up
+// front, a vote whose bin an earlier vote of the batch already updated continues from that vote's sum (the forwarding
+// selects below) -- the reference's order of additions per bin -- and the four sums are stored in vote order, so the later
+// of two stores to one bin stays.  One LDS round trip per 4 votes instead of per vote.
+template <bool TAIL>
+__device__ __forceinline__ void fh_vote_row(float *bins, const unsigned (&pw)[16], float wy, unsigned tailbits)
+{
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        float *a[4];
+        float w[4], r[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int kk = 4 * q + u;
+            a[u] = reinterpret_cast<float *>(reinterpret_cast<char *>(bins) + ((pw[kk] >> 27) << 9));
+            r[u] = *a[u];
+            const float x = __uint_as_float(pw[kk] & FH_VMASK);  // v * 2^-126
+            // :863-870: vy * (vx * v); scalar tail, :951-954: (vy * vx) * v
+            w[u] = TAIL && ((tailbits >> kk) & 1u) ? (wy * fh_weight(kk) * FH_2P126) * x : wy * ((fh_weight(kk) * FH_2P126) * x);
+        }
+        const float s0 = r[0] + w[0];
+        const float s1 = (a[1] == a[0] ? s0 : r[1]) + w[1];
+        const float s2 = (a[2] == a[1] ? s1 : (a[2] == a[0] ? s0 : r[2])) + w[2];
+        const float s3 = (a[3] == a[2] ? s2 : (a[3] == a[1] ? s1 : (a[3] == a[0] ? s0 : r[3]))) + w[3];
+        *a[0] = s0; *a[1] = s1; *a[2] = s2; *a[3] = s3;
+    }
+}
+
 // hist[(hr*HC + hc)*18 + o] for 1 <= hr <= cells_nr, 1 <= hc <= cells_nc (the layout of fhog_cell_hist) and the cell
 // energies norm[(hr-1)*cells_nc + hc-1] (:959-968).  grid: (cell columns / 16, band groups, frames).
-template <int SQ>
-__global__ void __launch_bounds__(FH_THREADS) fhog_hist8(const unsigned char *__restrict__ rgb, size_t frame_stride,
-                                                         const unsigned char *__restrict__ olut, float *__restrict__ hist,
+template <int NT>
+__global__ void __launch_bounds__(NT) fhog_hist8(const unsigned char *__restrict__ rgb, size_t frame_stride,
+                                                         const unsigned *__restrict__ lut, float *__restrict__ hist,
                                                          float *__restrict__ norm, FhogGeom g, int bands_per_wg)
 {
-    HIP_DYNAMIC_SHARED(float, lds)
-    float *V = lds;
-    unsigned short *O = reinterpret_cast<unsigned short *>(lds + FH_VDW);
-    float *H = reinterpret_cast<float *>(O + FH_RING * FH_PO);
+    HIP_DYNAMIC_SHARED(unsigned, lds)
+    unsigned *V = lds;
+    __shared__ unsigned lut_c[4 * FH_CEN * FH_CEN];
+    for (int e = threadIdx.x; e < 4 * FH_CEN * FH_CEN; e += NT)
+        lut_c[e] = lut[(e / (2 * FH_CEN) - FH_CEN + 255) * 512 + (e % (2 * FH_CEN) - FH_CEN + 255)];
+    __syncthreads();
+    __shared__ float H[18 * FH_NCELL];  // the cell histograms: an object of its own, so that the (v, o) reads of the next
+                                        // window row may be scheduled across the bin stores
 
     const int tid = threadIdx.x;
     const int f = blockIdx.z;
@@ -174,32 +230,39 @@ __global__ void __launch_bounds__(FH_THREADS) fhog_hist8(const unsigned char *__
     const int x0 = FH_CS * hc0 - 12;        // image column of window column 0 (128 bx - 4)
     const int Y0 = FH_CS * (1 + FH_CR * k0) - 12;  // image row of window row 0 (64 k0 - 4)
     // the two waves that run phase 2 alternate between workgroups (a workgroup's waves go to the four SIMDs in turn)
-    const int role = (blockIdx.x + blockIdx.y) & 1;
+    const int role = (blockIdx.x + blockIdx.y) & (NT / 128 - 1);
     const bool cols_inside = x0 >= 4 && x0 + FH_WX + 1 <= min(g.visible_nc, g.body_end);
     const bool tail_window = x0 + FH_WX > g.body_end;
 
     for (int k = k0; k < k1; k++) {
         const int i = k - k0;
-        // ---- phase 1: (v, o) of the window rows that are not in the ring yet
-        const int wr_first = i ? FH_NEW * i + FH_CS : 0;
-        const int seg_rows = i ? FH_CS : FH_CS + 1;  // 8 run segments of 8 rows (9 in the first band: 72 rows)
-        const int y_first = Y0 + wr_first, y_end = Y0 + FH_NEW * i + FH_RING;
+        // ---- phase 1: (v, o) of the window rows that are not in the ring yet: rows 8..71 of the band's window (and rows 0..7
+        // in the workgroup's first band).  The LDS window, not registers or wave slots, limits the workgroups per CU, so
+        // the workgroup is wide: NT / 32 run segments of 64 * 32 / NT rows each over window columns 0..127, then one
+        // row per thread for the leftovers (columns 128..135; rows 0..7 of a first band).
+        constexpr int SEGS = NT / 32, SEG_ROWS = FH_NEW / SEGS;
+        const int wr_main = FH_NEW * i + FH_CS;
+        const int y_first = Y0 + (i ? wr_main : 0), y_end = Y0 + FH_NEW * i + FH_RING;
         const bool edge = !(cols_inside && y_first >= 1 && y_end <= g.visible_nr);
-#pragma unroll 1
-        for (int pass = 0; pass < 2; pass++) {
+        {
             FhRows it;
-            if (pass == 0) {  // window columns 0..127: 32 groups x 8 run segments
-                const int grp = tid & 31, seg = tid >> 5;
-                it.x = x0 + 4 * grp; it.col = 4 * grp;
-                it.wr = wr_first + seg * seg_rows; it.y = Y0 + it.wr; it.nrows = seg_rows;
-            } else {          // window columns 128..135: one row per thread
-                if (tid >= 2 * 8 * seg_rows) break;
-                const int e = tid & 1, row = tid >> 1;
-                it.x = x0 + 128 + 4 * e; it.col = 128 + 4 * e;
-                it.wr = wr_first + row; it.y = Y0 + it.wr; it.nrows = 1;
+            it.live = true;
+            const int grp = tid & 31, seg = tid >> 5;
+            it.x = x0 + 4 * grp; it.col = 4 * grp;
+            it.wr = wr_main + seg * SEG_ROWS; it.y = Y0 + it.wr; it.nrows = SEG_ROWS;
+            if (edge) fh_phase1<true>(img, lut, lut_c, V, g, rd, it);
+            else fh_phase1<false>(img, lut, lut_c, V, g, rd, it);
+            const int n_left = 2 * FH_NEW + (i ? 0 : FH_CS * (FH_WX / 4));
+#pragma unroll 1
+            for (int first = 0; first < n_left; first += NT) {
+                it.live = first + tid < n_left;
+                const int item = min(first + tid, n_left - 1);
+                if (item < 2 * FH_NEW) { it.col = 128 + 4 * (item & 1); it.wr = wr_main + (item >> 1); }
+                else { const int u = item - 2 * FH_NEW; it.col = 4 * (u % (FH_WX / 4)); it.wr = u / (FH_WX / 4); }
+                it.x = x0 + it.col; it.y = Y0 + it.wr; it.nrows = 1;
+                if (edge) fh_phase1<true>(img, lut, lut_c, V, g, rd, it);
+                else fh_phase1<false>(img, lut, lut_c, V, g, rd, it);
             }
-            if (edge) fh_phase1<true, SQ>(img, olut, V, O, g, rd, it);
-            else fh_phase1<false, SQ>(img, olut, V, O, g, rd, it);
         }
         __syncthreads();
         // ---- phase 2: one thread per cell.  Lane <-> cell: lane bits 0,1 -> cell column bits 0,1; bit 3 -> column bit 2;
@@ -225,37 +288,18 @@ __global__ void __launch_bounds__(FH_THREADS) fhog_hist8(const unsigned char *__
             }();
 #pragma unroll
             for (int half = 0; half < 2; half++) {
-                const float *vrow = V + s8 * FH_VGROUP + FH_CS * cc;
-                const unsigned short *orow = O + s8 * 8 * FH_PO + FH_CS * cc;
+                const unsigned *vrow = V + s8 * FH_VGROUP + FH_CS * cc;
 #pragma unroll
                 for (int jj = 0; jj < 8; jj++) {
                     const float wy = fh_weight(8 * half + jj);
-                    float v[16];
-                    unsigned ow[8];
+                    unsigned pw[16];
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        const float4 a = *reinterpret_cast<const float4 *>(vrow + jj * FH_PV + 4 * q);
-                        v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+                        const uint4 a = *reinterpret_cast<const uint4 *>(vrow + jj * FH_PV + 4 * q);
+                        pw[4 * q] = a.x; pw[4 * q + 1] = a.y; pw[4 * q + 2] = a.z; pw[4 * q + 3] = a.w;
                     }
-#pragma unroll
-                    for (int q = 0; q < 2; q++) {
-                        const uint4 a = *reinterpret_cast<const uint4 *>(orow + jj * FH_PO + 8 * q);
-                        ow[4 * q] = a.x; ow[4 * q + 1] = a.y; ow[4 * q + 2] = a.z; ow[4 * q + 3] = a.w;
-                    }
-                    if (!tail_window) {
-#pragma unroll
-                        for (int kk = 0; kk < 16; kk++) {  // :863-870: vy * (vx * v)
-                            const unsigned off = (kk & 1) ? (ow[kk >> 1] >> 16) : (ow[kk >> 1] & 0xffffu);
-                            atomicAdd(reinterpret_cast<float *>(reinterpret_cast<char *>(bins) + off), wy * (fh_weight(kk) * v[kk]));
-                        }
-                    } else {
-#pragma unroll
-                        for (int kk = 0; kk < 16; kk++) {  // scalar tail, :951-954: (vy * vx) * v
-                            const unsigned off = (kk & 1) ? (ow[kk >> 1] >> 16) : (ow[kk >> 1] & 0xffffu);
-                            const float w = (tailbits >> kk) & 1u ? (wy * fh_weight(kk)) * v[kk] : wy * (fh_weight(kk) * v[kk]);
-                            atomicAdd(reinterpret_cast<float *>(reinterpret_cast<char *>(bins) + off), w);
-                        }
-                    }
+                    if (!tail_window) fh_vote_row<false>(bins, pw, wy, 0u);
+                    else fh_vote_row<true>(bins, pw, wy, tailbits);
                 }
                 s8 = s8 + 1 == 9 ? 0 : s8 + 1;
             }
@@ -276,17 +320,14 @@ __global__ void __launch_bounds__(FH_THREADS) fhog_hist8(const unsigned char *__
     }
 }
 
-__global__ void __launch_bounds__(512) fhog_build_olut(unsigned char *__restrict__ olut)
+// lut[(ty + 255) * 512 + tx + 255] = the packed word of the gradient (tx, ty): v = sqrtf(tx^2 + ty^2) (the compiler's correctly
+// rounded sqrtf, fhog.h:871 / :929), o by the reference's float chain
+__global__ void __launch_bounds__(512) fhog_build_lut(unsigned *__restrict__ lut)
 {
     const int tx = (int)threadIdx.x - 255, ty = (int)blockIdx.x - 255;
-    olut[blockIdx.x * 512 + threadIdx.x] = (unsigned char)(tx <= 255 ? fhog_best_orientation(tx, ty) : 0);
-}
-
-template <int SQ>
-__global__ void __launch_bounds__(256) fhog_sqrt_table(float *__restrict__ out, int n)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = fh_sqrt<SQ>(i);
+    unsigned w = 0;
+    if (tx <= 255) w = fh_pack(sqrtf((float)(tx * tx + ty * ty)), (unsigned)fhog_best_orientation(tx, ty));
+    lut[blockIdx.x * 512 + threadIdx.x] = w;
 }
 
 }  // namespace
@@ -299,13 +340,13 @@ bool fhog_fused_supported(const FhogGeom &g, const uint8_t *d_rgb, size_t frame_
 imgfd_status fhog_fused_hist(imgfd_ctx *ctx, const uint8_t *d_rgb, size_t frame_stride, const FhogGeom &g, int nf, float *hist,
                              float *norm)
 {
-    if (!ctx->fhog_olut) {
+    if (!ctx->fhog_lut) {
         void *p = nullptr;
-        if (hipMalloc(&p, FHOG_OLUT_BYTES) != hipSuccess) return imgfd_fail(ctx, IMGFD_ERR_OOM, "hipMalloc of the fHOG orientation table failed");
-        ctx->fhog_olut = (unsigned char *)p;
-        hipLaunchKernelGGL(fhog_build_olut, dim3(511), dim3(512), 0, ctx->stream, ctx->fhog_olut);
-        IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)fhog_hist8<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FH_LDS));
-        IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)fhog_hist8<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FH_LDS));
+        if (hipMalloc(&p, FHOG_LUT_BYTES) != hipSuccess) return imgfd_fail(ctx, IMGFD_ERR_OOM, "hipMalloc of the fHOG gradient table failed");
+        ctx->fhog_lut = (unsigned *)p;
+        hipLaunchKernelGGL(fhog_build_lut, dim3(511), dim3(512), 0, ctx->stream, ctx->fhog_lut);
+        IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)fhog_hist8<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FH_LDS));
+        IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)fhog_hist8<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FH_LDS));
     }
     const int tiles_x = ceil_div(g.cells_nc, FH_CC), n_bands = ceil_div(g.cells_nr, FH_CR);
     int bpw = ctx->tune.fhog_bands;
@@ -315,25 +356,30 @@ imgfd_status fhog_fused_hist(imgfd_ctx *ctx, const uint8_t *d_rgb, size_t frame_
     }
     bpw = std::min(bpw, n_bands);
     const dim3 grid(tiles_x, ceil_div(n_bands, bpw), nf);
-    if (ctx->tune.fhog_sqrt == 1)
-        hipLaunchKernelGGL(fhog_hist8<1>, grid, dim3(FH_THREADS), FH_LDS, ctx->stream, d_rgb, frame_stride, ctx->fhog_olut, hist, norm, g, bpw);
+    if (ctx->tune.fhog_threads == 512)
+        hipLaunchKernelGGL(fhog_hist8<512>, grid, dim3(512), FH_LDS, ctx->stream, d_rgb, frame_stride, ctx->fhog_lut, hist, norm, g, bpw);
     else
-        hipLaunchKernelGGL(fhog_hist8<0>, grid, dim3(FH_THREADS), FH_LDS, ctx->stream, d_rgb, frame_stride, ctx->fhog_olut, hist, norm, g, bpw);
+        hipLaunchKernelGGL(fhog_hist8<256>, grid, dim3(256), FH_LDS, ctx->stream, d_rgb, frame_stride, ctx->fhog_lut, hist, norm, g, bpw);
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }
 
 extern "C" {
 
-// stage doorway (tests): the sqrt of phase 1 for every argument 0 .. n-1 (n <= 2 * 255^2 + 1); variant as tune.fhog_sqrt
-imgfd_status imgfd_k_fhog_sqrt(imgfd_ctx *ctx, float *d_out, int n, int variant)
+// stage doorway (tests): the gradient table of the fused kernel, 511 x 512 packed words (built on first use)
+imgfd_status imgfd_k_fhog_lut(imgfd_ctx *ctx, uint32_t *d_out)
 {
-    if (!ctx || !d_out || n < 0) return IMGFD_ERR_INVALID;
+    if (!ctx || !d_out) return IMGFD_ERR_INVALID;
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
-    if (!n) return IMGFD_OK;
-    if (variant == 1) hipLaunchKernelGGL(fhog_sqrt_table<1>, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_out, n);
-    else hipLaunchKernelGGL(fhog_sqrt_table<0>, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_out, n);
-    IMGFD_HIP(ctx, hipGetLastError());
+    if (!ctx->fhog_lut) {
+        void *p = nullptr;
+        if (hipMalloc(&p, FHOG_LUT_BYTES) != hipSuccess) return imgfd_fail(ctx, IMGFD_ERR_OOM, "hipMalloc of the fHOG gradient table failed");
+        ctx->fhog_lut = (unsigned *)p;
+        hipLaunchKernelGGL(fhog_build_lut, dim3(511), dim3(512), 0, ctx->stream, ctx->fhog_lut);
+        IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)fhog_hist8<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FH_LDS));
+        IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)fhog_hist8<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FH_LDS));
+    }
+    IMGFD_HIP(ctx, hipMemcpyAsync(d_out, ctx->fhog_lut, FHOG_LUT_BYTES, hipMemcpyDeviceToDevice, ctx->stream));
     return IMGFD_OK;
 }
 

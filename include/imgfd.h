@@ -83,7 +83,7 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  * environment variable in brackets, which is read ONCE, when the context is created.
  *   "fhog_fused" [IMGFD_FHOG_FUSED]  1 (default): cell_size 8 runs the fused gradient + histogram kernel; 0: stage kernels
  *   "fhog_bands" [IMGFD_FHOG_BANDS]  bands of 8 cell rows one workgroup of that kernel marches through (0: from the batch)
- *   "fhog_sqrt"  [IMGFD_FHOG_SQRT]   0 (default): rsq + Newton step; 1: the compiler's sqrtf (both correctly rounded)
+ *   "fhog_threads" [IMGFD_FHOG_THREADS]  workgroup size of that kernel, 256 (default) or 512
  * Unknown names give IMGFD_ERR_INVALID. */
 IMGFD_API imgfd_status imgfd_set_tuning(imgfd_ctx *ctx, const char *name, int value);
 
@@ -274,8 +274,10 @@ IMGFD_API imgfd_status imgfd_k_gradient(imgfd_ctx *ctx, const float *d_I, float 
 /* K1 + K2 as the batch path runs them on u8 frames: discrete Gaussian of radius 3 (sigma_d in [1, 4/3)) and the gradient of
  * the smoothed frame in one kernel (gaussian.cpp:289-395 + gradient.cpp:17-106); the smoothed plane is not written.
  * d_u8: ny rows of nx bytes (pitch nx).  IMGFD_ERR_UNSUPPORTED for another radius. */
-/* the square root of the fused fHOG kernel for every argument 0 .. n-1 (n <= 2*255^2 + 1); variant as "fhog_sqrt" */
-IMGFD_API imgfd_status imgfd_k_fhog_sqrt(imgfd_ctx *ctx, float *d_out, int n, int variant);
+/* the gradient table of the fused fHOG kernel: 511 x 512 words, entry [(ty + 255) * 512 + tx + 255] for the integer gradient
+ * (tx, ty): bits 0..26 = sqrtf(tx^2 + ty^2) with the exponent field lowered by 126 (0 for a zero gradient), bits 27..31 = the
+ * orientation bin (fhog.h:846-859) */
+IMGFD_API imgfd_status imgfd_k_fhog_lut(imgfd_ctx *ctx, uint32_t *d_out);
 IMGFD_API imgfd_status imgfd_k_gauss_grad_u8(imgfd_ctx *ctx, const uint8_t *d_u8, float *d_Ix, float *d_Iy, int nx, int ny,
                                              float sigma_d, int grad_type);
 /* K3: the structure-tensor pass, compute_autocorrelation_matrix harris.cpp:44-70:

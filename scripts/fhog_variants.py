@@ -19,8 +19,8 @@ for N in [int(x) for x in os.environ.get("TILES", "16,1").split(",")]:
     out = torch.empty((N, 31, nc.value, nr.value), dtype=torch.float32, device="cuda")
     def run():
         det.ctx.check(lib.imgfd_fhog_dev(ctx, frames.data_ptr(), N, S, S, S * S * 3, 8, 1, 1, out.data_ptr()), "fhog_dev")
-    for fused, bands, sq in [(0, 0, 0), (1, 0, 0), (1, 1, 0), (1, 2, 0), (1, 4, 0), (1, 8, 0), (1, 16, 0), (1, 0, 1)]:
-        for k, v in (("fhog_fused", fused), ("fhog_bands", bands), ("fhog_sqrt", sq)):
+    for fused, bands, sq in [(0, 0, 256), (1, 0, 256), (1, 1, 256), (1, 2, 256), (1, 4, 256), (1, 8, 256), (1, 16, 256), (1, 0, 512)]:
+        for k, v in (("fhog_fused", fused), ("fhog_bands", bands), ("fhog_threads", sq)):
             det.ctx.check(lib.imgfd_set_tuning(ctx, k.encode(), v), k)
         for _ in range(2): run()
         torch.cuda.synchronize()
@@ -32,5 +32,5 @@ for N in [int(x) for x in os.environ.get("TILES", "16,1").split(",")]:
         for _ in range(reps): run()
         e1.record(); e1.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        print(json.dumps({"tiles": N, "fused": fused, "bands": bands, "sqrt": sq, "us_per_tile": round(1e3 * ms / N, 1),
+        print(json.dumps({"tiles": N, "fused": fused, "bands": bands, "threads": sq, "us_per_tile": round(1e3 * ms / N, 1),
                           "bits_equal_to_stage_kernels": same, "noise": bool(os.environ.get("NOISE"))}), flush=True)

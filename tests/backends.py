@@ -34,9 +34,10 @@ class _Base:
     def set_tuning(self, name, value):
         self.check(self.lib.imgfd_set_tuning(self.ctx, name.encode(), int(value)), "imgfd_set_tuning")
 
-    def k_fhog_sqrt(self, n, variant=0):
-        out = self.empty((n,), np.float32)
-        self.check(self.lib.imgfd_k_fhog_sqrt(self.ctx, self.ptr(out), n, variant), "k_fhog_sqrt")
+    def k_fhog_lut(self):
+        out = self.empty((511, 512), np.uint32)
+        self.check(self.lib.imgfd_k_fhog_lut(self.ctx, self.ptr(out)), "k_fhog_lut")
+        self.sync()
         return self.to_host(out)
 
     def frames(self, dev, n, nx, ny, dtype):

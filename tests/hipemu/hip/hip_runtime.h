@@ -315,6 +315,9 @@ static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 
 // ---- gfx950 builtins the product sources use unconditionally (emulated here, so that the kernels carry no test branches)
 static inline double __builtin_amdgcn_rsq(double x) { return 1.0 / sqrt(x); }  // v_rsq_f64: a seed, refined by the caller
+static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline float __builtin_amdgcn_rsqf(float x) { return (float)(1.0 / sqrt((double)x)); }  // v_rsq_f32 (1 ulp on the device)
 // v_perm_b32: byte k of the result is picked by selector byte k: 0..3 = bytes of b, 4..7 = bytes of a, 0x0c = 0x00
 static inline unsigned __builtin_amdgcn_perm(unsigned a, unsigned b, unsigned sel) {

@@ -72,28 +72,48 @@ def test_dlib_known_answer_vectors(be, golden):
             assert np.max(np.abs(got - ref)) < TOL, (what, name, float(np.max(np.abs(got - ref))))
 
 
-def test_fused_sqrt_exhaustive(be):
-    """the square root of the fused cell-size-8 kernel (fhog_fused.hip: one v_rsq_f32 + a Newton step) is the correctly
-    rounded one for every squared gradient length that can occur, 0 .. 2 * 255^2"""
-    n = 2 * 255 * 255 + 1
-    ref = np.sqrt(np.arange(n, dtype=np.float32))
-    for variant in (0, 1):
-        got = be.k_fhog_sqrt(n, variant)
-        bad = np.flatnonzero(got.view(np.uint32) != ref.view(np.uint32))
-        assert bad.size == 0, (variant, bad[:8], got[bad[:8]], ref[bad[:8]])
+def _orientation_table():
+    """fhog.h:846-859 in float32 for every integer gradient -255..255 (numpy rounds every product and sum to float32:
+    the reference's unfused arithmetic)"""
+    dirs = np.array([[1.0, 0.0], [0.9397, 0.3420], [0.7660, 0.6428], [0.500, 0.8660], [0.1736, 0.9848], [-0.1736, 0.9848],
+                     [-0.5000, 0.8660], [-0.7660, 0.6428], [-0.9397, 0.3420]], np.float32)
+    g = np.arange(-255, 256, dtype=np.int32)
+    tx, ty = np.meshgrid(g, g)
+    fx, fy = tx.astype(np.float32), ty.astype(np.float32)
+    best_dot = np.zeros_like(fx); best_o = np.zeros(fx.shape, np.int32)
+    for o in range(9):
+        dot = (fx * dirs[o, 0]).astype(np.float32) + (fy * dirs[o, 1]).astype(np.float32)
+        m1 = dot > best_dot
+        best_o = np.where(m1, o, best_o); best_dot = np.where(m1, dot, best_dot)
+        m2 = ~m1 & (-dot > best_dot)
+        best_o = np.where(m2, o + 9, best_o); best_dot = np.where(m2, -dot, best_dot)
+    return tx, ty, best_o
 
 
-@pytest.mark.parametrize("bands,sq", [(1, 0), (2, 0), (3, 1), (0, 0)])
+def test_fused_gradient_table_exhaustive(be):
+    """the table behind the fused cell-size-8 kernel (fhog_fused.hip), all 511 x 511 integer gradients: the magnitude is the
+    correctly rounded sqrtf(tx^2 + ty^2) (exponent field lowered by 126), the bin is the reference's float chain"""
+    lut = be.k_fhog_lut()[:, :511]
+    tx, ty, best_o = _orientation_table()
+    assert np.array_equal(lut >> 27, best_o.astype(np.uint32))
+    v = np.sqrt((tx * tx + ty * ty).astype(np.float32)).view(np.uint32)
+    want = np.where(v == 0, 0, v - (126 << 23)).astype(np.uint32)
+    assert np.array_equal(lut & 0x07FFFFFF, want)
+    assert want.max() < (1 << 27) and np.all((want >> 23)[v != 0] >= 1)  # a normal float after masking, never a denormal
+
+
+@pytest.mark.parametrize("bands,nt", [(1, 256), (2, 512), (3, 256), (0, 512)])
 @pytest.mark.parametrize("w,h", [(264, 200), (1032, 520), (136, 72), (264, 1100), (252, 131)])
-def test_fused_kernel_shapes(be, w, h, bands, sq):
+def test_fused_kernel_shapes(be, w, h, bands, nt):
     """fhog_hist8 (cell_size 8, width % 4 == 0): border / interior / tail-column workgroups, partial tiles, workgroups that
     march through several bands -- on noise (every orientation, colour ties, large gradients) as well as the synthetic
     frame; the stage kernels (fhog_fused 0) give the same bits"""
     rng = np.random.default_rng(w * 7 + h)
     noise = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    noise[h // 2:] = 100 + (noise[h // 2:] & 7)  # small gradients: the LDS copy of the table's centre
     noise[:, ::7] = noise[:, 1::7][:, :noise[:, ::7].shape[1]]  # equal neighbours: colour-channel ties
     try:
-        be.set_tuning("fhog_bands", bands); be.set_tuning("fhog_sqrt", sq)
+        be.set_tuning("fhog_bands", bands); be.set_tuning("fhog_threads", nt)
         for rgb in (noise, synth.frame_rgb(5, w, h)):
             ref = oracle.fhog(rgb)
             check(be.fhog(rgb), ref)
@@ -101,7 +121,7 @@ def test_fused_kernel_shapes(be, w, h, bands, sq):
             check(be.fhog(rgb), ref)
             be.set_tuning("fhog_fused", 1)
     finally:
-        be.set_tuning("fhog_bands", 0); be.set_tuning("fhog_sqrt", 0); be.set_tuning("fhog_fused", 1)
+        be.set_tuning("fhog_bands", 0); be.set_tuning("fhog_threads", 256); be.set_tuning("fhog_fused", 1)
 
 
 def test_batch_dev(be):
