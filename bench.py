@@ -35,17 +35,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 MEASURED_COPY_GBS = 6300.0      # float4 device-to-device copy on this part (profiles/r01/ubench.txt; the guide quotes the same)
 F64_LANE_OPS_PER_S = 34.0e12    # sustained f64 VALU lane-op/s of the add+fmac pattern at 8 waves/SIMD (profiles/r01/ubench2.txt)
+F64_LANE_OPS_HW = 256 * 4 * 16 * 2.4e9   # the hardware's issue peak: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-op/s
+RESPONSE_BYTES_PER_PX = 12.25   # the kernel the product launches: reads Ix, Iy (8 B), writes R (4 B) and a threshold byte per 4 pixels
 TENSOR_BYTES_PER_PX = 20        # read Ix,Iy (8 B), write A,B,C (12 B)
 TENSOR_F64_OPS_PER_PX = 90      # 2 passes x 3 planes x (1 mul + 7 add + 7 fma), the reference's own arithmetic
 
 
 # ------------------------------------------------------------------------------------------------ CPU legs
-def _best(fn, reps=2):
-    fn()  # warm-up (first run of a binary is several times slower in a VM)
+def _median(fn, reps=5):
+    """one warm-up run (the first run of a binary is several times slower in a VM), then the median of >= 5"""
+    fn()
     ts = []
     for _ in range(reps):
         t = time.perf_counter(); fn(); ts.append(time.perf_counter() - t)
-    return min(ts)
+    ts.sort()
+    return ts[len(ts) // 2]
 
 
 def _avail_cores():
@@ -72,25 +76,29 @@ def cpu_harris_fast9_canny(img, want_fast9=True, gpu_frame0=None):
     t_f = 0.0
     if have_ref:
         t_h = None
-        for th in sorted({min(avail, 64), min(avail, 32), min(avail, 16), min(avail, 8)}):
-            t = _best(lambda: oracle.ref_harris(f32, threads=th), reps=1)
+        sweep = {}
+        for th in sorted({min(avail, 64), min(avail, 32), min(avail, 16), min(avail, 8), avail}):   # nproc threads too
+            t = _median(lambda: oracle.ref_harris(f32, threads=th))
+            sweep[th] = round(1e3 * t, 2)
             if t_h is None or t < t_h:
                 t_h, cores = t, th
-        t_h1 = _best(lambda: oracle.ref_harris(f32, threads=1), reps=1)   # state the single-thread time too
+        t_h1 = _median(lambda: oracle.ref_harris(f32, threads=1))   # state the single-thread time too
         if want_fast9:
-            t_f = _best(lambda: oracle.ref_fast9(img, 20, True))
+            t_f = _median(lambda: oracle.ref_fast9(img, 20, True))
         kind = "reference"
     else:
-        t_h = _best(lambda: oracle.harris(f32))
+        sweep = None
+        t_h = _median(lambda: oracle.harris(f32))
         if want_fast9:
-            t_f = _best(lambda: oracle.fast9(img, 20, True))
+            t_f = _median(lambda: oracle.fast9(img, 20, True))
         kind = "port"
     parts = {"harris_ms": round(1e3 * t_h, 2)}
     if want_fast9:
         parts["fast9_ms"] = round(1e3 * t_f, 2)
     if have_ref:
         parts["harris_1_thread_ms"] = round(1e3 * t_h1, 2)
-    t_c = _best(lambda: oracle.canny(img), reps=1)
+        parts["harris_ms_by_threads"] = sweep
+    t_c = _median(lambda: oracle.canny(img))
     parts["canny_restatement_ms"] = round(1e3 * t_c, 2)
     if gpu_frame0 is not None:
         rh = oracle.ref_harris(f32, threads=cores) if have_ref else oracle.harris(f32)
@@ -108,7 +116,7 @@ def cpu_harris_fast9_canny(img, want_fast9=True, gpu_frame0=None):
     out.update({"value": round(px / total / 1e6, 3), "kind": kind, "cores": cores,
                 "reference_only": {"value": round(px / (t_h + t_f) / 1e6, 3), "unit": "Mpixels/s",
                                    "what": "Harris" + (" + FAST-9" if want_fast9 else "") + ": the reference's own sources only (no restated leg)"},
-                "sample": f"1 frame {nx}x{ny}, best of 2 after warm-up; Harris: reference src + OpenMP x{cores} (best of 8/16/32/64 threads, "
+                "sample": f"1 frame {nx}x{ny}, median of 5 after a warm-up; Harris: reference src + OpenMP x{cores} (the fastest of 8/16/32/64/{avail} threads, "
                           f"{avail} available); " + ("FAST-9: reference f9.cpp (1 thread); " if want_fast9 else "") +
                           "Canny: oracle restatement (pinned against the reference sources), 1 thread (reference needs FFTW3)",
                 "parts": parts})
@@ -248,6 +256,8 @@ class Detect4K(Workload):
              "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
              "frac_of_measured_copy": round(achieved / MEASURED_COPY_GBS, 4), "measured_copy_GBps": MEASURED_COPY_GBS,
              "frac_of_f64_issue_roof": round(f64_floor_us / us, 4),
+             "frac_of_f64_hardware_issue_peak": round(TENSOR_F64_OPS_PER_PX * NX * NY * B / F64_LANE_OPS_HW * 1e6 / us, 4),
+             "f64_hardware_issue_peak": "256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-op/s (34 T measured for dependent add+fmac chains)",
              "f64_issue_roof": f"{TENSOR_F64_OPS_PER_PX} f64 FIR lane-ops/px (the reference's double accumulation) at the {F64_LANE_OPS_PER_S / 1e12:.0f} T lane-op/s "
                                "the vector pipe sustains for add+fmac chains (profiles/r01/ubench2.txt): the kernel is bound by f64 issue, HBM second",
              "avg_launch_us": round(us, 2), "frames_per_launch": B, "algorithmic_bytes_per_launch": k3_bytes,
@@ -257,8 +267,12 @@ class Detect4K(Workload):
         if k3_pipe_n:
             per = k3_pipe_us / k3_pipe_n
             launches_per_pass = max(1, round(k3_pipe_n / max(1, steps * self.inner)))
+            fpl = max(1, self.B // launches_per_pass)
+            ach = RESPONSE_BYTES_PER_PX * NX * NY * fpl / (per * 1e-6) / 1e9
             r["in_pipeline"] = {"kernel": det.tensor_kernel_name(), "avg_launch_us": round(per, 2), "launches": k3_pipe_n,
-                                "frames_per_launch": self.B // launches_per_pass,
+                                "frames_per_launch": fpl, "algorithmic_bytes_per_px": RESPONSE_BYTES_PER_PX,
+                                "achieved": round(ach, 1), "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                                "frac_of_f64_issue_roof": round(TENSOR_F64_OPS_PER_PX * NX * NY * fpl / F64_LANE_OPS_PER_S * 1e6 / per, 4),
                                 "note": "the structure-tensor launches of the timed region itself (HIP events on the context's stream)"}
         return r
 
@@ -548,19 +562,39 @@ def free_port():
     return p
 
 
-def spawn_ranks(n, argv):
-    """`--gpus N` outside torchrun: start the N ranks ourselves, rank r on GPU r, rendezvous on 127.0.0.1."""
+def spawn_ranks(n, argv, rendezvous_timeout_s=None):
+    """`--gpus N` outside torchrun: start the N ranks ourselves, rank r on GPU r, rendezvous on 127.0.0.1.  The first rank
+    that exits with an error ends the job: its siblings are terminated (a rank that died before the rendezvous would leave
+    the others waiting for it) and its return code is the launcher's."""
     port = free_port()
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), IMGFD_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if rendezvous_timeout_s:
+            env["IMGFD_BENCH_RENDEZVOUS_S"] = str(int(rendezvous_timeout_s))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = rc or p.returncode
+    live = list(procs)
+    while live and rc == 0:
+        time.sleep(0.05)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = code
+                print(f"bench.py: rank {procs.index(p)} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                break
+    for p in live:   # only our own children, by handle
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill(); p.wait()
     return rc
 
 
@@ -571,11 +605,14 @@ def parse(argv):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configs[] entry (1-based as the judge counts them)")
     ap.add_argument("--batch", type=int, default=0, help="frames (tiles) per step per GPU; default 32 (config 2/5), 1024 (config 3), 256 (config 4)")
-    ap.add_argument("--inner", type=int, default=10, help="config 2: passes over the batch inside one step (a longer timed region)")
+    ap.add_argument("--inner", type=int, default=40, help="config 2: passes over the batch inside one step (default: a timed region of ~3 s)")
     ap.add_argument("--frames", type=int, default=10000, help="config 5: frames of the whole stream")
     ap.add_argument("--tile", type=int, default=4096, help="config 4: tile edge")
     ap.add_argument("--max-parity-frames", type=int, default=100)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="default run only: skip the short real-size runs of the other BASELINE configs that fill the line's \"configs\" entry")
+    ap.add_argument("--no-dist", action="store_true", help="N=1: do not create the (one-rank) RCCL process group for the count reductions")
     ap.add_argument("--fir-mode", type=int, default=1)
     ap.add_argument("--no-overlap", action="store_true",
                     help="run the three detectors back to back on one stream instead of imgfd_detect_dev's two-stream schedule")
@@ -585,7 +622,116 @@ def parse(argv):
                     help="test hook: every rank uses cuda:0 (functional check of the N>1 path on a 1-GPU box; not a measurement)")
     ap.add_argument("--dry-run", action="store_true",
                     help="test hook: no device work at all -- launch, rendezvous and count reduction only (CPU, gloo)")
+    ap.add_argument("--crash-rank", type=int, default=-1, help="test hook (with --dry-run): this rank exits with code 3 before the rendezvous")
     return ap.parse_args(argv)
+
+
+def measure(args, det, rank, world, dist, want_cpu, light=False):
+    """One configuration: stage the inputs, W warm-up steps, EXACTLY K timed steps between barriers (wall clock, max over
+    ranks; a HIP event pair around every step gives the per-step median beside it), counts reduced over the ranks."""
+    import torch
+
+    from image_amd import stream
+    wl = {2: lambda: Detect4K(args, det, rank, world), 3: lambda: Canny1080p(args, det, rank, world),
+          4: lambda: DlibTiles(args, det, rank, world), 5: lambda: Detect4K(args, det, rank, world, stream_mode=True)}[args.config]()
+    wl.prepare()
+    steps = args.steps if args.steps is not None else wl.default_steps()
+    on = dist is not None and dist.is_initialized()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if on and world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        wl.step()
+    barrier()
+    wl.reset()
+    det.lib.imgfd_profile_k3(det.ctx.handle, 1)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for k in range(steps):
+        ev[k][0].record()
+        wl.step()
+        ev[k][1].record()
+    barrier()
+    dt = time.perf_counter() - t0
+    k3_us, k3_n = det.profile_k3_read()
+    det.lib.imgfd_profile_k3(det.ctx.handle, 0)
+    step_ms = sorted(a.elapsed_time(b) for a, b in ev)
+
+    # the path's only collectives: feature counts (sum; per-frame vectors are gathered in stream mode) and the elapsed time (max)
+    counts, dt = stream.reduce_counts(wl.count_vector(), dt, dist if on else None)
+    px_local = torch.tensor([wl.px_total(steps)], dtype=torch.int64, device="cuda")
+    px_all, _ = stream.reduce_counts(px_local, 0.0, dist if on else None)
+    per_frame = None
+    if args.config == 5:
+        per_frame = stream.gather_frame_counts(wl.frame_counts[:, :wl.cursor], dist if on else None)
+    if (counts < 0).any():
+        raise SystemExit("bench.py: a detector reported a negative feature count (record buffer overflow)")
+    res = None
+    if rank == 0:
+        ms_per_step = 1e3 * dt / steps
+        res = {
+            "metric": wl.metric, "value": round(int(px_all[0]) / dt / 1e6, 2), "unit": "Mpixels/s",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "ms_per_step_median_hip_events": round(step_ms[len(step_ms) // 2], 4), "timed_region_s": round(dt, 3),
+            "higher_is_better": True, "scaling": "weak" if args.config != 5 else "strong", "vs_baseline": None,
+            "dtype": {2: "f64-accumulate/f32 (Harris), u8 (FAST-9), f64 (Canny)", 5: "f64-accumulate/f32 (Harris), f64 (Canny)",
+                      3: "f64 (Canny)", 4: "f32 (fHOG), int32/f64 (SURF)"}[args.config],
+            "data": "synthetic",
+            "config": {**({"note": "functional check only: ranks share one device / gloo collectives"} if (args.share_device or (world > 1 and args.backend != "nccl")) else {}),
+                       **wl.describe(counts)},
+        }
+        if on:
+            res["config"]["collectives"] = f"{dist.get_backend()} ({'RCCL' if dist.get_backend() == 'nccl' else 'functional check'}), world size {dist.get_world_size()}"
+        if per_frame is not None:
+            res["config"]["per_frame_counts_gathered"] = int(per_frame.shape[1])
+            res["config"]["per_frame_counts_checksum"] = {"harris": int(per_frame[0].sum()), "canny": int(per_frame[1].sum())}
+        if args.config in (2, 5):
+            res["roofline"] = wl.roofline(k3_us, k3_n, steps)
+        else:
+            res["roofline"] = wl.roofline(k3_us, k3_n, steps, ms_per_step=ms_per_step)
+        if world == 1:
+            cb = wl.parity_and_cpu(want_cpu)
+            if cb:
+                res["cpu_baseline" if want_cpu else "parity"] = cb
+    del wl
+    torch.cuda.empty_cache()
+    return res
+
+
+def extra_configs(args, det, dist):
+    """The other BASELINE.json configurations at their real sizes, a few steps each, in this same process (N = 1): the
+    driver's one line then carries all five.  configs[4] stages 2000 of its 10 000 frames (17 GB instead of 83): the stream
+    has no state between batches, so its rate is the rate of the 10 000."""
+    import copy
+    out = {}
+    plan = [("2_batch1", dict(config=2, batch=1, inner=50, steps=20, warmup=3), False),
+            ("3", dict(config=3, batch=0, steps=3, warmup=1), True),
+            ("4", dict(config=4, batch=0, steps=2, warmup=1), True),
+            ("5", dict(config=5, batch=0, frames=2000, steps=None, warmup=1, max_parity_frames=16), False)]
+    for name, over, cpu in plan:
+        a = copy.copy(args)
+        for k, v in over.items():
+            setattr(a, k, v)
+        t0 = time.perf_counter()
+        try:
+            r = measure(a, det, 0, 1, dist, want_cpu=cpu and not args.no_cpu)
+        except Exception as e:   # one configuration must not take the headline number with it
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+            continue
+        keep = {k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "ms_per_step_median_hip_events", "dtype", "config", "roofline") if k in r}
+        for k in ("cpu_baseline", "parity"):
+            if k in r:
+                keep[k] = r[k]
+        if name == "5":
+            keep["config"]["frames_staged"] = 2000
+            keep["config"]["note"] = "2000 of the 10 000 frames staged and streamed (one pass each): the per-frame rate is the stream's"
+        keep["wall_s_incl_staging_and_checks"] = round(time.perf_counter() - t0, 1)
+        out[name] = keep
+    return out
 
 
 def main(argv=None):
@@ -594,18 +740,23 @@ def main(argv=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, argv))
 
-    import torch
-    import torch.distributed as dist
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run and rank == args.crash_rank:
+        sys.exit(3)
+
+    import datetime
+
+    import torch
+    import torch.distributed as dist
 
     from image_amd import stream
+    rdv = datetime.timedelta(seconds=int(os.environ.get("IMGFD_BENCH_RENDEZVOUS_S", "600")))
     if args.dry_run:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world > 1:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=rdv)
         counts = torch.tensor([rank + 1, 10 * (rank + 1), 100 * (rank + 1)], dtype=torch.int64)
         counts, dt = stream.reduce_counts(counts, 1.0 + rank, dist if world > 1 else None)
         if rank == 0:
@@ -620,79 +771,40 @@ def main(argv=None):
     if args.share_device:
         local = 0
     elif local >= torch.cuda.device_count():
-        raise SystemExit(f"rank {rank}: GPU {local} requested but only {torch.cuda.device_count()} visible "
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local} but only {torch.cuda.device_count()} are visible: --gpus {world} is more than this node has "
                          "(--share-device runs a functional check of the N>1 path on one GPU)")
     torch.cuda.set_device(local)
+    dist_note = None
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl" and not args.share_device:
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"), timeout=rdv)
         else:
-            dist.init_process_group("gloo")   # ranks sharing one device cannot form an RCCL communicator
+            dist.init_process_group("gloo", timeout=rdv)   # ranks sharing one device cannot form an RCCL communicator
+    elif not args.no_dist:
+        # N = 1: the count reductions still go through a (one-rank) RCCL communicator -- the code path of N > 1
+        try:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(f"cuda:{local}"), timeout=rdv)
+        except Exception as e:
+            dist_note = f"one-rank RCCL group not created: {type(e).__name__}: {e}"
 
     from image_amd.device import DeviceDetector
 
     det = DeviceDetector(local)
     det.ctx.set_fir_mode(args.fir_mode)
-    wl = {2: lambda: Detect4K(args, det, rank, world), 3: lambda: Canny1080p(args, det, rank, world),
-          4: lambda: DlibTiles(args, det, rank, world), 5: lambda: Detect4K(args, det, rank, world, stream_mode=True)}[args.config]()
-    wl.prepare()
-    steps = args.steps if args.steps is not None else wl.default_steps()
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        wl.step()
-    barrier()
-    wl.reset()
-    det.lib.imgfd_profile_k3(det.ctx.handle, 1)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        wl.step()
-    barrier()
-    dt = time.perf_counter() - t0
-    k3_us, k3_n = det.profile_k3_read()
-    det.lib.imgfd_profile_k3(det.ctx.handle, 0)
-
-    # the path's only collectives: feature counts (sum; per-frame vectors are gathered in stream mode) and the elapsed time (max)
-    counts, dt = stream.reduce_counts(wl.count_vector(), dt, dist if world > 1 else None)
-    px_local = torch.tensor([wl.px_total(steps)], dtype=torch.int64, device="cuda")
-    px_all, _ = stream.reduce_counts(px_local, 0.0, dist if world > 1 else None)
-    per_frame = None
-    if args.config == 5:
-        per_frame = stream.gather_frame_counts(wl.frame_counts[:, :wl.cursor], dist if world > 1 else None)
-
+    res = measure(args, det, rank, world, dist, want_cpu=not args.no_cpu)
     if rank == 0:
-        ms_per_step = 1e3 * dt / steps
-        res = {
-            "metric": wl.metric, "value": round(int(px_all[0]) / dt / 1e6, 2), "unit": "Mpixels/s",
-            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak" if args.config != 5 else "strong", "vs_baseline": None,
-            "dtype": {2: "f64-accumulate/f32 (Harris), u8 (FAST-9), f64 (Canny)", 5: "f64-accumulate/f32 (Harris), f64 (Canny)",
-                      3: "f64 (Canny)", 4: "f32 (fHOG), int32/f64 (SURF)"}[args.config],
-            "data": "synthetic",
-            "config": {**({"note": "functional check only: ranks share one device / gloo collectives"} if (args.share_device or args.backend != "nccl") else {}),
-                       **wl.describe(counts)},
-        }
-        if per_frame is not None:
-            res["config"]["per_frame_counts_gathered"] = int(per_frame.shape[1])
-            res["config"]["per_frame_counts_checksum"] = {"harris": int(per_frame[0].sum()), "canny": int(per_frame[1].sum())}
-        if args.config in (2, 5):
-            res["roofline"] = wl.roofline(k3_us, k3_n, steps)
-        else:
-            res["roofline"] = wl.roofline(k3_us, k3_n, steps, ms_per_step=ms_per_step)
-        if world == 1:
-            cb = wl.parity_and_cpu(not args.no_cpu)
-            if cb:
-                res["cpu_baseline" if not args.no_cpu else "parity"] = cb
+        if dist_note:
+            res["config"]["collectives"] = dist_note
+        default_line = args.config == 2 and args.batch == 0 and world == 1 and not args.no_overlap
+        if default_line and not args.no_extra:
+            res["configs"] = extra_configs(args, det, dist)
         print(json.dumps(res))
         sys.stdout.flush()
-    if world > 1:
-        dist.barrier()
+    if dist.is_initialized():
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 

@@ -47,6 +47,9 @@ struct imgfd_ctx {
         int fhog_fused = 1;  // 1: cell_size 8 through fhog_hist8; 0: the three stage kernels
         int fhog_bands = 0;  // bands a workgroup of fhog_hist8 marches through (0: chosen from the batch size)
         int fhog_threads = 256;  // workgroup size of fhog_hist8 (256 | 512)
+        int surf_lanes = 2;      // imgfd_surf_dev: tiles alternate between the context's stream and its companion (1: one stream)
+        int surf_rec_cap = 1 << 18;  // imgfd_surf_dev: candidate records a tile's buffer holds before the tile is redone (tests lower it)
+        int surf_async = 0;      // imgfd_surf_dev: 1 = never wait for the host (a tile whose candidates overflow reports -candidates)
     } tune;
     // in-pipeline K3 timing (imgfd_profile_k3)
     bool prof_on = false;

@@ -11,6 +11,9 @@ const std::vector<TuneKey> &tune_keys()
         {"fhog_fused", "IMGFD_FHOG_FUSED", &imgfd_ctx::Tune::fhog_fused},
         {"fhog_bands", "IMGFD_FHOG_BANDS", &imgfd_ctx::Tune::fhog_bands},
         {"fhog_threads", "IMGFD_FHOG_THREADS", &imgfd_ctx::Tune::fhog_threads},
+        {"surf_lanes", "IMGFD_SURF_LANES", &imgfd_ctx::Tune::surf_lanes},
+        {"surf_async", "IMGFD_SURF_ASYNC", &imgfd_ctx::Tune::surf_async},
+        {"surf_rec_cap", "IMGFD_SURF_REC_CAP", &imgfd_ctx::Tune::surf_rec_cap},
     };
     return keys;
 }

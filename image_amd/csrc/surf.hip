@@ -193,6 +193,192 @@ __global__ void __launch_bounds__(256) surf_colscan_apply(unsigned *__restrict__
     for (; r < r1; r++) { acc += I[(size_t)r * cols + c]; I[(size_t)r * cols + c] = acc; }
 }
 
+// ---- K16, band / strip form: the image is read twice and the table written once (3 + 3 + 4 bytes per pixel; the row scan +
+// column scan above moves 3 + 4 + 4 + 8).  A WAVE owns a tile of SI_RB rows x 256 columns (4 pixels = 12 bytes per lane):
+//   surf_int_sums   per tile: the column sums over its rows (colsum[band][c]) and the row sums over its columns
+//                   (rowsum[row][strip])
+//                   and the tile total (bandstrip[band][strip])
+//   surf_int_carry  a thread per column turns colsum into the sum of the bands ABOVE (exclusive scan down the bands); one
+//                   more workgroup turns bandstrip into its 2-D exclusive prefix: the table's value above the band, left of
+//                   the strip
+//   surf_int_apply  per tile: I[r][c] = (bands above or rows of the band <= r, strips to the left: bandstrip + one wave scan
+//                   of the tile's row sums) + (rows above the band, columns of the strip <= c: one wave scan of colsum) +
+//                   (rows of the band <= r, columns of the strip <= c: running column sums and one wave scan per row).
+//                   No barrier in the two big kernels; all sums wrap like the reference's int32.
+constexpr int SI_RB = 32;       // rows per band
+constexpr int SI_MAX_STRIPS = 32;  // strips of 256 columns the carry kernel's LDS scan holds (wider images: row + column scans)
+
+__device__ __forceinline__ void si_gray4(unsigned w0, unsigned w1, unsigned w2, unsigned (&g)[4])
+{   // 4 pixels = 12 bytes; (r + g + b) / 3 in unsigned arithmetic (pixel.h:775-783)
+    g[0] = ((w0 & 0xffu) + ((w0 >> 8) & 0xffu) + ((w0 >> 16) & 0xffu)) / 3u;
+    g[1] = ((w0 >> 24) + (w1 & 0xffu) + ((w1 >> 8) & 0xffu)) / 3u;
+    g[2] = (((w1 >> 16) & 0xffu) + (w1 >> 24) + (w2 & 0xffu)) / 3u;
+    g[3] = (((w2 >> 8) & 0xffu) + ((w2 >> 16) & 0xffu) + (w2 >> 24)) / 3u;
+}
+__device__ __forceinline__ unsigned si_wave_sum(unsigned v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ unsigned si_wave_incl(unsigned v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+// rows r .. r+3 of a lane's 12-byte group (rows past `r1` read as the last row and count as zero)
+struct SiRows { unsigned w[4][3]; };
+__device__ __forceinline__ void si_fetch(const unsigned *src, size_t rd, int r, int r1, bool active, SiRows &o)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const bool in = active && r + k < r1;
+        const unsigned *p = src + (size_t)min(r + k, r1 - 1) * rd;
+        o.w[k][0] = in ? p[0] : 0u; o.w[k][1] = in ? p[1] : 0u; o.w[k][2] = in ? p[2] : 0u;
+    }
+}
+
+__global__ void __launch_bounds__(256) surf_int_sums(const unsigned char *__restrict__ rgb, unsigned *__restrict__ colsum,
+                                                     unsigned *__restrict__ rowsum, unsigned *__restrict__ bandstrip, int rows, int cols,
+                                                     int nstrips)
+{
+    const int lane = threadIdx.x & 63, s = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    const int c = 256 * s + 4 * lane;
+    const bool active = s < nstrips && c < cols;
+    const int r0 = b * SI_RB, r1 = min(rows, r0 + SI_RB);
+    const unsigned *src = reinterpret_cast<const unsigned *>(rgb) + 3 * (size_t)(active ? c >> 2 : 0);
+    const size_t rd = 3 * (size_t)(cols >> 2);  // dwords per row
+    unsigned acc[4] = {0u, 0u, 0u, 0u};
+    SiRows cur, nxt;
+    si_fetch(src, rd, r0, r1, active, cur);
+    for (int r = r0; r < r1; r += 4) {
+        si_fetch(src, rd, min(r + 4, r1 - 1), r1, active && r + 4 < r1, nxt);  // the next four rows are in flight during the sums
+        unsigned t[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            unsigned g[4];
+            si_gray4(cur.w[k][0], cur.w[k][1], cur.w[k][2], g);
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[e] += g[e];
+            t[k] = g[0] + g[1] + g[2] + g[3];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) t[k] = si_wave_sum(t[k]);  // four independent butterflies
+        if (lane < 4 && s < nstrips && r + lane < r1) rowsum[(size_t)(r + lane) * nstrips + s] = lane == 0 ? t[0] : lane == 1 ? t[1] : lane == 2 ? t[2] : t[3];
+        cur = nxt;
+    }
+    if (active) *reinterpret_cast<uint4 *>(colsum + (size_t)b * cols + c) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+    const unsigned tile_total = si_wave_sum(acc[0] + acc[1] + acc[2] + acc[3]);
+    if (lane == 0 && s < nstrips) bandstrip[(size_t)b * nstrips + s] = tile_total;
+}
+
+// blocks 0 .. ceil(cols / 256) - 1: the columns; the last block: the band x strip totals
+__global__ void __launch_bounds__(256) surf_int_carry(unsigned *__restrict__ colsum, unsigned *__restrict__ bandstrip, int nbands, int cols,
+                                                      int nstrips)
+{
+    __shared__ unsigned tot[SI_MAX_STRIPS][256 + 1];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < (int)gridDim.x - 1) {
+        const int c = 256 * blockIdx.x + tid;
+        if (c >= cols) return;
+        unsigned acc = 0;
+        int b = 0;
+        for (; b + 8 <= nbands; b += 8) {
+            unsigned v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = colsum[(size_t)(b + k) * cols + c];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { colsum[(size_t)(b + k) * cols + c] = acc; acc += v[k]; }
+        }
+        for (; b < nbands; b++) { const unsigned v = colsum[(size_t)b * cols + c]; colsum[(size_t)b * cols + c] = acc; acc += v; }
+        return;
+    }
+    // bandstrip[b][s] := sum over bands < b and strips < s (the table's value above the band, left of the strip), in place.
+    // Bands in chunks of 256 (a thread per band: exclusive prefix along its row), then per strip an exclusive scan down the
+    // chunk's bands (a wave per strip), carried from chunk to chunk.
+    __shared__ unsigned carry[SI_MAX_STRIPS];
+    for (int s = tid; s < nstrips; s += 256) carry[s] = 0;
+    for (int b0 = 0; b0 < nbands; b0 += 256) {
+        const int b = b0 + tid;
+        unsigned e = 0;
+        for (int s = 0; s < nstrips; s++) {
+            const unsigned x = b < nbands ? bandstrip[(size_t)b * nstrips + s] : 0u;
+            tot[s][tid] = e;
+            e += x;
+        }
+        __syncthreads();
+        const int lane = tid & 63;
+        for (int s = tid >> 6; s < nstrips; s += 4) {
+            unsigned v[4], sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { v[k] = tot[s][4 * lane + k]; sum += v[k]; }
+            unsigned run = carry[s] + si_wave_incl(sum, lane) - sum;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { tot[s][4 * lane + k] = run; run += v[k]; }
+            if (lane == 63) carry[s] = run;
+        }
+        __syncthreads();
+        if (b < nbands)
+            for (int s = 0; s < nstrips; s++) bandstrip[(size_t)b * nstrips + s] = tot[s][tid];
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) surf_int_apply(const unsigned char *__restrict__ rgb, const unsigned *__restrict__ colcarry,
+                                                      const unsigned *__restrict__ above_left, const unsigned *__restrict__ rowsum,
+                                                      unsigned *__restrict__ out, int rows, int cols, int nstrips)
+{
+    const int lane = threadIdx.x & 63, s = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    const int c = 256 * s + 4 * lane;
+    const bool active = s < nstrips && c < cols;
+    const int r0 = b * SI_RB, r1 = min(rows, r0 + SI_RB);
+    // rows above the band, columns of the strip up to c + k
+    unsigned base[4];
+    {
+        const uint4 cc = active ? *reinterpret_cast<const uint4 *>(colcarry + (size_t)b * cols + c) : make_uint4(0u, 0u, 0u, 0u);
+        base[0] = cc.x; base[1] = base[0] + cc.y; base[2] = base[1] + cc.z; base[3] = base[2] + cc.w;
+        const unsigned carry = si_wave_incl(base[3], lane) - base[3];
+#pragma unroll
+        for (int e = 0; e < 4; e++) base[e] += carry;
+    }
+    // rows <= the lane's row, strips to the left: above the band from surf_int_carry, inside it a wave scan over the row sums
+    unsigned left_of = 0;
+    if (lane < SI_RB && r0 + lane < r1 && s < nstrips)
+        for (int j = 0; j < s; j++) left_of += rowsum[(size_t)(r0 + lane) * nstrips + j];
+    left_of = si_wave_incl(left_of, lane) + (s < nstrips ? above_left[(size_t)b * nstrips + s] : 0u);
+    const unsigned *src = reinterpret_cast<const unsigned *>(rgb) + 3 * (size_t)(active ? c >> 2 : 0);
+    const size_t rd = 3 * (size_t)(cols >> 2);
+    unsigned v[4] = {0u, 0u, 0u, 0u};
+    SiRows cur, nxt;
+    si_fetch(src, rd, r0, r1, active, cur);
+    for (int r = r0; r < r1; r += 4) {
+        si_fetch(src, rd, min(r + 4, r1 - 1), r1, active && r + 4 < r1, nxt);
+        unsigned q[4][4], e[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            unsigned g[4];
+            si_gray4(cur.w[k][0], cur.w[k][1], cur.w[k][2], g);
+            v[0] += g[0]; v[1] += g[1]; v[2] += g[2]; v[3] += g[3];  // running column sums inside the band
+            q[k][0] = v[0]; q[k][1] = q[k][0] + v[1]; q[k][2] = q[k][1] + v[2]; q[k][3] = q[k][2] + v[3];
+            e[k] = q[k][3];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) e[k] = si_wave_incl(e[k], lane) - q[k][3];  // four independent scans
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned add = e[k] + __shfl(left_of, min(r + k, r1 - 1) - r0);
+            if (active && r + k < r1)
+                *reinterpret_cast<uint4 *>(out + (size_t)(r + k) * cols + c) =
+                    make_uint4(base[0] + add + q[k][0], base[1] + add + q[k][1], base[2] + add + q[k][2], base[3] + add + q[k][3]);
+        }
+        cur = nxt;
+    }
+}
+
 // (get_sum_of_area, integral_image.h:64-96, in uint32 arithmetic = the reference's wrapping int32, appears below in
 // its interior form: br - bl - tr + tl.)
 
@@ -617,12 +803,13 @@ __global__ void __launch_bounds__(NMS_WORDS) surf_nms_masked(const double *__res
 // point get_interest_points emitted first comes first (what a stable sort would do; the reference's std::sort over
 // reverse iterators leaves the order of exact ties to the library's introsort).  As a 128-bit value: (score bits, ~key),
 // larger = better (scores are non-negative doubles: their bit patterns order like the values; keys are unique).
-//   1. radix select, 16 passes of 8 bits from the top: the composite of the lim-th best record
-//   2. the <= lim records at or above it are collected, ranked among themselves (all pairs, composites staged through LDS)
+//   1. radix select, up to 16 passes of 8 bits from the top over shrinking candidate lists: the lim best records
+//   2. they are ranked among themselves (bitonic sort of up to 2048 composites in LDS; all pairs beyond)
 //   3. in rank order: drop the points whose 32*scale box leaves the image (:271-285), compact with a block scan, write
 //      x, y, scale for K19 and the head of the feature record (x, y, -, pyramid_scale, score, laplacian)
 // counts_out[0] = points kept (or -candidates when the record buffer overflowed: nothing is written then).
 #define SR_NT 1024
+#define SR_SORT 2048  /* selected records the LDS sort of surf_rank_select holds; more: all-pairs ranking */
 struct SurfRankParams {
     const SurfRecord *rec;
     const unsigned long long *count;
@@ -630,6 +817,7 @@ struct SurfRankParams {
     unsigned lim;            // min(max_points, rows of the feature buffer)
     int rows, cols;
     unsigned *sel, *order;   // scratch, lim entries each
+    unsigned *cand;          // scratch, 2 x cap entries (the candidate lists of the radix select)
     double *pts;             // lim x 3 for K19
     double *feat;            // lim x 70 feature records of this tile
     long long *count_out;    // d_counts[f]
@@ -656,9 +844,9 @@ __device__ __forceinline__ bool surf_better(unsigned long long sa, unsigned long
 __global__ void __launch_bounds__(SR_NT) surf_rank_select(SurfRankParams q)
 {
     __shared__ unsigned hist[256];
-    __shared__ unsigned long long thr_hi, thr_lo;   // composite of the lim-th best record (prefix built pass by pass)
-    __shared__ unsigned want, nsel, scan[SR_NT], carry;
-    __shared__ unsigned long long st_s[SR_NT], st_k[SR_NT];
+    __shared__ unsigned want, nsel, ncand, cut, scan[SR_NT], carry;
+    __shared__ unsigned long long st_s[SR_SORT], st_k[SR_SORT];
+    __shared__ unsigned perm[SR_SORT];
     const int tid = threadIdx.x;
     const unsigned long long cnt = *q.count;
     if (cnt > q.cap) {  // more candidates than the record buffer holds: report, leave the feature rows alone
@@ -671,69 +859,104 @@ __global__ void __launch_bounds__(SR_NT) surf_rank_select(SurfRankParams q)
         if (tid == 0) { *q.count_out = 0; *q.m_out = 0; }
         return;
     }
-    // ---- 1. threshold composite (only when something has to be cut)
-    if (tid == 0) { thr_hi = 0; thr_lo = 0; want = lim; nsel = 0; }
+    // ---- 1 + 2. radix select with shrinking candidate lists: a pass builds the histogram of one composite byte over the
+    // current candidates, finds the bin in which the `want`-th best of them lies, and parts them: candidates in higher bins
+    // are selected, those in that bin are the next pass's candidates (the first passes -- sign and exponent bytes, equal for
+    // nearly all records -- keep everything; from the first mantissa byte on a pass keeps ~1/256).  Every record is read
+    // twice in pass 0 and rarely again (round 2 scanned all n records in each of 8-16 passes: 205 us per tile).
+    if (tid == 0) { want = lim; nsel = 0; ncand = 0; }
     __syncthreads();
-    if (n > lim) {
-        for (int pass = 0; pass < 16; pass++) {
-            for (int i = tid; i < 256; i += SR_NT) hist[i] = 0;
-            __syncthreads();
-            const unsigned long long phi = thr_hi, plo = thr_lo;
-            for (unsigned i0 = 0; i0 < n; i0 += SR_NT) {  // every lane makes every trip (wave intrinsics inside)
-                const unsigned i = i0 + tid;
-                const SurfRecord &r = q.rec[min(i, n - 1)];
-                const unsigned long long hi = surf_score_bits(r.score), lo = ~r.key;
-                // records that match the prefix fixed so far (the top `pass` bytes)
-                bool match;
-                if (i >= n) match = false;
-                else if (pass == 0) match = true;
-                else if (pass <= 8) match = (hi >> (8 * (8 - pass))) == (phi >> (8 * (8 - pass)));
-                else match = hi == phi && (lo >> (8 * (16 - pass))) == (plo >> (8 * (16 - pass)));
-                // histogram increment, aggregated per wave: the top bytes of the scores (sign, exponent) are the same for
-                // almost every record, and thousands of atomics on one LDS word serialise
-                int b = match ? (int)surf_comp_byte(r, pass) : -1;
-                while (__any(b >= 0)) {
-                    const int lead = __shfl(b, __ffsll((long long)__ballot(b >= 0)) - 1);
-                    const unsigned long long same = __ballot(b == lead);
-                    if (b == lead) {
-                        if (((int)__lane_id()) == __ffsll((long long)same) - 1) atomicAdd(&hist[lead], (unsigned)__popcll(same));
-                        b = -1;
-                    }
-                }
-            }
-            __syncthreads();
-            if (tid == 0) {  // walk the bins from the top: the bin in which the `want`-th best record lies
-                unsigned w = want, b = 255;
-                for (;; b--) {
-                    if (hist[b] >= w) break;
-                    w -= hist[b];
-                    if (b == 0) break;
-                }
-                want = w;
-                if (pass < 8) thr_hi |= (unsigned long long)b << (8 * (7 - pass));
-                else thr_lo |= (unsigned long long)b << (8 * (15 - pass));
-                // after the 8 score bytes: hist[b] records share the threshold score and `want` of them are needed.  If that
-                // is all of them no tie straddles the cut: the key passes are not needed (thr_lo = 0 takes every key)
-                if (pass == 7 && hist[b] == w) want = 0;
-            }
-            __syncthreads();
-            if (pass >= 7 && want == 0) break;  // uniform: `want` was written before the barrier
-        }
+    unsigned mc = n;                      // candidates of the current pass (list `cur`; pass 0: all records)
+    unsigned *cur = q.cand, *nxt = q.cand + q.cap;
+    bool ident = true;                    // cur is the identity
+    if (n <= lim) {
+        for (unsigned i = tid; i < n; i += SR_NT) q.sel[i] = i;
+        if (tid == 0) nsel = n;
+        mc = 0;
     }
-    // ---- 2. collect (composite >= threshold; everything when nothing is cut), then rank among the collected
-    {
-        const unsigned long long thi = thr_hi, tlo = thr_lo;
-        for (unsigned i = tid; i < n; i += SR_NT) {
-            const SurfRecord &r = q.rec[i];
-            const unsigned long long hi = surf_score_bits(r.score), lo = ~r.key;
-            if (n <= lim || hi > thi || (hi == thi && lo >= tlo)) {
-                const unsigned k = atomicAdd(&nsel, 1u);
-                if (k < lim) q.sel[k] = i;
+    for (int pass = 0; pass < 16 && mc > 0; pass++) {
+        for (int i = tid; i < 256; i += SR_NT) hist[i] = 0;
+        __syncthreads();
+        for (unsigned i0 = 0; i0 < mc; i0 += SR_NT) {  // every lane makes every trip (wave intrinsics inside)
+            const unsigned i = i0 + tid;
+            int b = -1;
+            if (i < mc) b = (int)surf_comp_byte(q.rec[ident ? i : cur[i]], pass);
+            // histogram increment.  The sign / exponent bytes are the same for nearly every record, and thousands of atomics on
+            // one LDS word serialise: a wave whose live lanes all hold one value adds their number once.  Diverse bytes (the
+            // mantissa passes) go to their bins lane by lane (aggregating value by value took up to 64 rounds per trip there:
+            // most of the 200 us this kernel needed in round 2).
+            const unsigned long long livem = __ballot(b >= 0);
+            if (livem) {
+                const int lead = __shfl(b, __ffsll((long long)livem) - 1);
+                if (__all(b < 0 || b == lead)) {
+                    if (((int)__lane_id()) == __ffsll((long long)livem) - 1) atomicAdd(&hist[lead], (unsigned)__popcll(livem));
+                } else if (b >= 0) {
+                    atomicAdd(&hist[b], 1u);
+                }
             }
         }
+        __syncthreads();
+        if (tid == 0) {  // walk the bins from the top: the bin in which the `want`-th best candidate lies
+            unsigned w = want, b = 255;
+            for (;; b--) {
+                if (hist[b] >= w) break;
+                w -= hist[b];
+                if (b == 0) break;
+            }
+            want = w; cut = b; ncand = 0;
+        }
+        __syncthreads();
+        const unsigned cb = cut, keep_all = hist[cb] == want ? 1u : 0u;  // the whole bin is needed: no further pass
+        if (!keep_all && hist[cb] == mc) {  // every candidate holds this byte (sign / exponent): nothing to part
+            __syncthreads();
+            continue;
+        }
+        for (unsigned i0 = 0; i0 < mc; i0 += SR_NT) {
+            const unsigned i = i0 + tid;
+            unsigned idx = 0, b = 0;
+            const bool live = i < mc;
+            if (live) { idx = ident ? i : cur[i]; b = surf_comp_byte(q.rec[idx], pass); }
+            const bool win = live && (b > cb || (keep_all && b == cb)), stay = live && !keep_all && b == cb;
+            const unsigned long long mw = __ballot(win), ms = __ballot(stay);
+            const int lane = (int)__lane_id();
+            unsigned bw = 0, bs = 0;
+            if (lane == 0) { if (mw) bw = atomicAdd(&nsel, (unsigned)__popcll(mw)); if (ms) bs = atomicAdd(&ncand, (unsigned)__popcll(ms)); }
+            bw = __shfl(bw, 0); bs = __shfl(bs, 0);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (win) q.sel[bw + (unsigned)__popcll(mw & below)] = idx;
+            if (stay) nxt[bs + (unsigned)__popcll(ms & below)] = idx;
+        }
+        __syncthreads();
+        mc = keep_all ? 0u : ncand;
+        unsigned *t = cur; cur = nxt; nxt = t;
+        ident = false;
+        __syncthreads();
     }
     __syncthreads();
     const unsigned m = min(nsel, lim);  // == lim
+    if (m <= SR_SORT) {
+        // up to SR_SORT selected records: bitonic sort of their positions in LDS, better first (all pairs -- below -- cost
+        // 10^6 comparisons in this one workgroup for the R default of 1000 points: ~80 us of the kernel's 140)
+        unsigned N = 2;
+        while (N < m) N <<= 1;
+        for (unsigned i = tid; i < N; i += SR_NT) {
+            if (i < m) { const SurfRecord &r = q.rec[q.sel[i]]; st_s[i] = surf_score_bits(r.score); st_k[i] = r.key; }
+            else { st_s[i] = 0ull; st_k[i] = ~0ull; }  // padding ranks after every record
+            perm[i] = i;
+        }
+        __syncthreads();
+        for (unsigned k = 2; k <= N; k <<= 1)
+            for (unsigned j = k >> 1; j > 0; j >>= 1) {
+                for (unsigned t = tid; t < N / 2; t += SR_NT) {
+                    const unsigned lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                    const unsigned a = perm[lo], b = perm[hi];
+                    const bool a_first = surf_better(st_s[a], st_k[a], st_s[b], st_k[b]);
+                    if (a_first != ((lo & k) == 0)) { perm[lo] = b; perm[hi] = a; }
+                }
+                __syncthreads();
+            }
+        for (unsigned i = tid; i < m; i += SR_NT) q.order[i] = q.sel[perm[i]];
+    } else
     for (unsigned base = 0; base < m; base += SR_NT) {
         const unsigned i = base + tid;
         unsigned long long si = 0, ki = 0;
@@ -816,9 +1039,30 @@ size_t surf_ws_bytes(const SurfGeom &g, size_t pyr_total, unsigned long long cap
 
 // K16-K18 for one image already in device memory; leaves the records (unordered) + count on the device
 // K16 on the stream; scratch (optional): room for the column scan's segment sums
+// scratch the band / strip form needs (bytes)
+size_t surf_integral_scratch(int rows, int cols)
+{
+    const size_t nb = ceil_div(rows, SI_RB), ns = ceil_div(cols, 256);
+    return sizeof(unsigned) * (nb * (size_t)cols + (size_t)rows * ns + nb * ns) + 512;
+}
+
 void launch_surf_integral(imgfd_ctx *ctx, const uint8_t *d_rgb, unsigned *d_I, int rows, int cols, void *scratch, size_t scratch_bytes)
 {
-    if (cols % 4 == 0 && (size_t)d_rgb % 4 == 0 && (size_t)d_I % 16 == 0)
+    const bool vec = cols % 4 == 0 && (size_t)d_rgb % 4 == 0 && (size_t)d_I % 16 == 0;
+    if (vec && scratch && (size_t)scratch % 16 == 0 && scratch_bytes >= surf_integral_scratch(rows, cols) && (size_t)rows * cols >= 65536 &&
+        ceil_div(cols, 256) <= SI_MAX_STRIPS) {
+        const int nb = ceil_div(rows, SI_RB), ns = ceil_div(cols, 256);
+        unsigned *colsum = (unsigned *)scratch;          // nb x cols (16-byte aligned rows: cols % 4 == 0)
+        unsigned *rowsum = colsum + (size_t)nb * cols;   // rows x ns
+        unsigned *bandstrip = rowsum + (size_t)rows * ns;  // nb x ns
+        const dim3 grid(ceil_div(ns, 4), nb);
+        hipLaunchKernelGGL(surf_int_sums, grid, dim3(256), 0, ctx->stream, d_rgb, colsum, rowsum, bandstrip, rows, cols, ns);
+        hipLaunchKernelGGL(surf_int_carry, dim3(ceil_div(cols, 256) + 1), dim3(256), 0, ctx->stream, colsum, bandstrip, nb, cols, ns);
+        hipLaunchKernelGGL(surf_int_apply, grid, dim3(256), 0, ctx->stream, d_rgb, (const unsigned *)colsum, (const unsigned *)bandstrip,
+                           (const unsigned *)rowsum, d_I, rows, cols, ns);
+        return;
+    }
+    if (vec)
         hipLaunchKernelGGL(surf_gray_rowscan4, dim3(rows), dim3(256), 0, ctx->stream, d_rgb, d_I, cols);
     else
         hipLaunchKernelGGL(surf_gray_rowscan, dim3(rows), dim3(256), 0, ctx->stream, d_rgb, d_I, cols);
@@ -1029,7 +1273,7 @@ imgfd_status imgfd_k_surf_integral(imgfd_ctx *ctx, const uint8_t *rgb, int rows,
     if (!rgb || !out || rows < 1 || cols < 1) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_k_surf_integral: bad argument");
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)rows * cols;
-    const size_t part_bytes = sizeof(unsigned) * 32 * (size_t)cols;  // segment sums of the column scan
+    const size_t part_bytes = std::max(sizeof(unsigned) * 32 * (size_t)cols, surf_integral_scratch(rows, cols));  // scratch of the scans
     IMGFD_TRY(ws_reserve(ctx, align_up(3 * n, 256) + align_up(4 * n, 256) + align_up(part_bytes, 256) + 512));
     uint8_t *d_rgb = (uint8_t *)ws_alloc(ctx, 3 * n);
     unsigned *d_I = (unsigned *)ws_alloc(ctx, 4 * n);
@@ -1105,16 +1349,14 @@ try {
     SurfGeom g;
     const size_t total = surf_geometry(rows, cols, &g);
     const size_t n = (size_t)rows * cols;
-    const unsigned long long rec_cap = 1ull << 18;  // candidate records per tile (12 MB); a tile with more reports -candidates in d_counts
-    const unsigned lim = (unsigned)std::min<int64_t>(std::min<int64_t>((int64_t)max_points, cap), 1 << 24);
+    const unsigned long long rec_cap = (unsigned long long)std::max(16, ctx->tune.surf_rec_cap);  // candidate records per tile (262144: 14 MB); a tile with more is redone below
     // Two lanes: even tiles on the context's stream, odd tiles on its companion stream, each lane with its own buffers.
     // A tile is a chain of a dozen kernels, several of them small (the ranking runs in ONE workgroup, the descriptor grids
     // are a few hundred workgroups): with two tiles in flight those fill the gaps of the other tile's pyramid kernels.
-    // Within a lane the tiles go through the same buffers back to back; no host synchronisation anywhere.
-    struct Lane { imgfd_ctx *c; SurfDevice d; unsigned *sel; double *k19; unsigned *m_dev; };
+    // Within a lane the tiles go through the same buffers back to back; the host is not waited for until the batch is queued.
+    struct Lane { imgfd_ctx *c; SurfDevice d; unsigned *sel, *cand; double *k19; unsigned *m_dev; unsigned lim; };
     Lane lanes[2];
-    int nlanes = n_frames > 1 ? 2 : 1;
-    if (const char *e = getenv("IMGFD_SURF_LANES")) if (atoi(e) == 1) nlanes = 1;
+    const int nlanes = n_frames > 1 && ctx->tune.surf_lanes != 1 ? 2 : 1;
     lanes[0].c = ctx;
     if (nlanes == 2) {
         imgfd_ctx *side = nullptr;
@@ -1123,48 +1365,72 @@ try {
         IMGFD_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));          // the tiles (and whatever produced them) come first
         IMGFD_HIP(ctx, hipStreamWaitEvent(side->stream, ctx->ev_fork, 0));
     }
-    for (int l = 0; l < nlanes; l++) {
-        Lane &L = lanes[l];
+    auto carve = [&](Lane &L, unsigned long long rcap) -> imgfd_status {
         imgfd_ctx *c = L.c;
-        const imgfd_status st = ws_reserve(c, surf_ws_bytes(g, total, rec_cap) + align_up(sizeof(unsigned) * 2 * (size_t)lim, 256) +
-                                                  align_up(sizeof(double) * 8 * (size_t)lim, 256) + 1024);
+        // no more records than the buffer holds can be asked for (and the all-pairs ranking is quadratic in that number)
+        L.lim = (unsigned)std::min<unsigned long long>((unsigned long long)std::min<int64_t>((int64_t)max_points, cap), rcap);
+        const imgfd_status st = ws_reserve(c, surf_ws_bytes(g, total, rcap) + align_up(sizeof(unsigned) * 2 * (size_t)L.lim, 256) +
+                                                  align_up(sizeof(unsigned) * 2 * (size_t)rcap, 256) + align_up(sizeof(double) * 8 * (size_t)L.lim, 256) + 1024);
         if (st != IMGFD_OK) return imgfd_fail(ctx, st, "imgfd_surf_dev: workspace allocation failed");
         (void)ws_alloc(c, 3 * n);  // the slot imgfd_surf uses for the uploaded image (same carving, same size function)
-        L.d.cap = rec_cap;
+        L.d.cap = rcap;
         L.d.integral = (unsigned *)ws_alloc(c, 4 * n);
         L.d.residue = (unsigned *)ws_alloc(c, 4 * n);
         L.d.mask = (unsigned long long *)ws_alloc(c, 8 * std::max<size_t>(g.mask_words, 1));
         L.d.pyr = (double *)ws_alloc(c, 8 * std::max<size_t>(total, 1));
         L.d.pyr_bytes = 8 * std::max<size_t>(total, 1);
-        L.d.rec = (SurfRecord *)ws_alloc(c, sizeof(SurfRecord) * rec_cap);
+        L.d.rec = (SurfRecord *)ws_alloc(c, sizeof(SurfRecord) * rcap);
         L.d.count = (unsigned long long *)ws_alloc(c, 256);
-        L.sel = (unsigned *)ws_alloc(c, sizeof(unsigned) * 2 * (size_t)lim);
-        L.k19 = (double *)ws_alloc(c, sizeof(double) * 8 * (size_t)lim);  // x, y, scale | angle, sin, cos, sin(-), cos(-)
-        if (!L.d.integral || !L.d.pyr || !L.d.rec || !L.d.count || !L.sel || !L.k19) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+        L.sel = (unsigned *)ws_alloc(c, sizeof(unsigned) * 2 * (size_t)L.lim);
+        L.cand = (unsigned *)ws_alloc(c, sizeof(unsigned) * 2 * (size_t)rcap);
+        L.k19 = (double *)ws_alloc(c, sizeof(double) * 8 * (size_t)L.lim);  // x, y, scale | angle, sin, cos, sin(-), cos(-)
+        if (!L.d.integral || !L.d.pyr || !L.d.rec || !L.d.count || !L.sel || !L.cand || !L.k19) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
         L.m_dev = reinterpret_cast<unsigned *>(L.d.count) + 8;  // inside the 256-byte counter slot
-    }
-    for (int f = 0; f < n_frames; f++) {
-        Lane &L = lanes[f % nlanes];
+        return IMGFD_OK;
+    };
+    auto run_tile = [&](Lane &L, int f) -> imgfd_status {
         imgfd_ctx *c = L.c;
+        const unsigned lim = L.lim;
         double *d_pts = L.k19, *d_trig = L.k19 + 3 * (size_t)lim;
         imgfd_status st = surf_device_stages(c, d_rgb + (size_t)f * frame_stride_bytes, g, detection_threshold, L.d);
         double *feat = d_features + (size_t)f * (size_t)cap * 70;
         SurfRankParams q;
         q.rec = L.d.rec; q.count = L.d.count; q.cap = L.d.cap; q.lim = lim; q.rows = rows; q.cols = cols; q.sel = L.sel; q.order = L.sel + lim;
+        q.cand = L.cand;
         q.pts = d_pts; q.feat = feat; q.count_out = reinterpret_cast<long long *>(d_counts) + f; q.m_out = L.m_dev;
         if (st == IMGFD_OK) {
             hipLaunchKernelGGL(surf_rank_select, dim3(1), dim3(SR_NT), 0, c->stream, q);
             st = launch_surf_orient(c, L.d.integral, rows, cols, d_pts, (int)lim, nullptr, d_trig, L.m_dev);
         }
         if (st == IMGFD_OK) st = launch_surf_desc(c, L.d.integral, rows, cols, d_pts, d_trig, (int)lim, feat + 6, 70, feat + 2, L.m_dev);
-        if (st != IMGFD_OK) {
-            if (c != ctx) ctx->err = c->err;
-            return st;
-        }
-    }
+        if (st != IMGFD_OK && c != ctx) ctx->err = c->err;
+        return st;
+    };
+    for (int l = 0; l < nlanes; l++) IMGFD_TRY(carve(lanes[l], rec_cap));
+    for (int f = 0; f < n_frames; f++) IMGFD_TRY(run_tile(lanes[f % nlanes], f));
     if (nlanes == 2) {  // whoever waits for the context's stream waits for the odd tiles too
         IMGFD_HIP(ctx, hipEventRecord(ctx->ev_join, lanes[1].c->stream));
         IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    }
+    IMGFD_HIP(ctx, hipGetLastError());
+    // A tile with more candidates than the record buffer holds has left -candidates in its count and no features (its
+    // best records may be among those that found no room).  Once the batch is queued its counts are read back -- one wait
+    // per call, not per tile -- and such tiles are redone with a buffer of the size they asked for.  "surf_async" 1 skips the
+    // wait: the caller then finds the negative counts.
+    if (!ctx->tune.surf_async) {
+        std::vector<int64_t> h((size_t)n_frames);
+        IMGFD_HIP(ctx, hipMemcpyAsync(h.data(), d_counts, sizeof(int64_t) * (size_t)n_frames, hipMemcpyDeviceToHost, ctx->stream));
+        IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int f = 0; f < n_frames; f++) {
+            int64_t cnt = h[(size_t)f];
+            for (int tries = 0; cnt < 0 && tries < 4; tries++) {
+                IMGFD_TRY(carve(lanes[0], (unsigned long long)(-cnt) + 1024));
+                IMGFD_TRY(run_tile(lanes[0], f));
+                IMGFD_HIP(ctx, hipMemcpyAsync(&cnt, d_counts + f, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+                IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            }
+            if (cnt < 0) return imgfd_fail(ctx, IMGFD_ERR_OOM, "imgfd_surf_dev: a tile's candidates do not fit its record buffer");
+        }
     }
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;

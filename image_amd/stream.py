@@ -27,7 +27,7 @@ def reduce_counts(counts, elapsed_s: float, dist=None, device=None):
     counts: 1-D int64 torch tensor on the rank's device.  Returns (total_counts tensor, max elapsed float)."""
     import torch
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=counts.device if device is None else device)
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():   # one rank included: the reductions of N = 1 run through the communicator too
         if dist.get_backend() == "gloo" and counts.is_cuda:  # functional checks: gloo reduces host tensors
             c, tt = counts.cpu(), t.cpu()
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
@@ -42,7 +42,7 @@ def gather_frame_counts(frame_counts, dist=None):
     """configs[4]: every rank holds a [k, n_local] int64 tensor of per-frame counts of its contiguous block of the
     stream; returns the [k, n_total] tensor in stream order on every rank (one all_gather of padded blocks)."""
     import torch
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return frame_counts
     world = dist.get_world_size()
     use_host = dist.get_backend() == "gloo" and frame_counts.is_cuda

@@ -84,6 +84,10 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  *   "fhog_fused" [IMGFD_FHOG_FUSED]  1 (default): cell_size 8 runs the fused gradient + histogram kernel; 0: stage kernels
  *   "fhog_bands" [IMGFD_FHOG_BANDS]  bands of 8 cell rows one workgroup of that kernel marches through (0: from the batch)
  *   "fhog_threads" [IMGFD_FHOG_THREADS]  workgroup size of that kernel, 256 (default) or 512
+ *   "surf_lanes" [IMGFD_SURF_LANES]  2 (default): imgfd_surf_dev alternates tiles between two HIP streams; 1: one stream
+ *   "surf_async" [IMGFD_SURF_ASYNC]  0 (default): imgfd_surf_dev reads the tile counts back once per call and redoes tiles
+ *                                    whose candidates overflowed the record buffer; 1: no wait, such a tile reports -candidates
+ *   "surf_rec_cap" [IMGFD_SURF_REC_CAP]  candidate records per tile imgfd_surf_dev buffers before it redoes the tile (262144)
  * Unknown names give IMGFD_ERR_INVALID. */
 IMGFD_API imgfd_status imgfd_set_tuning(imgfd_ctx *ctx, const char *name, int value);
 
@@ -184,12 +188,14 @@ IMGFD_API imgfd_status imgfd_surf_points_dev(imgfd_ctx *ctx, const uint8_t *d_rg
  * pyramid_scale, score, laplacian, surf[64]: the columns dlib_surf_points returns (rcpp_surf.cpp:31-52) -- strongest
  * first as get_surf_points orders them (surf.h:268-285); d_counts[f] = records of frame f (<= min(max_points, cap)).
  * atan2/sin/cos come from the device libm here, so angles and descriptors agree with imgfd_surf to ~1e-12 rather than
- * bit for bit (SURVEY.md 8d asks for 1e-6); the interest points themselves are identical.  Everything runs on the
- * context's stream without host synchronisation: the candidates of a tile are ranked on the device (the max_points
- * strongest, strongest first; two candidates with exactly equal scores keep the order get_interest_points emitted them
- * in -- the reference leaves that order to std::sort) and the descriptor kernels read the point count on the device.
- * d_counts[f] < 0: tile f produced -d_counts[f] candidates, more than the library buffers (262144); its feature rows are
- * left untouched -- use imgfd_surf for such a tile. */
+ * bit for bit (SURVEY.md 8d asks for 1e-6); the interest points themselves are identical.  No tile waits for the host:
+ * the candidates of a tile are ranked on the device (the max_points strongest, strongest first; two candidates with
+ * exactly equal scores keep the order get_interest_points emitted them in -- the reference leaves that order to std::sort)
+ * and the descriptor kernels read the point count on the device.  A tile with more candidates than the record buffer
+ * holds (262144: a very low detection_threshold on a large tile) is redone with a larger buffer: for that the counts of
+ * the batch are read back ONCE, after the whole batch has been queued (the call returns with the context's stream
+ * drained).  With the lab switch "surf_async" 1 that wait is skipped and such a tile reports d_counts[f] = -candidates
+ * with its feature rows untouched. */
 IMGFD_API imgfd_status imgfd_surf_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, int rows, int cols,
                                       size_t frame_stride_bytes, long max_points, double detection_threshold,
                                       double *d_features, int64_t cap, int64_t *d_counts);

@@ -207,6 +207,17 @@ class _Base:
         self.sync()
         return self.to_host(idx), self.to_host(dist)
 
+    def surf_dev_counts(self, frames, max_points=1000, threshold=30.0):
+        """imgfd_surf_dev: the raw per-tile counts (negative: candidates that overflowed the record buffer, surf_async 1)"""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, rows, cols, _ = frames.shape
+        d = self.to_dev(frames)
+        feat = self.empty((n, max_points, 70), np.float64); cnt = self.empty((n,), np.int64)
+        self.check(self.lib.imgfd_surf_dev(self.ctx, self.ptr(d), n, rows, cols, rows * cols * 3, max_points, threshold,
+                                           self.ptr(feat), max_points, self.ptr(cnt)), "imgfd_surf_dev")
+        self.sync()
+        return self.to_host(cnt)
+
     def surf_dev(self, frames, max_points=1000, threshold=30.0, cap=None):
         """batch path with K19 on the device; per tile a dict like surf()"""
         frames = np.ascontiguousarray(frames, np.uint8)

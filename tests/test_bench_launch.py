@@ -57,3 +57,52 @@ def test_stream_config_shards_frames_and_checks_a_sample():
     assert par["frames_checked"] >= 1 and par["frames_with_different_corner_coordinates"] == 0
     assert par["frames_with_strength_rel_err_above_1e-4"] == 0 and par["canny_mismatching_pixels_total"] == 0
     assert par["frames_whose_streamed_counts_differ"] == 0
+
+
+def test_a_crashing_rank_does_not_hang_the_launcher():
+    """rank 1 of 3 exits before the rendezvous: the launcher stops the two ranks that would wait for it and returns rank 1's
+    code, within seconds"""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry-run", "--crash-rank", "1"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert p.returncode == 3, (p.returncode, p.stderr[-1000:])
+    assert "rank 1 exited with code 3" in p.stderr
+    assert time.time() - t0 < 200
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]   # no result line from a broken job
+
+
+@pytest.mark.gpu
+def test_more_ranks_than_gpus_is_an_error_not_a_hang():
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--no-cpu", "--steps", "1", "--inner", "1", "--batch", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert "is more than this node has" in p.stderr
+
+
+@pytest.mark.gpu
+def test_nccl_world1_collectives():
+    """N = 1 creates a one-rank RCCL communicator and sends the path's three collectives through it: all_reduce(sum) of the
+    feature counts, all_reduce(max) of the elapsed time, all_gather of the per-frame count vectors (configs[4])"""
+    out = run_bench("--config", "5", "--frames", "6", "--batch", "4", "--warmup", "1", "--no-cpu")
+    assert out["config"]["collectives"].startswith("nccl (RCCL), world size 1"), out["config"].get("collectives")
+    assert out["config"]["per_frame_counts_gathered"] == 6
+    # the same reductions directly, on device tensors
+    import torch
+    import torch.distributed as dist
+    from image_amd import stream
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ["MASTER_PORT"] = str(29500 + os.getpid() % 2000)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        assert dist.get_backend() == "nccl"
+        c = torch.tensor([3, 5, 7], dtype=torch.int64, device="cuda:0")
+        tot, dt = stream.reduce_counts(c, 1.5, dist)
+        assert tot.tolist() == [3, 5, 7] and dt == 1.5 and tot.is_cuda
+        fc = torch.arange(10, dtype=torch.int64, device="cuda:0").reshape(2, 5)
+        assert torch.equal(stream.gather_frame_counts(fc, dist), fc)
+    finally:
+        dist.destroy_process_group()

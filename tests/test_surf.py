@@ -21,8 +21,10 @@ def blobs(seed, w, h, n=60):
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
-@pytest.mark.parametrize("w,h", [(64, 48), (257, 129), (400, 300), (1031, 517)])
+@pytest.mark.parametrize("w,h", [(64, 48), (257, 129), (400, 300), (1031, 517), (1028, 70), (260, 300), (256, 256), (1284, 97), (2052, 33)])
 def test_integral_image_exact(be, w, h):
+    """widths that are multiples of 4 take the band / strip form (surf_int_sums / _carry / _apply: partial strips, partial
+    bands, a single band, several workgroups per band); the others the row scan + column scan"""
     rgb = synth.frame_rgb(81, w, h)
     assert np.array_equal(be.surf_integral(rgb), oracle.surf_integral(rgb))
 
@@ -109,6 +111,27 @@ def test_surf_dev_ranks_and_cuts_on_the_device(be, max_points):
             assert np.array_equal(got[f][k][untied], ref[k][untied]), (k, max_points)
         if untied.any():
             assert np.abs(got[f]["surf"][untied] - ref["surf"][untied]).max() <= 1e-9
+
+
+def test_surf_dev_redoes_tiles_whose_candidates_overflow(be):
+    """a tile with more candidates than the record buffer holds (lab switch surf_rec_cap lowers the buffer to 16 records) is
+    redone with a larger buffer after the batch: same features as with room for everything.  With surf_async 1 the call does
+    not wait for the host and such a tile reports -candidates instead."""
+    frames = np.stack([blobs(160 + f, 320, 224) for f in range(3)])
+    ref = be.surf_dev(frames, max_points=20, threshold=5.0)
+    ncand = [len(oracle.surf_interest_points(frames[f], 5.0)) for f in range(3)]
+    assert min(ncand) > 20
+    try:
+        be.set_tuning("surf_rec_cap", 16)
+        got = be.surf_dev(frames, max_points=20, threshold=5.0)
+        for f in range(3):
+            assert len(got[f]["x"]) == len(ref[f]["x"]) > 0
+            for k in ("x", "y", "score", "pyramid_scale", "laplacian", "angle", "surf"):
+                assert np.array_equal(got[f][k], ref[f][k]), (f, k)
+        be.set_tuning("surf_async", 1)
+        assert be.surf_dev_counts(frames, max_points=20, threshold=5.0).tolist() == [-c for c in ncand]
+    finally:
+        be.set_tuning("surf_rec_cap", 1 << 18); be.set_tuning("surf_async", 0)
 
 
 def test_surf_dev_exact_score_ties_keep_emission_order(be):
