@@ -21,6 +21,11 @@ def frame_seed(seed0: int, frame: int) -> int:
     return int(seed0) + int(frame)
 
 
+def device_backend(dist) -> str:
+    """the backend that serves device tensors in the default process group ("nccl" = RCCL, or "gloo")"""
+    return "nccl" if "nccl" in str(dist.get_backend()) else "gloo"
+
+
 def reduce_counts(counts, elapsed_s: float, dist=None, device=None):
     """Sum the per-rank feature counts and take the max elapsed time over ranks.
 
@@ -28,7 +33,7 @@ def reduce_counts(counts, elapsed_s: float, dist=None, device=None):
     import torch
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=counts.device if device is None else device)
     if dist is not None and dist.is_initialized():   # one rank included: the reductions of N = 1 run through the communicator too
-        if dist.get_backend() == "gloo" and counts.is_cuda:  # functional checks: gloo reduces host tensors
+        if device_backend(dist) == "gloo" and counts.is_cuda:  # functional checks: gloo reduces host tensors
             c, tt = counts.cpu(), t.cpu()
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -45,7 +50,7 @@ def gather_frame_counts(frame_counts, dist=None):
     if dist is None or not dist.is_initialized():
         return frame_counts
     world = dist.get_world_size()
-    use_host = dist.get_backend() == "gloo" and frame_counts.is_cuda
+    use_host = device_backend(dist) == "gloo" and frame_counts.is_cuda
     fc = frame_counts.cpu() if use_host else frame_counts
     n = torch.tensor([fc.shape[1]], dtype=torch.int64, device=fc.device)
     ns = [torch.zeros_like(n) for _ in range(world)]

@@ -89,7 +89,7 @@ def test_nccl_world1_collectives():
     """N = 1 creates a one-rank RCCL communicator and sends the path's three collectives through it: all_reduce(sum) of the
     feature counts, all_reduce(max) of the elapsed time, all_gather of the per-frame count vectors (configs[4])"""
     out = run_bench("--config", "5", "--frames", "6", "--batch", "4", "--warmup", "1", "--no-cpu")
-    assert out["config"]["collectives"].startswith("nccl (RCCL), world size 1"), out["config"].get("collectives")
+    assert out["config"]["collectives"].startswith("nccl (RCCL) for the device tensors, world size 1"), out["config"].get("collectives")
     assert out["config"]["per_frame_counts_gathered"] == 6
     # the same reductions directly, on device tensors
     import torch
