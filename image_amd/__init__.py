@@ -6,7 +6,8 @@ batches from torch tensors, ``image_amd.synth``/``image_amd.pnm`` are the ingest
 Importing the package does not load the library; calling any detector does, and fails loudly when
 the HIP build is absent.
 """
-from .api import (detect_corners, image_canny_edge_detector, image_detect_corners,  # noqa: F401
-                  image_harris)
+from .api import (detect_corners, get_knnx, image_canny_edge_detector, image_detect_corners,  # noqa: F401
+                  image_fhog, image_harris, image_surf)
 
-__all__ = ["image_harris", "detect_corners", "image_detect_corners", "image_canny_edge_detector"]
+__all__ = ["image_harris", "detect_corners", "image_detect_corners", "image_canny_edge_detector", "image_fhog", "image_surf",
+           "get_knnx"]

@@ -76,6 +76,39 @@ __global__ void __launch_bounds__(256) canny_blur_cols(const double *__restrict_
 }
 
 
+// the same two passes for kernels of more than CANNY_MAX_TAPS taps (s beyond ~10): taps in global memory
+__global__ void __launch_bounds__(256) canny_blur_rows_g(const unsigned char *__restrict__ in, int row_stride, size_t frame_stride,
+                                                         double *__restrict__ tmp, int nx, int ny, const int *__restrict__ off,
+                                                         const double *__restrict__ w, int nt)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= nx) return;
+    const unsigned char *row = in + (size_t)blockIdx.z * frame_stride + (size_t)y * row_stride;
+    double acc = 0;
+    for (int i = 0; i < nt; i++) {
+        int xs = x - off[i];
+        if (xs < 0) xs += nx;
+        acc += w[i] * (double)row[xs];
+    }
+    tmp[((size_t)blockIdx.z * ny + y) * nx + x] = acc;
+}
+__global__ void __launch_bounds__(256) canny_blur_cols_g(const double *__restrict__ tmp, float *__restrict__ out, int nx, int ny,
+                                                         const int *__restrict__ off, const double *__restrict__ w, int nt)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= nx) return;
+    const double *pl = tmp + (size_t)blockIdx.z * nx * ny;
+    double acc = 0;
+    for (int i = 0; i < nt; i++) {
+        int ys = y - off[i];
+        if (ys < 0) ys += ny;
+        acc += w[i] * pl[(size_t)ys * nx + x];
+    }
+    out[((size_t)blockIdx.z * ny + y) * nx + x] = (float)acc;
+}
+
 // ------------------------------------------------------------------ K9 fast path: fused separable blur
 // One 256-thread workgroup owns a 64-column strip and marches down a segment of rows in chunks of 32:
 //   load   : u8 rows (64 + 2*HL columns, wrap-around addressing) -> LDS, next chunk prefetched in registers
@@ -877,7 +910,9 @@ namespace {
 // at most 510 * 1.3e-19 = 7e-17 to a value of order 1..255 -- below half a unit in the last place of the double
 // accumulator except for near-black neighbourhoods, and thirteen orders below the float the result is rounded to.
 #define CANNY_TAP_MIN 1e-17
-imgfd_status make_taps(imgfd_ctx *ctx, int n, double s, BlurTaps *t)
+// off / w: every kept tap; t: the same as a kernel argument when they are at most CANNY_MAX_TAPS (t->n = 0 otherwise: the
+// caller takes the kernels that read the taps from memory -- tools.c:146-185 blurs with any s)
+void make_taps(int n, double s, std::vector<int> &off, std::vector<double> &w, BlurTaps *t)
 {
     std::vector<double> k(n);
     const double inv_s = 1 / s;
@@ -887,17 +922,16 @@ imgfd_status make_taps(imgfd_ctx *ctx, int n, double s, BlurTaps *t)
         k[i] = exp(-x * x * inv_s * inv_s);
         sum += k[i];
     }
-    t->n = 0;
+    off.clear(); w.clear();
     for (int i = 0; i < n; i++) {
-        const double w = k[i] / sum;
-        if (w >= CANNY_TAP_MIN) {
-            if (t->n == CANNY_MAX_TAPS) return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "canny: sigma too large (more than 129 taps)");
-            t->off[t->n] = i;
-            t->w[t->n] = w;
-            t->n++;
-        }
+        const double v = k[i] / sum;
+        if (v >= CANNY_TAP_MIN) { off.push_back(i); w.push_back(v); }
     }
-    return IMGFD_OK;
+    t->n = 0;
+    if (off.size() <= CANNY_MAX_TAPS) {
+        t->n = (int)off.size();
+        for (int i = 0; i < t->n; i++) { t->off[i] = off[i]; t->w[i] = w[i]; }
+    }
 }
 
 // radius of the taps make_taps keeps, when they form the symmetric set {0, 1..R, n-R..n-1} (n > 2R+1);
@@ -939,6 +973,7 @@ size_t canny_ws_bytes(int nx, int ny, int nf)
     const size_t n = (size_t)nx * ny * nf;
     const size_t words = (size_t)ceil_div(nx, 64) * ny * nf;
     return align_up(n * sizeof(double), 256) + align_up(n * sizeof(float), 256) + 2 * align_up(words * 8, 256) +
+           align_up(12 * ((size_t)nx + ny), 256) + 512 +  // taps in memory (kernels of more than CANNY_MAX_TAPS taps)
            align_up(2 * (size_t)nf * ceil_div(nx, 64) * ceil_div(ny, 8), 256) +
            align_up(2 * (size_t)nf * ceil_div(ceil_div(nx, 64), 4) * ceil_div(ny, 64), 256) + 4096;
 }
@@ -946,8 +981,9 @@ size_t canny_ws_bytes(int nx, int ny, int nf)
 #define HY_SWEEPS 24  // sweeps queued per batch (the bench frames converge in 10-12); flags[] holds one word per sweep
 // Region geometry: as large as LDS allows (15 words x 540 rows: 147 KB for both planes and the ring) when the batch alone
 // fills the device, smaller regions (more workgroups, more rounds) for small batches.
-HystGeom hyst_geometry(int wpr, int ny, int nf, int num_cu, bool small)
+HystGeom hyst_geometry(const imgfd_ctx *ctx, int wpr, int ny, int nf, bool small)
 {
+    const int num_cu = ctx->num_cu;
     HystGeom g;
     g.wpr = wpr; g.ny = ny;
     // small: the finishing kernel behind the sweeps -- 8 words x 128 rows = 23 KB of LDS, so that its one workgroup per
@@ -956,9 +992,9 @@ HystGeom hyst_geometry(int wpr, int ny, int nf, int num_cu, bool small)
     g.RW = std::min(wpr, small ? 8 : 15);
     g.RH = std::min(ny, small ? 128 : 540);
     auto count = [&]() { return (long)ceil_div(wpr, g.RW) * ceil_div(ny, g.RH) * nf; };
-    if (const char *e = getenv("IMGFD_HYST_REGION")) {  // tests: "RWxRH"
-        int a = 0, b = 0;
-        if (sscanf(e, "%dx%d", &a, &b) == 2 && a >= 1 && a <= 15 && b >= 8 && b <= 540) { g.RW = std::min(wpr, a); g.RH = std::min(ny, b); }
+    if (ctx->tune.hyst_region_w >= 1 && ctx->tune.hyst_region_h >= 8) {  // tests: a given region size
+        const int a = std::min(15, ctx->tune.hyst_region_w), b = std::min(540, ctx->tune.hyst_region_h);
+        g.RW = std::min(wpr, a); g.RH = std::min(ny, b);
     } else if (!small) {
         while (count() < 2L * num_cu && (g.RH > 128 || g.RW > 4)) {
             if (g.RH > 128 && g.RH / 64 >= g.RW / 4) g.RH = std::max(128, (g.RH / 2 + 63) / 64 * 64);
@@ -974,10 +1010,9 @@ HystGeom hyst_geometry(int wpr, int ny, int nf, int num_cu, bool small)
 size_t hyst_lds_bytes(const HystGeom &g) { return 8 * (size_t)g.pitch * ((g.RH + 2) + g.RH) + 16 + 2 * HY_MAXTILES; }
 // rounds queued before the finishing kernel: enough for a component to cross a few regions back and forth; what is left
 // after them (never seen on the test images) is finished by canny_hyst_finish
-int hyst_rounds(const HystGeom &g, int wpr, int ny)
+int hyst_rounds(const imgfd_ctx *ctx, const HystGeom &g)
 {
-    (void)wpr; (void)ny;
-    if (const char *e = getenv("IMGFD_HYST_ROUNDS")) if (atoi(e) >= 1) return atoi(e);
+    if (ctx->tune.hyst_rounds >= 1) return ctx->tune.hyst_rounds;
     return std::min(16, 4 + 2 * std::max(g.rx, g.ry) / 2);
 }
 
@@ -991,9 +1026,12 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
     const int wpr = ceil_div(nx, 64);
     const size_t words = (size_t)wpr * ny * nf;
     BlurTaps tx, ty;
-    IMGFD_TRY(make_taps(ctx, nx, s, &tx));
-    IMGFD_TRY(make_taps(ctx, ny, s, &ty));
-    const int Rx = symmetric_radius(tx, nx), Ry = symmetric_radius(ty, ny);
+    std::vector<int> offx, offy;
+    std::vector<double> wtx, wty;
+    make_taps(nx, s, offx, wtx, &tx);
+    make_taps(ny, s, offy, wty, &ty);
+    const bool big = tx.n == 0 || ty.n == 0;  // more than CANNY_MAX_TAPS taps along an axis
+    const int Rx = big ? -1 : symmetric_radius(tx, nx), Ry = big ? -1 : symmetric_radius(ty, ny);
     const int R = std::max(Rx, Ry);
     const bool fast = Rx >= 0 && Ry >= 0 && R <= 32;
     double *tmp = fast ? nullptr : (double *)ws_alloc(ctx, n * sizeof(double));
@@ -1005,11 +1043,12 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
     unsigned char *act = (unsigned char *)ws_alloc(ctx, act_bytes);
     const size_t rflag_bytes = 2 * (size_t)nf * wpr * ceil_div(ny, 8);  // region flags, two parities (a region is at least 1 word x 8 rows)
     unsigned char *rflag = (unsigned char *)ws_alloc(ctx, rflag_bytes);
-    if ((!fast && !tmp) || !blur || !S || !Wm || !flags || !act || !rflag) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    const size_t tap_bytes = big ? align_up(12 * (offx.size() + offy.size()), 256) + 256 : 0;
+    char *taps_dev = big ? (char *)ws_alloc(ctx, tap_bytes) : nullptr;
+    if ((!fast && !tmp) || !blur || !S || !Wm || !flags || !act || !rflag || (big && !taps_dev)) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
     // where the caller's hook (imgfd_detect_dev: FAST-9 and the Harris chain on the other stream) is released: before the
-    // blur by default; env IMGFD_GATE=1 | 2 releases it after the blur | after the gradient/NMS kernel (experiments)
-    static const char *gate_env = getenv("IMGFD_GATE");
-    const int gate_at = gate_env ? atoi(gate_env) : 0;
+    // blur by default; lab switch "canny_gate" 1 | 2 releases it after the blur | after the gradient/NMS kernel (experiments)
+    const int gate_at = ctx->tune.canny_gate;
     if (after_front && gate_at == 0) IMGFD_TRY((*after_front)());
     if (fast) {
         BlurMarchParams p;
@@ -1027,6 +1066,20 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
         else if (R <= 18) IMGFD_TRY(launch_blur_march<18>(ctx, p, nf));
         else if (R <= 24) IMGFD_TRY(launch_blur_march<24>(ctx, p, nf));
         else IMGFD_TRY(launch_blur_march<32>(ctx, p, nf));
+    } else if (big) {
+        // doubles first (8-byte aligned), then the offsets; the host vectors die with this call: wait for the copies
+        double *d_wx = (double *)taps_dev, *d_wy = d_wx + wtx.size();
+        int *d_ox = (int *)(d_wy + wty.size()), *d_oy = d_ox + offx.size();
+        IMGFD_HIP(ctx, hipMemcpyAsync(d_wx, wtx.data(), 8 * wtx.size(), hipMemcpyHostToDevice, ctx->stream));
+        IMGFD_HIP(ctx, hipMemcpyAsync(d_wy, wty.data(), 8 * wty.size(), hipMemcpyHostToDevice, ctx->stream));
+        IMGFD_HIP(ctx, hipMemcpyAsync(d_ox, offx.data(), 4 * offx.size(), hipMemcpyHostToDevice, ctx->stream));
+        IMGFD_HIP(ctx, hipMemcpyAsync(d_oy, offy.data(), 4 * offy.size(), hipMemcpyHostToDevice, ctx->stream));
+        IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        dim3 g1(ceil_div(nx, 256), ny, nf);
+        hipLaunchKernelGGL(canny_blur_rows_g, g1, dim3(256), 0, ctx->stream, d_in, row_stride, frame_stride, tmp, nx, ny, (const int *)d_ox,
+                           (const double *)d_wx, (int)offx.size());
+        hipLaunchKernelGGL(canny_blur_cols_g, g1, dim3(256), 0, ctx->stream, (const double *)tmp, blur, nx, ny, (const int *)d_oy,
+                           (const double *)d_wy, (int)offy.size());
     } else {
         dim3 g1(ceil_div(nx, 256), ny, nf);
         hipLaunchKernelGGL(canny_blur_rows, g1, dim3(256), 0, ctx->stream, d_in, row_stride, frame_stride, tmp, nx, ny, tx);
@@ -1042,15 +1095,14 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
     // predecessor changed nothing returns at once: an idle launch costs a few microseconds), then the finishing kernel,
     // which leaves at once when the last sweep was idle and otherwise completes the frames region by region.
     {
-        const char *mode = getenv("IMGFD_HYST_MODE");  // experiment switch: "regions" = LDS-resident region rounds instead of sweeps
-        const bool region_mode = mode && !strcmp(mode, "regions");
-        HystGeom g = hyst_geometry(wpr, ny, nf, ctx->num_cu, !region_mode);
+        const bool region_mode = ctx->tune.hyst_mode == 1;  // experiment switch: LDS-resident region rounds instead of sweeps
+        HystGeom g = hyst_geometry(ctx, wpr, ny, nf, !region_mode);
         const int regions = g.rx * g.ry;
         const size_t lds = hyst_lds_bytes(g) + 2 * (size_t)regions;
         IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)canny_hyst_regions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)canny_hyst_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (region_mode) {
-            const int rounds = hyst_rounds(g, wpr, ny);
+            const int rounds = hyst_rounds(ctx, g);
             for (int r = 0; r < rounds; r++)
                 hipLaunchKernelGGL(canny_hyst_regions, dim3(regions, nf), dim3(HY_NT), lds, ctx->stream, S, Wm, g, rflag, r);
             hipLaunchKernelGGL(canny_hyst_finish, dim3(nf), dim3(HY_NT), lds, ctx->stream, S, Wm, g, rflag, rounds - 1, (const unsigned *)nullptr);
@@ -1058,7 +1110,7 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
             // a small batch has nothing to hide idle launches behind (a single 4K frame: 24 launches were 184 of its 438 us):
             // fewer sweeps are queued, the finishing kernel completes whatever an unusually long chain of weak pixels leaves
             int sweeps = nf >= 8 ? HY_SWEEPS : 14;
-            if (const char *e = getenv("IMGFD_HYST_SWEEPS")) if (atoi(e) >= 1 && atoi(e) <= HY_SWEEPS) sweeps = atoi(e);  // tests: force the finishing kernel to work
+            if (ctx->tune.hyst_sweeps >= 1 && ctx->tune.hyst_sweeps <= HY_SWEEPS) sweeps = ctx->tune.hyst_sweeps;  // tests: force the finishing kernel to work
             const int tiles_x = ceil_div(wpr, HY_WORDS), tiles_y = ceil_div(ny, 64);
             dim3 g3(ceil_div(tiles_x * tiles_y, 4), nf);
             IMGFD_HIP(ctx, hipMemsetAsync(flags, 0, sizeof(unsigned) * HY_SWEEPS, ctx->stream));
@@ -1131,7 +1183,7 @@ try {
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
     const int nx = fr->nx, ny = fr->ny;
     const size_t per_frame = canny_ws_bytes(nx, ny, 1);
-    const int chunk = sub_batch_frames(fr->n_frames, per_frame, (size_t)12 << 30);
+    const int chunk = sub_batch_frames(ctx, fr->n_frames, per_frame, (size_t)12 << 30);
     IMGFD_TRY(ws_reserve(ctx, canny_ws_bytes(nx, ny, chunk) + 512));
     for (int f0 = 0; f0 < fr->n_frames; f0 += chunk) {
         const int nf = std::min(chunk, fr->n_frames - f0);

@@ -39,6 +39,9 @@ struct imgfd_ctx {
     // second context (own stream and workspace) for work that overlaps this context's stream (imgfd_detect_dev)
     imgfd_ctx *side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_gate = nullptr, ev_join = nullptr;
+    // Gaussian taps beyond the IMGFD_MAX_TAPS a kernel argument holds (sigma > 21): grow-only device copy (fir.hip)
+    double *taps_dev = nullptr;
+    size_t taps_cap = 0;
     // fHOG: magnitude + orientation of every integer gradient (fhog_fused.hip), built on first use
     unsigned *fhog_lut = nullptr;
     // lab switches (imgfd_set_tuning / IMGFD_* environment variables read ONCE at context creation; include/imgfd.h
@@ -47,6 +50,19 @@ struct imgfd_ctx {
         int fhog_fused = 1;  // 1: cell_size 8 through fhog_hist8; 0: the three stage kernels
         int fhog_bands = 0;  // bands a workgroup of fhog_hist8 marches through (0: chosen from the batch size)
         int fhog_threads = 256;  // workgroup size of fhog_hist8 (256 | 512)
+        // round-1/2 experiment switches (formerly getenv() at their point of use)
+        int hyst_mode = 0;          // Canny hysteresis: 0 = bit-plane sweeps + finishing kernel, 1 = LDS-resident region rounds
+        int hyst_sweeps = 0;        // sweeps queued before the finishing kernel (0: 24, or 14 for batches under 8 frames)
+        int hyst_rounds = 0;        // region mode: rounds queued (0: from the region grid)
+        int hyst_region_w = 0, hyst_region_h = 0;  // region size in words x rows (0: from the batch size)
+        int canny_gate = 0;         // imgfd_detect_dev: where Canny releases the second stream (0 before the blur, 1 after it, 2 after gradient/NMS)
+        int xcd_remap = 1;          // marching FIR kernels: workers of one XCD own neighbouring tiles
+        int fused_response = 1;     // Harris: corner response in the structure-tensor kernel's epilogue
+        int nms_tiled = 0;          // Harris batch path: 1 = the tiled NMS kernel instead of the sparse one
+        int tensor_per_cu = 0, tensor_seg = 0, tensor_workers = 0, tensor_tw = 0;  // fir_tensor launch geometry (0: chosen)
+        int surf_residue = 4;       // SURF octaves 1-3: modulus of the residue layout (0: plain table, 4, 16)
+        int max_chunk_frames = 0;   // frames per sub-batch of the *_dev entry points (0: from the 12 GiB / 1 GiB budgets)
+        int tile_run = 0;           // tiles per workgroup of the u8 tile kernels (0: from the batch size)
         int surf_lanes = 2;      // imgfd_surf_dev: tiles alternate between the context's stream and its companion (1: one stream)
         int surf_rec_cap = 1 << 18;  // imgfd_surf_dev: candidate records a tile's buffer holds before the tile is redone (tests lower it)
         int surf_async = 0;      // imgfd_surf_dev: 1 = never wait for the host (a tile whose candidates overflow reports -candidates)
@@ -98,16 +114,14 @@ static inline imgfd_status imgfd_guard(imgfd_ctx *ctx, F &&body) noexcept
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 // frames per sub-batch of a *_dev entry point: as many as fit `budget` bytes of stage planes, at least one.
-// IMGFD_MAX_CHUNK_FRAMES (tests) lowers it so that small batches cross sub-batch boundaries too.
-static inline int sub_batch_frames(int n_frames, size_t per_frame_bytes, size_t budget)
+// The lab switch "max_chunk_frames" (tests) lowers it so that small batches cross sub-batch boundaries too.
+static inline int sub_batch_frames(const imgfd_ctx *ctx, int n_frames, size_t per_frame_bytes, size_t budget)
 {
     size_t c = budget / (per_frame_bytes ? per_frame_bytes : 1);
     if (c > (size_t)n_frames) c = (size_t)n_frames;
     if (c < 1) c = 1;
-    if (const char *e = getenv("IMGFD_MAX_CHUNK_FRAMES")) {
-        const int m = atoi(e);
-        if (m >= 1 && (size_t)m < c) c = (size_t)m;
-    }
+    const int m = ctx->tune.max_chunk_frames;
+    if (m >= 1 && (size_t)m < c) c = (size_t)m;
     return (int)c;
 }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -148,8 +162,8 @@ static inline TileRuns tile_runs(int tiles_x, int bands, int frames, int run)
     t.total = (unsigned)t.runs_per_band * (unsigned)bands * (unsigned)frames;
     return t;
 }
-// run length for a frame batch (env IMGFD_TILE_RUN overrides: experiments)
-int tile_run_length(int tiles_x, int bands, int frames, int num_cu);
+// run length for a frame batch (lab switch "tile_run" overrides: experiments)
+int tile_run_length(const imgfd_ctx *ctx, int tiles_x, int bands, int frames);
 
 // workspace: all allocations of one API call are carved from one arena; ws_reserve() guarantees
 // capacity up front so no pointer handed out earlier in the call is invalidated.
@@ -189,7 +203,7 @@ imgfd_status launch_tensor_march(imgfd_ctx *ctx, const float *d_Ix, const float 
                                  int nx, int ny, int n_frames, int R, const double *B, float k, int out_mode,
                                  unsigned char *d_tq = nullptr, float Th = 0.f);
 // structure tensor + Harris response in one kernel (R plane only); false when that path does not apply
-bool tensor_response_supported(int nx, int ny, float sigma, int gauss, int measure, const float *d_Ix, const float *d_Iy, const float *d_R);
+bool tensor_response_supported(const imgfd_ctx *ctx, int nx, int ny, float sigma, int gauss, int measure, const float *d_Ix, const float *d_Iy, const float *d_R);
 imgfd_status launch_tensor_response(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_R, int nx, int ny,
                                     int n_frames, float sigma, float k, unsigned char *d_tq = nullptr, float Th = 0.f);
 // scratch (bytes) launch_gaussian / launch_structure_tensor need in d_tmp for `n_frames` frames
@@ -200,6 +214,8 @@ imgfd_status launch_sii_gaussian(imgfd_ctx *ctx, const float *d_in, float *d_out
                                  float *d_cum);
 // taps B[0..size-1] exactly as gaussian.cpp:307-330; returns size (= radius + 1), or -1 if more than IMGFD_MAX_TAPS
 int fir_coeffs(float sigma, int precision, double *B);
+// the size alone (any sigma)
+int fir_size(float sigma, int precision);
 // gauss_grad.hip: discrete Gaussian (radius 3) + gradient in one kernel; returns false when the fused kernel does not
 // apply (other radii, image narrower than the kernel) and the caller runs the two separate stages instead
 bool gauss_grad_fused_supported(int nx, int ny, float sigma, int gauss_type);

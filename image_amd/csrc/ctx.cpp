@@ -11,6 +11,23 @@ const std::vector<TuneKey> &tune_keys()
         {"fhog_fused", "IMGFD_FHOG_FUSED", &imgfd_ctx::Tune::fhog_fused},
         {"fhog_bands", "IMGFD_FHOG_BANDS", &imgfd_ctx::Tune::fhog_bands},
         {"fhog_threads", "IMGFD_FHOG_THREADS", &imgfd_ctx::Tune::fhog_threads},
+        {"hyst_mode", "IMGFD_HYST_MODE", &imgfd_ctx::Tune::hyst_mode},
+        {"hyst_sweeps", "IMGFD_HYST_SWEEPS", &imgfd_ctx::Tune::hyst_sweeps},
+        {"hyst_rounds", "IMGFD_HYST_ROUNDS", &imgfd_ctx::Tune::hyst_rounds},
+        {"hyst_region_w", "IMGFD_HYST_REGION_W", &imgfd_ctx::Tune::hyst_region_w},
+        {"hyst_region_h", "IMGFD_HYST_REGION_H", &imgfd_ctx::Tune::hyst_region_h},
+        {"canny_gate", "IMGFD_CANNY_GATE", &imgfd_ctx::Tune::canny_gate},
+        {"xcd_remap", "IMGFD_XCD_REMAP", &imgfd_ctx::Tune::xcd_remap},
+        {"fused_response", "IMGFD_FUSED_RESPONSE", &imgfd_ctx::Tune::fused_response},
+        {"nms_tiled", "IMGFD_NMS_TILED", &imgfd_ctx::Tune::nms_tiled},
+        {"tensor_per_cu", "IMGFD_TENSOR_PER_CU", &imgfd_ctx::Tune::tensor_per_cu},
+        {"tensor_seg", "IMGFD_TENSOR_SEG", &imgfd_ctx::Tune::tensor_seg},
+        {"tensor_workers", "IMGFD_TENSOR_WORKERS", &imgfd_ctx::Tune::tensor_workers},
+        {"tensor_tw", "IMGFD_TENSOR_TW", &imgfd_ctx::Tune::tensor_tw},
+        {"surf_residue", "IMGFD_SURF_RESIDUE", &imgfd_ctx::Tune::surf_residue},
+        {"max_chunk_frames", "IMGFD_MAX_CHUNK_FRAMES", &imgfd_ctx::Tune::max_chunk_frames},
+        {"tile_run", "IMGFD_TILE_RUN", &imgfd_ctx::Tune::tile_run},
+        {"fir_mode", "IMGFD_FIR_MODE", nullptr},
         {"surf_lanes", "IMGFD_SURF_LANES", &imgfd_ctx::Tune::surf_lanes},
         {"surf_async", "IMGFD_SURF_ASYNC", &imgfd_ctx::Tune::surf_async},
         {"surf_rec_cap", "IMGFD_SURF_REC_CAP", &imgfd_ctx::Tune::surf_rec_cap},
@@ -50,10 +67,11 @@ static imgfd_status ctx_init(int device, void *stream, bool own, imgfd_ctx **out
         delete ctx;
         return IMGFD_ERR_HIP;
     }
-    const char *m = getenv("IMGFD_FIR_MODE");
-    if (m) ctx->fir_mode = atoi(m) ? 1 : 0;
     for (const TuneKey &k : tune_keys())
-        if (const char *e = getenv(k.env)) ctx->tune.*(k.field) = atoi(e);
+        if (const char *e = getenv(k.env)) {
+            if (k.field) ctx->tune.*(k.field) = atoi(e);
+            else ctx->fir_mode = atoi(e) ? 1 : 0;  // "fir_mode": the one switch with a setter of its own (imgfd_set_fir_mode)
+        }
     *out = ctx;
     return IMGFD_OK;
 }
@@ -77,6 +95,7 @@ void imgfd_ctx_destroy(imgfd_ctx *ctx)
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->aux) (void)hipFree(ctx->aux);
     if (ctx->fhog_lut) (void)hipFree(ctx->fhog_lut);
+    if (ctx->taps_dev) (void)hipFree(ctx->taps_dev);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -112,6 +131,7 @@ imgfd_status imgfd_set_tuning(imgfd_ctx *ctx, const char *name, int value)
     if (!ctx || !name) return IMGFD_ERR_INVALID;
     for (const TuneKey &k : tune_keys())
         if (!strcmp(k.name, name)) {
+            if (!k.field) return imgfd_set_fir_mode(ctx, value);
             ctx->tune.*(k.field) = value;
             if (ctx->side) ctx->side->tune.*(k.field) = value;
             return IMGFD_OK;
@@ -158,10 +178,10 @@ imgfd_status prof_mark(imgfd_ctx *ctx)
     return IMGFD_OK;
 }
 
-int tile_run_length(int tiles_x, int bands, int frames, int num_cu)
+int tile_run_length(const imgfd_ctx *ctx, int tiles_x, int bands, int frames)
 {
-    static const char *env = getenv("IMGFD_TILE_RUN");
-    if (env && atoi(env) > 0) return atoi(env);
+    const int num_cu = ctx->num_cu;
+    if (ctx->tune.tile_run > 0) return ctx->tune.tile_run;
     // Measured on 32 x 4K frames (scripts/gpu_u8.sh, profiles/r02/u8_runs.txt): runs of 4 cut the fetched bytes by a third
     // at the same or a slightly better duration; longer runs fetch less still but serialise too much of a workgroup's
     // latency (staging -> phases -> barriers) and run slower, as does a grid of resident workgroups walking the runs

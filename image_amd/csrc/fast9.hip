@@ -244,7 +244,7 @@ imgfd_status launch_fast9(imgfd_ctx *ctx, const uint8_t *d_img, int w, int h, in
                           size_t frame_stride, int n_frames, int threshold, int nonmax, const CompactBuffers &cb)
 {
     const int bands = ceil_div(h, F9_TY);
-    const TileRuns runs = tile_runs(cb.words_per_row, bands, n_frames, tile_run_length(cb.words_per_row, bands, n_frames, ctx->num_cu));
+    const TileRuns runs = tile_runs(cb.words_per_row, bands, n_frames, tile_run_length(ctx, cb.words_per_row, bands, n_frames));
     dim3 grid(runs.total);
     const int aligned4 = ((size_t)d_img % 4 == 0) && stride % 4 == 0 && frame_stride % 4 == 0;
     const int aligned16 = ((size_t)d_img % 16 == 0) && stride % 16 == 0 && frame_stride % 16 == 0;

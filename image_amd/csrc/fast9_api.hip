@@ -75,7 +75,7 @@ imgfd_status imgfd_fast9_dev(imgfd_ctx *ctx, const imgfd_frames *fr, uint8_t thr
         return IMGFD_OK;
     }
     const size_t per_frame = compact_bytes(w, h, 1);
-    const int chunk = sub_batch_frames(fr->n_frames, per_frame, (size_t)1 << 30);
+    const int chunk = sub_batch_frames(ctx, fr->n_frames, per_frame, (size_t)1 << 30);
     IMGFD_TRY(ws_reserve(ctx, compact_bytes(w, h, chunk) + 4096));
     CompactBuffers cb;
     IMGFD_TRY(compact_carve(ctx, w, h, chunk, &cb));

@@ -293,6 +293,7 @@ struct FirGenericParams {
     int horizontal;
     int fma;
     long frame_stride;
+    const double *Bg;  // taps in memory when there are more than IMGFD_MAX_TAPS (nullptr: B below)
     double B[IMGFD_MAX_TAPS];
 };
 
@@ -309,11 +310,12 @@ __global__ void __launch_bounds__(256) fir_generic_pass(FirGenericParams p)
         const int r = fir_reflect(i, n);
         return (double)(p.horizontal ? in[(size_t)y * p.nx + r] : in[(size_t)r * p.nx + x]);
     };
-    double sum = p.B[0] * at(c);
+    const double *B = p.Bg ? p.Bg : p.B;
+    double sum = B[0] * at(c);
     for (int j = 1; j < p.size; j++) {
         const double pair = at(c - j) + at(c + j);
-        if (p.fma) sum = __builtin_fma(p.B[j], pair, sum);
-        else sum += p.B[j] * pair;
+        if (p.fma) sum = __builtin_fma(B[j], pair, sum);
+        else sum += B[j] * pair;
     }
     out[(size_t)y * p.nx + x] = (float)sum;
 }
@@ -343,18 +345,46 @@ __global__ void __launch_bounds__(256) plane_copy(const void *in, int in_is_u8, 
 
 // ------------------------------------------------------------------ host side
 // taps exactly as gaussian.cpp:307-330 (den in float, integer -i*i, pi = 3.1415926)
-int fir_coeffs(float sigma, int precision, double *B)
+int fir_size(float sigma, int precision) { return (int)(precision * sigma) + 1; }
+
+static void fir_coeffs_n(float sigma, int size, double *B)
 {
     double den = 2 * sigma * sigma;
-    int size = (int)(precision * sigma) + 1;
-    if (size > IMGFD_MAX_TAPS) return -1;
     for (int i = 0; i < size; i++) B[i] = 1 / (sigma * sqrt(2.0 * 3.1415926)) * exp(-i * i / den);
     double norm = 0;
     for (int i = 0; i < size; i++) norm += B[i];
     norm *= 2;
     norm -= B[0];
     for (int i = 0; i < size; i++) B[i] /= norm;
+}
+
+int fir_coeffs(float sigma, int precision, double *B)
+{
+    const int size = fir_size(sigma, precision);
+    if (size > IMGFD_MAX_TAPS) return -1;
+    fir_coeffs_n(sigma, size, B);
     return size;
+}
+
+// more taps than a kernel argument holds (the reference stops only at size > xdim, gaussian.cpp:312): the taps go to a
+// device buffer the context keeps.  Rare and not on any timed path: the copy is waited for.
+static imgfd_status fir_taps_device(imgfd_ctx *ctx, float sigma, int size, const double **d_B)
+{
+    std::vector<double> B((size_t)size);
+    fir_coeffs_n(sigma, size, B.data());
+    if ((size_t)size > ctx->taps_cap) {
+        IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->taps_dev) (void)hipFree(ctx->taps_dev);
+        ctx->taps_dev = nullptr; ctx->taps_cap = 0;
+        void *p = nullptr;
+        const size_t cap = align_up((size_t)size, 1024);
+        if (hipMalloc(&p, cap * sizeof(double)) != hipSuccess) return imgfd_fail(ctx, IMGFD_ERR_OOM, "hipMalloc of the Gaussian taps failed");
+        ctx->taps_dev = (double *)p; ctx->taps_cap = cap;
+    }
+    IMGFD_HIP(ctx, hipMemcpyAsync(ctx->taps_dev, B.data(), sizeof(double) * (size_t)size, hipMemcpyHostToDevice, ctx->stream));
+    IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *d_B = ctx->taps_dev;
+    return IMGFD_OK;
 }
 
 template <int R, int MODE, int TW, int CH, int FIR_PX = 8, int FIR_NT = 256>
@@ -386,8 +416,7 @@ static imgfd_status launch_march(imgfd_ctx *ctx, FirParams &p, int n_frames)
     }
     p.seg_rows = seg;
     dim3 grid(strips, ceil_div(p.ny, seg), n_frames);
-    static const char *env = getenv("IMGFD_XCD_REMAP");
-    p.xcd_remap = env ? atoi(env) : 1;
+    p.xcd_remap = ctx->tune.xcd_remap;
     // float4 tile loads need 16-byte aligned planes, pitch and frame stride, and whole quads per row
     p.vec4 = MODE != 1 && ((size_t)p.in0 % 16 == 0) && ((size_t)p.in1 % 16 == 0) && p.in_pitch % 4 == 0 &&
              p.in_frame_stride % 4 == 0 && p.nx % 4 == 0 && p.nx >= 4;
@@ -407,12 +436,13 @@ static imgfd_status launch_march(imgfd_ctx *ctx, FirParams &p, int n_frames)
 }
 
 static imgfd_status launch_generic(imgfd_ctx *ctx, const float *in, float *tmp, float *out, int nx, int ny,
-                                   int n_frames, int size, const double *B)
+                                   int n_frames, int size, const double *B, const double *d_B = nullptr)
 {
     FirGenericParams g;
     memset(&g, 0, sizeof g);
     g.nx = nx; g.ny = ny; g.size = size; g.fma = ctx->fir_mode; g.frame_stride = (long)nx * ny;
-    memcpy(g.B, B, sizeof(double) * size);
+    g.Bg = d_B;
+    if (!d_B) memcpy(g.B, B, sizeof(double) * size);
     dim3 grid(ceil_div(nx, 256), ny, n_frames);
     g.in = in; g.out = tmp; g.horizontal = 1;
     hipLaunchKernelGGL(fir_generic_pass, grid, dim3(256), 0, ctx->stream, g);
@@ -457,9 +487,11 @@ imgfd_status launch_gaussian(imgfd_ctx *ctx, const void *d_in, int in_is_u8, int
     if (type != 0 || sigma <= 0) return copy();  // NO_GAUSSIAN / sigma<=0: gaussian.cpp:299-305, 424-429
     FirParams p;
     memset(&p, 0, sizeof p);
-    int size = fir_coeffs(sigma, 3, p.B);
-    if (size < 0) return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "gaussian sigma too large (more than 64 taps)");
+    const int size = fir_size(sigma, 3);
     if (size > nx) return copy();  // gaussian.cpp:312: output untouched == input (the reference works in place)
+    const double *d_B = nullptr;
+    if (size > IMGFD_MAX_TAPS) IMGFD_TRY(fir_taps_device(ctx, sigma, size, &d_B));
+    else (void)fir_coeffs(sigma, 3, p.B);
     const int R = size - 1;
     p.in0 = d_in; p.in1 = nullptr; p.out0 = d_out; p.nx = nx; p.ny = ny; p.in_pitch = in_pitch;
     p.in_frame_stride = (long)in_frame_stride; p.out_frame_stride = (long)nx * ny;
@@ -474,19 +506,17 @@ imgfd_status launch_gaussian(imgfd_ctx *ctx, const void *d_in, int in_is_u8, int
                            in_frame_stride, d_out, nx, ny);
         src = d_out;
     }
-    return launch_generic(ctx, src, d_tmp, d_out, nx, ny, n_frames, size, p.B);
+    return launch_generic(ctx, src, d_tmp, d_out, nx, ny, n_frames, size, p.B, d_B);
 }
 
 // structure tensor + Harris response in one kernel: applies to the discrete Gaussian with a specialised radius on
 // 16-byte aligned planes whose rows are whole quads
-bool tensor_response_supported(int nx, int ny, float sigma, int gauss, int measure, const float *d_Ix, const float *d_Iy, const float *d_R)
+bool tensor_response_supported(const imgfd_ctx *ctx, int nx, int ny, float sigma, int gauss, int measure, const float *d_Ix, const float *d_Iy, const float *d_R)
 {
-    static const char *off = getenv("IMGFD_NO_FUSED_RESPONSE");
-    if (off && atoi(off)) return false;
+    if (!ctx->tune.fused_response) return false;
     if (gauss != IMGFD_STD_GAUSSIAN || measure != IMGFD_HARRIS_MEASURE || !(sigma > 0)) return false;
-    double B[IMGFD_MAX_TAPS];
-    const int size = fir_coeffs(sigma, 3, B);
-    if (size < 0 || size > nx || !tensor_fast_path(size - 1)) return false;
+    const int size = fir_size(sigma, 3);
+    if (size > nx || !tensor_fast_path(size - 1)) return false;
     return nx % 4 == 0 && nx >= 4 && (size_t)d_Ix % 16 == 0 && (size_t)d_Iy % 16 == 0 && (size_t)d_R % 16 == 0;
 }
 
@@ -497,7 +527,7 @@ imgfd_status launch_tensor_response(imgfd_ctx *ctx, const float *d_Ix, const flo
 {
     double B[IMGFD_MAX_TAPS];
     const int size = fir_coeffs(sigma, 3, B);
-    if (size < 0) return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "gaussian sigma too large (more than 64 taps)");
+    if (size < 0) return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "fused structure tensor + response: no such radius (callers ask tensor_response_supported first)");
     const imgfd_status st = launch_tensor_march(ctx, d_Ix, d_Iy, d_R, nullptr, nullptr, nx, ny, n_frames, size - 1, B, k, 2, d_tq, Th);
     if (st == IMGFD_ERR_UNSUPPORTED) return imgfd_fail(ctx, st, "fused structure tensor + response: unsupported shape");
     return st;
@@ -526,9 +556,11 @@ imgfd_status launch_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const fl
     if (sigma <= 0) return products();
     FirParams p;
     memset(&p, 0, sizeof p);
-    int size = fir_coeffs(sigma, 3, p.B);
-    if (size < 0) return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "gaussian sigma too large (more than 64 taps)");
+    const int size = fir_size(sigma, 3);
     if (size > nx) return products();
+    const double *d_taps = nullptr;
+    if (size > IMGFD_MAX_TAPS) IMGFD_TRY(fir_taps_device(ctx, sigma, size, &d_taps));
+    else (void)fir_coeffs(sigma, 3, p.B);
     const int R = size - 1;
     p.in0 = d_Ix; p.in1 = d_Iy; p.out0 = d_A; p.out1 = d_B; p.out2 = d_C; p.nx = nx; p.ny = ny;
     p.in_pitch = nx; p.in_frame_stride = (long)nx * ny; p.out_frame_stride = (long)nx * ny;
@@ -539,6 +571,6 @@ imgfd_status launch_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const fl
     if (!d_tmp) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "generic structure tensor needs a scratch plane");
     IMGFD_TRY(products());
     float *pl[3] = {d_A, d_B, d_C};
-    for (int i = 0; i < 3; i++) IMGFD_TRY(launch_generic(ctx, pl[i], d_tmp, pl[i], nx, ny, n_frames, size, p.B));
+    for (int i = 0; i < 3; i++) IMGFD_TRY(launch_generic(ctx, pl[i], d_tmp, pl[i], nx, ny, n_frames, size, p.B, d_taps));
     return IMGFD_OK;
 }

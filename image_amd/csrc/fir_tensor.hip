@@ -12,21 +12,26 @@
 // The reference's double accumulation makes this pass f64-issue bound on the vector pipe (90 f64 operations per
 // pixel before conversions), so the kernel is organised around the f64 instruction count, not around bytes:
 //
-//   * one 384-thread workgroup (6 waves) owns a 128-column strip of one frame and marches down a segment of rows in
-//     chunks of 16 rows; wave pair {0,1} / {2,3} / {4,5} works on plane A / B / C in both passes (wave-uniform).
+//   * one 768-thread workgroup (12 waves: three per SIMD; multiples of four load the SIMDs evenly) owns a 256-column strip
+//     (384 threads / 128 columns for narrow images); four waves work on plane A, four on B, four on C in both passes
+//     (wave-uniform).  Workgroups are persistent: one per CU, each walking its share of the (frame, strip, segment) tiles as
+//     ONE pipelined sequence of 16-row chunks.
 //   * row pass: a thread owns 16 consecutive pixels of one row of its plane: 16+2R window values are read from the raw
 //     Ix/Iy tile in LDS with ds_read_b128 (row pitch = odd number of 16-byte slots: every 16-lane group of the b128
 //     read pattern hits 16 distinct slot banks), multiplied in float, widened ONCE to double ((16+2R)/16 conversions
-//     per pixel) and slid through the 16 outputs in registers; the rounded floats go to an LDS ring [plane][16][128].
-//   * column pass: a thread owns ONE column of one plane for the whole segment and keeps the last 16 row-filtered
-//     values of that column in registers as doubles (a circular buffer indexed by row mod 16 -- static indices, since
-//     a chunk is 16 rows): per output row one ds_read_b32 (lane <-> column: conflict-free), one conversion, the 2R+1
-//     tap chain, one rounding, one coalesced 256-byte store per wave.  No window re-reads, no halo rows in LDS.
-//   * the Ix/Iy tile of chunk c+1 is fetched (aligned float4 loads, straight-line) while chunk c computes and is
-//     written to LDS between the passes; border strips rebuild the reflected halo columns inside LDS.
+//     per pixel) and slid through the 16 outputs in registers; the rounded floats go to an LDS ring [plane][16][TW + 4].
+//   * column pass, register-marching: a thread owns ONE column of one plane for the whole tile sequence and keeps the
+//     column's last 2R row-filtered floats in registers; per chunk it reads 16 new values (ds_read_b32, lane <-> column:
+//     conflict-free), converts the window once and emits 16 output rows.  No window re-reads, no halo rows in LDS.
+//   * both passes advance FOUR tap chains together (a dependent f64 instruction issues every ~15 cycles).
+//   * per step: barrier 1 -- small phase (ring -> registers, the prefetched Ix/Iy tile of the next chunk -> LDS, finished
+//     rows of chunk s-2 -> global, with the corner response and the threshold quads in the response variant) -- barrier 2
+//     -- big phase (global fetch of chunk s+1 first, column pass of chunk s-1, row pass of chunk s); border strips rebuild
+//     the reflected halo columns inside LDS.
 //
-// LDS: 2 x 16 x 37 float4 (raw) + 3 x 16 x 128 floats (ring) = 43.5 KB -> three workgroups (18 waves) per CU.
-// HBM traffic is the algorithmic 8 B read + 12 B (or 4 B) written per pixel plus strip/segment halos (served by L2).
+// LDS: 85 KB (response variant, 256 columns) to 135 KB (A/B/C doorway with its output buffer): one workgroup per CU.
+// 168 VGPRs (amdgpu_waves_per_eu(3, 3)).  HBM traffic is the algorithmic 8 B read + 12 B (or 4.25 B) written per pixel
+// plus strip / segment halos (served by L2): measured 1.027 x algorithmic (profiles/r02/c_k3_pmc_summary.txt).
 #include "common.h"
 #include "fir_device.h"
 #include "harris_device.h"
@@ -525,14 +530,12 @@ static imgfd_status launch_tensor_r(imgfd_ctx *ctx, TensorParams &p, int n_frame
     // Workers = the workgroups the chip holds at once (persistent: each walks its share of the tiles).  Segment length: a
     // tile is (rows + 2R) rows in chunks of CH; the pass takes ceil(tiles / workers) tiles of (chunks per tile) steps per
     // worker: pick the segment count that minimises that product (ties: fewer, longer segments = less halo work).
-    static int per_cu = 0;
-    if (!per_cu) {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)fir_tensor<R, TW, true, true, OUT>, G::NT, lds) != hipSuccess || n < 1)
-            n = 1;
-        per_cu = n;
-        if (const char *e = getenv("IMGFD_TENSOR_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
-    }
+    // One persistent workgroup per CU: 12 waves at 168 registers fill a CU's register file, and the hardware admitted one
+    // workgroup even where LDS (68 KB for the 128-column instance) and the occupancy API promised two
+    // (profiles/r02/k3_log.txt).  (Round 2 asked the occupancy API -- before the dynamic-LDS attribute was raised, cached
+    // across instances and devices -- and fell back to this value.)
+    int per_cu = 1;
+    if (ctx->tune.tensor_per_cu > 0) per_cu = ctx->tune.tensor_per_cu;
     const long slots = (long)per_cu * ctx->num_cu;
     long best_cost = -1;
     int seg = p.ny;
@@ -545,19 +548,18 @@ static imgfd_status launch_tensor_r(imgfd_ctx *ctx, TensorParams &p, int n_frame
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; seg = sr; }
     }
     p.seg_rows = seg;
-    if (const char *e = getenv("IMGFD_TENSOR_SEG")) if (atoi(e) > 0) p.seg_rows = atoi(e);
+    if (ctx->tune.tensor_seg > 0) p.seg_rows = ctx->tune.tensor_seg;
     p.nstrips = strips;
     p.nseg = ceil_div(p.ny, p.seg_rows);
     p.n_frames = n_frames;
     const long tiles = (long)p.nstrips * p.nseg * n_frames;
     long workers = std::min<long>(tiles, slots);
-    if (const char *e = getenv("IMGFD_TENSOR_WORKERS")) if (atoi(e) > 0) workers = std::min<long>(tiles, atoi(e));  // tests: several tiles per worker on small images
+    if (ctx->tune.tensor_workers > 0) workers = std::min<long>(tiles, ctx->tune.tensor_workers);  // tests: several tiles per worker on small images
     p.step_strip = (int)(workers % p.nstrips);
     p.step_seg = (int)((workers / p.nstrips) % p.nseg);
     p.step_frame = (int)(workers / ((long)p.nstrips * p.nseg));
     dim3 grid((unsigned)workers);
-    static const char *env = getenv("IMGFD_XCD_REMAP");
-    p.xcd_remap = env ? atoi(env) : 1;
+    p.xcd_remap = ctx->tune.xcd_remap;
     auto go = [&](auto kern) -> imgfd_status {
         IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, grid, dim3(G::NT), lds, ctx->stream, p);
@@ -593,8 +595,7 @@ imgfd_status launch_tensor_march(imgfd_ctx *ctx, const float *d_Ix, const float 
     if (out_mode != 0 && out_mode != 2) return IMGFD_ERR_UNSUPPORTED;
     if (out_mode != 0 && !vec) return IMGFD_ERR_UNSUPPORTED;
     // 256-column strips (12 waves: every SIMD carries three) unless the image is narrow
-    static const char *twe = getenv("IMGFD_TENSOR_TW");
-    const int tw = twe && atoi(twe) == 128 ? 128 : twe && atoi(twe) == 256 ? 256 : (nx > 384 ? 256 : 128);
+    const int tw = ctx->tune.tensor_tw == 128 ? 128 : ctx->tune.tensor_tw == 256 ? 256 : (nx > 384 ? 256 : 128);
 #define FT_GO(RR)                                                                                          \
     case RR:                                                                                               \
         if (tw == 256) {                                                                                   \

@@ -181,7 +181,7 @@ imgfd_status launch_gauss_grad_fused(imgfd_ctx *ctx, const void *d_in, int in_is
     p.vec16 = in_is_u8 && ((size_t)d_in % 16 == 0) && in_pitch % 16 == 0 && in_frame_stride % 16 == 0 && nx % 16 == 0;
     const bool sobel = grad_type == IMGFD_SOBEL_OPERATOR;
     const int tiles_x = ceil_div(nx, GG_TX), bands = ceil_div(ny, GG_TY);
-    p.runs = tile_runs(tiles_x, bands, n_frames, tile_run_length(tiles_x, bands, n_frames, ctx->num_cu));
+    p.runs = tile_runs(tiles_x, bands, n_frames, tile_run_length(ctx, tiles_x, bands, n_frames));
 #define GG_LAUNCH(G, U, F) hipLaunchKernelGGL((gauss_grad_tile<3, G, U, F>), dim3(p.runs.total), dim3(256), 0, ctx->stream, p)
     if (ctx->fir_mode) {
         if (in_is_u8) { if (sobel) GG_LAUNCH(1, true, true); else GG_LAUNCH(0, true, true); }

@@ -224,12 +224,11 @@ imgfd_status harris_device_stages(imgfd_ctx *ctx, const void *d_in, int in_is_u8
         IMGFD_TRY(tick(1));
     }
     const int radius = (int)(2 * a.sigma_i + 0.5);  // harris.cpp:523, double -> int truncation
-    if (!stage_seconds && tensor_response_supported(nx, ny, a.sigma_i, a.gauss, a.measure, hp.Ix, hp.Iy, hp.R)) {
+    if (!stage_seconds && tensor_response_supported(ctx, nx, ny, a.sigma_i, a.gauss, a.measure, hp.Ix, hp.Iy, hp.R)) {
         // the default path: the structure tensor never leaves the CU -- its kernel's epilogue evaluates the corner
         // response (harris.cpp:78-133) and only R is stored; NMS then reads 4 B/px instead of 12
         IMGFD_TRY(prof_mark(ctx));
-        static const char *nms_env = getenv("IMGFD_NMS");  // experiment switch: "tiled" = the round-2a kernel that streams R through LDS
-        const bool sparse = !(nms_env && nms_env[0] == 't');
+        const bool sparse = !ctx->tune.nms_tiled;  // experiment switch: the round-2a kernel that streams R through LDS
         unsigned char *tq = reinterpret_cast<unsigned char *>(hp.A);  // the A plane is idle on this path: it holds the threshold quads
         IMGFD_TRY(launch_tensor_response(ctx, hp.Ix, hp.Iy, hp.R, nx, ny, n_frames, a.sigma_i, a.k, sparse ? tq : nullptr, a.Th));
         IMGFD_TRY(prof_mark(ctx));
@@ -425,7 +424,7 @@ imgfd_status imgfd_harris_dev(imgfd_ctx *ctx, const imgfd_frames *fr, float k, f
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_harris_dev: strides must be multiples of the element size");
     // sub-batches bounded by 12 GiB of stage planes
     const size_t per_frame = 8 * sizeof(float) * (size_t)nx * ny;
-    const int chunk = sub_batch_frames(fr->n_frames, per_frame, (size_t)12 << 30);
+    const int chunk = sub_batch_frames(ctx, fr->n_frames, per_frame, (size_t)12 << 30);
     const size_t tmp_floats = harris_tmp_floats(nx, ny, sigma_d, sigma_i, gaussian);
     IMGFD_TRY(ws_reserve(ctx, harris_ws_bytes(nx, ny, chunk, 0, tmp_floats)));
     HarrisPlanes hp;
@@ -523,7 +522,7 @@ imgfd_status imgfd_k_tensor_response(imgfd_ctx *ctx, const float *d_Ix, const fl
 {
     if (!ctx || !d_Ix || !d_Iy || !d_R || nx < 1 || ny < 1)
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_k_tensor_response: bad argument");
-    if (!tensor_response_supported(nx, ny, sigma, IMGFD_STD_GAUSSIAN, IMGFD_HARRIS_MEASURE, d_Ix, d_Iy, d_R))
+    if (!tensor_response_supported(ctx, nx, ny, sigma, IMGFD_STD_GAUSSIAN, IMGFD_HARRIS_MEASURE, d_Ix, d_Iy, d_R))
         return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "imgfd_k_tensor_response: needs the discrete Gaussian with radius 7, 3 or 1, "
                                                       "16-byte aligned planes and rows of whole quads");
     return launch_tensor_response(ctx, d_Ix, d_Iy, d_R, nx, ny, 1, sigma, k);
@@ -531,9 +530,7 @@ imgfd_status imgfd_k_tensor_response(imgfd_ctx *ctx, const float *d_Ix, const fl
 
 const char *imgfd_tensor_kernel_name(imgfd_ctx *ctx)
 {
-    (void)ctx;
-    static const char *off = getenv("IMGFD_NO_FUSED_RESPONSE");
-    return off && atoi(off) ? "fir_tensor<7, fma, vec, A/B/C> (20 B/px)" : "fir_tensor<7, fma, vec, response> (structure tensor + Harris response, 12 B/px)";
+    return ctx && !ctx->tune.fused_response ? "fir_tensor<7, fma, vec, A/B/C> (20 B/px)" : "fir_tensor<7, fma, vec, response> (structure tensor + Harris response, 12 B/px)";
 }
 
 imgfd_status imgfd_time_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy,

@@ -1100,8 +1100,7 @@ imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const Surf
         }
         blocks.first[SURF_OCT] = nb;
         if (!nb) break;
-        static const char *res_env = getenv("IMGFD_SURF_RESIDUE");  // experiment switch: 0 = the plain table, 4 | 16 = modulus
-        const int modulus = res_env ? atoi(res_env) : 4;
+        const int modulus = ctx->tune.surf_residue;  // experiment switch: 0 = the plain table, 4 | 16 = modulus
         const dim3 lgrid(ceil_div(g.cols, RL_COLS), g.rows);
         if (o >= 1 && d.residue && g.cols % 16 == 0 && modulus == 4) {
             hipLaunchKernelGGL(surf_residue_layout<2>, lgrid, dim3(256), 0, ctx->stream, d.integral, d.residue, g.cols);

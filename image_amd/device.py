@@ -113,7 +113,9 @@ class DeviceDetector:
 
     def surf(self, tiles: torch.Tensor, feat: torch.Tensor, counts: torch.Tensor, max_points=1000, threshold=30.0):
         """imgfd_surf_dev: tiles [n, rows, cols, 3] u8 -> feat [n, cap, 70] f64 (x, y, angle, scale, score, laplacian,
-        surf[64]), counts [n] i64."""
+        surf[64]), counts [n] i64.  The call returns with the counts final: a tile whose candidates overflowed the record
+        buffer has been redone by then (with the lab switch "surf_async" it is not, and reports a NEGATIVE count: check
+        ``(counts < 0).any()`` before slicing with them)."""
         n, rows, cols, _ = tiles.shape
         assert tiles.is_contiguous() and feat.is_contiguous()
         self.ctx.check(self.lib.imgfd_surf_dev(self.ctx.handle, tiles.data_ptr(), n, rows, cols, rows * cols * 3, int(max_points),

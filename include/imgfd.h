@@ -84,6 +84,18 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  *   "fhog_fused" [IMGFD_FHOG_FUSED]  1 (default): cell_size 8 runs the fused gradient + histogram kernel; 0: stage kernels
  *   "fhog_bands" [IMGFD_FHOG_BANDS]  bands of 8 cell rows one workgroup of that kernel marches through (0: from the batch)
  *   "fhog_threads" [IMGFD_FHOG_THREADS]  workgroup size of that kernel, 256 (default) or 512
+ *   "fir_mode" [IMGFD_FIR_MODE]  as imgfd_set_fir_mode
+ *   "hyst_mode" [IMGFD_HYST_MODE]  Canny hysteresis: 0 (default) bit-plane sweeps + finishing kernel, 1 LDS-resident region rounds
+ *   "hyst_sweeps" [IMGFD_HYST_SWEEPS], "hyst_rounds" [IMGFD_HYST_ROUNDS]  sweeps / rounds queued before the finishing kernel
+ *   "hyst_region_w", "hyst_region_h" [IMGFD_HYST_REGION_W / _H]  region size of the finishing kernel (words x rows)
+ *   "canny_gate" [IMGFD_CANNY_GATE]  imgfd_detect_dev: where Canny releases the second stream (0 before the blur, 1, 2)
+ *   "xcd_remap" [IMGFD_XCD_REMAP]  1 (default): workers of one XCD own neighbouring tiles in the marching FIR kernels
+ *   "fused_response" [IMGFD_FUSED_RESPONSE]  1 (default): corner response in the structure-tensor kernel's epilogue
+ *   "nms_tiled" [IMGFD_NMS_TILED]  1: the tiled Harris NMS kernel instead of the sparse one
+ *   "tensor_per_cu", "tensor_seg", "tensor_workers", "tensor_tw" [IMGFD_TENSOR_*]  launch geometry of fir_tensor (0: chosen)
+ *   "surf_residue" [IMGFD_SURF_RESIDUE]  SURF octaves 1-3: modulus of the residue layout (4; 0 = plain table, 16)
+ *   "max_chunk_frames" [IMGFD_MAX_CHUNK_FRAMES]  frames per sub-batch of the *_dev entry points (0: from the memory budgets)
+ *   "tile_run" [IMGFD_TILE_RUN]  tiles per workgroup of the u8 tile kernels (0: from the batch size)
  *   "surf_lanes" [IMGFD_SURF_LANES]  2 (default): imgfd_surf_dev alternates tiles between two HIP streams; 1: one stream
  *   "surf_async" [IMGFD_SURF_ASYNC]  0 (default): imgfd_surf_dev reads the tile counts back once per call and redoes tiles
  *                                    whose candidates overflowed the record buffer; 1: no wait, such a tile reports -candidates
@@ -367,7 +379,7 @@ typedef struct {
 } imgfd_stream_result;
 
 /* One device-resident batch through the selected detectors, overlapped on two HIP streams (the Canny hysteresis
- * rounds, which occupy a few waves and need host read-backs, run beside FAST-9 and the Harris chain).  Results are
+ * sweeps, which end in a few idle launches and terminate on the device, run beside FAST-9 and the Harris chain).  Results are
  * exactly those of imgfd_harris_dev / imgfd_fast9_dev / imgfd_canny_dev with the parameters in *p (keep_edges is
  * ignored: d_edges is required whenever Canny is on).  d_counts: 3*n_frames int64 -- Harris counts, then FAST-9, then
  * Canny pixels_nonzero; the third of a detector that is off is left untouched.  Work queued on the context's stream

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Harris batch path: parity on the device, NMS from threshold bits vs the tiled kernel (IMGFD_NMS=tiled), per-kernel times
+# Harris batch path: parity on the device, NMS from threshold bits vs the tiled kernel (IMGFD_NMS_TILED=1), per-kernel times
 cd "$GRAFT_REPO_ROOT"; R="$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 python -m pytest tests/test_harris_stages.py tests/test_harris_api.py tests/test_full_size.py tests/test_sub_batches.py tests/test_fuzz_sizes.py -m gpu -x -q 2>&1 | tail -2
-for v in "" "IMGFD_NMS=tiled"; do
+for v in "" "IMGFD_NMS_TILED=1"; do
   env $v python bench.py --no-cpu 2>/dev/null | python -c "
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); print('$v', d['value'], d['ms_per_step'], d['parity'] if 'parity' in d else '')" | cut -c1-300

@@ -54,6 +54,23 @@ def test_small_and_odd_sizes(be, nx, ny):
         assert n == int(np.count_nonzero(edges))
 
 
+@pytest.mark.parametrize("s", [12.0, 16.0])
+def test_large_s_takes_the_taps_from_memory(be, s):
+    """tools.c:146-185 blurs with any s; beyond 129 kept taps (s above ~10) the device reads the wrapped kernel from memory
+    instead of a kernel argument.  320x240 against the restatement and, on a crop, against the reference's own sources
+    (oracle/_ref/libref_canny.so; its stand-in DFT for FFTW3 is O(n^3))"""
+    img = synth.frame(23, 320, 240)
+    edges, n = be.canny(img, s=s, low_thr=1.0, high_thr=2.0)
+    ref, rn = oracle.canny(img, s=s, low_thr=1.0, high_thr=2.0)
+    assert n == int(np.count_nonzero(edges)) and rn > 50
+    assert mismatch(edges, ref) <= max(2, 1e-3 * edges.size)
+    if oracle.have_ref("canny"):
+        small = img[:96, :128]
+        e2, n2 = be.canny(small, s=s, low_thr=1.0, high_thr=2.0)
+        r2, rn2 = oracle.ref_canny(small, s=s, low_thr=1.0, high_thr=2.0)
+        assert mismatch(e2, r2) <= max(2, 1e-3 * e2.size)
+
+
 def test_thresholds_are_int_truncated(be):
     img = synth.frame(22, 120, 90)
     a, _ = be.canny(img, low_thr=3.0, high_thr=10.0)
@@ -111,24 +128,29 @@ def test_serpentine_really_propagates():
 @pytest.mark.parametrize("mode,region,rounds,nx,ny", [("sweeps", "15x540", "24", 384, 200), ("sweeps", "4x128", "3", 384, 200),
                                                        ("sweeps", "2x64", "1", 320, 160), ("regions", "15x540", "8", 384, 200),
                                                        ("regions", "2x64", "2", 320, 160), ("regions", "1x16", "1", 200, 100)])
-def test_hysteresis_device_side_termination(be, mode, region, rounds, nx, ny, monkeypatch):
+def test_hysteresis_device_side_termination(be, mode, region, rounds, nx, ny):
     """The hysteresis never reports to the host: a fixed number of sweeps (or of LDS-resident region rounds) is queued and a
     finishing kernel completes whatever they left, region by region.  Few sweeps / rounds and small regions force the
     finishing kernel to do most of the work, with components crossing many region outlines."""
-    monkeypatch.setenv("IMGFD_HYST_MODE", mode)
-    monkeypatch.setenv("IMGFD_HYST_REGION", region)
-    monkeypatch.setenv("IMGFD_HYST_ROUNDS" if mode == "regions" else "IMGFD_HYST_SWEEPS", rounds)
-    img = _serpentine(nx, ny)
-    kw = SERP_KW
-    ref, rn, dbg = oracle.canny(img, debug=True, **kw)
-    assert rn > 3 * np.count_nonzero(dbg["nms"] == 2)                     # most of what is lit was only marked
-    edges, n = be.canny(img, **kw)
-    assert n == rn and mismatch(edges, ref) == 0, (region, rounds, n, rn)
-    frames = np.stack([img, synth.frame(31, nx, ny), img[::-1].copy()])
-    e, c = be.canny_dev(frames, **kw)
-    for f in range(3):
-        r, k = oracle.canny(frames[f], **kw)
-        assert c[f] == k and mismatch(e[f], r) <= (0 if f != 1 else 3)
+    rw, rh = (int(v) for v in region.split("x"))
+    try:
+        be.set_tuning("hyst_mode", 1 if mode == "regions" else 0)
+        be.set_tuning("hyst_region_w", rw); be.set_tuning("hyst_region_h", rh)
+        be.set_tuning("hyst_rounds" if mode == "regions" else "hyst_sweeps", int(rounds))
+        img = _serpentine(nx, ny)
+        kw = SERP_KW
+        ref, rn, dbg = oracle.canny(img, debug=True, **kw)
+        assert rn > 3 * np.count_nonzero(dbg["nms"] == 2)                     # most of what is lit was only marked
+        edges, n = be.canny(img, **kw)
+        assert n == rn and mismatch(edges, ref) == 0, (region, rounds, n, rn)
+        frames = np.stack([img, synth.frame(31, nx, ny), img[::-1].copy()])
+        e, c = be.canny_dev(frames, **kw)
+        for f in range(3):
+            r, k = oracle.canny(frames[f], **kw)
+            assert c[f] == k and mismatch(e[f], r) <= (0 if f != 1 else 3)
+    finally:
+        for k in ("hyst_mode", "hyst_region_w", "hyst_region_h", "hyst_rounds", "hyst_sweeps"):
+            be.set_tuning(k, 0)
 
 
 def test_batch_dev(be):

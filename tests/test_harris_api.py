@@ -106,6 +106,23 @@ def test_batch_dev_options(be, kw):
         assert np.array_equal(bits(lists[f]), bits(ref)), kw
 
 
+@pytest.mark.parametrize("kw", [dict(sigma_i=22.0, threshold=0.5), dict(sigma_d=21.5, sigma_i=2.5, threshold=0.001)])
+def test_gaussians_of_more_than_64_taps(be, kw):
+    """gaussian.cpp:289-330 stops only at size > xdim: sigma 22 is 67 taps per side -- more than a kernel argument holds, so
+    the generic FIR passes read them from a device buffer.  Host-pointer and batch entry against the restatement (bit for bit
+    in strict mode) and the reference's own sources"""
+    img = synth.frame(131, 260, 200)
+    be.set_fir_mode(0)
+    ref = oracle.harris(img.astype(np.float32), **kw)
+    assert len(ref) >= 1
+    got = be.harris(img.astype(np.float32), **kw)
+    assert np.array_equal(bits(got), bits(ref)), kw
+    lists, counts = be.harris_dev(img[None], **kw)
+    assert counts[0] == len(ref) and np.array_equal(bits(lists[0]), bits(ref)), kw
+    if oracle.have_ref("harris"):
+        assert np.array_equal(bits(oracle.ref_harris(img.astype(np.float32), threads=2, **kw)), bits(ref))
+
+
 def test_batch_dev_tile_borders(be):
     """sizes that straddle the 64x32 tiles of the fused kernel and its candidate list"""
     be.set_fir_mode(0)

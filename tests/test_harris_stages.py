@@ -139,22 +139,24 @@ def test_structure_tensor_rows_that_are_no_whole_quads(be, nx, ny):
 
 @pytest.mark.parametrize("workers", [1, 3, 7])
 @pytest.mark.parametrize("out", ["abc", "response"])
-def test_tensor_kernel_workers_walk_several_tiles(be, workers, out, monkeypatch):
+def test_tensor_kernel_workers_walk_several_tiles(be, workers, out):
     """the structure-tensor workgroups are persistent: each walks a list of (frame, strip, segment) tiles as one
     pipelined sequence of chunks.  Few workers and short segments: every worker crosses tile boundaries (strip change,
     segment change, last short segment)."""
-    monkeypatch.setenv("IMGFD_TENSOR_WORKERS", str(workers))
-    monkeypatch.setenv("IMGFD_TENSOR_SEG", "18")
-    nx, ny = 520, 77
-    ix, iy = _gradients(26, nx, ny)
-    be.set_fir_mode(0)
-    A, B, Cc = oracle.harris_stage("autocorrelation", ix, iy, sigma=2.5, gauss=0)
-    if out == "abc":
-        for g, r, nm in zip(be.k_structure_tensor(ix, iy, 2.5, 0), (A, B, Cc), "ABC"):
-            assert_bits_equal(g, r, f"structure tensor {nm}, {workers} workers")
-    else:
-        ref = oracle.harris_stage("response", A, B, Cc, measure=0, k=0.06)
-        assert_bits_equal(be.k_tensor_response(ix, iy, 2.5, 0.06), ref, f"tensor+response, {workers} workers")
+    try:
+        be.set_tuning("tensor_workers", workers); be.set_tuning("tensor_seg", 18)
+        nx, ny = 520, 77
+        ix, iy = _gradients(26, nx, ny)
+        be.set_fir_mode(0)
+        A, B, Cc = oracle.harris_stage("autocorrelation", ix, iy, sigma=2.5, gauss=0)
+        if out == "abc":
+            for g, r, nm in zip(be.k_structure_tensor(ix, iy, 2.5, 0), (A, B, Cc), "ABC"):
+                assert_bits_equal(g, r, f"structure tensor {nm}, {workers} workers")
+        else:
+            ref = oracle.harris_stage("response", A, B, Cc, measure=0, k=0.06)
+            assert_bits_equal(be.k_tensor_response(ix, iy, 2.5, 0.06), ref, f"tensor+response, {workers} workers")
+    finally:
+        be.set_tuning("tensor_workers", 0); be.set_tuning("tensor_seg", 0)
 
 
 def test_tensor_response_unsupported_shapes_are_refused(be):

@@ -1,5 +1,5 @@
 """The *_dev entry points cut large batches into sub-batches that fit their stage planes (imgfd_harris_dev / imgfd_canny_dev:
-12 GiB, imgfd_fast9_dev: 1 GiB; config 3's 1024 frames cross that boundary at real size).  IMGFD_MAX_CHUNK_FRAMES lowers the
+12 GiB, imgfd_fast9_dev: 1 GiB; config 3's 1024 frames cross that boundary at real size).  the lab switch "max_chunk_frames" lowers the
 limit so that a batch of 7 small frames crosses two boundaries with a ragged tail: results must not depend on the cut."""
 import numpy as np
 import pytest
@@ -16,14 +16,17 @@ def frames():
 
 
 @pytest.mark.parametrize("chunk", ["3", "1"])
-def test_harris_fast9_canny_batches_cut_into_sub_batches(be, frames, chunk, monkeypatch):
+def test_harris_fast9_canny_batches_cut_into_sub_batches(be, frames, chunk):
     whole_h, cnt_h = be.harris_dev(frames, threshold=20.0)
     whole_f, cnt_f = be.fast9_dev(frames, 20, True)
     whole_e, cnt_e = be.canny_dev(frames)
-    monkeypatch.setenv("IMGFD_MAX_CHUNK_FRAMES", chunk)
-    cut_h, ccnt_h = be.harris_dev(frames, threshold=20.0)
-    cut_f, ccnt_f = be.fast9_dev(frames, 20, True)
-    cut_e, ccnt_e = be.canny_dev(frames)
+    try:
+        be.set_tuning("max_chunk_frames", int(chunk))
+        cut_h, ccnt_h = be.harris_dev(frames, threshold=20.0)
+        cut_f, ccnt_f = be.fast9_dev(frames, 20, True)
+        cut_e, ccnt_e = be.canny_dev(frames)
+    finally:
+        be.set_tuning("max_chunk_frames", 0)
     assert np.array_equal(cnt_h, ccnt_h) and np.array_equal(cnt_f, ccnt_f) and np.array_equal(cnt_e, ccnt_e)
     assert np.array_equal(whole_e, cut_e)
     be.set_fir_mode(0)
