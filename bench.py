@@ -801,6 +801,7 @@ def main(argv=None):
 
     from image_amd.device import DeviceDetector
 
+    torch.cuda.set_stream(torch.cuda.Stream())   # everything below runs on one non-default stream (a default stream cannot be captured into the small-batch graph of imgfd_detect_dev)
     det = DeviceDetector(local)
     det.ctx.set_fir_mode(args.fir_mode)
     res = measure(args, det, rank, world, dist, want_cpu=not args.no_cpu)

@@ -831,8 +831,9 @@ __global__ void __launch_bounds__(HY_NT) canny_hyst_regions(unsigned long long *
 // workgroups (S only ever grows, and it is bounded by W).
 __global__ void __launch_bounds__(HY_NT) canny_hyst_finish(unsigned long long *__restrict__ S, const unsigned long long *__restrict__ Wm,
                                                           HystGeom g, const unsigned char *__restrict__ rflag, int last_round,
-                                                          const unsigned *__restrict__ sweep_flag)
+                                                          const unsigned *__restrict__ sweep_flag, unsigned long long *__restrict__ counts)
 {
+    if (threadIdx.x == 0) counts[blockIdx.x] = 0;  // pixels_nonzero of this frame: canny_expand_count adds to it
     if (sweep_flag && *sweep_flag == 0) return;  // the last queued sweep was idle: converged (the case in practice)
     HIP_DYNAMIC_SHARED(unsigned long long, hy_smem)
     unsigned long long *sS = hy_smem, *sW = sS + (size_t)(g.RH + 2) * g.pitch;
@@ -884,6 +885,41 @@ __global__ void __launch_bounds__(256) canny_expand_bits(const unsigned long lon
 }
 
 // per-frame count of edge pixels (rcpp_canny.cpp:226-233): popcount of the strong plane
+#define EXP_BLOCKS 128
+// rcpp_canny.cpp:226-243: the edge map as 0/255 bytes and its number of non-zero pixels; a workgroup walks every
+// EXP_BLOCKS-th row and adds its count once
+__global__ void __launch_bounds__(256) canny_expand_count(const unsigned long long *__restrict__ S, int wpr, unsigned char *__restrict__ edges,
+                                                          int nx, int ny, unsigned long long *__restrict__ counts)
+{
+    __shared__ unsigned wsum[4];
+    const bool vec = (nx & 15) == 0 && (reinterpret_cast<size_t>(edges) & 15) == 0;
+    unsigned c = 0;
+    for (int y = blockIdx.x; y < ny; y += gridDim.x) {
+        for (int x = 16 * (int)threadIdx.x; x < nx; x += 16 * 256) {
+            const unsigned long long word = S[((size_t)blockIdx.y * ny + y) * wpr + (x >> 6)];
+            unsigned bits = (unsigned)(word >> (x & 63)) & 0xffffu;
+            if (x + 16 > nx) bits &= (1u << (nx - x)) - 1u;
+            c += (unsigned)__popc(bits);
+            unsigned v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = ((((bits >> (4 * k)) & 0xfu) * 0x00204081u) & 0x01010101u) * 0xffu;
+            unsigned char *dst = edges + ((size_t)blockIdx.y * ny + y) * nx + x;
+            if (vec) {
+                *reinterpret_cast<uint4 *>(dst) = make_uint4(v[0], v[1], v[2], v[3]);
+            } else {
+                for (int k = 0; k < 16 && x + k < nx; k++) dst[k] = (unsigned char)(v[k >> 2] >> (8 * (k & 3)));
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (t) atomicAdd(&counts[blockIdx.y], (unsigned long long)t);
+    }
+}
 #define CNT_BLOCKS 16
 __global__ void __launch_bounds__(256) canny_count_bits(const unsigned long long *__restrict__ S, size_t words_per_frame,
                                                         unsigned long long *__restrict__ counts)
@@ -953,12 +989,23 @@ imgfd_status launch_blur_march(imgfd_ctx *ctx, BlurMarchParams &p, int nf)
 {
     using G = BlurGeom<R>;
     const int strips = ceil_div(p.nx, BM_TW);
-    int want = ceil_div(6 * ctx->num_cu, strips * nf);
-    if (want < 1) want = 1;
-    int seg = ceil_div(p.ny, want);
-    int m = ceil_div(seg + 2 * R, BM_CH);
-    if (m < 2) m = 2;
-    seg = m * BM_CH - 2 * R;  // (rows + 2R) fills whole chunks
+    // Segment length: a workgroup walks (rows + 2R) rows in chunks of BM_CH.  With `slots` workgroups resident on the chip
+    // the pass takes ceil(workgroups / slots) rounds of (chunks per segment) steps: the segment count that minimises that
+    // product (ties: fewer, longer segments = less halo work).  (Round 2 aimed at 6 workgroups per CU whatever the chip
+    // holds: a single 4K frame got 1260 workgroups of 4 chunks for 1024 slots -- two rounds, the second a quarter full:
+    // 69 us instead of the 21 us per frame of a batch.)
+    const long slots = (long)std::max(1, std::min(8, (int)((size_t)160 * 1024 / G::LDS_BYTES))) * ctx->num_cu;
+    long best_cost = -1;
+    int seg = p.ny;
+    for (int nseg = 1; nseg <= ceil_div(p.ny, BM_CH); nseg++) {
+        int m = ceil_div(ceil_div(p.ny, nseg) + 2 * R, BM_CH);
+        if (m < 2) m = 2;
+        const int sr = m * BM_CH - 2 * R;  // (rows + 2R) fills whole chunks
+        if (sr < 1) continue;
+        const long wgs = (long)strips * ceil_div(p.ny, sr) * nf;
+        const long cost = ((wgs + slots - 1) / slots) * m;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; seg = sr; }
+    }
     p.seg_rows = seg;
     dim3 grid(strips, ceil_div(p.ny, seg), nf);
     IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)canny_blur_march<R>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1105,25 +1152,26 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
             const int rounds = hyst_rounds(ctx, g);
             for (int r = 0; r < rounds; r++)
                 hipLaunchKernelGGL(canny_hyst_regions, dim3(regions, nf), dim3(HY_NT), lds, ctx->stream, S, Wm, g, rflag, r);
-            hipLaunchKernelGGL(canny_hyst_finish, dim3(nf), dim3(HY_NT), lds, ctx->stream, S, Wm, g, rflag, rounds - 1, (const unsigned *)nullptr);
+            hipLaunchKernelGGL(canny_hyst_finish, dim3(nf), dim3(HY_NT), lds, ctx->stream, S, Wm, g, rflag, rounds - 1, (const unsigned *)nullptr,
+                               (unsigned long long *)d_counts);
         } else {
             // a small batch has nothing to hide idle launches behind (a single 4K frame: 24 launches were 184 of its 438 us):
             // fewer sweeps are queued, the finishing kernel completes whatever an unusually long chain of weak pixels leaves
-            int sweeps = nf >= 8 ? HY_SWEEPS : 14;
+            int sweeps = nf >= 8 ? HY_SWEEPS : 9;
             if (ctx->tune.hyst_sweeps >= 1 && ctx->tune.hyst_sweeps <= HY_SWEEPS) sweeps = ctx->tune.hyst_sweeps;  // tests: force the finishing kernel to work
             const int tiles_x = ceil_div(wpr, HY_WORDS), tiles_y = ceil_div(ny, 64);
             dim3 g3(ceil_div(tiles_x * tiles_y, 4), nf);
             IMGFD_HIP(ctx, hipMemsetAsync(flags, 0, sizeof(unsigned) * HY_SWEEPS, ctx->stream));
             for (int i = 0; i < sweeps; i++)
                 hipLaunchKernelGGL(canny_hyst_bits, g3, dim3(256), 0, ctx->stream, S, Wm, wpr, ny, tiles_x, tiles_y, flags, i, act, i);
-            hipLaunchKernelGGL(canny_hyst_finish, dim3(nf), dim3(HY_NT), lds, ctx->stream, S, Wm, g, rflag, 0, (const unsigned *)(flags + sweeps - 1));
+            hipLaunchKernelGGL(canny_hyst_finish, dim3(nf), dim3(HY_NT), lds, ctx->stream, S, Wm, g, rflag, 0, (const unsigned *)(flags + sweeps - 1),
+                               (unsigned long long *)d_counts);
         }
         IMGFD_HIP(ctx, hipGetLastError());
     }
-    IMGFD_HIP(ctx, hipMemsetAsync(d_counts, 0, sizeof(int64_t) * nf, ctx->stream));
-    hipLaunchKernelGGL(canny_expand_bits, dim3(ceil_div(ceil_div(nx, 16), 256), ny, nf), dim3(256), 0, ctx->stream, S, wpr,
-                       d_edges, nx, ny);
-    hipLaunchKernelGGL(canny_count_bits, dim3(CNT_BLOCKS, nf), dim3(256), 0, ctx->stream, S, (size_t)wpr * ny,
+    // 0/255 bytes and pixels_nonzero in one kernel (the finishing kernel zeroed the counts): round 2 queued a memset, the
+    // expansion and a 16-workgroup count -- 25 us of a single frame's critical path
+    hipLaunchKernelGGL(canny_expand_count, dim3(std::min(EXP_BLOCKS, ny), nf), dim3(256), 0, ctx->stream, S, wpr, d_edges, nx, ny,
                        (unsigned long long *)d_counts);
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;

@@ -42,6 +42,10 @@ struct imgfd_ctx {
     // Gaussian taps beyond the IMGFD_MAX_TAPS a kernel argument holds (sigma > 21): grow-only device copy (fir.hip)
     double *taps_dev = nullptr;
     size_t taps_cap = 0;
+    // imgfd_detect_dev: the recorded launch sequence of a repeating small-batch call (detect.hip)
+    void *detect_exec = nullptr;          // hipGraphExec_t
+    long detect_replays = 0, detect_records = 0;  // statistics (imgfd_get_counter)
+    std::string detect_key, detect_seen;  // the call it was recorded for / the call seen last (raw bytes of a DetectKey)
     // fHOG: magnitude + orientation of every integer gradient (fhog_fused.hip), built on first use
     unsigned *fhog_lut = nullptr;
     // lab switches (imgfd_set_tuning / IMGFD_* environment variables read ONCE at context creation; include/imgfd.h
@@ -63,6 +67,7 @@ struct imgfd_ctx {
         int surf_residue = 4;       // SURF octaves 1-3: modulus of the residue layout (0: plain table, 4, 16)
         int max_chunk_frames = 0;   // frames per sub-batch of the *_dev entry points (0: from the 12 GiB / 1 GiB budgets)
         int tile_run = 0;           // tiles per workgroup of the u8 tile kernels (0: from the batch size)
+        int detect_graph = 8;       // imgfd_detect_dev: batches of fewer frames replay a recorded hipGraph when the call repeats (0: never)
         int surf_lanes = 2;      // imgfd_surf_dev: tiles alternate between the context's stream and its companion (1: one stream)
         int surf_rec_cap = 1 << 18;  // imgfd_surf_dev: candidate records a tile's buffer holds before the tile is redone (tests lower it)
         int surf_async = 0;      // imgfd_surf_dev: 1 = never wait for the host (a tile whose candidates overflow reports -candidates)
@@ -174,6 +179,8 @@ imgfd_status pin_reserve(imgfd_ctx *ctx, size_t bytes);
 imgfd_status aux_reserve(imgfd_ctx *ctx, size_t bytes);
 // the context's companion (created on first use): same device, own non-blocking stream, own workspace
 imgfd_status ctx_side(imgfd_ctx *ctx, imgfd_ctx **side);
+// detect.hip: forget the recorded launch sequence (context destruction)
+void detect_graph_drop(imgfd_ctx *ctx);
 // records a profiling event on the stream when K3 profiling is on (no-op otherwise)
 imgfd_status prof_mark(imgfd_ctx *ctx);
 

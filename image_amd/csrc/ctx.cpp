@@ -28,6 +28,7 @@ const std::vector<TuneKey> &tune_keys()
         {"max_chunk_frames", "IMGFD_MAX_CHUNK_FRAMES", &imgfd_ctx::Tune::max_chunk_frames},
         {"tile_run", "IMGFD_TILE_RUN", &imgfd_ctx::Tune::tile_run},
         {"fir_mode", "IMGFD_FIR_MODE", nullptr},
+        {"detect_graph", "IMGFD_DETECT_GRAPH", &imgfd_ctx::Tune::detect_graph},
         {"surf_lanes", "IMGFD_SURF_LANES", &imgfd_ctx::Tune::surf_lanes},
         {"surf_async", "IMGFD_SURF_ASYNC", &imgfd_ctx::Tune::surf_async},
         {"surf_rec_cap", "IMGFD_SURF_REC_CAP", &imgfd_ctx::Tune::surf_rec_cap},
@@ -87,6 +88,7 @@ void imgfd_ctx_destroy(imgfd_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    detect_graph_drop(ctx);
     if (ctx->side) imgfd_ctx_destroy(ctx->side);
     for (hipEvent_t e : {ctx->ev_fork, ctx->ev_gate, ctx->ev_join})
         if (e) (void)hipEventDestroy(e);
@@ -137,6 +139,16 @@ imgfd_status imgfd_set_tuning(imgfd_ctx *ctx, const char *name, int value)
             return IMGFD_OK;
         }
     return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_set_tuning: unknown switch");
+}
+
+imgfd_status imgfd_get_counter(imgfd_ctx *ctx, const char *name, int64_t *value)
+{
+    if (!ctx || !name || !value) return IMGFD_ERR_INVALID;
+    if (!strcmp(name, "detect_graph_replays")) { *value = ctx->detect_replays; return IMGFD_OK; }
+    if (!strcmp(name, "detect_graph_records")) { *value = ctx->detect_records; return IMGFD_OK; }
+    for (const TuneKey &k : tune_keys())
+        if (!strcmp(k.name, name)) { *value = k.field ? ctx->tune.*(k.field) : ctx->fir_mode; return IMGFD_OK; }
+    return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_get_counter: unknown name");
 }
 
 imgfd_status imgfd_profile_k3(imgfd_ctx *ctx, int enable)

@@ -12,16 +12,33 @@
 //      context stream   :  FAST-9 | gauss+grad | structure tensor + response | NMS | compaction |
 #include "common.h"
 
-extern "C" {
+namespace {
 
-imgfd_status imgfd_detect_dev(imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_stream_params *p, imgfd_corner *d_corners,
-                              imgfd_point *d_points, uint8_t *d_edges, int64_t *d_counts)
-try {
-    if (!ctx) return IMGFD_ERR_INVALID;
-    if (!fr || !p || !d_counts || fr->n_frames < 0 || (!p->harris && !p->fast9 && !p->canny) || (p->harris && p->corner_cap < 0) ||
-        (p->fast9 && p->point_cap < 0) || (p->canny && !d_edges) || p->fast9_threshold < 0 || p->fast9_threshold > 255)
-        return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_detect_dev: bad argument");
-    IMGFD_HIP(ctx, hipSetDevice(ctx->device));
+// Everything a recorded launch sequence depends on: the arguments (pointers included: they are baked into the kernel
+// nodes) and the two workspace arenas the kernels were pointed at.
+struct DetectKey {
+    imgfd_frames fr;
+    imgfd_stream_params p;
+    const void *corners, *points, *edges, *counts;
+    const void *ws, *side_ws;
+    size_t ws_size, side_ws_size;
+    int fir_mode;
+    imgfd_ctx::Tune tune;
+};
+
+void make_key(const imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_stream_params *p, const void *c, const void *pt, const void *e,
+              const void *n, DetectKey *k)
+{
+    memset(k, 0, sizeof *k);  // padding bytes take part in the comparison
+    k->fr = *fr; k->p = *p; k->corners = c; k->points = pt; k->edges = e; k->counts = n;
+    k->ws = ctx->ws; k->ws_size = ctx->ws_size;
+    if (ctx->side) { k->side_ws = ctx->side->ws; k->side_ws_size = ctx->side->ws_size; }
+    k->fir_mode = ctx->fir_mode; k->tune = ctx->tune;
+}
+
+imgfd_status detect_body(imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_stream_params *p, imgfd_corner *d_corners,
+                         imgfd_point *d_points, uint8_t *d_edges, int64_t *d_counts)
+{
     const int B = fr->n_frames;
     auto fast9 = [&]() -> imgfd_status {
         if (!p->fast9) return IMGFD_OK;
@@ -56,6 +73,78 @@ try {
     // whoever waits for the context's stream waits for the edges too
     IMGFD_HIP(ctx, hipEventRecord(ctx->ev_join, side->stream));
     IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    return IMGFD_OK;
+}
+
+}  // namespace
+
+void detect_graph_drop(imgfd_ctx *ctx)
+{
+    if (ctx->detect_exec) (void)hipGraphExecDestroy((hipGraphExec_t)ctx->detect_exec);
+    ctx->detect_exec = nullptr;
+    ctx->detect_key.clear();
+    ctx->detect_seen.clear();
+}
+
+extern "C" {
+
+imgfd_status imgfd_detect_dev(imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_stream_params *p, imgfd_corner *d_corners,
+                              imgfd_point *d_points, uint8_t *d_edges, int64_t *d_counts)
+try {
+    if (!ctx) return IMGFD_ERR_INVALID;
+    if (!fr || !p || !d_counts || fr->n_frames < 0 || (!p->harris && !p->fast9 && !p->canny) || (p->harris && p->corner_cap < 0) ||
+        (p->fast9 && p->point_cap < 0) || (p->canny && !d_edges) || p->fast9_threshold < 0 || p->fast9_threshold > 255)
+        return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_detect_dev: bad argument");
+    IMGFD_HIP(ctx, hipSetDevice(ctx->device));
+    // A small batch is bound by the host: ~45 launches at 3-4 us each are more than a single 4K frame's kernels take.  The
+    // launch sequence of a call that repeats -- same frames buffer, same outputs, same parameters: a camera loop -- is
+    // therefore recorded into a hipGraph the second time it is seen and replayed from the third (one ~15 us submission).
+    // The first sight runs eagerly: it sizes the workspaces, which a capture must not do.
+    const int limit = ctx->tune.detect_graph;  // batches of fewer frames than this use the graph (0: never)
+    if (fr->n_frames < 1 || fr->n_frames >= limit || ctx->prof_on || !ctx->stream)  // (the default stream cannot be captured)
+        return detect_body(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
+    DetectKey key;
+    make_key(ctx, fr, p, d_corners, d_points, d_edges, d_counts, &key);
+    const std::string kb(reinterpret_cast<const char *>(&key), sizeof key);
+    if (ctx->detect_exec && kb == ctx->detect_key) {
+        IMGFD_HIP(ctx, hipGraphLaunch((hipGraphExec_t)ctx->detect_exec, ctx->stream));
+        ctx->detect_replays++;
+        return IMGFD_OK;
+    }
+    if (kb != ctx->detect_seen) {  // first sight
+        const imgfd_status st = detect_body(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
+        DetectKey after;  // the run may have grown a workspace: remember the state the NEXT call will see
+        make_key(ctx, fr, p, d_corners, d_points, d_edges, d_counts, &after);
+        ctx->detect_seen.assign(reinterpret_cast<const char *>(&after), sizeof after);
+        return st;
+    }
+    detect_graph_drop(ctx);
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {  // no capture here: eager from now on
+        (void)hipGetLastError();
+        ctx->detect_seen.clear();
+        return detect_body(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
+    }
+    const imgfd_status st = detect_body(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
+    const hipError_t ec = hipStreamEndCapture(ctx->stream, &graph);
+    if (st != IMGFD_OK || ec != hipSuccess || !graph) {  // not recordable (or failed): as before, without a graph from now on
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        ctx->detect_seen.clear();
+        if (st != IMGFD_OK) return st;
+        return detect_body(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
+    }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess || !exec) {
+        (void)hipGetLastError();
+        return detect_body(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
+    }
+    ctx->detect_exec = exec;
+    ctx->detect_key = kb;
+    ctx->detect_records++;
+    IMGFD_HIP(ctx, hipGraphLaunch(exec, ctx->stream));
     return IMGFD_OK;
 } catch (const std::bad_alloc &) {
     return imgfd_fail(ctx, IMGFD_ERR_OOM, "imgfd_detect_dev: out of host memory");

@@ -96,12 +96,16 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  *   "surf_residue" [IMGFD_SURF_RESIDUE]  SURF octaves 1-3: modulus of the residue layout (4; 0 = plain table, 16)
  *   "max_chunk_frames" [IMGFD_MAX_CHUNK_FRAMES]  frames per sub-batch of the *_dev entry points (0: from the memory budgets)
  *   "tile_run" [IMGFD_TILE_RUN]  tiles per workgroup of the u8 tile kernels (0: from the batch size)
+ *   "detect_graph" [IMGFD_DETECT_GRAPH]  imgfd_detect_dev replays a recorded hipGraph for batches of fewer frames than this (8; 0: never)
  *   "surf_lanes" [IMGFD_SURF_LANES]  2 (default): imgfd_surf_dev alternates tiles between two HIP streams; 1: one stream
  *   "surf_async" [IMGFD_SURF_ASYNC]  0 (default): imgfd_surf_dev reads the tile counts back once per call and redoes tiles
  *                                    whose candidates overflowed the record buffer; 1: no wait, such a tile reports -candidates
  *   "surf_rec_cap" [IMGFD_SURF_REC_CAP]  candidate records per tile imgfd_surf_dev buffers before it redoes the tile (262144)
  * Unknown names give IMGFD_ERR_INVALID. */
 IMGFD_API imgfd_status imgfd_set_tuning(imgfd_ctx *ctx, const char *name, int value);
+/* reads a switch back, or a statistic: "detect_graph_records" / "detect_graph_replays" (launch sequences imgfd_detect_dev
+ * recorded into a hipGraph / replayed from one on this context) */
+IMGFD_API imgfd_status imgfd_get_counter(imgfd_ctx *ctx, const char *name, int64_t *value);
 
 /* ------------------------------------------------------------------ Harris */
 typedef struct {

@@ -3,7 +3,7 @@
 # instruction counts (PMC passes, separate from the trace and from each other).  -> $1/pmc_all_kernels.txt
 cd "$GRAFT_REPO_ROOT"; R="$GRAFT_REPO_ROOT"; O="${1:-$R/gpurun_out/pmc_all}"; mkdir -p "$O"; export TMPDIR=/tmp
 cd /tmp; rm -rf /tmp/pall
-B="python $R/bench.py --no-cpu --no-overlap --inner 1"
+B="python $R/bench.py --no-cpu --no-extra --no-dist --no-overlap --inner 1"
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/pall/t -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d /tmp/pall/a -o p -- $B --steps 2 --warmup 1 > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pall/b -o p -- $B --steps 2 --warmup 1 > /dev/null 2>&1

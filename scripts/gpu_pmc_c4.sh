@@ -4,7 +4,7 @@
 cd "$GRAFT_REPO_ROOT"; R="$GRAFT_REPO_ROOT"; O="${1:-$R/gpurun_out/pmc_c4}"; mkdir -p "$O"; export TMPDIR=/tmp
 T="${TILES:-8}"
 cd /tmp; rm -rf /tmp/pc4
-B="python $R/bench.py --config 4 --no-cpu --batch $T"
+B="python $R/bench.py --config 4 --no-cpu --no-dist --batch $T"
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/pc4/t -o p -- $B --steps 4 --warmup 1 > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d /tmp/pc4/a -o p -- $B --steps 1 --warmup 1 > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pc4/b -o p -- $B --steps 1 --warmup 1 > /dev/null 2>&1

@@ -36,6 +36,45 @@ def test_detect_all_equals_the_separate_calls_and_the_oracle():
         assert np.array_equal(edges[f].cpu().numpy(), oracle.canny(host[f])[0])
 
 
+def test_small_batches_replay_a_recorded_graph():
+    """a repeating imgfd_detect_dev call on fewer than 8 frames is recorded into a hipGraph on its second sight and replayed
+    from the third (detect.hip): same buffers, new frame CONTENTS every call -- every call's outputs equal the separate
+    entry points' on that content; a call with other arguments in between falls back to eager launches and re-records"""
+    import torch
+    from image_amd.device import DeviceDetector
+    s = torch.cuda.Stream()                                 # the default stream cannot be captured
+    with torch.cuda.stream(s):
+        det = DeviceDetector(0)
+        nx, ny, n = 448, 280, 3
+        frames = torch.empty((n, ny, nx), dtype=torch.uint8, device="cuda")
+        corners = torch.zeros((n, 4096, 3), dtype=torch.float32, device="cuda"); points = torch.zeros((n, 8192, 2), dtype=torch.int32, device="cuda")
+        edges = torch.zeros((n, ny, nx), dtype=torch.uint8, device="cuda"); counts = torch.zeros((3, n), dtype=torch.int64, device="cuda")
+        other = torch.zeros((3, n), dtype=torch.int64, device="cuda")
+        for it in range(7):
+            host = np.stack([synth.frame(500 + 10 * it + f, nx, ny, n_rect=25) for f in range(n)])
+            frames.copy_(torch.from_numpy(host).cuda())
+            if it == 4:                                     # other arguments: eager; the next calls re-record
+                det.detect_all(frames, corners, points, edges, other, threshold=60.0, fast9_threshold=15, suppress_non_max=1)
+            det.detect_all(frames, corners, points, edges, counts, threshold=50.0, fast9_threshold=15, suppress_non_max=1)
+            det.ctx.sync()
+            got = (counts.clone(), corners.clone(), points.clone(), edges.clone())
+            c1, hc = det.harris(frames, cap=4096, threshold=50.0)
+            p1, fc = det.fast9(frames, threshold=15, suppress_non_max=True, cap=8192)
+            e1, cc = det.canny(frames)
+            det.ctx.sync()
+            assert torch.equal(got[0][0], hc) and torch.equal(got[0][1], fc) and torch.equal(got[0][2], cc), it
+            assert torch.equal(got[3], e1), it
+            for f in range(n):
+                k, m = int(hc[f]), int(fc[f])
+                assert k > 0 and m > 0
+                assert torch.equal(got[1][f, :k], c1[f, :k]) and torch.equal(got[2][f, :m], p1[f, :m]), (it, f)
+        import ctypes as C
+        rec, rep = C.c_int64(), C.c_int64()
+        det.lib.imgfd_get_counter(det.ctx.handle, b"detect_graph_records", C.byref(rec))
+        det.lib.imgfd_get_counter(det.ctx.handle, b"detect_graph_replays", C.byref(rep))
+        assert rec.value >= 1 and rep.value >= 3, (rec.value, rep.value)   # recorded on the second sight, replayed afterwards (the recording survives the other call)
+
+
 def test_synth_frames_match_the_host_generator():
     from image_amd.device import DeviceDetector
     det = DeviceDetector(0)
