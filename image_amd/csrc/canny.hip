@@ -549,6 +549,7 @@ __device__ __forceinline__ unsigned long long lane_below(unsigned long long v)
 // of sweeps without ever reading a flag back.  act[] holds one byte per
 // tile and sweep parity: "this tile changed in that sweep"; a tile can only change if itself or one of its 8
 // neighbours changed in the previous sweep (its inputs are its own words and their halo), so all others leave at once.
+template <int HW>  // words per tile: HY_WORDS for batches (throughput), 2 for one or two frames (twice the waves, shorter sweeps)
 __global__ void __launch_bounds__(256) canny_hyst_bits(unsigned long long *__restrict__ S,
                                                        const unsigned long long *__restrict__ Wm, int wpr, int ny,
                                                        int tiles_x, int tiles_y, unsigned *__restrict__ flags, int sweep,
@@ -575,19 +576,19 @@ __global__ void __launch_bounds__(256) canny_hyst_bits(unsigned long long *__res
     }
     const int y = ty * 64 + lane;
     const bool rowok = y < ny;
-    const int w0 = tx * HY_WORDS;
+    const int w0 = tx * HW;
     unsigned long long *Sf = S + (size_t)blockIdx.y * ny * wpr;
     const unsigned long long *Wf = Wm + (size_t)blockIdx.y * ny * wpr;
-    unsigned long long s[HY_WORDS + 2], w[HY_WORDS];  // s[0] / s[HY_WORDS+1]: halo words left / right
+    unsigned long long s[HW + 2], w[HW];  // s[0] / s[HW+1]: halo words left / right
     const size_t rowbase = (size_t)(rowok ? y : 0) * wpr;
 #pragma unroll
-    for (int q = 0; q < HY_WORDS + 2; q++) {
+    for (int q = 0; q < HW + 2; q++) {
         const int wi = w0 - 1 + q;
         s[q] = (rowok && wi >= 0 && wi < wpr) ? Sf[rowbase + wi] : 0ull;
     }
     bool todo = false;
 #pragma unroll
-    for (int q = 0; q < HY_WORDS; q++) {
+    for (int q = 0; q < HW; q++) {
         const int wi = w0 + q;
         w[q] = (rowok && wi < wpr) ? Wf[rowbase + wi] : 0ull;
         todo = todo || (w[q] & ~s[q + 1]) != 0ull;
@@ -601,33 +602,33 @@ __global__ void __launch_bounds__(256) canny_hyst_bits(unsigned long long *__res
     {
         const int wi = w0 - 1 + lane;
         const int yt = ty * 64 - 1, yb = ty * 64 + 64;
-        if (lane < HY_WORDS + 2 && wi >= 0 && wi < wpr) {
+        if (lane < HW + 2 && wi >= 0 && wi < wpr) {
             if (yt >= 0) trow = Sf[(size_t)yt * wpr + wi];
             if (yb < ny) brow = Sf[(size_t)yb * wpr + wi];
         }
     }
-    unsigned long long top_d[HY_WORDS], bot_d[HY_WORDS];
+    unsigned long long top_d[HW], bot_d[HW];
     {
-        unsigned long long t[HY_WORDS + 2], b[HY_WORDS + 2];
+        unsigned long long t[HW + 2], b[HW + 2];
 #pragma unroll
-        for (int q = 0; q < HY_WORDS + 2; q++) { t[q] = __shfl(trow, q); b[q] = __shfl(brow, q); }
+        for (int q = 0; q < HW + 2; q++) { t[q] = __shfl(trow, q); b[q] = __shfl(brow, q); }
 #pragma unroll
-        for (int q = 0; q < HY_WORDS; q++) {
+        for (int q = 0; q < HW; q++) {
             top_d[q] = dilate_h(t[q + 1], t[q], t[q + 2]);
             bot_d[q] = dilate_h(b[q + 1], b[q], b[q + 2]);
         }
     }
-    unsigned long long halo_d[HY_WORDS];  // the dilated halo row a border lane sees: row above for lane 0, row below for lane 63
+    unsigned long long halo_d[HW];  // the dilated halo row a border lane sees: row above for lane 0, row below for lane 63
 #pragma unroll
-    for (int q = 0; q < HY_WORDS; q++) halo_d[q] = (lane == 0 ? top_d[q] : 0ull) | (lane == 63 ? bot_d[q] : 0ull);
+    for (int q = 0; q < HW; q++) halo_d[q] = (lane == 0 ? top_d[q] : 0ull) | (lane == 63 ? bot_d[q] : 0ull);
     bool any = false;
     for (;;) {
         bool ch = false;
-        unsigned long long d[HY_WORDS];
+        unsigned long long d[HW];
 #pragma unroll
-        for (int q = 0; q < HY_WORDS; q++) d[q] = dilate_h(s[q + 1], s[q], s[q + 2]);
+        for (int q = 0; q < HW; q++) d[q] = dilate_h(s[q + 1], s[q], s[q + 2]);
 #pragma unroll
-        for (int q = 0; q < HY_WORDS; q++) {
+        for (int q = 0; q < HW; q++) {
             // lane_above / lane_below give 0 to lanes 0 / 63: their neighbours are the halo rows, OR-ed in (halo_d)
             const unsigned long long cand = w[q] & ~s[q + 1] & (d[q] | lane_above(d[q]) | lane_below(d[q]) | halo_d[q]);
             if (cand) {
@@ -640,7 +641,7 @@ __global__ void __launch_bounds__(256) canny_hyst_bits(unsigned long long *__res
     }
     if (any) {
 #pragma unroll
-        for (int q = 0; q < HY_WORDS; q++) {
+        for (int q = 0; q < HW; q++) {
             const int wi = w0 + q;
             if (rowok && wi < wpr) Sf[rowbase + wi] = s[q + 1];
         }
@@ -1022,7 +1023,7 @@ size_t canny_ws_bytes(int nx, int ny, int nf)
     return align_up(n * sizeof(double), 256) + align_up(n * sizeof(float), 256) + 2 * align_up(words * 8, 256) +
            align_up(12 * ((size_t)nx + ny), 256) + 512 +  // taps in memory (kernels of more than CANNY_MAX_TAPS taps)
            align_up(2 * (size_t)nf * ceil_div(nx, 64) * ceil_div(ny, 8), 256) +
-           align_up(2 * (size_t)nf * ceil_div(ceil_div(nx, 64), 4) * ceil_div(ny, 64), 256) + 4096;
+           align_up(2 * (size_t)nf * ceil_div(ceil_div(nx, 64), 2) * ceil_div(ny, 64), 256) + 4096;
 }
 
 #define HY_SWEEPS 24  // sweeps queued per batch (the bench frames converge in 10-12); flags[] holds one word per sweep
@@ -1086,7 +1087,7 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
     unsigned long long *S = (unsigned long long *)ws_alloc(ctx, words * 8);
     unsigned long long *Wm = (unsigned long long *)ws_alloc(ctx, words * 8);
     unsigned *flags = (unsigned *)ws_alloc(ctx, 256);
-    const size_t act_bytes = 2 * (size_t)nf * ceil_div(wpr, HY_WORDS) * ceil_div(ny, 64);  // tile activity of the sweeps, two parities
+    const size_t act_bytes = 2 * (size_t)nf * ceil_div(wpr, 2) * ceil_div(ny, 64);  // tile activity of the sweeps, two parities (tiles of 2 words at the least)
     unsigned char *act = (unsigned char *)ws_alloc(ctx, act_bytes);
     const size_t rflag_bytes = 2 * (size_t)nf * wpr * ceil_div(ny, 8);  // region flags, two parities (a region is at least 1 word x 8 rows)
     unsigned char *rflag = (unsigned char *)ws_alloc(ctx, rflag_bytes);
@@ -1157,13 +1158,19 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
         } else {
             // a small batch has nothing to hide idle launches behind (a single 4K frame: 24 launches were 184 of its 438 us):
             // fewer sweeps are queued, the finishing kernel completes whatever an unusually long chain of weak pixels leaves
-            int sweeps = nf >= 8 ? HY_SWEEPS : 9;
+            // One or two frames: tiles of 2 words instead of 4 -- a sweep's length is its slowest wave's in-register fixpoint
+            // loop, and 510 waves leave half the SIMDs of the chip empty (single 4K frame 0.258 -> 0.228 ms; from four frames
+            // on the wider tile wins again: fewer sweeps until nothing changes).
+            const int hw = ctx->tune.hyst_words == 2 || ctx->tune.hyst_words == 4 ? ctx->tune.hyst_words : (nf <= 2 ? 2 : HY_WORDS);
+            int sweeps = nf >= 8 ? HY_SWEEPS : (hw == 2 ? 10 : 9);
             if (ctx->tune.hyst_sweeps >= 1 && ctx->tune.hyst_sweeps <= HY_SWEEPS) sweeps = ctx->tune.hyst_sweeps;  // tests: force the finishing kernel to work
-            const int tiles_x = ceil_div(wpr, HY_WORDS), tiles_y = ceil_div(ny, 64);
+            const int tiles_x = ceil_div(wpr, hw), tiles_y = ceil_div(ny, 64);
             dim3 g3(ceil_div(tiles_x * tiles_y, 4), nf);
             IMGFD_HIP(ctx, hipMemsetAsync(flags, 0, sizeof(unsigned) * HY_SWEEPS, ctx->stream));
-            for (int i = 0; i < sweeps; i++)
-                hipLaunchKernelGGL(canny_hyst_bits, g3, dim3(256), 0, ctx->stream, S, Wm, wpr, ny, tiles_x, tiles_y, flags, i, act, i);
+            for (int i = 0; i < sweeps; i++) {
+                if (hw == 2) hipLaunchKernelGGL(canny_hyst_bits<2>, g3, dim3(256), 0, ctx->stream, S, Wm, wpr, ny, tiles_x, tiles_y, flags, i, act, i);
+                else hipLaunchKernelGGL(canny_hyst_bits<HY_WORDS>, g3, dim3(256), 0, ctx->stream, S, Wm, wpr, ny, tiles_x, tiles_y, flags, i, act, i);
+            }
             hipLaunchKernelGGL(canny_hyst_finish, dim3(nf), dim3(HY_NT), lds, ctx->stream, S, Wm, g, rflag, 0, (const unsigned *)(flags + sweeps - 1),
                                (unsigned long long *)d_counts);
         }

@@ -57,6 +57,7 @@ struct imgfd_ctx {
         // round-1/2 experiment switches (formerly getenv() at their point of use)
         int hyst_mode = 0;          // Canny hysteresis: 0 = bit-plane sweeps + finishing kernel, 1 = LDS-resident region rounds
         int hyst_sweeps = 0;        // sweeps queued before the finishing kernel (0: 24, or 14 for batches under 8 frames)
+        int hyst_words = 0;         // words per sweep tile: 2 or 4 (0: 2 for one or two frames, else 4)
         int hyst_rounds = 0;        // region mode: rounds queued (0: from the region grid)
         int hyst_region_w = 0, hyst_region_h = 0;  // region size in words x rows (0: from the batch size)
         int canny_gate = 0;         // imgfd_detect_dev: where Canny releases the second stream (0 before the blur, 1 after it, 2 after gradient/NMS)

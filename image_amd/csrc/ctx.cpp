@@ -14,6 +14,7 @@ const std::vector<TuneKey> &tune_keys()
         {"hyst_mode", "IMGFD_HYST_MODE", &imgfd_ctx::Tune::hyst_mode},
         {"hyst_sweeps", "IMGFD_HYST_SWEEPS", &imgfd_ctx::Tune::hyst_sweeps},
         {"hyst_rounds", "IMGFD_HYST_ROUNDS", &imgfd_ctx::Tune::hyst_rounds},
+        {"hyst_words", "IMGFD_HYST_WORDS", &imgfd_ctx::Tune::hyst_words},
         {"hyst_region_w", "IMGFD_HYST_REGION_W", &imgfd_ctx::Tune::hyst_region_w},
         {"hyst_region_h", "IMGFD_HYST_REGION_H", &imgfd_ctx::Tune::hyst_region_h},
         {"canny_gate", "IMGFD_CANNY_GATE", &imgfd_ctx::Tune::canny_gate},

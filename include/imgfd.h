@@ -87,6 +87,7 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  *   "fir_mode" [IMGFD_FIR_MODE]  as imgfd_set_fir_mode
  *   "hyst_mode" [IMGFD_HYST_MODE]  Canny hysteresis: 0 (default) bit-plane sweeps + finishing kernel, 1 LDS-resident region rounds
  *   "hyst_sweeps" [IMGFD_HYST_SWEEPS], "hyst_rounds" [IMGFD_HYST_ROUNDS]  sweeps / rounds queued before the finishing kernel
+ *   "hyst_words" [IMGFD_HYST_WORDS]  words per tile of a sweep, 2 or 4 (0: 2 for one or two frames, else 4)
  *   "hyst_region_w", "hyst_region_h" [IMGFD_HYST_REGION_W / _H]  region size of the finishing kernel (words x rows)
  *   "canny_gate" [IMGFD_CANNY_GATE]  imgfd_detect_dev: where Canny releases the second stream (0 before the blur, 1, 2)
  *   "xcd_remap" [IMGFD_XCD_REMAP]  1 (default): workers of one XCD own neighbouring tiles in the marching FIR kernels

@@ -153,6 +153,27 @@ def test_hysteresis_device_side_termination(be, mode, region, rounds, nx, ny):
             be.set_tuning(k, 0)
 
 
+@pytest.mark.parametrize("words", [2, 4])
+def test_hysteresis_tile_widths(be, words):
+    """the sweeps walk tiles of 2 words (one or two frames) or 4 words (batches): same fixpoint, with few sweeps queued the
+    finishing kernel completes either"""
+    img = _serpentine(384, 200)
+    frames = np.stack([img, synth.frame(44, 384, 200), img[:, ::-1].copy()])
+    try:
+        be.set_tuning("hyst_words", words)
+        for sweeps in (0, 2):
+            be.set_tuning("hyst_sweeps", sweeps)
+            edges, n = be.canny(img, **SERP_KW)
+            ref, rn = oracle.canny(img, **SERP_KW)
+            assert n == rn and mismatch(edges, ref) == 0, (words, sweeps)
+            e, c = be.canny_dev(frames, **SERP_KW)
+            for f in range(3):
+                r, k = oracle.canny(frames[f], **SERP_KW)
+                assert c[f] == k and mismatch(e[f], r) <= (0 if f != 1 else 3), (words, sweeps, f)
+    finally:
+        be.set_tuning("hyst_words", 0); be.set_tuning("hyst_sweeps", 0)
+
+
 def test_batch_dev(be):
     frames = np.stack([synth.frame(300 + f, 160, 96) for f in range(3)])
     edges, counts = be.canny_dev(frames)
