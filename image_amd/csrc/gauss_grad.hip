@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256) gauss_grad_tile(GaussGradParams p)
 #pragma unroll
             for (int k = 0; k < GG_PX + 2 * R; k++) {
                 constexpr int sh = OFFX % 4;
-                d[k] = (double)(float)((wv[(sh + k) >> 2] >> (8 * ((sh + k) & 3))) & 0xffu);
+                d[k] = (double)((wv[(sh + k) >> 2] >> (8 * ((sh + k) & 3))) & 0xffu);  // one v_cvt_f64_u32 (bytes are exact either way)
             }
         } else {
 #pragma unroll
@@ -149,9 +149,10 @@ __global__ void __launch_bounds__(256) gauss_grad_tile(GaussGradParams p)
                          1. / 8. * (is[i - 1][j + 1] + is[i + 1][j + 1] - is[i - 1][j - 1] - is[i + 1][j - 1]));
             gy = (float)(1. / 4. * (is[i + 1][j] - is[i - 1][j]) +
                          1. / 8. * (is[i + 1][j + 1] + is[i + 1][j - 1] - is[i - 1][j + 1] - is[i - 1][j - 1]));
-        } else {                             // gradient.cpp:34-35
-            gx = (float)(0.5 * (is[i][j + 1] - is[i][j - 1]));
-            gy = (float)(0.5 * (is[i + 1][j] - is[i - 1][j]));
+        } else {                             // gradient.cpp:34-35: (float)(0.5 * (a - b)) with a - b in float.  Halving a float in
+            // double and rounding back is halving it in float (one exact product, one rounding): no conversions needed
+            gx = 0.5f * (is[i][j + 1] - is[i][j - 1]);
+            gy = 0.5f * (is[i + 1][j] - is[i - 1][j]);
         }
         // streaming stores: the 8 B/px written here would otherwise push the u8 lines a run of tiles shares out of the L2
         // before the next tile of the run reads them again
