@@ -69,7 +69,7 @@ struct imgfd_ctx {
         int max_chunk_frames = 0;   // frames per sub-batch of the *_dev entry points (0: from the 12 GiB / 1 GiB budgets)
         int tile_run = 0;           // tiles per workgroup of the u8 tile kernels (0: from the batch size)
         int detect_graph = 8;       // imgfd_detect_dev: batches of fewer frames replay a recorded hipGraph when the call repeats (0: never)
-        int surf_lanes = 2;      // imgfd_surf_dev: tiles alternate between the context's stream and its companion (1: one stream)
+        int surf_lanes = 4;      // imgfd_surf_dev: tiles go round-robin over this many HIP streams (1..4), each with its own buffers
         int surf_rec_cap = 1 << 18;  // imgfd_surf_dev: candidate records a tile's buffer holds before the tile is redone (tests lower it)
         int surf_async = 0;      // imgfd_surf_dev: 1 = never wait for the host (a tile whose candidates overflow reports -candidates)
     } tune;

@@ -129,11 +129,13 @@ __device__ __forceinline__ void fh_phase1(const unsigned *__restrict__ img, cons
             txs[p] = tx + FH_CEN; tys[p] = ty + FH_CEN;
             span |= (unsigned)txs[p] | (unsigned)tys[p];
         }
-        // the whole wave inside the table's centre: 4 LDS reads; otherwise 4 gathers from the table in L2 (wave-uniform)
-        if (__all(span < 2u * FH_CEN || !it.live)) {
+        // a lane whose four gradients lie inside the table's centre reads them from LDS (masked indices: always in bounds);
+        // the other lanes -- edges, strong texture -- gather theirs from the table in L2.  ONE divergent region per row: a
+        // gather's cost in the texture unit follows its number of active lanes, and the gathers bound phase 1.
 #pragma unroll
-            for (int p = 0; p < 4; p++) nw[p] = lut_c[tys[p] * (2 * FH_CEN) + txs[p]];
-        } else {
+        for (int p = 0; p < 4; p++)
+            nw[p] = lut_c[((unsigned)tys[p] & (2u * FH_CEN - 1u)) * (2 * FH_CEN) + ((unsigned)txs[p] & (2u * FH_CEN - 1u))];
+        if (span >= 2u * FH_CEN && it.live) {
 #pragma unroll
             for (int p = 0; p < 4; p++) nw[p] = lut[(unsigned)((tys[p] + 255 - FH_CEN) * 512 + (txs[p] + 255 - FH_CEN))];
         }

@@ -98,7 +98,7 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  *   "max_chunk_frames" [IMGFD_MAX_CHUNK_FRAMES]  frames per sub-batch of the *_dev entry points (0: from the memory budgets)
  *   "tile_run" [IMGFD_TILE_RUN]  tiles per workgroup of the u8 tile kernels (0: from the batch size)
  *   "detect_graph" [IMGFD_DETECT_GRAPH]  imgfd_detect_dev replays a recorded hipGraph for batches of fewer frames than this (8; 0: never)
- *   "surf_lanes" [IMGFD_SURF_LANES]  2 (default): imgfd_surf_dev alternates tiles between two HIP streams; 1: one stream
+ *   "surf_lanes" [IMGFD_SURF_LANES]  4 (default): imgfd_surf_dev deals the tiles round-robin to this many HIP streams (1..4)
  *   "surf_async" [IMGFD_SURF_ASYNC]  0 (default): imgfd_surf_dev reads the tile counts back once per call and redoes tiles
  *                                    whose candidates overflowed the record buffer; 1: no wait, such a tile reports -candidates
  *   "surf_rec_cap" [IMGFD_SURF_REC_CAP]  candidate records per tile imgfd_surf_dev buffers before it redoes the tile (262144)
