@@ -135,9 +135,39 @@ __global__ void __launch_bounds__(256) gauss_grad_tile(GaussGradParams p)
         for (int k = 0; k < GG_PX; k++) is[r0 + k][c] = o[k];  // rows SH .. SHP-1 are padding
     }
     __syncthreads();
-    // ---- gradient: lane = column (coalesced 256-byte row segments)
-    const int lane = tid & 63;
+    // ---- gradient.  Interior tiles (no pixel on the image border, whole quads, aligned planes): a thread takes 8 consecutive
+    // pixels of a row -- 26 LDS words, 32 float operations, four 16-byte streaming stores; one pixel per thread spent more
+    // instructions on addresses and the loop than on the two differences (22 of the kernel's 66 per pixel)
     float *Ix = p.Ix + (size_t)frame * p.nx * p.ny, *Iy = p.Iy + (size_t)frame * p.nx * p.ny;
+    if (GRAD != IMGFD_SOBEL_OPERATOR && p.vec4 && x0 >= 1 && x0 + GG_TX <= p.nx - 1 && y0 >= 1 && y0 + GG_TY <= p.ny - 1 &&
+        (reinterpret_cast<size_t>(Ix) & 15) == 0 && (reinterpret_cast<size_t>(Iy) & 15) == 0) {
+        for (int item = tid; item < GG_TY * (GG_TX / 8); item += 256) {
+            const int r = item / (GG_TX / 8), c = (item - r * (GG_TX / 8)) * 8;
+            const int i = r + 2, j = c + 2;  // tile coordinates of the first pixel
+            float mid[10], up[8], dn[8];
+#pragma unroll
+            for (int k = 0; k < 10; k++) mid[k] = is[i][j - 1 + k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { up[k] = is[i - 1][j + k]; dn[k] = is[i + 1][j + k]; }
+            float gx[8], gy[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {  // gradient.cpp:34-35, as below
+                gx[k] = 0.5f * (mid[k + 2] - mid[k]);
+                gy[k] = 0.5f * (dn[k] - up[k]);
+            }
+            const size_t o = (size_t)(y0 + r) * p.nx + (x0 + c);
+            typedef float v4f __attribute__((vector_size(16)));
+            const v4f x0v = {gx[0], gx[1], gx[2], gx[3]}, x1v = {gx[4], gx[5], gx[6], gx[7]};
+            const v4f y0v = {gy[0], gy[1], gy[2], gy[3]}, y1v = {gy[4], gy[5], gy[6], gy[7]};
+            IMGFD_STREAM_STORE(x0v, reinterpret_cast<v4f *>(Ix + o));
+            IMGFD_STREAM_STORE(x1v, reinterpret_cast<v4f *>(Ix + o + 4));
+            IMGFD_STREAM_STORE(y0v, reinterpret_cast<v4f *>(Iy + o));
+            IMGFD_STREAM_STORE(y1v, reinterpret_cast<v4f *>(Iy + o + 4));
+        }
+        continue;
+    }
+    // border tiles, Sobel, unaligned planes: lane = column (coalesced 256-byte row segments)
+    const int lane = tid & 63;
     for (int r = tid >> 6; r < GG_TY; r += 4) {
         const int x = x0 + lane, y = y0 + r;
         if (x >= p.nx || y >= p.ny) continue;
