@@ -71,6 +71,7 @@ struct imgfd_ctx {
         int detect_graph = 8;       // imgfd_detect_dev: batches of fewer frames replay a recorded hipGraph when the call repeats (0: never)
         int surf_lanes = 4;      // imgfd_surf_dev: tiles go round-robin over this many HIP streams (1..4), each with its own buffers
         int surf_rec_cap = 1 << 18;  // imgfd_surf_dev: candidate records a tile's buffer holds before the tile is redone (tests lower it)
+        int surf_sort_cap = 2048;    // imgfd_surf_dev: selected records ranked by the LDS sort; more are ranked all-pairs (tests lower it)
         int surf_async = 0;      // imgfd_surf_dev: 1 = never wait for the host (a tile whose candidates overflow reports -candidates)
     } tune;
     // in-pipeline K3 timing (imgfd_profile_k3)

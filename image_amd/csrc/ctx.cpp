@@ -32,6 +32,7 @@ const std::vector<TuneKey> &tune_keys()
         {"detect_graph", "IMGFD_DETECT_GRAPH", &imgfd_ctx::Tune::detect_graph},
         {"surf_lanes", "IMGFD_SURF_LANES", &imgfd_ctx::Tune::surf_lanes},
         {"surf_async", "IMGFD_SURF_ASYNC", &imgfd_ctx::Tune::surf_async},
+        {"surf_sort_cap", "IMGFD_SURF_SORT_CAP", &imgfd_ctx::Tune::surf_sort_cap},
         {"surf_rec_cap", "IMGFD_SURF_REC_CAP", &imgfd_ctx::Tune::surf_rec_cap},
     };
     return keys;

@@ -818,6 +818,7 @@ struct SurfRankParams {
     int rows, cols;
     unsigned *sel, *order;   // scratch, lim entries each
     unsigned *cand;          // scratch, 2 x cap entries (the candidate lists of the radix select)
+    unsigned sort_cap;       // selected records the LDS sort takes (SR_SORT; tests lower it to reach the all-pairs ranking)
     double *pts;             // lim x 3 for K19
     double *feat;            // lim x 70 feature records of this tile
     long long *count_out;    // d_counts[f]
@@ -934,7 +935,7 @@ __global__ void __launch_bounds__(SR_NT) surf_rank_select(SurfRankParams q)
     }
     __syncthreads();
     const unsigned m = min(nsel, lim);  // == lim
-    if (m <= SR_SORT) {
+    if (m <= min((unsigned)SR_SORT, q.sort_cap)) {
         // up to SR_SORT selected records: bitonic sort of their positions in LDS, better first (all pairs -- below -- cost
         // 10^6 comparisons in this one workgroup for the R default of 1000 points: ~80 us of the kernel's 140)
         unsigned N = 2;
@@ -1400,7 +1401,7 @@ try {
         double *feat = d_features + (size_t)f * (size_t)cap * 70;
         SurfRankParams q;
         q.rec = L.d.rec; q.count = L.d.count; q.cap = L.d.cap; q.lim = lim; q.rows = rows; q.cols = cols; q.sel = L.sel; q.order = L.sel + lim;
-        q.cand = L.cand;
+        q.cand = L.cand; q.sort_cap = (unsigned)std::max(0, ctx->tune.surf_sort_cap);
         q.pts = d_pts; q.feat = feat; q.count_out = reinterpret_cast<long long *>(d_counts) + f; q.m_out = L.m_dev;
         if (st == IMGFD_OK) {
             hipLaunchKernelGGL(surf_rank_select, dim3(1), dim3(SR_NT), 0, c->stream, q);

@@ -91,11 +91,16 @@ def test_batch_surf_dev_descriptors_on_the_device(be):
 
 
 @pytest.mark.parametrize("max_points", [1, 9, 25])
-def test_surf_dev_ranks_and_cuts_on_the_device(be, max_points):
+@pytest.mark.parametrize("sort_cap", [2048, 4])
+def test_surf_dev_ranks_and_cuts_on_the_device(be, max_points, sort_cap):
     """imgfd_surf_dev orders the candidates on the device (radix select of the max_points best, rank, box test, compaction):
     with fewer slots than candidates the strongest survive, in the reference's order"""
     frames = np.stack([blobs(140 + f, 384, 256) for f in range(2)])
-    got = be.surf_dev(frames, max_points=max_points, threshold=5.0)
+    try:
+        be.set_tuning("surf_sort_cap", sort_cap)   # 4: more than 4 selected records take the all-pairs ranking instead of the LDS sort
+        got = be.surf_dev(frames, max_points=max_points, threshold=5.0)
+    finally:
+        be.set_tuning("surf_sort_cap", 2048)
     for f in range(2):
         allp = oracle.surf_interest_points(frames[f], 5.0)
         assert len(allp) > max_points                           # the cut really cuts
