@@ -82,6 +82,7 @@ SIGNATURES = {
     "imgfd_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "imgfd_ctx_sync": (C.c_int, [C.c_void_p]),
     "imgfd_free": (None, [C.c_void_p]),
+    "imgfd_device_count": (C.c_int, [c_int_p]),
     "imgfd_set_fir_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "imgfd_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "imgfd_get_counter": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),

@@ -79,6 +79,16 @@ static imgfd_status ctx_init(int device, void *stream, bool own, imgfd_ctx **out
     return IMGFD_OK;
 }
 
+imgfd_status imgfd_device_count(int *count)
+{
+    if (!count) return IMGFD_ERR_INVALID;
+    *count = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return IMGFD_ERR_NO_DEVICE;
+    *count = n;
+    return IMGFD_OK;
+}
+
 imgfd_status imgfd_ctx_create(int device, imgfd_ctx **out) { return ctx_init(device, nullptr, true, out); }
 
 imgfd_status imgfd_ctx_create_on_stream(int device, void *stream, imgfd_ctx **out)

@@ -78,6 +78,9 @@ IMGFD_API int imgfd_version(void);
  *   1 = fused-accumulate (default): sum = fma(B[j], pair, sum) inside the f64 accumulation only; the
  *       f32 stages (products, response) never contract.  Results differ from strict only when the
  *       f64 sum sits within ~1e-16 relative of a float rounding boundary. */
+/* number of HIP devices this process sees (0 and IMGFD_ERR_NO_DEVICE when there is none).  The path shards by frame: one
+ * context per device, each with its own share of the frames, no exchange between them (examples/multi_gpu_counts.c). */
+IMGFD_API imgfd_status imgfd_device_count(int *count);
 IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
 /* Lab switches.  None changes a result; the defaults are the measured best.  Each can also be given through the
  * environment variable in brackets, which is read ONCE, when the context is created.
