@@ -68,7 +68,8 @@ struct imgfd_ctx {
         int surf_residue = 4;       // SURF octaves 1-3: modulus of the residue layout (0: plain table, 4, 16)
         int max_chunk_frames = 0;   // frames per sub-batch of the *_dev entry points (0: from the 12 GiB / 1 GiB budgets)
         int tile_run = 0;           // tiles per workgroup of the u8 tile kernels (0: from the batch size)
-        int detect_graph = 8;       // imgfd_detect_dev: batches of fewer frames replay a recorded hipGraph when the call repeats (0: never)
+        int detect_graph = 0;       // imgfd_detect_dev: batches of fewer frames than this replay a recorded hipGraph when the call repeats
+                                    // (0 = never, the default: replay measured no faster than eager launches, profiles/r03)
         int surf_lanes = 4;      // imgfd_surf_dev: tiles go round-robin over this many HIP streams (1..4), each with its own buffers
         int surf_rec_cap = 1 << 18;  // imgfd_surf_dev: candidate records a tile's buffer holds before the tile is redone (tests lower it)
         int surf_sort_cap = 2048;    // imgfd_surf_dev: selected records ranked by the LDS sort; more are ranked all-pairs (tests lower it)

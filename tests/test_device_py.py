@@ -45,6 +45,7 @@ def test_small_batches_replay_a_recorded_graph():
     s = torch.cuda.Stream()                                 # the default stream cannot be captured
     with torch.cuda.stream(s):
         det = DeviceDetector(0)
+        det.ctx.check(det.lib.imgfd_set_tuning(det.ctx.handle, b"detect_graph", 8), "detect_graph")   # a lab switch, off by default
         nx, ny, n = 448, 280, 3
         frames = torch.empty((n, ny, nx), dtype=torch.uint8, device="cuda")
         corners = torch.zeros((n, 4096, 3), dtype=torch.float32, device="cuda"); points = torch.zeros((n, 8192, 2), dtype=torch.int32, device="cuda")
