@@ -495,11 +495,15 @@ __device__ __forceinline__ void canny_grad_nms_tile(double (*sb)[GN_TX + 2 * GN_
 
 __global__ void __launch_bounds__(256) canny_grad_nms(const float *__restrict__ blur, unsigned long long *__restrict__ S,
                                                       unsigned long long *__restrict__ Wm, int nx, int ny,
-                                                      int words_per_row, int accGrad, int low_thr, int high_thr, int vec4)
+                                                      int words_per_row, int accGrad, int low_thr, int high_thr, int vec4,
+                                                      unsigned *__restrict__ sweep_flags, int n_sweep_flags)
 {
     __shared__ __attribute__((aligned(16))) double sb[GN_TY + 4][GN_TX + 2 * GN_XO + 4];
     __shared__ double sg[GN_TY + 2][GN_TX + 2 + 1];
     const int x0 = blockIdx.x * GN_TX, y0 = blockIdx.y * GN_TY;
+    // the hysteresis sweeps behind this kernel start from cleared "changed" words (a memset of their own was 5 us of a
+    // single frame's critical path)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (int)threadIdx.x < n_sweep_flags) sweep_flags[threadIdx.x] = 0;
     // workgroup-uniform: interior tiles skip every clamp and fetch the blurred tile as float4s
     const bool inside = vec4 && x0 - GN_XO >= 0 && x0 + GN_TX + GN_XO <= nx && y0 - 2 >= 0 && y0 + GN_TY + 2 <= ny;
     if (inside) canny_grad_nms_tile<true>(sb, sg, blur, S, Wm, nx, ny, words_per_row, accGrad, low_thr, high_thr);
@@ -1136,7 +1140,7 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
     if (after_front && gate_at == 1) IMGFD_TRY((*after_front)());
     dim3 g2(wpr, ceil_div(ny, GN_TY), nf);
     hipLaunchKernelGGL(canny_grad_nms, g2, dim3(256), 0, ctx->stream, blur, S, Wm, nx, ny, wpr, accGrad, (int)low_thr,
-                       (int)high_thr, (int)(nx % 4 == 0 && (size_t)blur % 16 == 0));
+                       (int)high_thr, (int)(nx % 4 == 0 && (size_t)blur % 16 == 0), flags, HY_SWEEPS);
     IMGFD_HIP(ctx, hipGetLastError());
     if (after_front && gate_at != 0 && gate_at != 1) IMGFD_TRY((*after_front)());
     // Hysteresis, terminated on the device -- no host read-back anywhere.  A fixed number of sweeps is queued (a sweep whose
@@ -1166,7 +1170,6 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
             if (ctx->tune.hyst_sweeps >= 1 && ctx->tune.hyst_sweeps <= HY_SWEEPS) sweeps = ctx->tune.hyst_sweeps;  // tests: force the finishing kernel to work
             const int tiles_x = ceil_div(wpr, hw), tiles_y = ceil_div(ny, 64);
             dim3 g3(ceil_div(tiles_x * tiles_y, 4), nf);
-            IMGFD_HIP(ctx, hipMemsetAsync(flags, 0, sizeof(unsigned) * HY_SWEEPS, ctx->stream));
             for (int i = 0; i < sweeps; i++) {
                 if (hw == 2) hipLaunchKernelGGL(canny_hyst_bits<2>, g3, dim3(256), 0, ctx->stream, S, Wm, wpr, ny, tiles_x, tiles_y, flags, i, act, i);
                 else hipLaunchKernelGGL(canny_hyst_bits<HY_WORDS>, g3, dim3(256), 0, ctx->stream, S, Wm, wpr, ny, tiles_x, tiles_y, flags, i, act, i);
