@@ -1071,7 +1071,8 @@ int hyst_rounds(const imgfd_ctx *ctx, const HystGeom &g)
 // all device work for nf frames; d_edges / d_counts are device buffers
 imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, size_t frame_stride, int nx, int ny,
                           int nf, double s, double low_thr, double high_thr, int accGrad, uint8_t *d_edges,
-                          int64_t *d_counts, const std::function<imgfd_status()> *after_front = nullptr)
+                          int64_t *d_counts, const std::function<imgfd_status()> *after_front = nullptr,
+                          const std::function<imgfd_status()> *after_nms = nullptr)
 {
     if (!(s > 0)) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "canny: s must be positive");
     const size_t n = (size_t)nx * ny * nf;
@@ -1143,6 +1144,7 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
                        (int)high_thr, (int)(nx % 4 == 0 && (size_t)blur % 16 == 0), flags, HY_SWEEPS);
     IMGFD_HIP(ctx, hipGetLastError());
     if (after_front && gate_at != 0 && gate_at != 1) IMGFD_TRY((*after_front)());
+    if (after_nms) IMGFD_TRY((*after_nms)());  // second hook of imgfd_detect_dev: the gradient/NMS kernel is queued
     // Hysteresis, terminated on the device -- no host read-back anywhere.  A fixed number of sweeps is queued (a sweep whose
     // predecessor changed nothing returns at once: an idle launch costs a few microseconds), then the finishing kernel,
     // which leaves at once when the last sweep was idle and otherwise completes the frames region by region.
@@ -1227,17 +1229,21 @@ imgfd_status imgfd_canny_i32(imgfd_ctx *ctx, const int32_t *image, int nx, int n
 imgfd_status imgfd_canny_dev(imgfd_ctx *ctx, const imgfd_frames *fr, double s, double low_thr,
                              double high_thr, int accGrad, uint8_t *d_edges, int64_t *d_counts)
 {
-    return canny_dev_hooked(ctx, fr, s, low_thr, high_thr, accGrad, d_edges, d_counts, nullptr);
+    return canny_dev_hooked(ctx, fr, s, low_thr, high_thr, accGrad, d_edges, d_counts, nullptr, nullptr);
 }
 
 }  // extern "C"
 
 imgfd_status canny_dev_hooked(imgfd_ctx *ctx, const imgfd_frames *fr, double s, double low_thr, double high_thr, int accGrad,
-                              uint8_t *d_edges, int64_t *d_counts, const std::function<imgfd_status()> *after_front)
+                              uint8_t *d_edges, int64_t *d_counts, const std::function<imgfd_status()> *after_front,
+                              const std::function<imgfd_status()> *after_nms)
 try {
     if (!ctx || !fr || !fr->d_frames || !d_edges || !d_counts || fr->n_frames < 0 || fr->dtype != 0 || fr->nx < 1 || fr->ny < 1)
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_canny_dev: bad argument (frames must be u8)");
-    if (!fr->n_frames) return after_front ? (*after_front)() : IMGFD_OK;
+    if (!fr->n_frames) {
+        if (after_front) IMGFD_TRY((*after_front)());
+        return after_nms ? (*after_nms)() : IMGFD_OK;
+    }
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
     const int nx = fr->nx, ny = fr->ny;
     const size_t per_frame = canny_ws_bytes(nx, ny, 1);
@@ -1248,7 +1254,8 @@ try {
         ctx->ws_used = 0;
         IMGFD_TRY(canny_device(ctx, (const uint8_t *)fr->d_frames + (size_t)f0 * fr->frame_stride_bytes,
                                fr->row_stride_bytes, fr->frame_stride_bytes, nx, ny, nf, s, low_thr, high_thr, accGrad,
-                               d_edges + (size_t)f0 * nx * ny, d_counts + f0, f0 == 0 ? after_front : nullptr));
+                               d_edges + (size_t)f0 * nx * ny, d_counts + f0, f0 == 0 ? after_front : nullptr,
+                               f0 + chunk >= fr->n_frames ? after_nms : nullptr));
     }
     return IMGFD_OK;
 } catch (const std::bad_alloc &) {

@@ -38,7 +38,7 @@ struct imgfd_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // second context (own stream and workspace) for work that overlaps this context's stream (imgfd_detect_dev)
     imgfd_ctx *side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_gate = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_gate = nullptr, ev_gate2 = nullptr, ev_join = nullptr;
     // Gaussian taps beyond the IMGFD_MAX_TAPS a kernel argument holds (sigma > 21): grow-only device copy (fir.hip)
     double *taps_dev = nullptr;
     size_t taps_cap = 0;
@@ -60,6 +60,7 @@ struct imgfd_ctx {
         int hyst_words = 0;         // words per sweep tile: 2 or 4 (0: 2 for one or two frames, else 4)
         int hyst_rounds = 0;        // region mode: rounds queued (0: from the region grid)
         int hyst_region_w = 0, hyst_region_h = 0;  // region size in words x rows (0: from the batch size)
+        int harris_gate = 1;        // imgfd_detect_dev: the Harris chain is released when Canny's gradient/NMS kernel has finished (0: together with FAST-9)
         int canny_gate = 0;         // imgfd_detect_dev: where Canny releases the second stream (0 before the blur, 1 after it, 2 after gradient/NMS)
         int xcd_remap = 1;          // marching FIR kernels: workers of one XCD own neighbouring tiles
         int fused_response = 1;     // Harris: corner response in the structure-tensor kernel's epilogue
@@ -272,4 +273,5 @@ imgfd_status launch_fast9(imgfd_ctx *ctx, const uint8_t *d_img, int w, int h, in
 // canny.hip: imgfd_canny_dev with a hook that runs on the host while the (first chunk of the) batch is being queued --
 // before the blur kernel by default (IMGFD_GATE, canny_device); imgfd_detect_dev queues the other detectors from it
 imgfd_status canny_dev_hooked(imgfd_ctx *ctx, const imgfd_frames *fr, double s, double low_thr, double high_thr, int accGrad,
-                              uint8_t *d_edges, int64_t *d_counts, const std::function<imgfd_status()> *after_front);
+                              uint8_t *d_edges, int64_t *d_counts, const std::function<imgfd_status()> *after_front,
+                              const std::function<imgfd_status()> *after_nms = nullptr);

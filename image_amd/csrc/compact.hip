@@ -12,7 +12,7 @@
 #include "common.h"
 #include "harris_device.h"
 
-#define SCAN_NT 1024
+#define SCAN_NT 256  // four waves: a 16-wave workgroup never found a CU with 16 free slots while another stream kept refilling them with 4-wave workgroups (rows_scan: 686 us in the two-stream step)
 
 size_t compact_bytes(int nx, int ny, int n_frames)
 {

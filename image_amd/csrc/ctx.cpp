@@ -18,6 +18,7 @@ const std::vector<TuneKey> &tune_keys()
         {"hyst_region_w", "IMGFD_HYST_REGION_W", &imgfd_ctx::Tune::hyst_region_w},
         {"hyst_region_h", "IMGFD_HYST_REGION_H", &imgfd_ctx::Tune::hyst_region_h},
         {"canny_gate", "IMGFD_CANNY_GATE", &imgfd_ctx::Tune::canny_gate},
+        {"harris_gate", "IMGFD_HARRIS_GATE", &imgfd_ctx::Tune::harris_gate},
         {"xcd_remap", "IMGFD_XCD_REMAP", &imgfd_ctx::Tune::xcd_remap},
         {"fused_response", "IMGFD_FUSED_RESPONSE", &imgfd_ctx::Tune::fused_response},
         {"nms_tiled", "IMGFD_NMS_TILED", &imgfd_ctx::Tune::nms_tiled},
@@ -102,7 +103,7 @@ void imgfd_ctx_destroy(imgfd_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     detect_graph_drop(ctx);
     if (ctx->side) imgfd_ctx_destroy(ctx->side);
-    for (hipEvent_t e : {ctx->ev_fork, ctx->ev_gate, ctx->ev_join})
+    for (hipEvent_t e : {ctx->ev_fork, ctx->ev_gate, ctx->ev_gate2, ctx->ev_join})
         if (e) (void)hipEventDestroy(e);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
@@ -255,15 +256,15 @@ imgfd_status ctx_side(imgfd_ctx *ctx, imgfd_ctx **side)
         s->fir_mode = ctx->fir_mode;
         s->tune = ctx->tune;
         // the three events first; the companion is published only when everything it needs exists
-        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-        for (int i = 0; i < 3; i++) {
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int i = 0; i < 4; i++) {
             if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) {
                 for (int j = 0; j < i; j++) (void)hipEventDestroy(ev[j]);
                 imgfd_ctx_destroy(s);
                 return imgfd_fail(ctx, IMGFD_ERR_HIP, "could not create the companion context's events");
             }
         }
-        ctx->ev_fork = ev[0]; ctx->ev_gate = ev[1]; ctx->ev_join = ev[2];
+        ctx->ev_fork = ev[0]; ctx->ev_gate = ev[1]; ctx->ev_join = ev[2]; ctx->ev_gate2 = ev[3];
         ctx->side = s;
     }
     *side = ctx->side;

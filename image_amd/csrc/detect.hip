@@ -59,13 +59,26 @@ imgfd_status detect_body(imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_str
     // the frames (and anything else queued on the context's stream) come first
     IMGFD_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     IMGFD_HIP(ctx, hipStreamWaitEvent(side->stream, ctx->ev_fork, 0));
+    // FAST-9 starts with Canny's blur.  The Harris chain is held back until Canny's gradient/NMS kernel has finished: its
+    // Gaussian/gradient kernel then runs beside the hysteresis sweeps (latency-bound, a fraction of the chip), and the
+    // structure-tensor kernel -- whose workgroups fill every CU they sit on -- does not stretch Canny's VALU-bound front.
+    // (Round 2 got this order by accident: the 16-wave rows_scan workgroup of FAST-9's compaction found no CU with 16 free
+    // wave slots until the gradient/NMS kernel had drained.  Released together with FAST-9: 43.5 instead of 40.3 ms per
+    // 10 passes of 32 4K frames, profiles/r03/experiments_log.txt.)
+    const bool hold_harris = ctx->tune.harris_gate != 0 && ctx->tune.canny_gate == 0;
     const std::function<imgfd_status()> gate = [&]() -> imgfd_status {
         IMGFD_HIP(ctx, hipEventRecord(ctx->ev_gate, side->stream));
         IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gate, 0));
         IMGFD_TRY(fast9());
+        return hold_harris ? IMGFD_OK : harris();
+    };
+    const std::function<imgfd_status()> gate2 = [&]() -> imgfd_status {
+        if (!hold_harris) return IMGFD_OK;
+        IMGFD_HIP(ctx, hipEventRecord(ctx->ev_gate2, side->stream));
+        IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gate2, 0));
         return harris();
     };
-    const imgfd_status st = canny_dev_hooked(side, fr, p->s, p->low_thr, p->high_thr, p->accGrad, d_edges, d_counts + 2 * B, &gate);
+    const imgfd_status st = canny_dev_hooked(side, fr, p->s, p->low_thr, p->high_thr, p->accGrad, d_edges, d_counts + 2 * B, &gate, &gate2);
     if (st != IMGFD_OK) {
         if (ctx->err.empty() || !side->err.empty()) ctx->err = side->err.empty() ? ctx->err : side->err;
         return st;

@@ -22,14 +22,19 @@ def test_detect_all_equals_the_separate_calls_and_the_oracle():
     edges, cc = det.canny(frames)
     c2 = torch.zeros_like(corners); p2 = torch.zeros_like(points); e2 = torch.zeros_like(edges)
     counts = torch.zeros((3, n), dtype=torch.int64, device="cuda")
-    for _ in range(2):                                   # twice: the companion context is created on the first call
-        det.detect_all(frames, c2, p2, e2, counts, threshold=50.0, fast9_threshold=15, suppress_non_max=1)
-    det.ctx.sync()
-    assert torch.equal(counts[0], hc) and torch.equal(counts[1], fc) and torch.equal(counts[2], cc)
-    assert torch.equal(e2, edges)
+    for gate in (1, 0):                                  # both schedules of the second stream (harris_gate, imgfd.h)
+        det.ctx.check(det.lib.imgfd_set_tuning(det.ctx.handle, b"harris_gate", gate), "harris_gate")
+        c2.zero_(); p2.zero_(); e2.zero_(); counts.zero_()
+        for _ in range(2):                               # twice: the companion context is created on the first call
+            det.detect_all(frames, c2, p2, e2, counts, threshold=50.0, fast9_threshold=15, suppress_non_max=1)
+        det.ctx.sync()
+        assert torch.equal(counts[0], hc) and torch.equal(counts[1], fc) and torch.equal(counts[2], cc)
+        assert torch.equal(e2, edges)
+        for f in range(n):
+            k, m = int(hc[f]), int(fc[f])
+            assert torch.equal(c2[f, :k], corners[f, :k]) and torch.equal(p2[f, :m], points[f, :m])
     for f in range(n):
         k, m = int(hc[f]), int(fc[f])
-        assert torch.equal(c2[f, :k], corners[f, :k]) and torch.equal(p2[f, :m], points[f, :m])
         ref = oracle.harris(host[f].astype(np.float32), threshold=50.0)
         assert np.array_equal(corners[f, :k].cpu().numpy().view(np.uint32), ref.view(np.uint32))
         assert np.array_equal(points[f, :m].cpu().numpy(), oracle.fast9(host[f], 15, True))
