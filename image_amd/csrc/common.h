@@ -45,6 +45,7 @@ struct imgfd_ctx {
     // imgfd_detect_dev: the recorded launch sequence of a repeating small-batch call (detect.hip)
     void *detect_exec = nullptr;          // hipGraphExec_t
     long detect_replays = 0, detect_records = 0;  // statistics (imgfd_get_counter)
+    long gauss_march_launches = 0;
     std::string detect_key, detect_seen;  // the call it was recorded for / the call seen last (raw bytes of a DetectKey)
     // fHOG: magnitude + orientation of every integer gradient (fhog_fused.hip), built on first use
     unsigned *fhog_lut = nullptr;
@@ -60,6 +61,8 @@ struct imgfd_ctx {
         int hyst_words = 0;         // words per sweep tile: 2 or 4 (0: 2 for one or two frames, else 4)
         int hyst_rounds = 0;        // region mode: rounds queued (0: from the region grid)
         int hyst_region_w = 0, hyst_region_h = 0;  // region size in words x rows (0: from the batch size)
+        int gauss_march = 1;        // u8 frames whose width is a multiple of 16: the marching Gaussian + gradient kernel (0: the tile kernel)
+        int gauss_march_seg = 0;    // rows per segment of that kernel (0: from the batch)
         int harris_gate = 1;        // imgfd_detect_dev: the Harris chain is released when Canny's gradient/NMS kernel has finished (0: together with FAST-9)
         int canny_gate = 0;         // imgfd_detect_dev: where Canny releases the second stream (0 before the blur, 1 after it, 2 after gradient/NMS)
         int xcd_remap = 1;          // marching FIR kernels: workers of one XCD own neighbouring tiles
@@ -230,6 +233,10 @@ int fir_size(float sigma, int precision);
 // gauss_grad.hip: discrete Gaussian (radius 3) + gradient in one kernel; returns false when the fused kernel does not
 // apply (other radii, image narrower than the kernel) and the caller runs the two separate stages instead
 bool gauss_grad_fused_supported(int nx, int ny, float sigma, int gauss_type);
+bool gauss_grad_march_supported(const void *d_in, int in_is_u8, int in_pitch, size_t in_frame_stride, const float *d_Ix,
+                                const float *d_Iy, int nx, int ny);
+imgfd_status launch_gauss_grad_march(imgfd_ctx *ctx, const void *d_in, int in_pitch, size_t in_frame_stride, float *d_Ix,
+                                     float *d_Iy, int nx, int ny, int n_frames, const double *B, int grad_type);
 imgfd_status launch_gauss_grad_fused(imgfd_ctx *ctx, const void *d_in, int in_is_u8, int in_pitch, size_t in_frame_stride,
                                      float *d_Ix, float *d_Iy, int nx, int ny, int n_frames, float sigma, int grad_type);
 // harris_stages.hip

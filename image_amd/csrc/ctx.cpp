@@ -19,6 +19,8 @@ const std::vector<TuneKey> &tune_keys()
         {"hyst_region_h", "IMGFD_HYST_REGION_H", &imgfd_ctx::Tune::hyst_region_h},
         {"canny_gate", "IMGFD_CANNY_GATE", &imgfd_ctx::Tune::canny_gate},
         {"harris_gate", "IMGFD_HARRIS_GATE", &imgfd_ctx::Tune::harris_gate},
+        {"gauss_march", "IMGFD_GAUSS_MARCH", &imgfd_ctx::Tune::gauss_march},
+        {"gauss_march_seg", "IMGFD_GAUSS_MARCH_SEG", &imgfd_ctx::Tune::gauss_march_seg},
         {"xcd_remap", "IMGFD_XCD_REMAP", &imgfd_ctx::Tune::xcd_remap},
         {"fused_response", "IMGFD_FUSED_RESPONSE", &imgfd_ctx::Tune::fused_response},
         {"nms_tiled", "IMGFD_NMS_TILED", &imgfd_ctx::Tune::nms_tiled},
@@ -159,6 +161,7 @@ imgfd_status imgfd_get_counter(imgfd_ctx *ctx, const char *name, int64_t *value)
     if (!ctx || !name || !value) return IMGFD_ERR_INVALID;
     if (!strcmp(name, "detect_graph_replays")) { *value = ctx->detect_replays; return IMGFD_OK; }
     if (!strcmp(name, "detect_graph_records")) { *value = ctx->detect_records; return IMGFD_OK; }
+    if (!strcmp(name, "gauss_march_launches")) { *value = ctx->gauss_march_launches; return IMGFD_OK; }
     for (const TuneKey &k : tune_keys())
         if (!strcmp(k.name, name)) { *value = k.field ? ctx->tune.*(k.field) : ctx->fir_mode; return IMGFD_OK; }
     return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_get_counter: unknown name");

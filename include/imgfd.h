@@ -95,6 +95,8 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  *   "canny_gate" [IMGFD_CANNY_GATE]  imgfd_detect_dev: where Canny releases the second stream (0 before the blur, 1, 2)
  *   "harris_gate" [IMGFD_HARRIS_GATE]  imgfd_detect_dev: 1 (default) the Harris chain starts when Canny's gradient/NMS kernel
  *                                      has finished (FAST-9 starts with the blur); 0: together with FAST-9
+ *   "gauss_march" [IMGFD_GAUSS_MARCH]  1 (default): u8 frames whose width is a multiple of 16 (>= 256) take the marching
+ *                                      Gaussian + gradient kernel; 0: the tile kernel.  "gauss_march_seg": its rows per segment
  *   "xcd_remap" [IMGFD_XCD_REMAP]  1 (default): workers of one XCD own neighbouring tiles in the marching FIR kernels
  *   "fused_response" [IMGFD_FUSED_RESPONSE]  1 (default): corner response in the structure-tensor kernel's epilogue
  *   "nms_tiled" [IMGFD_NMS_TILED]  1: the tiled Harris NMS kernel instead of the sparse one
@@ -112,7 +114,8 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  * Unknown names give IMGFD_ERR_INVALID. */
 IMGFD_API imgfd_status imgfd_set_tuning(imgfd_ctx *ctx, const char *name, int value);
 /* reads a switch back, or a statistic: "detect_graph_records" / "detect_graph_replays" (launch sequences imgfd_detect_dev
- * recorded into a hipGraph / replayed from one on this context) */
+ * recorded into a hipGraph / replayed from one on this context), "gauss_march_launches" (launches of the marching
+ * Gaussian + gradient kernel) */
 IMGFD_API imgfd_status imgfd_get_counter(imgfd_ctx *ctx, const char *name, int64_t *value);
 
 /* ------------------------------------------------------------------ Harris */

@@ -34,6 +34,12 @@ class _Base:
     def set_tuning(self, name, value):
         self.check(self.lib.imgfd_set_tuning(self.ctx, name.encode(), int(value)), "imgfd_set_tuning")
 
+    def get_counter(self, name):
+        import ctypes as C
+        v = C.c_int64(0)
+        self.check(self.lib.imgfd_get_counter(self.ctx, name.encode(), C.byref(v)), "imgfd_get_counter")
+        return int(v.value)
+
     def k_fhog_lut(self):
         out = self.empty((511, 512), np.uint32)
         self.check(self.lib.imgfd_k_fhog_lut(self.ctx, self.ptr(out)), "k_fhog_lut")

@@ -87,6 +87,34 @@ def test_fused_gauss_grad_u8_strict_bit_exact(be, nx, ny, type):
     assert_bits_equal(iy, ry, f"Iy {nx}x{ny}")
 
 
+@pytest.mark.parametrize("type", [0, 1])
+@pytest.mark.parametrize("nx,ny,seg", [(256, 16, 0), (256, 41, 0), (496, 33, 10), (480, 100, 24), (512, 17, 16), (736, 130, 0), (736, 130, 43),
+                                       (240 * 3 + 16, 66, 33), (1040, 50, 49)])
+def test_marching_gauss_grad_u8_bit_exact(be, nx, ny, seg, type):
+    """gauss_grad_march (u8 frames whose width is a multiple of 16): strips of 240 columns -- first, interior, a last strip of
+    16 columns --, segments of every length class (one chunk, a last segment of two rows, the top / bottom clamp of the
+    gradient inside a segment), against the two reference stages bit for bit in strict mode; with fused accumulation the
+    tile kernel's bits"""
+    img = synth.frame(29, nx, ny)
+    sm = oracle.harris_stage("gaussian", img.astype(np.float32), sigma=1.0, type=0)
+    rx, ry = oracle.harris_stage("gradient", sm, type=type)
+    try:
+        be.set_tuning("gauss_march_seg", seg)
+        be.set_fir_mode(0)
+        n0 = be.get_counter("gauss_march_launches")
+        ix, iy = be.k_gauss_grad_u8(img, 1.0, type)
+        assert be.get_counter("gauss_march_launches") == n0 + 1, "the marching kernel did not run"
+        assert_bits_equal(ix, rx, f"Ix {nx}x{ny}")
+        assert_bits_equal(iy, ry, f"Iy {nx}x{ny}")
+        be.set_fir_mode(1)
+        ix, iy = be.k_gauss_grad_u8(img, 1.0, type)
+        be.set_tuning("gauss_march", 0)
+        tx, ty = be.k_gauss_grad_u8(img, 1.0, type)
+        assert_bits_equal(ix, tx, "Ix, fused accumulation"); assert_bits_equal(iy, ty, "Iy, fused accumulation")
+    finally:
+        be.set_tuning("gauss_march", 1); be.set_tuning("gauss_march_seg", 0); be.set_fir_mode(0)
+
+
 def _gradients(seed, nx, ny):
     img = oracle.harris_stage("gaussian", synth.frame(seed, nx, ny).astype(np.float32), sigma=1.0, type=0)
     return oracle.harris_stage("gradient", img, type=0)
