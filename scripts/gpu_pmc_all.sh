@@ -5,9 +5,9 @@ cd "$GRAFT_REPO_ROOT"; R="$GRAFT_REPO_ROOT"; O="${1:-$R/gpurun_out/pmc_all}"; mk
 cd /tmp; rm -rf /tmp/pall
 B="python $R/bench.py --no-cpu --no-extra --no-dist --no-overlap --inner 1"
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/pall/t -o p -- $B --steps 8 --warmup 2 > /dev/null 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d /tmp/pall/a -o p -- $B --steps 2 --warmup 1 > /dev/null 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pall/b -o p -- $B --steps 2 --warmup 1 > /dev/null 2>&1
-timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --output-format csv -d /tmp/pall/c -o p -- $B --steps 2 --warmup 1 > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d /tmp/pall/a -o p -- $B --steps 2 --warmup 1 > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pall/b -o p -- $B --steps 2 --warmup 1 > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --output-format csv -d /tmp/pall/c -o p -- $B --steps 2 --warmup 1 > /dev/null 2>&1
 python - > "$O/pmc_all_kernels.txt" <<'PY'
 import csv, glob, collections, re
 def short(k):

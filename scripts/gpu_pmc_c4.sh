@@ -6,10 +6,10 @@ T="${TILES:-8}"
 cd /tmp; rm -rf /tmp/pc4
 B="python $R/bench.py --config 4 --no-cpu --no-dist --batch $T"
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/pc4/t -o p -- $B --steps 4 --warmup 1 > /dev/null 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d /tmp/pc4/a -o p -- $B --steps 1 --warmup 1 > /dev/null 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pc4/b -o p -- $B --steps 1 --warmup 1 > /dev/null 2>&1
-timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --output-format csv -d /tmp/pc4/c -o p -- $B --steps 1 --warmup 1 > /dev/null 2>&1
-timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY --output-format csv -d /tmp/pc4/d -o p -- $B --steps 1 --warmup 1 > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d /tmp/pc4/a -o p -- $B --steps 1 --warmup 1 > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pc4/b -o p -- $B --steps 1 --warmup 1 > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --output-format csv -d /tmp/pc4/c -o p -- $B --steps 1 --warmup 1 > /dev/null 2>&1
+timeout 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY --output-format csv -d /tmp/pc4/d -o p -- $B --steps 1 --warmup 1 > /dev/null 2>&1
 TILES_N=$T python - > "$O/pmc_config4.txt" <<'PY'
 import csv, glob, collections, re, os
 T = int(os.environ["TILES_N"])

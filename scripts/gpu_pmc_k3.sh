@@ -9,7 +9,7 @@ KERN="${1:-fir_tensor}"
 cd /tmp
 pmc() {
   name=$1; shift
-  BATCHES=32 ITERS=4 timeout 600 rocprofv3 --pmc "$@" --output-format csv -d "$O/pmc_$name" -o p -- python $R/scripts/k3_variants.py > "$O/pmc_$name.log" 2>&1
+  BATCHES=32 ITERS=4 timeout 200 rocprofv3 --pmc "$@" --output-format csv -d "$O/pmc_$name" -o p -- python $R/scripts/k3_variants.py > "$O/pmc_$name.log" 2>&1
   f=$(find "$O/pmc_$name" -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python - "$f" "$KERN" "$O/pmc_$name.json" <<'PY'
 import csv, sys, collections, json

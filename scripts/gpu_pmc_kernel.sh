@@ -7,7 +7,7 @@ cd /tmp
 pmc() {
   name=$1; shift
   rm -rf /tmp/pk_$name
-  ITERS=3 timeout 600 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pk_$name -o p -- $cmd > /tmp/pk_$name.log 2>&1
+  ITERS=3 timeout 150 rocprofv3 --pmc "$@" --output-format csv -d /tmp/pk_$name -o p -- $cmd > /tmp/pk_$name.log 2>&1
   f=$(find /tmp/pk_$name -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python - "$f" "$pat" <<'PY'
 import csv, sys, collections
@@ -25,4 +25,5 @@ PY
 }
 pmc a SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE
 pmc b SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU
-pmc c FETCH_SIZE WRITE_SIZE
+pmc c FETCH_SIZE
+pmc d WRITE_SIZE   # (FETCH_SIZE and WRITE_SIZE in ONE pass hung rocprofv3 until the timeout)

@@ -30,6 +30,7 @@ BATCHES=1,8,32 python scripts/k3_variants.py 2>/dev/null | grep kernel > "$O/k3_
 bash scripts/gpu_pmc_all.sh "$O" > /dev/null 2>&1
 bash scripts/gpu_pmc_c4.sh "$O" > /dev/null 2>&1
 bash scripts/gpu_b1_timeline.sh > "$O/single_frame_timeline.txt" 2>&1
+bash scripts/gpu_b32_timeline.sh > "$O/two_stream_timeline.txt" 2>&1
 IMGFD_SURF_LANES=1 python scripts/surf_dev_time.py > "$O/surf_one_lane.txt" 2>/dev/null
 python scripts/surf_dev_time.py > "$O/surf_two_lanes.txt" 2>/dev/null
 TILES1=1 python scripts/surf_dev_time.py > "$O/surf_single_tile.txt" 2>/dev/null
