@@ -611,30 +611,35 @@ __global__ void __launch_bounds__(256) canny_hyst_bits(unsigned long long *__res
             if (yb < ny) brow = Sf[(size_t)yb * wpr + wi];
         }
     }
+    // the dilated halo rows are wave-uniform: kept in scalar registers (readlane), a border lane picks its row per use
     unsigned long long top_d[HW], bot_d[HW];
     {
         unsigned long long t[HW + 2], b[HW + 2];
 #pragma unroll
-        for (int q = 0; q < HW + 2; q++) { t[q] = __shfl(trow, q); b[q] = __shfl(brow, q); }
+        for (int q = 0; q < HW + 2; q++) {
+            t[q] = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(trow >> 32), q) << 32) |
+                   (unsigned)__builtin_amdgcn_readlane((int)(unsigned)trow, q);
+            b[q] = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(brow >> 32), q) << 32) |
+                   (unsigned)__builtin_amdgcn_readlane((int)(unsigned)brow, q);
+        }
 #pragma unroll
         for (int q = 0; q < HW; q++) {
             top_d[q] = dilate_h(t[q + 1], t[q], t[q + 2]);
             bot_d[q] = dilate_h(b[q + 1], b[q], b[q + 2]);
         }
     }
-    unsigned long long halo_d[HW];  // the dilated halo row a border lane sees: row above for lane 0, row below for lane 63
-#pragma unroll
-    for (int q = 0; q < HW; q++) halo_d[q] = (lane == 0 ? top_d[q] : 0ull) | (lane == 63 ? bot_d[q] : 0ull);
+    const bool first = lane == 0, last = lane == 63;
     bool any = false;
     for (;;) {
         bool ch = false;
-        unsigned long long d[HW];
-#pragma unroll
-        for (int q = 0; q < HW; q++) d[q] = dilate_h(s[q + 1], s[q], s[q + 2]);
 #pragma unroll
         for (int q = 0; q < HW; q++) {
-            // lane_above / lane_below give 0 to lanes 0 / 63: their neighbours are the halo rows, OR-ed in (halo_d)
-            const unsigned long long cand = w[q] & ~s[q + 1] & (d[q] | lane_above(d[q]) | lane_below(d[q]) | halo_d[q]);
+            // a word's dilation is taken when the word is visited (words to its left already hold this pass's additions: the
+            // fixpoint is the same, reached no later).  lane_above / lane_below give 0 to lanes 0 / 63: their neighbours are
+            // the halo rows
+            const unsigned long long d = dilate_h(s[q + 1], s[q], s[q + 2]);
+            const unsigned long long halo = first ? top_d[q] : (last ? bot_d[q] : 0ull);
+            const unsigned long long cand = w[q] & ~s[q + 1] & (d | lane_above(d) | lane_below(d) | halo);
             if (cand) {
                 s[q + 1] |= flood_runs(w[q], cand);
                 ch = true;
@@ -1071,8 +1076,8 @@ int hyst_rounds(const imgfd_ctx *ctx, const HystGeom &g)
 // all device work for nf frames; d_edges / d_counts are device buffers
 imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, size_t frame_stride, int nx, int ny,
                           int nf, double s, double low_thr, double high_thr, int accGrad, uint8_t *d_edges,
-                          int64_t *d_counts, const std::function<imgfd_status()> *after_front = nullptr,
-                          const std::function<imgfd_status()> *after_nms = nullptr)
+                          int64_t *d_counts, const std::function<imgfd_status(int)> *hook = nullptr, bool first = true,
+                          bool last = true)
 {
     if (!(s > 0)) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "canny: s must be positive");
     const size_t n = (size_t)nx * ny * nf;
@@ -1099,10 +1104,13 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
     const size_t tap_bytes = big ? align_up(12 * (offx.size() + offy.size()), 256) + 256 : 0;
     char *taps_dev = big ? (char *)ws_alloc(ctx, tap_bytes) : nullptr;
     if ((!fast && !tmp) || !blur || !S || !Wm || !flags || !act || !rflag || (big && !taps_dev)) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
-    // where the caller's hook (imgfd_detect_dev: FAST-9 and the Harris chain on the other stream) is released: before the
-    // blur by default; lab switch "canny_gate" 1 | 2 releases it after the blur | after the gradient/NMS kernel (experiments)
-    const int gate_at = ctx->tune.canny_gate;
-    if (after_front && gate_at == 0) IMGFD_TRY((*after_front)());
+    // the caller's hook (imgfd_detect_dev releases FAST-9 and the Harris chain on its other stream through it) is called
+    // with the position reached: 0 before the blur, 1 behind it, 2 behind the gradient/NMS kernel
+    auto at = [&](int pos) -> imgfd_status {
+        if (!hook || (pos < 2 ? !first : !last)) return IMGFD_OK;
+        return (*hook)(pos);
+    };
+    IMGFD_TRY(at(0));
     if (fast) {
         BlurMarchParams p;
         memset(&p, 0, sizeof p);
@@ -1138,13 +1146,12 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
         hipLaunchKernelGGL(canny_blur_rows, g1, dim3(256), 0, ctx->stream, d_in, row_stride, frame_stride, tmp, nx, ny, tx);
         hipLaunchKernelGGL(canny_blur_cols, g1, dim3(256), 0, ctx->stream, tmp, blur, nx, ny, ty);
     }
-    if (after_front && gate_at == 1) IMGFD_TRY((*after_front)());
+    IMGFD_TRY(at(1));
     dim3 g2(wpr, ceil_div(ny, GN_TY), nf);
     hipLaunchKernelGGL(canny_grad_nms, g2, dim3(256), 0, ctx->stream, blur, S, Wm, nx, ny, wpr, accGrad, (int)low_thr,
                        (int)high_thr, (int)(nx % 4 == 0 && (size_t)blur % 16 == 0), flags, HY_SWEEPS);
     IMGFD_HIP(ctx, hipGetLastError());
-    if (after_front && gate_at != 0 && gate_at != 1) IMGFD_TRY((*after_front)());
-    if (after_nms) IMGFD_TRY((*after_nms)());  // second hook of imgfd_detect_dev: the gradient/NMS kernel is queued
+    IMGFD_TRY(at(2));
     // Hysteresis, terminated on the device -- no host read-back anywhere.  A fixed number of sweeps is queued (a sweep whose
     // predecessor changed nothing returns at once: an idle launch costs a few microseconds), then the finishing kernel,
     // which leaves at once when the last sweep was idle and otherwise completes the frames region by region.
@@ -1229,20 +1236,19 @@ imgfd_status imgfd_canny_i32(imgfd_ctx *ctx, const int32_t *image, int nx, int n
 imgfd_status imgfd_canny_dev(imgfd_ctx *ctx, const imgfd_frames *fr, double s, double low_thr,
                              double high_thr, int accGrad, uint8_t *d_edges, int64_t *d_counts)
 {
-    return canny_dev_hooked(ctx, fr, s, low_thr, high_thr, accGrad, d_edges, d_counts, nullptr, nullptr);
+    return canny_dev_hooked(ctx, fr, s, low_thr, high_thr, accGrad, d_edges, d_counts, nullptr);
 }
 
 }  // extern "C"
 
 imgfd_status canny_dev_hooked(imgfd_ctx *ctx, const imgfd_frames *fr, double s, double low_thr, double high_thr, int accGrad,
-                              uint8_t *d_edges, int64_t *d_counts, const std::function<imgfd_status()> *after_front,
-                              const std::function<imgfd_status()> *after_nms)
+                              uint8_t *d_edges, int64_t *d_counts, const std::function<imgfd_status(int)> *hook)
 try {
     if (!ctx || !fr || !fr->d_frames || !d_edges || !d_counts || fr->n_frames < 0 || fr->dtype != 0 || fr->nx < 1 || fr->ny < 1)
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_canny_dev: bad argument (frames must be u8)");
     if (!fr->n_frames) {
-        if (after_front) IMGFD_TRY((*after_front)());
-        return after_nms ? (*after_nms)() : IMGFD_OK;
+        for (int pos = 0; hook && pos < 3; pos++) IMGFD_TRY((*hook)(pos));
+        return IMGFD_OK;
     }
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
     const int nx = fr->nx, ny = fr->ny;
@@ -1254,8 +1260,7 @@ try {
         ctx->ws_used = 0;
         IMGFD_TRY(canny_device(ctx, (const uint8_t *)fr->d_frames + (size_t)f0 * fr->frame_stride_bytes,
                                fr->row_stride_bytes, fr->frame_stride_bytes, nx, ny, nf, s, low_thr, high_thr, accGrad,
-                               d_edges + (size_t)f0 * nx * ny, d_counts + f0, f0 == 0 ? after_front : nullptr,
-                               f0 + chunk >= fr->n_frames ? after_nms : nullptr));
+                               d_edges + (size_t)f0 * nx * ny, d_counts + f0, hook, f0 == 0, f0 + chunk >= fr->n_frames));
     }
     return IMGFD_OK;
 } catch (const std::bad_alloc &) {

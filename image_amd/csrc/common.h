@@ -63,7 +63,7 @@ struct imgfd_ctx {
         int hyst_region_w = 0, hyst_region_h = 0;  // region size in words x rows (0: from the batch size)
         int gauss_march = 1;        // u8 frames whose width is a multiple of 16: the marching Gaussian + gradient kernel (0: the tile kernel)
         int gauss_march_seg = 0;    // rows per segment of that kernel (0: from the batch)
-        int harris_gate = 1;        // imgfd_detect_dev: the Harris chain is released when Canny's gradient/NMS kernel has finished (0: together with FAST-9)
+        int harris_gate = 1;        // imgfd_detect_dev: the Harris chain is released behind Canny's gradient/NMS kernel (1), behind its blur (2), or together with FAST-9 (0)
         int canny_gate = 0;         // imgfd_detect_dev: where Canny releases the second stream (0 before the blur, 1 after it, 2 after gradient/NMS)
         int xcd_remap = 1;          // marching FIR kernels: workers of one XCD own neighbouring tiles
         int fused_response = 1;     // Harris: corner response in the structure-tensor kernel's epilogue
@@ -280,5 +280,4 @@ imgfd_status launch_fast9(imgfd_ctx *ctx, const uint8_t *d_img, int w, int h, in
 // canny.hip: imgfd_canny_dev with a hook that runs on the host while the (first chunk of the) batch is being queued --
 // before the blur kernel by default (IMGFD_GATE, canny_device); imgfd_detect_dev queues the other detectors from it
 imgfd_status canny_dev_hooked(imgfd_ctx *ctx, const imgfd_frames *fr, double s, double low_thr, double high_thr, int accGrad,
-                              uint8_t *d_edges, int64_t *d_counts, const std::function<imgfd_status()> *after_front,
-                              const std::function<imgfd_status()> *after_nms = nullptr);
+                              uint8_t *d_edges, int64_t *d_counts, const std::function<imgfd_status(int)> *hook);

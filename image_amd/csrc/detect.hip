@@ -65,20 +65,22 @@ imgfd_status detect_body(imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_str
     // (Round 2 got this order by accident: the 16-wave rows_scan workgroup of FAST-9's compaction found no CU with 16 free
     // wave slots until the gradient/NMS kernel had drained.  Released together with FAST-9: 43.5 instead of 40.3 ms per
     // 10 passes of 32 4K frames, profiles/r03/experiments_log.txt.)
-    const bool hold_harris = ctx->tune.harris_gate != 0 && ctx->tune.canny_gate == 0;
-    const std::function<imgfd_status()> gate = [&]() -> imgfd_status {
-        IMGFD_HIP(ctx, hipEventRecord(ctx->ev_gate, side->stream));
-        IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gate, 0));
-        IMGFD_TRY(fast9());
-        return hold_harris ? IMGFD_OK : harris();
+    const int fast_at = ctx->tune.canny_gate == 1 ? 1 : (ctx->tune.canny_gate == 0 ? 0 : 2);
+    const int harris_at = ctx->tune.harris_gate == 0 ? fast_at : (ctx->tune.harris_gate == 2 ? 1 : 2);
+    const std::function<imgfd_status(int)> hook = [&](int pos) -> imgfd_status {  // pos: 0 before Canny's blur, 1 behind it, 2 behind gradient/NMS
+        if (pos == fast_at) {
+            IMGFD_HIP(ctx, hipEventRecord(ctx->ev_gate, side->stream));
+            IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gate, 0));
+            IMGFD_TRY(fast9());
+        }
+        if (pos == harris_at) {
+            IMGFD_HIP(ctx, hipEventRecord(ctx->ev_gate2, side->stream));
+            IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gate2, 0));
+            IMGFD_TRY(harris());
+        }
+        return IMGFD_OK;
     };
-    const std::function<imgfd_status()> gate2 = [&]() -> imgfd_status {
-        if (!hold_harris) return IMGFD_OK;
-        IMGFD_HIP(ctx, hipEventRecord(ctx->ev_gate2, side->stream));
-        IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gate2, 0));
-        return harris();
-    };
-    const imgfd_status st = canny_dev_hooked(side, fr, p->s, p->low_thr, p->high_thr, p->accGrad, d_edges, d_counts + 2 * B, &gate, &gate2);
+    const imgfd_status st = canny_dev_hooked(side, fr, p->s, p->low_thr, p->high_thr, p->accGrad, d_edges, d_counts + 2 * B, &hook);
     if (st != IMGFD_OK) {
         if (ctx->err.empty() || !side->err.empty()) ctx->err = side->err.empty() ? ctx->err : side->err;
         return st;

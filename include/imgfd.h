@@ -93,8 +93,8 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  *   "hyst_words" [IMGFD_HYST_WORDS]  words per tile of a sweep, 2 or 4 (0: 2 for one or two frames, else 4)
  *   "hyst_region_w", "hyst_region_h" [IMGFD_HYST_REGION_W / _H]  region size of the finishing kernel (words x rows)
  *   "canny_gate" [IMGFD_CANNY_GATE]  imgfd_detect_dev: where Canny releases the second stream (0 before the blur, 1, 2)
- *   "harris_gate" [IMGFD_HARRIS_GATE]  imgfd_detect_dev: 1 (default) the Harris chain starts when Canny's gradient/NMS kernel
- *                                      has finished (FAST-9 starts with the blur); 0: together with FAST-9
+ *   "harris_gate" [IMGFD_HARRIS_GATE]  imgfd_detect_dev: 1 (default) the Harris chain starts behind Canny's gradient/NMS kernel
+ *                                      (FAST-9 starts with the blur); 2: behind the blur; 0: together with FAST-9
  *   "gauss_march" [IMGFD_GAUSS_MARCH]  1 (default): u8 frames whose width is a multiple of 16 (>= 256) take the marching
  *                                      Gaussian + gradient kernel; 0: the tile kernel.  "gauss_march_seg": its rows per segment
  *   "xcd_remap" [IMGFD_XCD_REMAP]  1 (default): workers of one XCD own neighbouring tiles in the marching FIR kernels

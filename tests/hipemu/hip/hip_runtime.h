@@ -312,6 +312,8 @@ static inline double max(double a, double b) { return fmax(a, b); }
 
 // wave-uniform values are what kernels pass here: every emulated lane already holds the same value
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+// v_readlane_b32: the value lane `src` holds (src wave-uniform) -- a shuffle every lane of the wave takes part in
+static inline int __builtin_amdgcn_readlane(int v, int src) { return __shfl(v, src); }
 
 // ---- gfx950 builtins the product sources use unconditionally (emulated here, so that the kernels carry no test branches)
 static inline double __builtin_amdgcn_rsq(double x) { return 1.0 / sqrt(x); }  // v_rsq_f64: a seed, refined by the caller
