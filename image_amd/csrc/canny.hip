@@ -1175,7 +1175,10 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
             // loop, and 510 waves leave half the SIMDs of the chip empty (single 4K frame 0.258 -> 0.228 ms; from four frames
             // on the wider tile wins again: fewer sweeps until nothing changes).
             const int hw = ctx->tune.hyst_words == 2 || ctx->tune.hyst_words == 4 ? ctx->tune.hyst_words : (nf <= 2 ? 2 : HY_WORDS);
-            int sweeps = nf >= 8 ? 16 : (hw == 2 ? 10 : 9);  // (24 for batches in round 2: the bench frames need 9, an idle launch costs ~5 us)
+            // Batches: 24 (the bench frames need 9-12; an idle launch costs ~5 us, and in imgfd_detect_dev the idle tail runs
+            // beside the structure-tensor kernel, off the critical path: 16 and 24 measure the same there).  The margin is what
+            // keeps images with long chains of weak pixels off the finishing kernel's one workgroup per frame.
+            int sweeps = nf >= 8 ? HY_SWEEPS : (hw == 2 ? 10 : 9);
             if (ctx->tune.hyst_sweeps >= 1 && ctx->tune.hyst_sweeps <= HY_SWEEPS) sweeps = ctx->tune.hyst_sweeps;  // tests: force the finishing kernel to work
             const int tiles_x = ceil_div(wpr, hw), tiles_y = ceil_div(ny, 64);
             dim3 g3(ceil_div(tiles_x * tiles_y, 4), nf);

@@ -71,6 +71,23 @@ def test_large_s_takes_the_taps_from_memory(be, s):
         assert mismatch(e2, r2) <= max(2, 1e-3 * e2.size)
 
 
+@pytest.mark.parametrize("s", [0.5, 0.7])
+@pytest.mark.parametrize("acc", [0, 1])
+def test_small_s_on_sparse_impulses(be, s, acc):
+    """isolated bright pixels under a narrow Gaussian: neighbouring blurred values lie dozens of binades apart, where the
+    gradient kernel's shared row terms (d(y), e(y): a regrouping of rcpp_canny.cpp:157-163) are no longer sums of exactly
+    representable partials -- the edge map must still be the reference's"""
+    rng = np.random.default_rng(5)
+    img = np.zeros((96, 192), np.uint8)
+    ys, xs = rng.integers(4, 92, 60), rng.integers(4, 188, 60)
+    img[ys, xs] = rng.integers(40, 256, 60)
+    img[40:44, 100:140] = 255                      # and one solid bar
+    for low, high in ((0, 1), (1, 3), (3, 10)):
+        edges, n = be.canny(img, s=s, low_thr=low, high_thr=high, accGrad=bool(acc))
+        ref, rn = oracle.canny(img, s=s, low_thr=low, high_thr=high, accGrad=bool(acc))
+        assert mismatch(edges, ref) == 0 and n == rn, (s, acc, low, high, mismatch(edges, ref))
+
+
 def test_thresholds_are_int_truncated(be):
     img = synth.frame(22, 120, 90)
     a, _ = be.canny(img, low_thr=3.0, high_thr=10.0)
