@@ -61,6 +61,7 @@ struct imgfd_ctx {
         int hyst_words = 0;         // words per sweep tile: 2 or 4 (0: 2 for one or two frames, else 4)
         int hyst_rounds = 0;        // region mode: rounds queued (0: from the region grid)
         int hyst_region_w = 0, hyst_region_h = 0;  // region size in words x rows (0: from the batch size)
+        int surf_taps = 1;          // SURF octaves 1-3: look-ups as buffer loads with host-made offsets (0: address arithmetic per look-up)
         int gauss_march = 1;        // u8 frames whose width is a multiple of 16: the marching Gaussian + gradient kernel (0: the tile kernel)
         int gauss_march_seg = 0;    // rows per segment of that kernel (0: from the batch)
         int harris_gate = 1;        // imgfd_detect_dev: the Harris chain is released behind Canny's gradient/NMS kernel (1), behind its blur (2), or together with FAST-9 (0)

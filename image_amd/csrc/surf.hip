@@ -612,6 +612,93 @@ __global__ void __launch_bounds__(256) surf_pyramid(const unsigned *__restrict__
     }
 }
 
+// ---- K17, gather form with the look-ups as buffer loads (octaves 1-3 from the residue layout with M = 4, the default).
+// In surf_pyramid<2> every look-up costs ~7 vector instructions of address arithmetic (column residue, quotient, row x pitch
+// in 64 bits): 224 of them per level pixel value against ~60 for the determinant itself.  But a level pixel of these octaves
+// sits on a column that is a multiple of 4, so the word of look-up (dy, dx) is
+//     (r + dy) * cols + ((c + dx) & 3) * per + ((c + dx) >> 2)  =  [r * cols + c / 4]  +  [dy * cols + (dx & 3) * per + (dx >> 2)]:
+// a per-lane base plus a constant of the (octave, interval, look-up).  The 18 x 32 constants come from the host
+// (SurfTaps, made non-negative by moving the interval's smallest one into the base), land in scalar registers, and each
+// look-up is ONE buffer load with the lane's byte offset in a VGPR and the constant in an SGPR.
+struct SurfTaps {
+    int w[(SURF_OCT - 1) * SURF_INT][32];  // word offsets >= 0 of the 32 look-ups from (lane base + adj), box by box, corner by corner
+    int adj[(SURF_OCT - 1) * SURF_INT];    // the interval's smallest offset (<= 0)
+};
+static void surf_make_taps(const SurfGeom &g, SurfTaps *t)
+{
+    const int cols = g.cols, per = cols >> 2;
+    for (int o = 1; o < SURF_OCT; o++)
+        for (int it = 0; it < SURF_INT; it++) {
+            const SurfLevel &L = g.lev[o * SURF_INT + it];
+            const int lobe = L.lobe, off = L.off;
+            long w[32];
+            int n = 0;
+            auto at = [&](int dy, int dx) { w[n++] = (long)dy * cols + (long)(dx & 3) * per + (dx >> 2); };
+            auto box = [&](int cx, int cy, int bw, int bh) {  // the corners in the order surf_pyramid's box() reads them
+                const int l = cx - bw / 2, tp = cy - bh / 2, rr = l + bw - 1, b = tp + bh - 1;
+                at(b, rr); at(b, l - 1); at(tp - 1, rr); at(tp - 1, l - 1);
+            };
+            box(0, 0, lobe * 3, 2 * lobe - 1); box(0, 0, lobe, 2 * lobe - 1);
+            box(0, 0, 2 * lobe - 1, lobe * 3); box(0, 0, 2 * lobe - 1, lobe);
+            box(-off, off, lobe, lobe); box(off, -off, lobe, lobe); box(-off, -off, lobe, lobe); box(off, off, lobe, lobe);
+            long lo = 0;
+            for (int k = 0; k < 32; k++) lo = std::min(lo, w[k]);
+            const int e = (o - 1) * SURF_INT + it;
+            t->adj[e] = (int)lo;
+            for (int k = 0; k < 32; k++) t->w[e][k] = (int)(w[k] - lo);
+        }
+}
+
+__global__ void __launch_bounds__(256) surf_pyramid_taps(const unsigned *__restrict__ J, double *__restrict__ pyr, SurfGeom g, SurfBlocks blocks,
+                                                         SurfTaps taps, unsigned long long *__restrict__ mask, double thr)
+{
+    const int o = surf_octave_of_block(blocks, blockIdx.x);  // >= 1
+    const int gx = (g.nc[o] + 63) / 64, gy = (g.nr[o] + 3) / 4;
+    int bx, by;
+    {
+        const int id = blockIdx.x - blocks.first[o], padded = blocks.first[o + 1] - blocks.first[o];
+        const int nid = (id & 7) * (padded >> 3) + (id >> 3);
+        if (nid >= gx * gy) return;
+        bx = nid % gx;
+        by = nid / gx;
+    }
+    const int lc = bx * 64 + (threadIdx.x & 63);
+    const int lr = by * 4 + (threadIdx.x >> 6);
+    const int step = g.lev[o * SURF_INT].step, cols = g.cols;
+    const int r = lr * step, c = lc * step;
+    const bool in_level = lr < g.nr[o] && lc < g.nc[o];
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(J), 0, (int)((unsigned)g.rows * (unsigned)cols * 4u), 0x00027000);
+    const int base = r * cols + (c >> 2);  // word of (r, c) in J: c is a multiple of 4
+#pragma unroll 1
+    for (int it = 0; it < SURF_INT; it++) {
+        const SurfLevel &L = g.lev[o * SURF_INT + it];
+        const int e = (o - 1) * SURF_INT + it;
+        const bool inside = in_level && !(r < L.border_px || r >= g.rows - L.border_px || c < L.border_px || c >= cols - L.border_px);
+        bool hot = false;
+        if (inside) {
+            const int voff = (base + taps.adj[e]) * 4;
+            unsigned v[32];
+#pragma unroll
+            for (int k = 0; k < 32; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, taps.w[e][k] * 4, 0);
+            auto box = [&](int j) __attribute__((always_inline)) -> int { return (int)(v[4 * j] - v[4 * j + 1] - v[4 * j + 2] + v[4 * j + 3]); };
+            double Dxx = box(0) - box(1) * 3.0;                                                           // :141-142
+            double Dyy = box(2) - box(3) * 3.0;                                                           // :144-145
+            double Dxy = (int)((unsigned)box(4) + (unsigned)box(5) - (unsigned)box(6) - (unsigned)box(7));  // :147-150
+            Dxx *= L.area_inv; Dyy *= L.area_inv; Dxy *= L.area_inv;
+            double sign = +1;
+            if (Dxx + Dyy < 0) sign = -1;
+            double det = Dxx * Dyy - 0.81 * Dxy * Dxy;
+            if (det < 0) det = 0;
+            pyr[L.plane + (size_t)lr * g.nc[o] + lc] = sign * det;
+            hot = det >= thr;
+        }
+        if (mask) {
+            const unsigned long long word = __ballot(hot);
+            if ((threadIdx.x & 63) == 0 && in_level) mask[L.mask + (size_t)lr * ((g.nc[o] + 63) / 64) + (lc >> 6)] = word;
+        }
+    }
+}
+
 struct SurfRecord {
     unsigned long long key;  // ((octave*8 + interval) << 40) | row << 20 | column : the reference's emission order
     double x, y, scale, score, laplacian;
@@ -1105,7 +1192,13 @@ imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const Surf
         const dim3 lgrid(ceil_div(g.cols, RL_COLS), g.rows);
         if (o >= 1 && d.residue && g.cols % 16 == 0 && modulus == 4) {
             hipLaunchKernelGGL(surf_residue_layout<2>, lgrid, dim3(256), 0, ctx->stream, d.integral, d.residue, g.cols);
-            hipLaunchKernelGGL(surf_pyramid<2>, dim3(nb), dim3(256), 0, ctx->stream, d.residue, d.pyr, g, blocks, d.mask, thr);
+            if (ctx->tune.surf_taps && (size_t)g.rows * g.cols * 4 < ((size_t)1 << 31)) {
+                SurfTaps taps;
+                surf_make_taps(g, &taps);
+                hipLaunchKernelGGL(surf_pyramid_taps, dim3(nb), dim3(256), 0, ctx->stream, d.residue, d.pyr, g, blocks, taps, d.mask, thr);
+            } else {
+                hipLaunchKernelGGL(surf_pyramid<2>, dim3(nb), dim3(256), 0, ctx->stream, d.residue, d.pyr, g, blocks, d.mask, thr);
+            }
         } else if (o >= 1 && d.residue && g.cols % 16 == 0 && modulus == 16) {
             hipLaunchKernelGGL(surf_residue_layout<4>, lgrid, dim3(256), 0, ctx->stream, d.integral, d.residue, g.cols);
             hipLaunchKernelGGL(surf_pyramid<4>, dim3(nb), dim3(256), 0, ctx->stream, d.residue, d.pyr, g, blocks, d.mask, thr);

@@ -106,6 +106,7 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  *   "tile_run" [IMGFD_TILE_RUN]  tiles per workgroup of the u8 tile kernels (0: from the batch size)
  *   "detect_graph" [IMGFD_DETECT_GRAPH]  imgfd_detect_dev replays a recorded hipGraph for repeating calls on fewer frames than this
  *                                        (0 = never, the default: a single 4K frame took 0.259 ms either way)
+ *   "surf_taps" [IMGFD_SURF_TAPS]  1 (default): SURF octaves 1-3 look their 32 table words up with buffer loads and host-made offsets
  *   "surf_lanes" [IMGFD_SURF_LANES]  4 (default): imgfd_surf_dev deals the tiles round-robin to this many HIP streams (1..4)
  *   "surf_async" [IMGFD_SURF_ASYNC]  0 (default): imgfd_surf_dev reads the tile counts back once per call and redoes tiles
  *                                    whose candidates overflowed the record buffer; 1: no wait, such a tile reports -candidates

@@ -366,6 +366,12 @@ static inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned data, __amdgpu
     memcpy(r.base + (size_t)(unsigned)voffset + (size_t)(unsigned)soffset, &data, 4);
 }
 
+static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
+    unsigned v;
+    memcpy(&v, r.base + (size_t)(unsigned)voffset + (size_t)(unsigned)soffset, 4);
+    return v;
+}
+
 // ------------------------------------------------------------------ host API
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100 };

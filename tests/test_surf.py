@@ -90,6 +90,22 @@ def test_batch_surf_dev_descriptors_on_the_device(be):
     assert len(few["x"]) <= 7 and np.array_equal(few["score"], np.sort(few["score"])[::-1])
 
 
+@pytest.mark.parametrize("w,h", [(384, 256), (400, 304), (640, 272)])
+def test_upper_octaves_both_gather_forms(be, w, h):
+    """octaves 1-3: the look-ups as buffer loads with host-made offsets (surf_pyramid_taps, the default) and with per-look-up
+    address arithmetic (surf_pyramid<2>, "surf_taps" 0) give the reference's interest points, bit for bit"""
+    img = blobs(170 + w, w, h)
+    ref = oracle.surf_interest_points(img, 2.0)
+    assert len(ref) > 20 and len({int(round(np.log2(p[2]))) for p in ref}) >= 2   # points from more than one octave
+    try:
+        for taps in (1, 0):
+            be.set_tuning("surf_taps", taps)
+            got = be.surf_interest_points(img, 2.0)
+            assert got.shape == ref.shape and np.array_equal(got.view(np.uint64), ref.view(np.uint64)), taps
+    finally:
+        be.set_tuning("surf_taps", 1)
+
+
 @pytest.mark.parametrize("max_points", [1, 9, 25])
 @pytest.mark.parametrize("sort_cap", [2048, 4])
 def test_surf_dev_ranks_and_cuts_on_the_device(be, max_points, sort_cap):
