@@ -400,6 +400,7 @@ struct SurfPyrLds {
     static constexpr int W = STEP * (LX - 1) + 1 + HL + HR, H = STEP * (LY - 1) + 1 + HL + HR;
     static constexpr int P = (W + 3) / 4 * 4;                          // row pitch in words, a multiple of 4 and of STEP
     static constexpr int PX_PER_THREAD = LX * LY / 256;
+    static constexpr int BIAS = HL * P + HL / STEP;                    // window words from (row - HL, column - HL) to the centre
     static_assert(HL % STEP == 0 && P % STEP == 0 && (LX * LY) % 256 == 0 && LX <= 64 && 64 % LX == 0, "tile geometry");
     static_assert(sizeof(unsigned) * (size_t)H * P <= 120 * 1024, "window fits the LDS");
     // window word of image column x0 + dx: columns are stored by residue mod STEP, so that the lanes of a look-up
@@ -411,14 +412,18 @@ struct SurfPyrLds {
 // window).  The lobe is a compile-time constant, so every look-up is a ds_read with an immediate offset from `ctr`.
 // For a centre at least border_px inside the image all four corners of every box exist (l - 1 >= 3*lobe/2 - 1 > 0), so
 // integral_image.h:64-96's border cases cannot occur here and br - bl - tr + tl is evaluated directly.
+// The window is addressed from `top` = the word of (row - HL, column - HL), the top-left corner of what any filter reaches
+// from this centre, as an index the optimiser cannot see through: every look-up then has a NON-NEGATIVE constant offset,
+// i.e. an immediate of its ds_read.  (Addressed from the centre, half of the look-ups sit at negative offsets, which the
+// 16-bit unsigned offset field cannot hold: one v_add_u32 each, 17 of the kernel's 98 vector instructions per value.)
 template <int O, int IT>
-__device__ __forceinline__ double surf_lds_interval(const unsigned *__restrict__ ctr, double area_inv)
+__device__ __forceinline__ double surf_lds_interval(const unsigned *__restrict__ win, unsigned top, double area_inv)
 {
     using G = SurfPyrLds<O>;
     constexpr int lobe = G::STEP * (IT + 1) + 1, off = lobe / 2 + 1;
     auto at = [&](int dy, int dx) __attribute__((always_inline)) -> unsigned {
         const int m = ((dx % G::STEP) + G::STEP) % G::STEP;  // residue of a possibly negative offset
-        return ctr[dy * G::P + m * (G::P / G::STEP) + (dx - m) / G::STEP];
+        return win[top + (unsigned)(G::BIAS + dy * G::P + m * (G::P / G::STEP) + (dx - m) / G::STEP)];
     };
     auto box = [&](int cx, int cy, int w, int h) __attribute__((always_inline)) -> int {  // centered_rect(cx, cy, w, h), relative to the centre
         const int l = cx - w / 2, t = cy - h / 2, r = l + w - 1, b = t + h - 1;
@@ -469,7 +474,8 @@ __global__ void __launch_bounds__(256) surf_pyramid_lds(const unsigned *__restri
         // a wave = 64 consecutive level pixels of one row (LX = 64, lc0 a multiple of 64): its ballot is one word of the
         // level's threshold mask (|det| >= thr: the only pixels surf_nms_interp has to look at); every lane votes
         const bool inside = lr < g.nr[O] && lc < g.nc[O];
-        const unsigned *ctr = win + (r - y0) * G::P + (c - x0) / G::STEP;  // (c - x0) is a multiple of STEP: residue plane 0
+        unsigned top = (unsigned)((r - y0) * G::P + (c - x0) / G::STEP - G::BIAS);  // (c - x0) is a multiple of STEP: residue plane 0
+        IMGFD_OPAQUE(top);
         double *dst = pyr + (size_t)lr * g.nc[O] + lc;
 #define SPL_DO(IT)                                                                                        \
         {                                                                                                  \
@@ -477,7 +483,7 @@ __global__ void __launch_bounds__(256) surf_pyramid_lds(const unsigned *__restri
             const int bp = L.border_px;                                                                    \
             bool hot = false;                                                                              \
             if (inside && !(r < bp || r >= rows - bp || c < bp || c >= cols - bp)) {                       \
-                const double v = surf_lds_interval<O, IT>(ctr, L.area_inv);                                \
+                const double v = surf_lds_interval<O, IT>(win, top, L.area_inv);                           \
                 dst[L.plane] = v;                                                                          \
                 hot = fabs(v) >= thr;                                                                      \
             }                                                                                              \
