@@ -3,7 +3,9 @@ TILES (default 16), SIZE (4096), NOISE=1: uniform-noise tile (every gradient, wo
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from image_amd import synth
+from image_amd import synth, _lib
+if os.environ.get("VARIANT_LIB"):   # experiment builds of the library (scripts/variants/*.so, not tracked)
+    _lib.LIB_PATH = os.path.abspath(os.environ["VARIANT_LIB"])
 from image_amd.device import DeviceDetector
 S = int(os.environ.get("SIZE", 4096))
 det = DeviceDetector(0); lib, ctx = det.lib, det.ctx.handle
