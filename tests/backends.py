@@ -50,6 +50,34 @@ class _Base:
         esz = 1 if dtype == 0 else 4
         return _binding.Frames(self.ptr(dev), n, nx, ny, nx * ny * esz, nx * esz, dtype)
 
+    # frames that are NOT packed: rows `row_pad` bytes apart beyond their pixels, `gap_rows` unused rows between frames
+    _pad = None
+
+    def padded(self, row_pad, gap_rows):
+        """context manager: the *_dev helpers of this backend upload u8 frames with padded rows / gaps between frames"""
+        be = self
+
+        class _P:
+            def __enter__(self_):
+                be._pad = (row_pad, gap_rows)
+
+            def __exit__(self_, *a):
+                be._pad = None
+        return _P()
+
+    def upload_frames_u8(self, frames):
+        """-> (device buffer, imgfd_frames): packed, or laid out as self.padded() says (the padding holds 0xAB)"""
+        n, ny, nx = frames.shape
+        if not self._pad:
+            d = self.to_dev(np.ascontiguousarray(frames, np.uint8))
+            return d, self.frames(d, n, nx, ny, 0)
+        row_pad, gap = self._pad
+        pitch = nx + row_pad
+        host = np.full((n, ny + gap, pitch), 0xAB, np.uint8)
+        host[:, :ny, :nx] = frames
+        d = self.to_dev(host)
+        return d, _binding.Frames(self.ptr(d), n, nx, ny, (ny + gap) * pitch, pitch, 0)
+
     # ---- stage doorways on host arrays -----------------------------------------------------
     def k_gaussian(self, img, sigma, type=0):
         ny, nx = img.shape
@@ -274,10 +302,13 @@ class _Base:
         p.update(kw)
         n, ny, nx = frames.shape
         dtype = 0 if frames.dtype == np.uint8 else 1
-        d = self.to_dev(np.ascontiguousarray(frames))
+        if dtype == 0:
+            d, fr = self.upload_frames_u8(frames)
+        else:
+            d = self.to_dev(np.ascontiguousarray(frames))
+            fr = self.frames(d, n, nx, ny, dtype)
         cap = cap or nx * ny // 4 + 16
         out = self.empty((n, cap, 3), np.float32); cnt = self.empty((n,), np.int64)
-        fr = self.frames(d, n, nx, ny, dtype)
         self.check(self.lib.imgfd_harris_dev(self.ctx, C.byref(fr), p["k"], p["sigma_d"], p["sigma_i"], p["threshold"],
                                              p["gaussian"], p["gradient"], p["measure"], self.ptr(out), cap,
                                              self.ptr(cnt)), "imgfd_harris_dev")
@@ -287,10 +318,9 @@ class _Base:
 
     def fast9_dev(self, frames, threshold, nonmax=False, cap=None):
         n, ny, nx = frames.shape
-        d = self.to_dev(np.ascontiguousarray(frames, np.uint8))
+        d, fr = self.upload_frames_u8(frames)
         cap = cap or (nx * ny // 2 + 16)
         out = self.empty((n, cap, 2), np.int32); cnt = self.empty((n,), np.int64)
-        fr = self.frames(d, n, nx, ny, 0)
         self.check(self.lib.imgfd_fast9_dev(self.ctx, C.byref(fr), threshold & 0xFF, int(nonmax), self.ptr(out), cap,
                                             self.ptr(cnt)), "imgfd_fast9_dev")
         self.sync()
@@ -299,9 +329,8 @@ class _Base:
 
     def canny_dev(self, frames, s=2.0, low_thr=3.0, high_thr=10.0, accGrad=True):
         n, ny, nx = frames.shape
-        d = self.to_dev(np.ascontiguousarray(frames, np.uint8))
+        d, fr = self.upload_frames_u8(frames)
         edges = self.empty((n, ny, nx), np.uint8); cnt = self.empty((n,), np.int64)
-        fr = self.frames(d, n, nx, ny, 0)
         self.check(self.lib.imgfd_canny_dev(self.ctx, C.byref(fr), s, low_thr, high_thr, int(accGrad),
                                             self.ptr(edges), self.ptr(cnt)), "imgfd_canny_dev")
         self.sync()
