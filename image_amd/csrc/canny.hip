@@ -814,6 +814,19 @@ __device__ __forceinline__ bool hyst_region_due(const unsigned char *flags, cons
     return false;
 }
 
+// canny_hyst_finish walks the regions of a pass in raster order or (every other pass) against it: did one of the neighbours
+// it has ALREADY visited in this pass report a changed outline?  (fwd: the three above and the one to the left.)
+__device__ __forceinline__ bool hyst_region_due_visited(const unsigned char *flags, const HystGeom &g, int reg, bool fwd)
+{
+    const int rgx = reg % g.rx, rgy = reg / g.rx, sy = fwd ? -1 : 1;
+    for (int dx = -1; dx <= 1; dx++) {
+        const int x = rgx + dx, y = rgy + sy;
+        if (x >= 0 && x < g.rx && y >= 0 && y < g.ry && flags[y * g.rx + x]) return true;
+    }
+    const int x = rgx + sy;  // fwd: the left neighbour; backwards: the right one
+    return x >= 0 && x < g.rx && flags[rgy * g.rx + x];
+}
+
 // one round: every region whose neighbourhood changed in the previous round (all of them in round 0) is driven to its
 // fixpoint by its own workgroup; rflag[parity][frame][region] = "the region's outline changed in this round"
 __global__ void __launch_bounds__(HY_NT) canny_hyst_regions(unsigned long long *__restrict__ S, const unsigned long long *__restrict__ Wm,
@@ -860,16 +873,22 @@ __global__ void __launch_bounds__(HY_NT) canny_hyst_finish(unsigned long long *_
         bool any = false;
         for (int i = 0; i < regions; i++) any = any || cur[i];
         if (!any) break;
-        for (int reg = 0; reg < regions; reg++) {
+        // A pass visits the regions in raster order, the next one against it, and a region is due when its neighbourhood
+        // changed in the previous pass OR in a region this pass has already visited: a chain of weak pixels then crosses as
+        // many regions per pass as lie in its direction (one region per pass before: a single edge snaking through a 4K frame
+        // took 330 ms here, scripts/canny_serpentine_time.py).
+        const bool fwd = !(pass & 1);
+        for (int k = 0; k < regions; k++) {
+            const int reg = fwd ? k : regions - 1 - k;
             bool border = false;
-            if (hyst_region_due(cur, g, reg)) {
+            if (hyst_region_due(cur, g, reg) || hyst_region_due_visited(nxt, g, reg, fwd)) {
                 border = hyst_region(S + frame * plane, Wm + frame * plane, g, reg, sS, sW, tact, lflag);
                 __threadfence();  // the next region reads this one's rows from global memory
             }
             __syncthreads();
             if (threadIdx.x == 0) nxt[reg] = border ? 1 : 0;
+            __syncthreads();  // the next region's "due" test reads it
         }
-        __syncthreads();
     }
 }
 
@@ -1044,8 +1063,9 @@ HystGeom hyst_geometry(const imgfd_ctx *ctx, int wpr, int ny, int nf, bool small
     HystGeom g;
     g.wpr = wpr; g.ny = ny;
     // small: the finishing kernel behind the sweeps -- 8 words x 128 rows = 23 KB of LDS, so that its one workgroup per
-    // frame finds room beside whatever else occupies the CUs (the structure-tensor workgroups hold 135 KB each for the whole
-    // of their kernel: a 147 KB workgroup had to wait for all of them, 460 us in the two-stream schedule)
+    // frame finds room beside whatever else occupies the CUs.  (The largest regions the LDS holds, 15 x 540, were tried for
+    // it: a single edge snaking through a 4K frame, all of it left to this kernel, took 107 instead of 113 ms -- the cost is
+    // tile rounds along the chain, not region visits.)
     g.RW = std::min(wpr, small ? 8 : 15);
     g.RH = std::min(ny, small ? 128 : 540);
     auto count = [&]() { return (long)ceil_div(wpr, g.RW) * ceil_div(ny, g.RH) * nf; };
