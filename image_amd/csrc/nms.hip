@@ -282,15 +282,23 @@ imgfd_status launch_harris_resp_nms(imgfd_ctx *ctx, const float *d_A, const floa
 #ifndef SN_WORDS
 #define SN_WORDS 256
 #endif
+#ifndef SN_LIST
+#define SN_LIST 4096  // list entries (8 KB)
+#endif
 template <int HC>
 __global__ void __launch_bounds__(SN_WORDS) harris_nms_sparse(const float *__restrict__ Rp, const unsigned char *__restrict__ tq,
                                                             int nx, int ny, float Th, int radius_rt,
                                                             unsigned long long *__restrict__ mask, unsigned *__restrict__ rowcount,
                                                             int wpr, size_t nwords)
 {
-    __shared__ unsigned short list[SN_WORDS * 64];  // (thread << 6) | bit
+    // The list holds SN_LIST entries: a workgroup's words carry a few hundred candidate bits in practice (a fraction of a
+    // percent of 16 384 pixels), and 32 KB for the worst case left four workgroups per CU where the kernel -- a chain of
+    // four dependent memory round trips per workgroup -- wants as many resident as there are wave slots.  Words whose bits
+    // do not fit are taken in several GROUPS of waves, one after the other (a wave's 64 words hold 4096 bits at the most).
+    __shared__ unsigned short list[SN_LIST];  // (thread << 6) | bit
     __shared__ unsigned long long res[SN_WORDS];
     __shared__ unsigned wave_sum[SN_WORDS / 64], nsurv;
+    static_assert(SN_LIST >= 4096, "one wave's words always fit");
     const int radius = HC > 0 ? HC : radius_rt;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t w0 = (size_t)blockIdx.x * SN_WORDS, w = w0 + tid;
@@ -323,7 +331,6 @@ __global__ void __launch_bounds__(SN_WORDS) harris_nms_sparse(const float *__res
         }
     }
     res[tid] = 0ull;
-    if (tid == 0) nsurv = 0u;
     const unsigned cnt = (unsigned)__popcll(word);
     unsigned incl = cnt;
 #pragma unroll
@@ -333,18 +340,9 @@ __global__ void __launch_bounds__(SN_WORDS) harris_nms_sparse(const float *__res
     }
     if (lane == 63) wave_sum[wv] = incl;
     __syncthreads();
-    unsigned pos = incl - cnt, total = 0;
+    unsigned all = 0;
 #pragma unroll
-    for (int k = 0; k < SN_WORDS / 64; k++) {
-        if (k < wv) pos += wave_sum[k];
-        total += wave_sum[k];
-    }
-    while (word) {
-        const int bit = __ffsll((long long)word) - 1;
-        word &= word - 1;
-        list[pos++] = (unsigned short)(tid << 6 | bit);
-    }
-    __syncthreads();
+    for (int k = 0; k < SN_WORDS / 64; k++) all += wave_sum[k];
     // pixel of a list entry: plane pointer of its frame, coordinates
     auto locate = [&](unsigned e, const float *&Rf, int &x, int &yy) __attribute__((always_inline)) {
         const size_t we = w0 + (e >> 6), rw = we / (size_t)wpr;
@@ -353,56 +351,78 @@ __global__ void __launch_bounds__(SN_WORDS) harris_nms_sparse(const float *__res
         x = (int)(we - rw * (size_t)wpr) * 64 + (int)(e & 63u);
         Rf = Rp + frame * (size_t)nx * ny;
     };
-    // ---- (2) threshold (already in the bits) + 3x3 pre-test with the window rule's own comparisons
-    for (unsigned k0 = 0; k0 < total; k0 += SN_WORDS) {  // uniform trip count: barriers inside
-        const unsigned k = k0 + tid;
-        unsigned e = 0;
-        bool ok = false;
-        if (k < total) {
-            e = list[k];
+    const int side = 2 * radius + 1, npos = side * side;
+    // groups of waves whose bits fit the list: all four together (the case in practice), else one wave at a time
+    const int gw = all <= SN_LIST ? SN_WORDS / 64 : 1;
+    for (int g0 = 0; g0 < SN_WORDS / 64; g0 += gw) {  // workgroup-uniform
+        const bool mine = wv >= g0 && wv < g0 + gw;
+        unsigned pos = incl - cnt, total = 0;
+#pragma unroll
+        for (int k = 0; k < SN_WORDS / 64; k++) {
+            const bool in = k >= g0 && k < g0 + gw;
+            if (in && k < wv) pos += wave_sum[k];
+            if (in) total += wave_sum[k];
+        }
+        if (tid == 0) nsurv = 0u;
+        if (mine) {
+            unsigned long long rest = word;
+            while (rest) {
+                const int bit = __ffsll((long long)rest) - 1;
+                rest &= rest - 1;
+                list[pos++] = (unsigned short)(tid << 6 | bit);
+            }
+        }
+        __syncthreads();
+        // ---- (2) threshold (already in the bits) + 3x3 pre-test with the window rule's own comparisons
+        for (unsigned k0 = 0; k0 < total; k0 += SN_WORDS) {  // uniform trip count: barriers inside
+            const unsigned k = k0 + tid;
+            unsigned e = 0;
+            bool ok = false;
+            if (k < total) {
+                e = list[k];
+                const float *Rf; int x, yy;
+                locate(e, Rf, x, yy);
+                const float *c = Rf + (size_t)yy * nx + x;
+                const float v = c[0];
+                ok = !(c[-nx - 1] >= v) && !(c[-nx] >= v) && !(c[-nx + 1] >= v) && !(c[1] >= v) && !(c[-1] > v) &&
+                     !(c[nx - 1] > v) && !(c[nx] > v) && !(c[nx + 1] > v);
+            }
+            __syncthreads();  // every entry of this trip has been read: survivors may overwrite the front of the list
+            if (ok) list[atomicAdd(&nsurv, 1u)] = (unsigned short)e;
+            __syncthreads();
+        }
+        // ---- (3) full window, one survivor per wave at a time, window positions spread over the lanes
+        const int n = (int)nsurv;
+        for (int ci = wv; ci < n; ci += SN_WORDS / 64) {
+            const unsigned e = list[ci];
             const float *Rf; int x, yy;
             locate(e, Rf, x, yy);
             const float *c = Rf + (size_t)yy * nx + x;
             const float v = c[0];
-            ok = !(c[-nx - 1] >= v) && !(c[-nx] >= v) && !(c[-nx + 1] >= v) && !(c[1] >= v) && !(c[-1] > v) &&
-                 !(c[nx - 1] > v) && !(c[nx] > v) && !(c[nx + 1] > v);
-        }
-        __syncthreads();  // every entry of this trip has been read: survivors may overwrite the front of the list
-        if (ok) list[atomicAdd(&nsurv, 1u)] = (unsigned short)e;
-        __syncthreads();
-    }
-    // ---- (3) full window, one survivor per wave at a time, window positions spread over the lanes
-    const int n = (int)nsurv;
-    const int side = 2 * radius + 1, npos = side * side;
-    for (int ci = wv; ci < n; ci += SN_WORDS / 64) {
-        const unsigned e = list[ci];
-        const float *Rf; int x, yy;
-        locate(e, Rf, x, yy);
-        const float *c = Rf + (size_t)yy * nx + x;
-        const float v = c[0];
-        bool fail = false;
-        for (int pidx = lane; pidx < npos; pidx += 64) {
-            const int dy = pidx / side - radius, dx = pidx % side - radius;
-            if (dy == 0 && dx == 0) continue;
-            const float q = c[(long)dy * nx + dx];
-            const bool strict = dy < 0 || (dy == 0 && dx > 0);  // above, or to the right on the same row: must be <
-            fail = fail || (strict ? (q >= v) : (q > v));
-        }
-        if (!__any(fail) && lane == 0) {
-            // start-of-row rule of the scan line (harris_row_start_blocks): only for an exact tie with the left neighbour
-            bool blocked = false;
-            if (c[-1] == v) {
-                blocked = true;
-                const float *rowp = Rf + (size_t)yy * nx;
-                for (int j = x; j >= radius && blocked; j--) {
-                    const float rj = rowp[j], rl = rowp[j - 1];
-                    if (!(rj < Th) && !(rl >= rj)) blocked = false;
-                }
+            bool fail = false;
+            for (int pidx = lane; pidx < npos; pidx += 64) {
+                const int dy = pidx / side - radius, dx = pidx % side - radius;
+                if (dy == 0 && dx == 0) continue;
+                const float q = c[(long)dy * nx + dx];
+                const bool strict = dy < 0 || (dy == 0 && dx > 0);  // above, or to the right on the same row: must be <
+                fail = fail || (strict ? (q >= v) : (q > v));
             }
-            if (!blocked) atomicOr(&res[e >> 6], 1ull << (e & 63u));
+            if (!__any(fail) && lane == 0) {
+                // start-of-row rule of the scan line (harris_row_start_blocks): only for an exact tie with the left neighbour
+                bool blocked = false;
+                if (c[-1] == v) {
+                    blocked = true;
+                    const float *rowp = Rf + (size_t)yy * nx;
+                    for (int j = x; j >= radius && blocked; j--) {
+                        const float rj = rowp[j], rl = rowp[j - 1];
+                        if (!(rj < Th) && !(rl >= rj)) blocked = false;
+                    }
+                }
+                if (!blocked) atomicOr(&res[e >> 6], 1ull << (e & 63u));
+            }
         }
+        __syncthreads();  // the list and nsurv are free for the next group
     }
-    __syncthreads();
     // ---- (4)
     if (w < nwords) {
         const unsigned long long out = res[tid];

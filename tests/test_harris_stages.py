@@ -254,6 +254,18 @@ def test_nms_start_of_row_rule_on_exact_ties(be, quads):
     assert got.shape == ref.shape and np.array_equal(bits(got), bits(ref))
 
 
+@pytest.mark.parametrize("radius", [1, 5])
+def test_nms_dense_candidates(be, radius):
+    """every pixel at or above the threshold (noise, Th = 0): a workgroup's 256 mask words carry far more candidate bits
+    than its list holds (4096), so the sparse kernel takes them wave by wave -- same corners as the scan line"""
+    R = (np.random.default_rng(11).random((96, 640)) * 1000 + 1).astype(np.float32)
+    ref = oracle.harris_stage("nms", R, Th=0.0, radius=radius)
+    assert len(ref) > 50
+    for quads in (True, False):
+        got = be.k_nms(R, 0.0, radius, quads=quads)
+        assert got.shape == ref.shape and np.array_equal(bits(got), bits(ref)), quads
+
+
 def test_nms_small_image_is_empty(be):
     R = np.random.default_rng(0).random((11, 40)).astype(np.float32) * 1000
     assert be.k_nms(R, 0.0, 5).shape[0] == 0
