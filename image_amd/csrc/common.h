@@ -237,9 +237,10 @@ bool gauss_grad_fused_supported(int nx, int ny, float sigma, int gauss_type);
 bool gauss_grad_march_supported(const void *d_in, int in_is_u8, int in_pitch, size_t in_frame_stride, const float *d_Ix,
                                 const float *d_Iy, int nx, int ny);
 imgfd_status launch_gauss_grad_march(imgfd_ctx *ctx, const void *d_in, int in_pitch, size_t in_frame_stride, float *d_Ix,
-                                     float *d_Iy, int nx, int ny, int n_frames, const double *B, int grad_type);
+                                     float *d_Iy, int nx, int ny, int n_frames, const double *B, int grad_type, unsigned *d_rowcount = nullptr);
 imgfd_status launch_gauss_grad_fused(imgfd_ctx *ctx, const void *d_in, int in_is_u8, int in_pitch, size_t in_frame_stride,
-                                     float *d_Ix, float *d_Iy, int nx, int ny, int n_frames, float sigma, int grad_type);
+                                     float *d_Ix, float *d_Iy, int nx, int ny, int n_frames, float sigma, int grad_type,
+                                     unsigned *d_rowcount = nullptr, bool *rowcount_cleared = nullptr);  // optional: ny counters per frame to clear on the way
 // harris_stages.hip
 imgfd_status launch_gradient(imgfd_ctx *ctx, const float *d_I, float *d_Ix, float *d_Iy, int nx, int ny,
                              int n_frames, int type);

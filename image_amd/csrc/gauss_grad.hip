@@ -201,14 +201,18 @@ bool gauss_grad_fused_supported(int nx, int ny, float sigma, int gauss_type)
 }
 
 imgfd_status launch_gauss_grad_fused(imgfd_ctx *ctx, const void *d_in, int in_is_u8, int in_pitch, size_t in_frame_stride,
-                                     float *d_Ix, float *d_Iy, int nx, int ny, int n_frames, float sigma, int grad_type)
+                                     float *d_Ix, float *d_Iy, int nx, int ny, int n_frames, float sigma, int grad_type,
+                                     unsigned *d_rowcount, bool *rowcount_cleared)
 {
+    if (rowcount_cleared) *rowcount_cleared = false;
     GaussGradParams p;
     memset(&p, 0, sizeof p);
     if (fir_coeffs(sigma, 3, p.B) != 4) return imgfd_fail(ctx, IMGFD_ERR_UNSUPPORTED, "fused gaussian+gradient: radius is not 3");
     p.in = d_in; p.Ix = d_Ix; p.Iy = d_Iy; p.nx = nx; p.ny = ny; p.in_pitch = in_pitch; p.in_frame_stride = (long)in_frame_stride;
-    if (ctx->tune.gauss_march && gauss_grad_march_supported(d_in, in_is_u8, in_pitch, in_frame_stride, d_Ix, d_Iy, nx, ny))
-        return launch_gauss_grad_march(ctx, d_in, in_pitch, in_frame_stride, d_Ix, d_Iy, nx, ny, n_frames, p.B, grad_type);
+    if (ctx->tune.gauss_march && gauss_grad_march_supported(d_in, in_is_u8, in_pitch, in_frame_stride, d_Ix, d_Iy, nx, ny)) {
+        if (rowcount_cleared) *rowcount_cleared = d_rowcount != nullptr;
+        return launch_gauss_grad_march(ctx, d_in, in_pitch, in_frame_stride, d_Ix, d_Iy, nx, ny, n_frames, p.B, grad_type, d_rowcount);
+    }
     const size_t esz = in_is_u8 ? 1 : 4;
     p.vec4 = ((size_t)d_in % (4 * esz) == 0) && in_pitch % 4 == 0 && in_frame_stride % 4 == 0 && nx % 4 == 0;
     p.vec16 = in_is_u8 && ((size_t)d_in % 16 == 0) && in_pitch % 16 == 0 && in_frame_stride % 16 == 0 && nx % 16 == 0;

@@ -40,6 +40,8 @@ struct GaussMarchParams {
     int nx, ny, in_pitch;
     long in_frame_stride;
     int seg_rows, nstrips, nseg;
+    unsigned *rowcount;  // optional: ny counters per frame, cleared by the workgroups of strip 0 (for the NMS kernel two launches on:
+                         // a fill of its own, queued behind the structure-tensor kernel, sat 20 us on the chain's critical path)
     double B[8];
 };
 
@@ -89,6 +91,8 @@ __global__ void __launch_bounds__(GM_NT) IMGFD_WAVES_PER_EU(4, 4) gauss_grad_mar
     const int k_last = max(0, (nrows - 1 - (13 - 2 * R) + GM_CH - 1) / GM_CH);
     const unsigned char *inf = p.in + (size_t)frame * p.in_frame_stride;
     const bool border_strip = x0 == 0 || x0 - 16 + 16 * GM_RAWQ > p.nx;
+    if (p.rowcount && strip == 0)
+        for (int i = tid; i < nrows; i += GM_NT) p.rowcount[(size_t)frame * p.ny + y0 + i] = 0;
 
     // ---- staging: slot i = (row, 16-byte slot q) of a chunk's 16 x 17 slots; thread tid owns slot tid, the first 16 also 256 + tid
     const int s0_row = tid / GM_RAWQ, s0_q = tid - s0_row * GM_RAWQ;
@@ -273,13 +277,14 @@ bool gauss_grad_march_supported(const void *d_in, int in_is_u8, int in_pitch, si
 }
 
 imgfd_status launch_gauss_grad_march(imgfd_ctx *ctx, const void *d_in, int in_pitch, size_t in_frame_stride, float *d_Ix,
-                                     float *d_Iy, int nx, int ny, int n_frames, const double *B, int grad_type)
+                                     float *d_Iy, int nx, int ny, int n_frames, const double *B, int grad_type, unsigned *d_rowcount)
 {
     constexpr int R = 3;
     GaussMarchParams p;
     memset(&p, 0, sizeof p);
     p.in = (const unsigned char *)d_in; p.Ix = d_Ix; p.Iy = d_Iy; p.nx = nx; p.ny = ny; p.in_pitch = in_pitch;
     p.in_frame_stride = (long)in_frame_stride;
+    p.rowcount = d_rowcount;
     memcpy(p.B, B, sizeof(double) * (R + 1));
     p.nstrips = ceil_div(nx, GM_TW);
     // Segment length: a segment of sr rows takes m = ceil((sr + 2R - 13) / 16) + 1 steps, so sr = 16 m - 2 - 2R fills them; the

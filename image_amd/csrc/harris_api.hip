@@ -211,12 +211,13 @@ imgfd_status harris_device_stages(imgfd_ctx *ctx, const void *d_in, int in_is_u8
         return IMGFD_OK;
     };
     IMGFD_TRY(tick(-1));
+    bool rc_cleared = false;  // the marching Gaussian/gradient kernel clears the row counters on its way
     // (the row counts are cleared right before the NMS kernel that fills them: queued first, the 0.3 MB fill sat 89 us in
     // front of the Gaussian/gradient kernel in imgfd_detect_dev, waiting for a slot beside the first hysteresis sweep)
     if (!stage_seconds && gauss_grad_fused_supported(nx, ny, a.sigma_d, a.gauss)) {
         // the default path: Gaussian (radius 3) and gradient in one kernel, the smoothed plane stays on chip
         IMGFD_TRY(launch_gauss_grad_fused(ctx, d_in, in_is_u8, in_pitch, in_frame_stride, hp.Ix, hp.Iy, nx, ny, n_frames,
-                                          a.sigma_d, a.grad));
+                                          a.sigma_d, a.grad, hp.cb.rowcount, &rc_cleared));
     } else {
         IMGFD_TRY(launch_gaussian(ctx, d_in, in_is_u8, in_pitch, in_frame_stride, hp.Is, nx, ny, n_frames, a.sigma_d,
                                   a.gauss, hp.tmp));
@@ -233,7 +234,7 @@ imgfd_status harris_device_stages(imgfd_ctx *ctx, const void *d_in, int in_is_u8
         unsigned char *tq = reinterpret_cast<unsigned char *>(hp.A);  // the A plane is idle on this path: it holds the threshold quads
         IMGFD_TRY(launch_tensor_response(ctx, hp.Ix, hp.Iy, hp.R, nx, ny, n_frames, a.sigma_i, a.k, sparse ? tq : nullptr, a.Th));
         IMGFD_TRY(prof_mark(ctx));
-        IMGFD_TRY(compact_clear(ctx, hp.cb, ny, n_frames));
+        if (!rc_cleared) IMGFD_TRY(compact_clear(ctx, hp.cb, ny, n_frames));
         if (sparse) IMGFD_TRY(launch_harris_nms_sparse(ctx, hp.R, tq, nx, ny, n_frames, a.Th, radius, hp.cb));
         else IMGFD_TRY(launch_harris_nms_tiled(ctx, hp.R, nx, ny, n_frames, a.Th, radius, hp.cb));
         IMGFD_TRY(compact_emit(ctx, hp.cb, nx, ny, n_frames, 0, hp.R, d_corners, cap, d_counts));
@@ -244,7 +245,7 @@ imgfd_status harris_device_stages(imgfd_ctx *ctx, const void *d_in, int in_is_u8
                                       hp.tmp));
     IMGFD_TRY(prof_mark(ctx));
     IMGFD_TRY(tick(2));
-    IMGFD_TRY(compact_clear(ctx, hp.cb, ny, n_frames));
+    if (!rc_cleared) IMGFD_TRY(compact_clear(ctx, hp.cb, ny, n_frames));
     if (!need_R_plane && harris_resp_nms_supports(nx, ny, radius)) {
         // batch path: response + NMS in one kernel, strengths recomputed for the corner records (no R plane)
         IMGFD_TRY(launch_harris_resp_nms(ctx, hp.A, hp.B, hp.C, nx, ny, n_frames, a.measure, a.k, a.Th, radius, hp.cb));
