@@ -115,6 +115,28 @@ def test_marching_gauss_grad_u8_bit_exact(be, nx, ny, seg, type):
         be.set_tuning("gauss_march", 1); be.set_tuning("gauss_march_seg", 0); be.set_fir_mode(0)
 
 
+def test_marching_gauss_grad_random_shapes(be):
+    """twenty random shapes the marching kernel serves (widths 256..1264 in steps of 16, heights 16..160, random segment
+    lengths, both gradient types): the tile kernel's bits in both accumulation modes"""
+    rng = np.random.default_rng(77)
+    try:
+        for _ in range(20):
+            nx, ny = 16 * int(rng.integers(16, 80)), int(rng.integers(16, 161))
+            seg, typ, mode = int(rng.choice([0, 2, 9, 24, 40, 57])), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+            img = rng.integers(0, 256, (ny, nx), dtype=np.uint8)
+            be.set_fir_mode(mode)
+            be.set_tuning("gauss_march", 1); be.set_tuning("gauss_march_seg", seg)
+            n0 = be.get_counter("gauss_march_launches")
+            ix, iy = be.k_gauss_grad_u8(img, 1.0, typ)
+            assert be.get_counter("gauss_march_launches") == n0 + 1
+            be.set_tuning("gauss_march", 0)
+            tx, ty = be.k_gauss_grad_u8(img, 1.0, typ)
+            assert_bits_equal(ix, tx, f"Ix {nx}x{ny} seg {seg} type {typ} mode {mode}")
+            assert_bits_equal(iy, ty, f"Iy {nx}x{ny} seg {seg} type {typ} mode {mode}")
+    finally:
+        be.set_tuning("gauss_march", 1); be.set_tuning("gauss_march_seg", 0); be.set_fir_mode(0)
+
+
 def _gradients(seed, nx, ny):
     img = oracle.harris_stage("gaussian", synth.frame(seed, nx, ny).astype(np.float32), sigma=1.0, type=0)
     return oracle.harris_stage("gradient", img, type=0)
