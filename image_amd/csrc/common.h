@@ -46,6 +46,7 @@ struct imgfd_ctx {
     void *detect_exec = nullptr;          // hipGraphExec_t
     long detect_replays = 0, detect_records = 0;  // statistics (imgfd_get_counter)
     long gauss_march_launches = 0;
+    long tensor_wave_launches = 0;
     std::string detect_key, detect_seen;  // the call it was recorded for / the call seen last (raw bytes of a DetectKey)
     // fHOG: magnitude + orientation of every integer gradient (fhog_fused.hip), built on first use
     unsigned *fhog_lut = nullptr;
@@ -70,6 +71,7 @@ struct imgfd_ctx {
         int fused_response = 1;     // Harris: corner response in the structure-tensor kernel's epilogue
         int nms_tiled = 0;          // Harris batch path: 1 = the tiled NMS kernel instead of the sparse one
         int tensor_per_cu = 0, tensor_seg = 0, tensor_workers = 0, tensor_tw = 0;  // fir_tensor launch geometry (0: chosen)
+        int tensor_wave = 0;        // structure tensor: 1 = the wave-autonomous kernel (fir_tensor_wave.hip) where it applies, 0 = the workgroup-marching one
         int surf_residue = 4;       // SURF octaves 1-3: modulus of the residue layout (0: plain table, 4, 16)
         int max_chunk_frames = 0;   // frames per sub-batch of the *_dev entry points (0: from the 12 GiB / 1 GiB budgets)
         int tile_run = 0;           // tiles per workgroup of the u8 tile kernels (0: from the batch size)
@@ -241,6 +243,9 @@ imgfd_status launch_gauss_grad_march(imgfd_ctx *ctx, const void *d_in, int in_pi
 imgfd_status launch_gauss_grad_fused(imgfd_ctx *ctx, const void *d_in, int in_is_u8, int in_pitch, size_t in_frame_stride,
                                      float *d_Ix, float *d_Iy, int nx, int ny, int n_frames, float sigma, int grad_type,
                                      unsigned *d_rowcount = nullptr, bool *rowcount_cleared = nullptr);  // optional: ny counters per frame to clear on the way
+// harris_subpixel.hip: compute_subpixel_precision (harris.cpp:340-381) over a compacted corner list, d_out != d_in
+imgfd_status launch_harris_refine(imgfd_ctx *ctx, const float *d_R, int nx, const imgfd_corner *d_in, int64_t n, int precision,
+                                  imgfd_corner *d_out);
 // harris_stages.hip
 imgfd_status launch_gradient(imgfd_ctx *ctx, const float *d_I, float *d_Ix, float *d_Iy, int nx, int ny,
                              int n_frames, int type);

@@ -28,6 +28,7 @@ const std::vector<TuneKey> &tune_keys()
         {"tensor_seg", "IMGFD_TENSOR_SEG", &imgfd_ctx::Tune::tensor_seg},
         {"tensor_workers", "IMGFD_TENSOR_WORKERS", &imgfd_ctx::Tune::tensor_workers},
         {"tensor_tw", "IMGFD_TENSOR_TW", &imgfd_ctx::Tune::tensor_tw},
+        {"tensor_wave", "IMGFD_TENSOR_WAVE", &imgfd_ctx::Tune::tensor_wave},
         {"surf_residue", "IMGFD_SURF_RESIDUE", &imgfd_ctx::Tune::surf_residue},
         {"max_chunk_frames", "IMGFD_MAX_CHUNK_FRAMES", &imgfd_ctx::Tune::max_chunk_frames},
         {"tile_run", "IMGFD_TILE_RUN", &imgfd_ctx::Tune::tile_run},
@@ -163,6 +164,7 @@ imgfd_status imgfd_get_counter(imgfd_ctx *ctx, const char *name, int64_t *value)
     if (!strcmp(name, "detect_graph_replays")) { *value = ctx->detect_replays; return IMGFD_OK; }
     if (!strcmp(name, "detect_graph_records")) { *value = ctx->detect_records; return IMGFD_OK; }
     if (!strcmp(name, "gauss_march_launches")) { *value = ctx->gauss_march_launches; return IMGFD_OK; }
+    if (!strcmp(name, "tensor_wave_launches")) { *value = ctx->tensor_wave_launches; return IMGFD_OK; }
     for (const TuneKey &k : tune_keys())
         if (!strcmp(k.name, name)) { *value = k.field ? ctx->tune.*(k.field) : ctx->fir_mode; return IMGFD_OK; }
     return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_get_counter: unknown name");

@@ -35,10 +35,14 @@
 #include "common.h"
 #include "fir_device.h"
 #include "harris_device.h"
+#include "fir_tensor_device.h"
 
 #include <algorithm>
 #include <type_traits>
 
+#ifndef FT_PRIO
+#define FT_PRIO 1
+#endif
 #ifdef FT_PROFILE
 // experiment build only (make EXTRA=-DFT_PROFILE): per-phase shader-clock sums over all waves of fir_tensor
 __device__ unsigned long long g_ft_prof[8];
@@ -61,29 +65,15 @@ extern "C" __attribute__((visibility("default"))) int imgfd_debug_ft_profile(uns
 #define FT_T(i)
 #endif
 
-typedef float ft_v4f __attribute__((vector_size(16)));  // native vector: always promoted to registers
-// a volatile 16-byte read that is known to address LDS (a volatile access through a generic pointer becomes a flat load)
-typedef volatile IMGFD_LDS_SPACE ft_v4f ft_lds_v4f;
 
-struct TensorParams {
-    const float *ix;
-    const float *iy;
-    float *out0, *out1, *out2;  // A, B, C -- or R in out0 (OUT = 2)
-    int nx, ny;
-    long frame_stride;  // elements between frames (planes are packed: pitch nx)
-    int seg_rows;       // output rows per segment
-    int nstrips, nseg, n_frames;  // tiles = strips x segments x frames, numbered strip-fastest
-    int step_strip, step_seg, step_frame;  // the number of workers as (strips, segments, frames) digits: a worker's next tile
-    int xcd_remap;
-    float k;            // Harris constant (OUT = 2)
-    // OUT = 2, optional: one byte per quad of pixels, bit e = "the response of pixel x + e is not below the threshold
-    // (harris.cpp:160-162: skip = R < Th) nor beaten by a neighbour inside the quad", quad (frame, y, x / 4) at tq[(frame * ny + y) * (nx / 4) + x / 4]: what the
-    // sparse NMS kernel starts from.  (A byte per lane: no cross-lane traffic in the output phase, which every wave of the
-    // workgroup waits for.  Assembling 64-bit mask words here -- four ballots and a bit spread per row -- cost 14 %.)
-    unsigned char *tq;
-    float Th;
-    double B[8];        // taps B[0..R], R <= 7
-};
+// s_setprio takes an immediate: the unrolled callers pass compile-time values, this folds to one instruction
+__device__ __forceinline__ void ft_setprio(int level)
+{
+    if (level >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (level == 2) __builtin_amdgcn_s_setprio(2);
+    else if (level == 1) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+}
 
 template <int R, int TW_>
 struct TensorGeom {
@@ -104,16 +94,6 @@ struct TensorGeom {
     static_assert(16 * (NS - 1) + 4 * NW4 <= W, "row-pass window reads stay inside the tile row");
 };
 
-// a float plane addressed as a hardware buffer: store(value) at byte offset lane_off (per lane) + row_off (wave-uniform)
-struct FtBuffer { __amdgpu_buffer_rsrc_t r; };
-__device__ __forceinline__ FtBuffer ft_make_buffer(float *base, unsigned bytes)
-{
-    return FtBuffer{__builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00027000)};  // raw buffer, 32-bit data format
-}
-__device__ __forceinline__ void ft_buffer_store(const FtBuffer &b, unsigned lane_off, unsigned row_off, float v)
-{
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, (int)lane_off, (int)row_off, 0);
-}
 
 // ring position of column c of a row: the four float4 slots of each 16-column strip are rotated by (strip / 2), so the
 // row pass's ds_write_b128 (8 lanes = 8 strips of one row) covers 8 distinct slots mod 8 and the column pass's
@@ -121,37 +101,6 @@ __device__ __forceinline__ void ft_buffer_store(const FtBuffer &b, unsigned lane
 __device__ __forceinline__ int ft_ring_slot4(int s, int h) { return 4 * s + ((h + (s >> 1)) & 3); }
 __device__ __forceinline__ int ft_ring_col(int c) { return 4 * ft_ring_slot4(c >> 4, (c >> 2) & 3) + (c & 3); }
 
-// N outputs of one 1-D pass over a register window: out[o] = B[0]*d[o+R] + sum_j B[j]*(d[o+R-j] + d[o+R+j]), pair added
-// first, j ascending, in double, one rounding to float (gaussian.cpp:351-359).  One output is a chain of 2R+1 DEPENDENT
-// f64 instructions (15.4 cycles each when issued back to back, profiles/r01/ubench2.txt): ILP outputs advance together,
-// tap by tap, so that the chains of a wave cover each other's latency.  Each chain keeps the reference's own order.
-#ifndef FT_ILP
-#define FT_ILP 4
-#endif
-template <int R, bool FMA, int N, int ILP>
-__device__ __forceinline__ void ft_taps(const double (&d)[N + 2 * R], const double *B, float (&out)[N])
-{
-    static_assert(N % ILP == 0, "groups of ILP outputs");
-#pragma unroll
-    for (int o0 = 0; o0 < N; o0 += ILP) {
-        double sum[ILP];
-#pragma unroll
-        for (int g = 0; g < ILP; g++) sum[g] = B[0] * d[o0 + g + R];
-#pragma unroll
-        for (int j = 1; j <= R; j++) {
-            double pair[ILP];
-#pragma unroll
-            for (int g = 0; g < ILP; g++) pair[g] = d[o0 + g + R - j] + d[o0 + g + R + j];
-#pragma unroll
-            for (int g = 0; g < ILP; g++) {
-                if (FMA) sum[g] = __builtin_fma(B[j], pair[g], sum[g]);
-                else sum[g] += B[j] * pair[g];
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < ILP; g++) out[o0 + g] = (float)sum[g];
-    }
-}
 
 // row pass, first half: the 16+2R float products of one (row, strip) of plane PL from the raw Ix/Iy tile
 template <int R, int TW, int PL>
@@ -184,31 +133,6 @@ __device__ __forceinline__ void ft_row_products(const float4 *raw4, int r, int s
     }
 }
 
-// ILP outputs o0 .. o0+ILP-1 of one 1-D pass from the float window w (converted to double on first use: dw[] is the
-// same window in double, filled up to index `have`): the reference's sum, chains interleaved tap by tap.
-template <int R, bool FMA, int ILP, int NWIN>
-__device__ __forceinline__ void ft_group(const float (&w)[NWIN], double (&dw)[NWIN], int o0, const double *B, float (&out)[ILP])
-{
-    // the group needs dw[o0 .. o0 + ILP + 2R); everything below o0 + 2R was converted by the previous groups
-#pragma unroll
-    for (int k = (o0 == 0 ? 0 : o0 + 2 * R); k < o0 + ILP + 2 * R; k++) dw[k] = (double)w[k];
-    double sum[ILP];
-#pragma unroll
-    for (int g = 0; g < ILP; g++) sum[g] = B[0] * dw[o0 + g + R];
-#pragma unroll
-    for (int j = 1; j <= R; j++) {
-        double pair[ILP];
-#pragma unroll
-        for (int g = 0; g < ILP; g++) pair[g] = dw[o0 + g + R - j] + dw[o0 + g + R + j];
-#pragma unroll
-        for (int g = 0; g < ILP; g++) {
-            if (FMA) sum[g] = __builtin_fma(B[j], pair[g], sum[g]);
-            else sum[g] += B[j] * pair[g];
-        }
-    }
-#pragma unroll
-    for (int g = 0; g < ILP; g++) out[g] = (float)sum[g];
-}
 
 // Register budget = what the wave placement needs, not what the occupancy API answers.  A workgroup's waves are dealt to
 // the CU's four SIMDs in turn, so only multiples of 4 waves load the SIMDs evenly:
@@ -424,6 +348,13 @@ __global__ void __launch_bounds__(3 * TW) FT_WAVES_PER_EU(TW) fir_tensor(TensorP
         float4 *rdst = reinterpret_cast<float4 *>(ring + (plane * CH + rr) * RP);
 #pragma unroll
         for (int g = 0; g < NG; g++) {
+            // Progress equalisation.  The SIMD's arbiter serves priority first, then age: left alone, the oldest of a SIMD's three
+            // waves runs the big phase at full speed and then idles at the barrier while the youngest finishes ALONE -- and one wave
+            // issues f64 at little more than half the rate three sustain (profiles/r01/ubench2.txt; FT_PROFILE: 22 % of the wave
+            // cycles waited at barrier 1).  Each wave therefore lowers its own priority as it advances (column groups 3, 3, 2, 2,
+            // row groups 1, 1, 0, 0): whoever is behind is served first, and the three reach the barrier together.
+            if (FT_PRIO == 1) ft_setprio((DO_COL ? 3 : 1) - (2 * g) / NG);
+            else if (FT_PRIO == 2 && g == 0) ft_setprio(DO_COL ? 1 : 0);  // experiment: two levels
             if (DO_COL) {
                 float o[ILP];
                 ft_group<R, FMA, ILP, CH + 2 * R>(cw, dcw, ILP * g, p.B, o);
@@ -519,6 +450,7 @@ __global__ void __launch_bounds__(3 * TW) FT_WAVES_PER_EU(TW) fir_tensor(TensorP
 }
 
 // ------------------------------------------------------------------ host side
+imgfd_status launch_tensor_wave(imgfd_ctx *ctx, TensorParams &p, int n_frames, int R, int out_mode);  // fir_tensor_wave.hip
 bool tensor_fast_path(int R) { return R == 7 || R == 3 || R == 1; }
 
 template <int R, int TW, int OUT>
@@ -594,6 +526,10 @@ imgfd_status launch_tensor_march(imgfd_ctx *ctx, const float *d_Ix, const float 
                      (out_mode == 2 || ((size_t)d_B % 16 == 0 && (size_t)d_C % 16 == 0));
     if (out_mode != 0 && out_mode != 2) return IMGFD_ERR_UNSUPPORTED;
     if (out_mode != 0 && !vec) return IMGFD_ERR_UNSUPPORTED;
+    if (vec && ctx->tune.tensor_wave) {  // the wave-autonomous kernel (fir_tensor_wave.hip) where it applies
+        const imgfd_status st = launch_tensor_wave(ctx, p, n_frames, R, out_mode);
+        if (st != IMGFD_ERR_UNSUPPORTED) return st;
+    }
     // 256-column strips (12 waves: every SIMD carries three) unless the image is narrow
     const int tw = ctx->tune.tensor_tw == 128 ? 128 : ctx->tune.tensor_tw == 256 ? 256 : (nx > 384 ? 256 : 128);
 #define FT_GO(RR)                                                                                          \

@@ -2,11 +2,10 @@
 //
 // Mirrors detect_corners() (image.CornerDetectionHarris/src/rcpp_harris.cpp:19-60), harris_scale()
 // (harris.cpp:554-608) and harris() (:473-546): the per-pixel stages run on the device (fir.hip,
-// harris_stages.hip, nms.hip, compact.hip); the per-corner stages that the reference runs on a few
-// thousand items -- select_output_corners (:263-332), compute_subpixel_precision (:340-381 with
-// interpolation.cpp), select_corners (:443-465) -- run on the host over the compacted list, in the
-// reference's own arithmetic (float variables, double-promoted constants, std::sort with the same
-// comparator).
+// harris_stages.hip, nms.hip, compact.hip), and so does the sub-pixel fit of the compacted corner list
+// (compute_subpixel_precision :340-381 with interpolation.cpp -> harris_subpixel.hip); what stays on the host is the
+// ranking / selection of a few thousand records (select_output_corners :263-332, select_corners :443-465), because the
+// reference's order among equal strengths is std::sort's.
 #include "common.h"
 
 #include <math.h>
@@ -26,130 +25,70 @@ __global__ void __launch_bounds__(256) zoom_out_kernel(const float *__restrict__
     if (j1 < nxx && i1 < nyy) Iz[(size_t)i1 * nxx + j1] = I[(size_t)(2 * i1) * nx + 2 * j1];
 }
 
-// 3x3 neighbourhood of R around each corner (harris.cpp:353-370), for the host-side sub-pixel step
-__global__ void __launch_bounds__(256) gather3x3_kernel(const float *__restrict__ R, int nx,
-                                                        const imgfd_corner *__restrict__ c, long long n,
-                                                        float *__restrict__ M)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int x = (int)c[i].x, y = (int)c[i].y;
-    const float *p = R + (size_t)y * nx + x;
-    float *m = M + 9 * i;
-    m[0] = p[-nx - 1]; m[1] = p[-nx]; m[2] = p[-nx + 1];
-    m[3] = p[-1];      m[4] = p[0];   m[5] = p[1];
-    m[6] = p[nx - 1];  m[7] = p[nx];  m[8] = p[nx + 1];
-}
-
 namespace {
 
-struct HCorner {
-    float x, y, R;
-    float M[9];
+// ---- the per-corner host stages: ranking and selection (select_output_corners(), harris.cpp:263-332; the scale check
+// select_corners(), :443-465).  They run over the few thousand records the device stages leave, on the host, because the
+// reference's own order among corners of EQUAL strength is whatever std::sort leaves, and only the same std::sort over the
+// same sequence with the same "stronger first" comparison (harris.cpp:29-36) reproduces it.  Everything here works on
+// indices into the raster-ordered list; the records themselves (and their sub-pixel refinements, made on the device:
+// harris_subpixel.hip) are only looked up at the end.
+using CornerIdx = uint32_t;
+
+struct StrongerFirst {
+    const imgfd_corner *c;
+    bool operator()(CornerIdx a, CornerIdx b) const { return c[a].R > c[b].R; }
 };
-// inverse sort, harris.cpp:29-36
-inline bool operator<(const HCorner &a, const HCorner &b) { return a.R > b.R; }
 
-// quadratic_approximation, interpolation.cpp:27-54
-bool quadratic_approximation(const float *M, float &x, float &y, float &Mo)
+// ranks [first, last) strongest first and keeps at most `limit` of them (limit < 0: all); returns the new end
+CornerIdx *rank_and_cut(CornerIdx *first, CornerIdx *last, const imgfd_corner *c, long limit)
 {
-    float fx = 0.5 * (M[5] - M[3]);
-    float fy = 0.5 * (M[7] - M[1]);
-    float fxx = (M[5] - 2 * M[4] + M[3]);
-    float fyy = (M[7] - 2 * M[4] + M[1]);
-    float fxy = 0.25 * (M[0] - M[2] - M[6] + M[8]);
-    float det = fxx * fyy - fxy * fxy;
-    if (det * det < 1E-6) return false;
-    float dx = (fyy * fx - fxy * fy) / det;
-    float dy = (fxx * fy - fxy * fx) / det;
-    x -= dx;
-    y -= dy;
-    Mo = M[4] + fx * dx + fy * dy + 0.5 * (fxx * dx * dx + 2 * dx * dy * fxy + fyy * dy * dy);
-    return true;
+    std::sort(first, last, StrongerFirst{c});
+    if (limit >= 0 && last - first > limit) last = first + limit;
+    return last;
 }
 
-// quartic_interpolation, interpolation.cpp:171-212 (+ helpers :62-160)
-bool quartic_interpolation(const float *M, float &x, float &y, float &Mo)
+// The corners to report, as indices into c[0..n), in output order.
+//   ALL_CORNERS: raster order.  ALL_CORNERS_SORTED: by strength.  N_CORNERS: the N strongest.
+//   DISTRIBUTED_N_CORNERS: the image is cut into cells x cells boxes, every box contributes its N / cells^2 strongest
+//   (at least one), and the union is ranked and cut to N.
+std::vector<CornerIdx> select_output(const std::vector<imgfd_corner> &c, int strategy, int cells, int N, int nx, int ny)
 {
-    const float TOL = 1E-10;
-    float D[2], b[2], H[3], a[9];
-    float dx = 0, dy = 0;
-    a[0] = M[4] - 0.5 * (M[1] + M[3] + M[5] + M[7]) + 0.25 * (M[0] + M[2] + M[6] + M[8]);
-    a[1] = 0.5 * (M[1] - M[7]) + 0.25 * (-M[0] - M[2] + M[6] + M[8]);
-    a[2] = 0.5 * (M[3] - M[5]) + 0.25 * (-M[0] + M[2] - M[6] + M[8]);
-    a[3] = 0.5 * (M[3] + M[5]) - M[4];
-    a[4] = 0.5 * (M[1] + M[7]) - M[4];
-    a[5] = 0.25 * (M[0] - M[2] - M[6] + M[8]);
-    a[6] = 0.5 * (M[5] - M[3]);
-    a[7] = 0.5 * (M[7] - M[1]);
-    a[8] = M[4];
-    int i = 0;
-    do {
-        D[0] = 2 * a[0] * dx * dy * dy + 2 * a[1] * dx * dy + 2 * a[2] * dy * dy + 2 * a[3] * dx + a[5] * dy + a[6];
-        D[1] = 2 * a[0] * dx * dx * dy + 2 * a[1] * dx * dx + 2 * a[2] * dx * dy + 2 * a[4] * dy + a[5] * dx + a[7];
-        H[0] = 2 * a[0] * dy * dy + 2 * a[1] * dy + 2 * a[3];
-        H[1] = 4 * a[0] * dx * dy + 2 * a[1] * dx + 2 * a[2] * dy + a[5];
-        H[2] = 2 * a[0] * dx * dx + 2 * a[2] * dx + 2 * a[4];
-        float det = H[0] * H[2] - H[1] * H[1];
-        if (det * det < 1E-10) return false;
-        b[0] = (D[0] * H[2] - D[1] * H[1]) / det;
-        b[1] = (D[1] * H[0] - D[0] * H[1]) / det;
-        dx -= b[0];
-        dy -= b[1];
-        i++;
-    } while (D[0] * D[0] + D[1] * D[1] > TOL && i < 20);
-    if (dx > 1 || dx < -1 || dy > 1 || dy < -1 || std::isnan(dx) || std::isnan(dy)) return false;
-    x += dx;
-    y += dy;
-    Mo = a[0] * dx * dx * dy * dy + a[1] * dx * dx * dy + a[2] * dx * dy * dy + a[3] * dx * dx + a[4] * dy * dy +
-         a[5] * dx * dy + a[6] * dx + a[7] * dy + a[8];
-    return true;
-}
-
-// select_output_corners, harris.cpp:263-332
-void select_output_corners(std::vector<HCorner> &corners, int strategy, int cells, int N, int nx, int ny)
-{
-    switch (strategy) {
-        default:
-        case IMGFD_ALL_CORNERS: break;
-        case IMGFD_ALL_CORNERS_SORTED: std::sort(corners.begin(), corners.end()); break;
-        case IMGFD_N_CORNERS:
-            std::sort(corners.begin(), corners.end());
-            if (N < (int)corners.size()) corners.erase(corners.begin() + (N < 0 ? 0 : N), corners.end());
-            break;
-        case IMGFD_DISTRIBUTED_N_CORNERS: {
-            int cellx = cells, celly = cells;
-            if (cellx > nx) cellx = nx;
-            if (celly > ny) celly = ny;
-            if (cellx < 1) cellx = 1;
-            if (celly < 1) celly = 1;
-            int size = cellx * celly;
-            int Ncell = N / size;
-            if (Ncell < 1) Ncell = 1;
-            std::vector<std::vector<HCorner>> cell_corners(size);
-            float Dx = (float)nx / cellx;
-            float Dy = (float)ny / celly;
-            for (size_t i = 0; i < corners.size(); i++) {
-                int px = (float)corners[i].x / Dx;
-                int py = (float)corners[i].y / Dy;
-                int idx = py * cellx + px;
-                if (idx < 0) idx = 0;
-                if (idx >= size) idx = size - 1;
-                cell_corners[idx].push_back(corners[i]);
-            }
-            for (int i = 0; i < size; i++) std::sort(cell_corners[i].begin(), cell_corners[i].end());
-            corners.resize(0);
-            for (int i = 0; i < size; i++) {
-                if ((int)cell_corners[i].size() > Ncell)
-                    corners.insert(corners.end(), cell_corners[i].begin(), cell_corners[i].begin() + Ncell);
-                else
-                    corners.insert(corners.end(), cell_corners[i].begin(), cell_corners[i].end());
-            }
-            std::sort(corners.begin(), corners.end());
-            if (N < (int)corners.size()) corners.erase(corners.begin() + (N < 0 ? 0 : N), corners.end());
-            break;
+    const size_t n = c.size();
+    std::vector<CornerIdx> keep(n);
+    for (size_t i = 0; i < n; i++) keep[i] = (CornerIdx)i;
+    const long limit = N < 0 ? 0 : N;
+    if (strategy == IMGFD_ALL_CORNERS_SORTED) {
+        rank_and_cut(keep.data(), keep.data() + n, c.data(), -1);
+    } else if (strategy == IMGFD_N_CORNERS) {
+        keep.resize((size_t)(rank_and_cut(keep.data(), keep.data() + n, c.data(), limit) - keep.data()));
+    } else if (strategy == IMGFD_DISTRIBUTED_N_CORNERS) {
+        const int bx = std::max(1, std::min(cells, nx)), by = std::max(1, std::min(cells, ny));
+        const int boxes = bx * by;
+        const long quota = std::max(1, N / boxes);
+        const float box_w = (float)nx / bx, box_h = (float)ny / by;  // float division and truncation, as the reference bins
+        // a stable counting sort by box: inside a box the corners stay in raster order, the sequence the reference sorts
+        std::vector<int> box_of(n);
+        std::vector<size_t> begin((size_t)boxes + 1, 0);
+        for (size_t i = 0; i < n; i++) {
+            const int col = (int)(c[i].x / box_w), row = (int)(c[i].y / box_h);
+            box_of[i] = std::max(0, std::min(boxes - 1, row * bx + col));
+            begin[(size_t)box_of[i] + 1]++;
         }
+        for (int b = 0; b < boxes; b++) begin[(size_t)b + 1] += begin[b];
+        std::vector<CornerIdx> by_box(n);
+        {
+            std::vector<size_t> fill(begin.begin(), begin.end() - 1);
+            for (size_t i = 0; i < n; i++) by_box[fill[(size_t)box_of[i]]++] = (CornerIdx)i;
+        }
+        keep.clear();
+        for (int b = 0; b < boxes; b++) {
+            CornerIdx *first = by_box.data() + begin[b];
+            keep.insert(keep.end(), first, rank_and_cut(first, by_box.data() + begin[(size_t)b + 1], c.data(), quota));
+        }
+        keep.resize((size_t)(rank_and_cut(keep.data(), keep.data() + keep.size(), c.data(), limit) - keep.data()));
     }
+    return keep;
 }
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -174,7 +113,7 @@ size_t harris_ws_bytes(int nx, int ny, int n_frames, int64_t cap, size_t tmp_flo
 {
     const size_t plane = align_up(sizeof(float) * (size_t)nx * ny * n_frames, 256);
     return 7 * plane + align_up(sizeof(float) * tmp_floats * n_frames, 256) + compact_bytes(nx, ny, n_frames) + align_up(sizeof(imgfd_corner) * (size_t)cap * n_frames, 256) +
-           align_up(sizeof(float) * 9 * (size_t)cap * n_frames, 256) + align_up(sizeof(int64_t) * n_frames, 256) + 4096;
+           align_up(sizeof(imgfd_corner) * (size_t)cap * n_frames, 256) + align_up(sizeof(int64_t) * n_frames, 256) + 4096;
 }
 
 struct HarrisPlanes {
@@ -261,67 +200,57 @@ imgfd_status harris_device_stages(imgfd_ctx *ctx, const void *d_in, int in_is_u8
     return IMGFD_OK;
 }
 
-// harris(): one scale, device stages + host stages; d_I is an f32 device plane
+// harris(): one scale.  Device: the per-pixel stages, the raster-ordered corner list and -- when asked for -- the sub-pixel
+// fit of EVERY corner beside it (a few thousand threads; the selection below needs the integer records' strengths, so both
+// lists come back, 12 bytes per corner each).  Host: the selection.  d_I is an f32 device plane.
 imgfd_status harris_one(imgfd_ctx *ctx, const float *d_I, int nx, int ny, const HarrisArgs &a,
-                        std::vector<HCorner> &corners, double *stage_seconds)
+                        std::vector<imgfd_corner> &corners, double *stage_seconds)
 {
     corners.clear();
     if (nx < 3 || ny < 3) return IMGFD_OK;  // harris.cpp:493
     // the window rule admits at most one corner per 2x2 block (radius >= 1)
     const int64_t cap = (int64_t)nx * ny / 4 + 16;
-    {
-        // d_I lives in the caller's arena slice; planes are carved after the current watermark
-        const size_t mark = ctx->ws_used;
-        HarrisPlanes hp;
-        IMGFD_TRY(carve_planes(ctx, nx, ny, 1, harris_tmp_floats(nx, ny, a.sigma_d, a.sigma_i, a.gauss), &hp));
-        imgfd_corner *d_corners = (imgfd_corner *)ws_alloc(ctx, sizeof(imgfd_corner) * (size_t)cap);
-        float *d_M = (float *)ws_alloc(ctx, sizeof(float) * 9 * (size_t)cap);
-        int64_t *d_count = (int64_t *)ws_alloc(ctx, sizeof(int64_t));
-        if (!d_corners || !d_M || !d_count) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
-        const bool sub_px = a.precision == IMGFD_QUADRATIC_APPROXIMATION || a.precision == IMGFD_QUARTIC_INTERPOLATION;
-        IMGFD_TRY(harris_device_stages(ctx, d_I, 0, nx, (size_t)nx * ny, nx, ny, 1, a, hp, d_corners, cap, d_count,
-                                       stage_seconds, /*need_R_plane=*/sub_px || stage_seconds != nullptr));
-        int64_t n = 0;
-        IMGFD_HIP(ctx, hipMemcpyAsync(&n, d_count, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
+    // d_I lives in the caller's arena slice; planes are carved after the current watermark
+    const size_t mark = ctx->ws_used;
+    HarrisPlanes hp;
+    IMGFD_TRY(carve_planes(ctx, nx, ny, 1, harris_tmp_floats(nx, ny, a.sigma_d, a.sigma_i, a.gauss), &hp));
+    imgfd_corner *d_corners = (imgfd_corner *)ws_alloc(ctx, sizeof(imgfd_corner) * (size_t)cap);
+    imgfd_corner *d_refined = (imgfd_corner *)ws_alloc(ctx, sizeof(imgfd_corner) * (size_t)cap);
+    int64_t *d_count = (int64_t *)ws_alloc(ctx, sizeof(int64_t));
+    if (!d_corners || !d_refined || !d_count) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    const bool sub_px = a.precision == IMGFD_QUADRATIC_APPROXIMATION || a.precision == IMGFD_QUARTIC_INTERPOLATION;
+    IMGFD_TRY(harris_device_stages(ctx, d_I, 0, nx, (size_t)nx * ny, nx, ny, 1, a, hp, d_corners, cap, d_count,
+                                   stage_seconds, /*need_R_plane=*/sub_px || stage_seconds != nullptr));
+    int64_t n = 0;
+    IMGFD_HIP(ctx, hipMemcpyAsync(&n, d_count, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
+    IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n > cap) n = cap;
+    std::vector<imgfd_corner> found((size_t)n), refined;
+    double t = now_s();
+    if (n) {
+        if (sub_px) {
+            IMGFD_TRY(launch_harris_refine(ctx, hp.R, nx, d_corners, n, a.precision, d_refined));
+            refined.resize((size_t)n);
+            IMGFD_HIP(ctx, hipMemcpyAsync(refined.data(), d_refined, sizeof(imgfd_corner) * n, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        IMGFD_HIP(ctx, hipMemcpyAsync(found.data(), d_corners, sizeof(imgfd_corner) * n, hipMemcpyDeviceToHost, ctx->stream));
         IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (n > cap) n = cap;
-        std::vector<imgfd_corner> host((size_t)n);
-        std::vector<float> M;
-        const bool sub = a.precision == IMGFD_QUADRATIC_APPROXIMATION || a.precision == IMGFD_QUARTIC_INTERPOLATION;
-        if (n) {
-            if (sub) {
-                hipLaunchKernelGGL(gather3x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                                   hp.R, nx, d_corners, (long long)n, d_M);
-                M.resize(9 * (size_t)n);
-                IMGFD_HIP(ctx, hipMemcpyAsync(M.data(), d_M, sizeof(float) * 9 * n, hipMemcpyDeviceToHost, ctx->stream));
-            }
-            IMGFD_HIP(ctx, hipMemcpyAsync(host.data(), d_corners, sizeof(imgfd_corner) * n, hipMemcpyDeviceToHost,
-                                          ctx->stream));
-            IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        }
-        corners.resize((size_t)n);
-        for (int64_t i = 0; i < n; i++) {
-            corners[i].x = host[i].x; corners[i].y = host[i].y; corners[i].R = host[i].R;
-            if (sub) memcpy(corners[i].M, &M[9 * i], sizeof(float) * 9);
-        }
-        double t = now_s();
-        select_output_corners(corners, a.strategy, a.cells, a.N, nx, ny);
-        if (stage_seconds) { stage_seconds[5] = now_s() - t; t = now_s(); }
-        if (sub) {
-            for (auto &c : corners) {
-                if (a.precision == IMGFD_QUADRATIC_APPROXIMATION) quadratic_approximation(c.M, c.x, c.y, c.R);
-                else quartic_interpolation(c.M, c.x, c.y, c.R);
-            }
-            if (stage_seconds) stage_seconds[6] = now_s() - t;
-        }
-        ctx->ws_used = mark;
-        return IMGFD_OK;
     }
+    if (stage_seconds && sub_px) stage_seconds[6] = now_s() - t;  // the fit and its way back
+    t = now_s();
+    const std::vector<CornerIdx> keep = select_output(found, a.strategy, a.cells, a.N, nx, ny);
+    const std::vector<imgfd_corner> &src = sub_px ? refined : found;
+    corners.reserve(keep.size());
+    for (CornerIdx i : keep) corners.push_back(src[i]);
+    if (stage_seconds) stage_seconds[5] = now_s() - t;
+    ctx->ws_used = mark;
+    return IMGFD_OK;
 }
 
-// harris_scale(): harris.cpp:554-608
+// harris_scale(): harris.cpp:554-608.  A corner of this scale stays when some corner of the half-size image lies within
+// sigma_i of its halved position (select_corners, :443-465; the halving runs in double, the distance in float)
 imgfd_status harris_scale(imgfd_ctx *ctx, const float *d_I, int nx, int ny, int Nscales, HarrisArgs a,
-                          std::vector<HCorner> &corners, double *stage_seconds)
+                          std::vector<imgfd_corner> &corners, double *stage_seconds)
 {
     if (Nscales <= 1 || nx <= 64 || ny <= 64) return harris_one(ctx, d_I, nx, ny, a, corners, stage_seconds);
     const int nxx = nx / 2, nyy = ny / 2;
@@ -330,24 +259,21 @@ imgfd_status harris_scale(imgfd_ctx *ctx, const float *d_I, int nx, int ny, int 
     if (!d_Iz) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
     hipLaunchKernelGGL(zoom_out_kernel, dim3(ceil_div(nxx, 256), nyy), dim3(256), 0, ctx->stream, d_I, d_Iz, nx, nxx,
                        nyy);
-    std::vector<HCorner> corners_z;
+    std::vector<imgfd_corner> coarse;
     HarrisArgs az = a;
     az.sigma_i = a.sigma_i / 2;
-    IMGFD_TRY(harris_scale(ctx, d_Iz, nxx, nyy, Nscales - 1, az, corners_z, nullptr));
+    IMGFD_TRY(harris_scale(ctx, d_Iz, nxx, nyy, Nscales - 1, az, coarse, nullptr));
     ctx->ws_used = mark;
     IMGFD_TRY(harris_one(ctx, d_I, nx, ny, a, corners, stage_seconds));
-    // select_corners / distance2, harris.cpp:425-465
-    std::vector<HCorner> kept;
-    for (size_t i = 0; i < corners.size(); i++) {
-        size_t j = 0;
-        for (; j < corners_z.size(); j++) {
-            float dx = (corners_z[j].x - corners[i].x / 2.);
-            float dy = (corners_z[j].y - corners[i].y / 2.);
-            if (!(dx * dx + dy * dy > a.sigma_i * a.sigma_i)) break;
+    const float reach2 = a.sigma_i * a.sigma_i;
+    auto confirmed = [&](const imgfd_corner &fine) {
+        for (const imgfd_corner &z : coarse) {
+            const float ex = (float)((double)z.x - (double)fine.x / 2.), ey = (float)((double)z.y - (double)fine.y / 2.);
+            if (!(ex * ex + ey * ey > reach2)) return true;
         }
-        if (j < corners_z.size()) kept.push_back(corners[i]);
-    }
-    corners.swap(kept);
+        return false;
+    };
+    corners.erase(std::remove_if(corners.begin(), corners.end(), [&](const imgfd_corner &c) { return !confirmed(c); }), corners.end());
     return IMGFD_OK;
 }
 
@@ -379,15 +305,13 @@ static imgfd_status harris_host(imgfd_ctx *ctx, const void *img, int kind, int n
     if (!d_I) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
     IMGFD_TRY(upload_image(ctx, img, kind, (size_t)nx * ny, d_I));
     HarrisArgs a{k, sigma_d, sigma_i, threshold, gaussian, gradient, measure, strategy, cells, Nselect, precision, verbose};
-    std::vector<HCorner> corners;
+    std::vector<imgfd_corner> corners;
     IMGFD_TRY(harris_scale(ctx, d_I, nx, ny, Nscales, a, corners, verbose ? out->stage_seconds : nullptr));
     out->n = (int64_t)corners.size();
     if (out->n) {
         out->corners = (imgfd_corner *)malloc(sizeof(imgfd_corner) * corners.size());
         if (!out->corners) return imgfd_fail(ctx, IMGFD_ERR_OOM, "malloc of the corner list failed");
-        for (size_t i = 0; i < corners.size(); i++) {
-            out->corners[i].x = corners[i].x; out->corners[i].y = corners[i].y; out->corners[i].R = corners[i].R;
-        }
+        memcpy(out->corners, corners.data(), sizeof(imgfd_corner) * corners.size());
     }
     return IMGFD_OK;
 }

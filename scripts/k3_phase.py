@@ -2,6 +2,9 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from image_amd import _lib
+if os.environ.get("VARIANT_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["VARIANT_LIB"])
 from image_amd.device import DeviceDetector
 NX, NY, B = 3840, 2160, int(os.environ.get("BATCH", "32"))
 det = DeviceDetector(0); lib = det.lib

@@ -24,7 +24,7 @@ ix = torch.empty((bmax, NY, NX), dtype=torch.float32, device="cuda")
 iy = torch.empty_like(ix)
 for f in range(bmax):
     det.gradients_of(frames[f], ix[f], iy[f])
-tag = {k: os.environ[k] for k in ("VARIANT_LIB", "IMGFD_XCD_REMAP", "IMGFD_TENSOR_SEG", "IMGFD_TENSOR_PER_CU", "FIR_MODE") if k in os.environ}
+tag = {k: os.environ[k] for k in ("VARIANT_LIB", "IMGFD_XCD_REMAP", "IMGFD_TENSOR_SEG", "IMGFD_TENSOR_PER_CU", "IMGFD_TENSOR_WAVE", "FIR_MODE") if k in os.environ}
 for b in batches:
     us = det.time_structure_tensor_batch(ix[:b], iy[:b], warmup=int(os.environ.get("WARMUP", "3")), iters=int(os.environ.get("ITERS", "30")))
     gbs = 20 * NX * NY * b / (us * 1e-6) / 1e9

@@ -318,6 +318,7 @@ static inline int __builtin_amdgcn_readlane(int v, int src) { return __shfl(v, s
 // ---- gfx950 builtins the product sources use unconditionally (emulated here, so that the kernels carry no test branches)
 static inline double __builtin_amdgcn_rsq(double x) { return 1.0 / sqrt(x); }  // v_rsq_f64: a seed, refined by the caller
 static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline float __builtin_amdgcn_rsqf(float x) { return (float)(1.0 / sqrt((double)x)); }  // v_rsq_f32 (1 ulp on the device)
@@ -337,6 +338,11 @@ static inline unsigned __builtin_amdgcn_perm(unsigned a, unsigned b, unsigned se
 // v_mov_b32_dpp with bound_ctrl: wave_shr:1 (0x138: lane i reads lane i-1) and wave_shl:1 (0x130: lane i reads lane i+1);
 // a lane without a source reads 0
 static inline unsigned __builtin_amdgcn_mov_dpp(unsigned v, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    if (ctrl >= 0 && ctrl <= 0xff && row_mask == 0xf && bank_mask == 0xf) {  // quad_perm: lane i reads lane (i & ~3) + perm[i & 3] of its quad
+        const int l = (int)__lane_id();
+        const unsigned long long *s = hipemu::wave_exchange(v);
+        return (unsigned)s[(l & ~3) + ((ctrl >> (2 * (l & 3))) & 3)];
+    }
     if ((ctrl != 0x138 && ctrl != 0x130) || row_mask != 0xf || bank_mask != 0xf || !bound_ctrl) {
         fprintf(stderr, "hipemu: DPP control 0x%x not emulated\n", ctrl);
         abort();
@@ -366,6 +372,16 @@ static inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned data, __amdgpu
     memcpy(r.base + (size_t)(unsigned)voffset + (size_t)(unsigned)soffset, &data, 4);
 }
 
+struct hipemu_v4u { unsigned x, y, z, w; };
+static inline hipemu_v4u __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
+    hipemu_v4u v;
+    memcpy(&v, r.base + (size_t)(unsigned)voffset + (size_t)(unsigned)soffset, 16);
+    return v;
+}
+// wavefront-scope fence: no instruction on the device; wave barrier: on the device a scheduling fence (the wave's lanes run in
+// lock step), here the rendezvous of the wave's 64 fibers that lock step stands for
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+static inline void __builtin_amdgcn_wave_barrier() { (void)hipemu::wave_exchange(0); }
 static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
     unsigned v;
     memcpy(&v, r.base + (size_t)(unsigned)voffset + (size_t)(unsigned)soffset, 4);
