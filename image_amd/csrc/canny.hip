@@ -504,6 +504,7 @@ __global__ void __launch_bounds__(256) canny_grad_nms(const float *__restrict__ 
     // the hysteresis sweeps behind this kernel start from cleared "changed" words (a memset of their own was 5 us of a
     // single frame's critical path)
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (int)threadIdx.x < n_sweep_flags) sweep_flags[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sweep_flags[n_sweep_flags + blockIdx.z] = 0;  // per frame: the last sweep that changed it
     // workgroup-uniform: interior tiles skip every clamp and fetch the blurred tile as float4s
     const bool inside = vec4 && x0 - GN_XO >= 0 && x0 + GN_TX + GN_XO <= nx && y0 - 2 >= 0 && y0 + GN_TY + 2 <= ny;
     if (inside) canny_grad_nms_tile<true>(sb, sg, blur, S, Wm, nx, ny, words_per_row, accGrad, low_thr, high_thr);
@@ -544,9 +545,22 @@ __device__ __forceinline__ unsigned long long lane_below(unsigned long long v)
     return ((unsigned long long)hi << 32) | lo;
 }
 
+#define HY_SWEEPS 14      // sweeps queued per batch of 8 frames or more (the bench frames converge in 10)
+#define HY_SWEEPS_MAX 32  // flags[]: one word per sweep, one word per frame ("the last sweep that changed this frame" + 1), one more per frame (union-find)
 #ifndef HY_WORDS
 #define HY_WORDS 4
 #endif
+#ifndef HY_EXP
+#define HY_EXP 0  // timing experiments only (wrong results): 1 no S stores, 4 no tile loads, 8 no halo-row loads
+#endif
+// a wave turns its own LDS patch round (written lane = (row, word), read lane = row): program order inside the wave is the
+// only synchronisation; the fences keep the compiler from moving one lane's read over another lane's write
+__device__ __forceinline__ void hyst_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 // HY_WORDS: a wave's tile: 4 words (256 columns) x 64 rows (lane = row), iterated to a fixpoint in registers
 // One sweep over all tiles of all frames (a wave per tile, the tile iterated to its fixpoint in registers).  flags[sweep]
 // is raised when any tile changed; a sweep whose predecessor was idle returns at once, so the host queues a fixed number
@@ -578,23 +592,40 @@ __global__ void __launch_bounds__(256) canny_hyst_bits(unsigned long long *__res
             return;
         }
     }
-    const int y = ty * 64 + lane;
-    const bool rowok = y < ny;
     const int w0 = tx * HW;
     unsigned long long *Sf = S + (size_t)blockIdx.y * ny * wpr;
     const unsigned long long *Wf = Wm + (size_t)blockIdx.y * ny * wpr;
     unsigned long long s[HW + 2], w[HW];  // s[0] / s[HW+1]: halo words left / right
-    const size_t rowbase = (size_t)(rowok ? y : 0) * wpr;
+    // The tile comes in through LDS.  In registers a lane owns a ROW (its HW + 2 words of S, HW of W), and rows lie wpr * 8
+    // bytes apart: loaded lane = row, every 8-byte load of a wave touched 64 different 128-byte lines and the twelve loads of
+    // a tile fetched 96 KB from L2 for 5 KB of bits -- PMC, round 4: 69 % of the sweep's wave cycles waited for them (215 us
+    // for the first sweep over 32 4K frames, 75 us of VALU work in it).  Loaded lane = (row, word) -- LPR lanes per row, 64 /
+    // LPR rows per instruction -- an instruction touches one line per row; the wave's own LDS patch turns the tile round.
+    constexpr int LPR = HW + 2 <= 4 ? 4 : 8, SP = (HW + 2) | 1, WP = HW | 1;  // lanes per row; odd pitches: lane = row reads hit distinct banks
+    __shared__ unsigned long long hb_lds[4][64 * (SP + WP)];
+    unsigned long long *ls = hb_lds[threadIdx.x >> 6], *lw = ls + 64 * SP;
+    {
+        const int c = lane % LPR, rsub = lane / LPR;
 #pragma unroll
-    for (int q = 0; q < HW + 2; q++) {
-        const int wi = w0 - 1 + q;
-        s[q] = (rowok && wi >= 0 && wi < wpr) ? Sf[rowbase + wi] : 0ull;
+        for (int i = 0; i < LPR; i++) {
+            const int r = i * (64 / LPR) + rsub, yy = ty * 64 + r, wi = w0 - 1 + c;
+            if (c < HW + 2) ls[r * SP + c] = (!(HY_EXP & 4) && yy < ny && wi >= 0 && wi < wpr) ? Sf[(size_t)yy * wpr + wi] : (HY_EXP & 4 ? 0x0101010101010101ull * (unsigned)(lane & 1) : 0ull);
+        }
+        constexpr int LPW = HW <= 2 ? 2 : 4;
+        const int cw_ = lane % LPW, rw_ = lane / LPW;
+#pragma unroll
+        for (int i = 0; i < LPW; i++) {
+            const int r = i * (64 / LPW) + rw_, yy = ty * 64 + r, wi = w0 + cw_;
+            if (cw_ < HW) lw[r * WP + cw_] = (!(HY_EXP & 4) && yy < ny && wi < wpr) ? Wf[(size_t)yy * wpr + wi] : (HY_EXP & 4 ? 0x0303030303030303ull : 0ull);
+        }
     }
+    hyst_wave_sync();
+#pragma unroll
+    for (int q = 0; q < HW + 2; q++) s[q] = ls[lane * SP + q];
     bool todo = false;
 #pragma unroll
     for (int q = 0; q < HW; q++) {
-        const int wi = w0 + q;
-        w[q] = (rowok && wi < wpr) ? Wf[rowbase + wi] : 0ull;
+        w[q] = lw[lane * WP + q];
         todo = todo || (w[q] & ~s[q + 1]) != 0ull;
     }
     if (!__any(todo)) {  // no marked-but-not-strong pixel in the tile
@@ -606,7 +637,7 @@ __global__ void __launch_bounds__(256) canny_hyst_bits(unsigned long long *__res
     {
         const int wi = w0 - 1 + lane;
         const int yt = ty * 64 - 1, yb = ty * 64 + 64;
-        if (lane < HW + 2 && wi >= 0 && wi < wpr) {
+        if (!(HY_EXP & 8) && lane < HW + 2 && wi >= 0 && wi < wpr) {
             if (yt >= 0) trow = Sf[(size_t)yt * wpr + wi];
             if (yb < ny) brow = Sf[(size_t)yb * wpr + wi];
         }
@@ -630,302 +661,233 @@ __global__ void __launch_bounds__(256) canny_hyst_bits(unsigned long long *__res
     }
     const bool first = lane == 0, last = lane == 63;
     bool any = false;
+    // Only words whose neighbourhood moved are visited again: bit q of `prev` / `cur` = "word q of some row changed in the
+    // previous / in this pass" (wave-uniform, scalar tests).  A chain that climbs through one word of the tile no longer
+    // drags the other three through every pass.
+#ifdef HY_MAXITER
+    int hy_it = 0;
+#endif
+    unsigned prev = (1u << HW) - 1u;
     for (;;) {
-        bool ch = false;
+        unsigned cur = 0;
 #pragma unroll
         for (int q = 0; q < HW; q++) {
+            const unsigned around = ((7u << q) >> 1) & ((1u << HW) - 1u);  // words q-1, q, q+1
+            if (!((prev & around) || (q > 0 && (cur & (1u << (q - 1)))))) continue;
             // a word's dilation is taken when the word is visited (words to its left already hold this pass's additions: the
             // fixpoint is the same, reached no later).  lane_above / lane_below give 0 to lanes 0 / 63: their neighbours are
             // the halo rows
             const unsigned long long d = dilate_h(s[q + 1], s[q], s[q + 2]);
             const unsigned long long halo = first ? top_d[q] : (last ? bot_d[q] : 0ull);
             const unsigned long long cand = w[q] & ~s[q + 1] & (d | lane_above(d) | lane_below(d) | halo);
-            if (cand) {
-                s[q + 1] |= flood_runs(w[q], cand);
-                ch = true;
+            if (__any(cand != 0ull)) {
+                s[q + 1] |= flood_runs(w[q], cand);  // flood_runs(m, 0) = 0: lanes without a candidate keep their word
+                cur |= 1u << q;
             }
         }
-        if (!__any(ch)) break;
+        if (!cur) break;
         any = true;
+        prev = cur;
+#ifdef HY_MAXITER
+        if (++hy_it >= HY_MAXITER) break;  // timing experiment only (wrong results)
+#endif
     }
-    if (any) {
+    if (any) {  // wave-uniform
+        // back the way it came: rows to the LDS patch, then lane = (row, word) stores
+        hyst_wave_sync();
 #pragma unroll
-        for (int q = 0; q < HW; q++) {
-            const int wi = w0 + q;
-            if (rowok && wi < wpr) Sf[rowbase + wi] = s[q + 1];
+        for (int q = 0; q < HW; q++) lw[lane * WP + q] = s[q + 1];
+        hyst_wave_sync();
+        constexpr int LPW = HW <= 2 ? 2 : 4;
+        const int cw_ = lane % LPW, rw_ = lane / LPW;
+#pragma unroll
+        for (int i = 0; i < LPW; i++) {
+            const int r = i * (64 / LPW) + rw_, yy = ty * 64 + r, wi = w0 + cw_;
+            if (!(HY_EXP & 1) && cw_ < HW && yy < ny && wi < wpr) Sf[(size_t)yy * wpr + wi] = lw[r * WP + cw_];
         }
-        if (lane == 0) atomicOr(&flags[sweep], 1u);
+        // a plain store: every writer stores the same 1.  (An atomicOr here -- sixteen thousand waves of a 32-frame sweep on ONE
+        // address -- WAS the first two sweeps: 215 and 190 us, against 43 and 38 with the store; round 4, scripts/gpu_canny_variants.sh.)
+        if (lane == 0) {
+            flags[sweep] = 1u;
+            flags[HY_SWEEPS_MAX + blockIdx.y] = (unsigned)sweep + 1u;  // frame blockIdx.y moved in this sweep (the union-find kernel asks about the last one)
+        }
     }
     if (lane == 0) act_w[tile] = any ? 1 : 0;
 }
 
 
-#define HY_NT 512    // threads per region workgroup (8 waves)
-#define HY_MAXTILES 96
-
-// A REGION of the frame -- RW words x RH rows of both bit planes plus a one-pixel ring of S -- lives in LDS while one
-// workgroup drives it to its fixpoint: the waves take the region's tiles in turn (halo words / rows of a tile are read
-// from LDS, i.e. from what the neighbouring tiles' waves wrote last), rounds separated by __syncthreads, until a whole
-// round changed nothing.  Tiles whose 3x3 tile neighbourhood did not change in the previous round are skipped.
-// Afterwards the region's S goes back to global memory, and `border` says whether a pixel on the region's outline
-// changed: only those can make a neighbouring region change.
-struct HystGeom {
-    int wpr, ny;          // bit-plane words per row, rows
-    int RW, RH;           // region size in words / rows
-    int rx, ry;           // regions per frame
-    int pitch;            // LDS row pitch in words (odd: lane <-> row accesses of ds_read_b64 hit 32 distinct bank pairs)
+// ---- what the queued sweeps leave: union-find
+// A sweep carries the strong label across one tile outline, so a chain of weak pixels that winds through the frame can outlast
+// any fixed number of sweeps (one edge snaking through a 4K frame crosses sixteen thousand outlines in a row).  When the last
+// queued sweep still changed a frame, two kernels finish the frame WITHOUT walking chains: the runs of still-unlit marked
+// pixels (a run = consecutive bits of one 64-bit word of W & ~S) are the nodes of a forest in the dead blur plane (4 bytes per
+// pixel, a node's parent at its first pixel).  canny_uf_init makes every run its own root; canny_uf_merge unites runs that
+// touch (union by smaller label, lock-free: atomicMin, path halving) and unites a run that touches a strong pixel with the
+// label LIT = 0; canny_expand_count, which writes the edge map anyway, counts the runs of such a frame whose root is LIT as
+// strong.  Work and depth depend on the number of runs, not on how they are chained; all workgroups of a frame that the last
+// sweep left alone (the case in practice) leave at once.
+#define UF_NT 256
+__device__ __forceinline__ unsigned uf_load(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }  // never a stale L1 line
+__device__ __forceinline__ unsigned uf_find(const unsigned *P, unsigned x)
+{
+    while (x != 0u) {
+        const unsigned up = uf_load(P + (x - 1u));
+        if (up == x) break;
+        x = up;
+    }
+    return x;
+}
+// the same walk with path halving: every node passed is re-hung below its grandparent (labels only ever fall along a path, so
+// an atomicMin keeps the forest a forest whatever the other threads do meanwhile)
+__device__ __forceinline__ unsigned uf_find_halving(unsigned *P, unsigned x)
+{
+    while (x != 0u) {
+        const unsigned up = uf_load(P + (x - 1u));
+        if (up == x) break;
+        if (up != 0u) {
+            const unsigned upup = uf_load(P + (up - 1u));
+            if (upup != up) atomicMin(P + (x - 1u), upup);
+            x = upup == up ? up : upup;
+        } else {
+            x = 0u;
+        }
+    }
+    return x;
+}
+__device__ __forceinline__ void uf_union(unsigned *P, unsigned a, unsigned b)
+{
+    for (;;) {
+        a = uf_find_halving(P, a);
+        b = uf_find_halving(P, b);
+        if (a == b) return;
+        if (a < b) { const unsigned t = a; a = b; b = t; }  // hang the larger root below the smaller label
+        const unsigned old = atomicMin(P + (a - 1u), b);
+        if (old == a) return;  // a was still a root: linked
+        a = old;               // somebody linked a meanwhile: go on from there
+    }
+}
+// the run of `m` that holds bit `bit` (set in m): its lowest bit
+__device__ __forceinline__ int uf_run_start(unsigned long long m, int bit)
+{
+    const unsigned long long below = ~m & ((bit == 63 ? ~0ull : ((2ull << bit) - 1ull)));  // zeros of m at or below `bit`
+    return below ? 64 - __clzll((long long)below) : 0;
+}
+// the run of `m` that starts at bit b (set in m, bit b-1 clear): m's ones from b up to the first zero
+__device__ __forceinline__ unsigned long long uf_run_from(unsigned long long m, int b)
+{
+    const unsigned long long zeros_above = b == 63 ? 0ull : (~m >> (b + 1)) << (b + 1);
+    return zeros_above ? (((zeros_above & (0ull - zeros_above)) - 1ull) & ~((1ull << b) - 1ull)) : (~0ull << b);
+}
+struct UfFrame {  // the planes of one frame
+    unsigned long long *Sf;
+    const unsigned long long *Wf;
+    unsigned *P;
+    int wpr, nx, ny;
+    __device__ __forceinline__ unsigned label(int y, int wi, int bit) const { return (unsigned)(y * nx + wi * 64 + bit) + 1u; }
+    __device__ __forceinline__ unsigned long long lit(int y, int wi) const
+    {
+        return (y < 0 || y >= ny || wi < 0 || wi >= wpr) ? 0ull : Sf[(size_t)y * wpr + wi];
+    }
+    __device__ __forceinline__ unsigned long long rem(int y, int wi) const  // marked and not (yet) strong
+    {
+        if (y < 0 || y >= ny || wi < 0 || wi >= wpr) return 0ull;
+        const size_t i = (size_t)y * wpr + wi;
+        return Wf[i] & ~Sf[i];
+    }
 };
-
-__device__ __forceinline__ bool hyst_region(unsigned long long *__restrict__ Sf, const unsigned long long *__restrict__ Wf,
-                                            const HystGeom &g, int reg, unsigned long long *sS, unsigned long long *sW,
-                                            unsigned char *tact, unsigned *lflag)
+// flags layout (see HY_SWEEPS_MAX): [sweep flags][per frame: last sweep that changed it + 1]
+__global__ void __launch_bounds__(UF_NT) canny_uf_init(const unsigned long long *__restrict__ S, const unsigned long long *__restrict__ Wm,
+                                                      int wpr, int nx, int ny, unsigned *__restrict__ parents, const unsigned *__restrict__ flags,
+                                                      unsigned last_sweep, unsigned long long *__restrict__ counts)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nwaves = HY_NT / 64;
-    const int rgx = reg % g.rx, rgy = reg / g.rx;
-    const int w0 = rgx * g.RW, y0 = rgy * g.RH;             // region origin in the plane
-    const int rw = min(g.RW, g.wpr - w0), rh = min(g.RH, g.ny - y0);
-    const int P = g.pitch;
-    // ---- load: S with its ring (LDS row r+1, word c+1 <-> plane row y0+r, word w0+c; outside the plane = 0), W interior
-    for (int i = tid; i < (rh + 2) * (rw + 2); i += HY_NT) {
-        const int r = i / (rw + 2) - 1, c = i - (r + 1) * (rw + 2) - 1;
-        const int y = y0 + r, wi = w0 + c;
-        const bool in = y >= 0 && y < g.ny && wi >= 0 && wi < g.wpr;
-        sS[(r + 1) * P + c + 1] = in ? Sf[(size_t)y * g.wpr + wi] : 0ull;
-        if (r >= 0 && r < rh && c >= 0 && c < rw) sW[r * P + c] = Wf[(size_t)y * g.wpr + wi];
-    }
-    const int tiles_x = (rw + HY_WORDS - 1) / HY_WORDS, tiles_y = (rh + 63) / 64, ntiles = tiles_x * tiles_y;
-    for (int i = tid; i < 2 * HY_MAXTILES; i += HY_NT) tact[i] = 1;  // round 0: every tile
-    if (tid < 4) lflag[tid] = 0;
-    __syncthreads();
-    bool region_changed = false;
-    for (int round = 0;; round++) {
-        unsigned char *act_w = tact + (round & 1) * HY_MAXTILES;
-        const unsigned char *act_r = tact + ((round + 1) & 1) * HY_MAXTILES;
-        bool wave_changed = false;
-        for (int tile = wv; tile < ntiles; tile += nwaves) {
-            const int tx = tile % tiles_x, ty = tile / tiles_x;
-            if (round > 0) {  // a tile can only change if itself or one of its 8 neighbours changed in the previous round
-                bool near = false;
-                if (lane < 9) {
-                    const int nx_ = tx + lane % 3 - 1, ny_ = ty + lane / 3 - 1;
-                    near = nx_ >= 0 && nx_ < tiles_x && ny_ >= 0 && ny_ < tiles_y && act_r[ny_ * tiles_x + nx_] != 0;
-                }
-                if (!__any(near)) { if (lane == 0) act_w[tile] = 0; continue; }
-            }
-            const int r = ty * 64 + lane;           // region row of this lane
-            const bool rowok = r < rh;              // r == rh: the ring row below the region (a source of S, never changed)
-            const int c0 = tx * HY_WORDS;
-            unsigned long long sv[HY_WORDS + 2], wvw[HY_WORDS];  // sv[0] / sv[HY_WORDS+1]: the words left / right of the tile
-            const unsigned long long *srow = sS + ((r <= rh ? r : 0) + 1) * P + c0;  // word c0-1 of the row (ring offset +1)
-#pragma unroll
-            for (int q = 0; q < HY_WORDS + 2; q++) sv[q] = (r <= rh && c0 - 1 + q <= rw) ? srow[q] : 0ull;
-            bool todo = false;
-#pragma unroll
-            for (int q = 0; q < HY_WORDS; q++) {
-                wvw[q] = (rowok && c0 + q < rw) ? sW[r * P + c0 + q] : 0ull;
-                todo = todo || (wvw[q] & ~sv[q + 1]) != 0ull;
-            }
-            if (!__any(todo)) { if (lane == 0) act_w[tile] = 0; continue; }  // no marked-but-not-strong pixel in the tile
-            // rows above / below the tile: lanes 0..5 fetch the six words, everybody gets them by shuffle
-            unsigned long long trow = 0ull, brow = 0ull;
-            if (lane < HY_WORDS + 2 && c0 - 1 + lane <= rw) {
-                trow = sS[(ty * 64) * P + c0 + lane];                                   // region row ty*64 - 1
-                if (ty * 64 + 64 <= rh) brow = sS[(ty * 64 + 65) * P + c0 + lane];      // region row ty*64 + 64 (<= rh: the ring)
-            }
-            unsigned long long top_d[HY_WORDS], bot_d[HY_WORDS];
-            {
-                unsigned long long t[HY_WORDS + 2], b[HY_WORDS + 2];
-#pragma unroll
-                for (int q = 0; q < HY_WORDS + 2; q++) { t[q] = __shfl(trow, q); b[q] = __shfl(brow, q); }
-#pragma unroll
-                for (int q = 0; q < HY_WORDS; q++) {
-                    top_d[q] = dilate_h(t[q + 1], t[q], t[q + 2]);
-                    bot_d[q] = dilate_h(b[q + 1], b[q], b[q + 2]);
-                }
-            }
-            bool any = false;
-            for (;;) {
-                bool ch = false;
-                unsigned long long d[HY_WORDS];
-#pragma unroll
-                for (int q = 0; q < HY_WORDS; q++) d[q] = dilate_h(sv[q + 1], sv[q], sv[q + 2]);
-#pragma unroll
-                for (int q = 0; q < HY_WORDS; q++) {
-                    unsigned long long up = lane_above(d[q]), dn = lane_below(d[q]);
-                    if (lane == 0) up = top_d[q];
-                    if (lane == 63) dn = bot_d[q];
-                    const unsigned long long cand = wvw[q] & ~sv[q + 1] & (d[q] | up | dn);
-                    if (cand) {
-                        sv[q + 1] |= flood_runs(wvw[q], cand);
-                        ch = true;
-                    }
-                }
-                if (!__any(ch)) break;
-                any = true;
-            }
-            if (any) {
-#pragma unroll
-                for (int q = 0; q < HY_WORDS; q++)
-                    if (rowok && c0 + q < rw) sS[(r + 1) * P + c0 + q + 1] = sv[q + 1];
-                wave_changed = true;
-            }
-            if (lane == 0) act_w[tile] = any ? 1 : 0;
-        }
-        if (wave_changed && lane == 0) lflag[round % 3] = 1;
-        __syncthreads();
-        const bool more = lflag[round % 3] != 0;
-        if (tid == 0) lflag[(round + 2) % 3] = 0;  // last read before this barrier, next written after the one that follows
-        if (!more) break;
-        region_changed = true;
-    }
-    // ---- write back, and tell whether the region's outline changed (compare with the plane, which still holds the old S)
-    bool border = false;
-    if (region_changed) {
-        const unsigned long long lastmask = 1ull << 63;  // a region ends on a word boundary or at the plane's last word: its last
-                                                         // column is bit 63 of its last word or lies on the image border
-        for (int i = tid; i < rh * rw; i += HY_NT) {
-            const int r = i / rw, c = i - r * rw;
-            const unsigned long long nv = sS[(r + 1) * P + c + 1];
-            unsigned long long *dst = Sf + (size_t)(y0 + r) * g.wpr + w0 + c;
-            const unsigned long long diff = nv & ~*dst;
-            if (diff) {
-                *dst = nv;
-                if (r == 0 || r == rh - 1) border = true;
-                else if ((c == 0 && (diff & 1ull)) || (c == rw - 1 && (diff & lastmask))) border = true;
-            }
+    const int frame = blockIdx.y;
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[frame] = 0;  // pixels_nonzero of this frame: canny_expand_count adds to it
+    if (flags[HY_SWEEPS_MAX + frame] != last_sweep) return;  // the last queued sweep left this frame alone: converged
+    const size_t plane = (size_t)ny * wpr;
+    const unsigned long long *Sf = S + frame * plane, *Wf = Wm + frame * plane;
+    unsigned *P = parents + (size_t)frame * nx * ny;
+    for (long i = (long)blockIdx.x * UF_NT + threadIdx.x; i < (long)plane; i += (long)gridDim.x * UF_NT) {
+        const unsigned long long m = Wf[i] & ~Sf[i];
+        if (!m) continue;
+        const int y = (int)(i / wpr), wi = (int)(i - (long)y * wpr);
+        unsigned long long starts = m & ~(m << 1);
+        while (starts) {  // every run is its own root
+            const int b = __ffsll((long long)starts) - 1;
+            starts &= starts - 1ull;
+            const unsigned l = (unsigned)(y * nx + wi * 64 + b) + 1u;
+            P[l - 1u] = l;
         }
     }
-    if (border) lflag[3] = 1;
-    __syncthreads();
-    const bool any_border = lflag[3] != 0;
-    __syncthreads();  // everybody has read the verdict before the next region resets the flags
-    return any_border;
 }
-
-// did region `reg` or one of its 8 neighbours report a changed outline (flags of the previous round)?
-__device__ __forceinline__ bool hyst_region_due(const unsigned char *flags, const HystGeom &g, int reg)
+__global__ void __launch_bounds__(UF_NT) canny_uf_merge(unsigned long long *__restrict__ S, const unsigned long long *__restrict__ Wm,
+                                                       int wpr, int nx, int ny, unsigned *__restrict__ parents, const unsigned *__restrict__ flags,
+                                                       unsigned last_sweep)
 {
-    const int rgx = reg % g.rx, rgy = reg / g.rx;
-    for (int dy = -1; dy <= 1; dy++)
-        for (int dx = -1; dx <= 1; dx++) {
-            const int x = rgx + dx, y = rgy + dy;
-            if (x >= 0 && x < g.rx && y >= 0 && y < g.ry && flags[y * g.rx + x]) return true;
-        }
-    return false;
-}
-
-// canny_hyst_finish walks the regions of a pass in raster order or (every other pass) against it: did one of the neighbours
-// it has ALREADY visited in this pass report a changed outline?  (fwd: the three above and the one to the left.)
-__device__ __forceinline__ bool hyst_region_due_visited(const unsigned char *flags, const HystGeom &g, int reg, bool fwd)
-{
-    const int rgx = reg % g.rx, rgy = reg / g.rx, sy = fwd ? -1 : 1;
-    for (int dx = -1; dx <= 1; dx++) {
-        const int x = rgx + dx, y = rgy + sy;
-        if (x >= 0 && x < g.rx && y >= 0 && y < g.ry && flags[y * g.rx + x]) return true;
-    }
-    const int x = rgx + sy;  // fwd: the left neighbour; backwards: the right one
-    return x >= 0 && x < g.rx && flags[rgy * g.rx + x];
-}
-
-// one round: every region whose neighbourhood changed in the previous round (all of them in round 0) is driven to its
-// fixpoint by its own workgroup; rflag[parity][frame][region] = "the region's outline changed in this round"
-__global__ void __launch_bounds__(HY_NT) canny_hyst_regions(unsigned long long *__restrict__ S, const unsigned long long *__restrict__ Wm,
-                                                           HystGeom g, unsigned char *__restrict__ rflag, int round)
-{
-    HIP_DYNAMIC_SHARED(unsigned long long, hy_smem)
-    unsigned long long *sS = hy_smem, *sW = sS + (size_t)(g.RH + 2) * g.pitch;
-    unsigned *lflag = reinterpret_cast<unsigned *>(sW + (size_t)g.RH * g.pitch);
-    unsigned char *tact = reinterpret_cast<unsigned char *>(lflag + 4);
-    const int reg = blockIdx.x, frame = blockIdx.y, regions = g.rx * g.ry, nf = gridDim.y;
-    unsigned char *fl_w = rflag + ((size_t)(round & 1) * nf + frame) * regions;
-    const unsigned char *fl_r = rflag + ((size_t)((round + 1) & 1) * nf + frame) * regions;
-    if (round > 0 && !hyst_region_due(fl_r, g, reg)) {  // workgroup-uniform
-        if (threadIdx.x == 0) fl_w[reg] = 0;
-        return;
-    }
-    const size_t plane = (size_t)g.ny * g.wpr;
-    const bool border = hyst_region(S + frame * plane, Wm + frame * plane, g, reg, sS, sW, tact, lflag);
-    if (threadIdx.x == 0) fl_w[reg] = border ? 1 : 0;
-}
-
-// Termination on the device: after the queued rounds ONE workgroup per frame looks at the last round's flags.  Nothing
-// set (the case in practice): it leaves.  Otherwise it finishes the frame alone -- passes over the regions in turn, each
-// to its fixpoint, until a whole pass changed no outline -- which always terminates and needs no synchronisation between
-// workgroups (S only ever grows, and it is bounded by W).
-__global__ void __launch_bounds__(HY_NT) canny_hyst_finish(unsigned long long *__restrict__ S, const unsigned long long *__restrict__ Wm,
-                                                          HystGeom g, const unsigned char *__restrict__ rflag, int last_round,
-                                                          const unsigned *__restrict__ sweep_flag, unsigned long long *__restrict__ counts)
-{
-    if (threadIdx.x == 0) counts[blockIdx.x] = 0;  // pixels_nonzero of this frame: canny_expand_count adds to it
-    if (sweep_flag && *sweep_flag == 0) return;  // the last queued sweep was idle: converged (the case in practice)
-    HIP_DYNAMIC_SHARED(unsigned long long, hy_smem)
-    unsigned long long *sS = hy_smem, *sW = sS + (size_t)(g.RH + 2) * g.pitch;
-    unsigned *lflag = reinterpret_cast<unsigned *>(sW + (size_t)g.RH * g.pitch);
-    unsigned char *tact = reinterpret_cast<unsigned char *>(lflag + 4);
-    unsigned char *fl = tact + 2 * HY_MAXTILES;  // [2][regions]
-    const int frame = blockIdx.x, regions = g.rx * g.ry, nf = gridDim.x;
-    const unsigned char *last = rflag + ((size_t)(last_round & 1) * nf + frame) * regions;
-    for (int i = threadIdx.x; i < regions; i += HY_NT) fl[i] = sweep_flag ? 1 : last[i];  // after sweeps: every region is due
-    __syncthreads();
-    const size_t plane = (size_t)g.ny * g.wpr;
-    for (int pass = 0;; pass++) {
-        unsigned char *cur = fl + (pass & 1) * regions, *nxt = fl + ((pass + 1) & 1) * regions;
-        bool any = false;
-        for (int i = 0; i < regions; i++) any = any || cur[i];
-        if (!any) break;
-        // A pass visits the regions in raster order, the next one against it, and a region is due when its neighbourhood
-        // changed in the previous pass OR in a region this pass has already visited: a chain of weak pixels then crosses as
-        // many regions per pass as lie in its direction (one region per pass before: a single edge snaking through a 4K frame
-        // took 330 ms here, scripts/canny_serpentine_time.py).
-        const bool fwd = !(pass & 1);
-        for (int k = 0; k < regions; k++) {
-            const int reg = fwd ? k : regions - 1 - k;
-            bool border = false;
-            if (hyst_region_due(cur, g, reg) || hyst_region_due_visited(nxt, g, reg, fwd)) {
-                border = hyst_region(S + frame * plane, Wm + frame * plane, g, reg, sS, sW, tact, lflag);
-                __threadfence();  // the next region reads this one's rows from global memory
+    const int frame = blockIdx.y;
+    if (flags[HY_SWEEPS_MAX + frame] != last_sweep) return;
+    const size_t plane = (size_t)ny * wpr;
+    UfFrame f{S + frame * plane, Wm + frame * plane, parents + (size_t)frame * nx * ny, wpr, nx, ny};
+    unsigned *P = f.P;
+    // unite what touches (8-neighbourhood): the run to the left in the row, the runs of the row above, and LIT
+    for (long i = (long)blockIdx.x * UF_NT + threadIdx.x; i < (long)plane; i += (long)gridDim.x * UF_NT) {
+        const unsigned long long m = f.Wf[i] & ~f.Sf[i];
+        if (!m) continue;
+        const int y = (int)(i / wpr), wi = (int)(i - (long)y * wpr);
+        const unsigned long long up_m = f.rem(y - 1, wi), up_l = f.rem(y - 1, wi - 1), up_r = f.rem(y - 1, wi + 1), left_m = f.rem(y, wi - 1);
+        const unsigned long long s_any = f.lit(y - 1, wi) | f.lit(y, wi) | f.lit(y + 1, wi);
+        const bool sl = ((f.lit(y - 1, wi - 1) | f.lit(y, wi - 1) | f.lit(y + 1, wi - 1)) >> 63) != 0ull;  // a strong pixel left of column 0
+        const bool sr = ((f.lit(y - 1, wi + 1) | f.lit(y, wi + 1) | f.lit(y + 1, wi + 1)) & 1ull) != 0ull;  // right of column 63
+        unsigned long long starts = m & ~(m << 1);
+        while (starts) {
+            const int b = __ffsll((long long)starts) - 1;
+            starts &= starts - 1ull;
+            const unsigned long long run = uf_run_from(m, b);
+            const unsigned long long wide = run | (run << 1) | (run >> 1);
+            const bool at0 = (run & 1ull) != 0ull, at63 = (run >> 63) != 0ull;
+            const unsigned me = f.label(y, wi, b);
+            if ((s_any & wide) || (at0 && sl) || (at63 && sr)) uf_union(P, me, 0u);
+            if (at0 && (left_m >> 63)) uf_union(P, me, f.label(y, wi - 1, uf_run_start(left_m, 63)));
+            unsigned long long hit = up_m & wide;
+            while (hit) {  // one union per run of the row above that the dilated run meets
+                const int st = uf_run_start(up_m, __ffsll((long long)hit) - 1);
+                uf_union(P, me, f.label(y - 1, wi, st));
+                hit &= ~uf_run_from(up_m, st);
             }
-            __syncthreads();
-            if (threadIdx.x == 0) nxt[reg] = border ? 1 : 0;
-            __syncthreads();  // the next region's "due" test reads it
+            if (at0 && (up_l >> 63)) uf_union(P, me, f.label(y - 1, wi - 1, uf_run_start(up_l, 63)));
+            if (at63 && (up_r & 1ull)) uf_union(P, me, f.label(y - 1, wi + 1, 0));
         }
     }
 }
 
-// edges = 255 where strong, else 0 (rcpp_canny.cpp:210-215); thread = 16 pixels
-__global__ void __launch_bounds__(256) canny_expand_bits(const unsigned long long *__restrict__ S, int wpr,
-                                                         unsigned char *__restrict__ edges, int nx, int ny)
-{
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;  // 16-pixel group along x
-    const int y = blockIdx.y;
-    const int x = 16 * g;
-    if (x >= nx) return;
-    const unsigned long long word = S[((size_t)blockIdx.z * ny + y) * wpr + (x >> 6)];
-    const unsigned bits = (unsigned)(word >> (x & 63)) & 0xffffu;
-    unsigned v[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = ((((bits >> (4 * k)) & 0xfu) * 0x00204081u) & 0x01010101u) * 0xffu;
-    unsigned char *dst = edges + ((size_t)blockIdx.z * ny + y) * nx + x;
-    if ((nx & 15) == 0 && (reinterpret_cast<size_t>(edges) & 15) == 0) {
-        *reinterpret_cast<uint4 *>(dst) = make_uint4(v[0], v[1], v[2], v[3]);
-    } else {
-        for (int k = 0; k < 16 && x + k < nx; k++) dst[k] = (unsigned char)(v[k >> 2] >> (8 * (k & 3)));
-    }
-}
-
-// per-frame count of edge pixels (rcpp_canny.cpp:226-233): popcount of the strong plane
 #define EXP_BLOCKS 128
 // rcpp_canny.cpp:226-243: the edge map as 0/255 bytes and its number of non-zero pixels; a workgroup walks every
 // EXP_BLOCKS-th row and adds its count once
+// A frame that went through the union-find kernels (uf != nullptr and its flag says so): the runs of W & ~S whose root is LIT
+// count as strong (plain loads of the forest: it was finished by the previous kernel).
 __global__ void __launch_bounds__(256) canny_expand_count(const unsigned long long *__restrict__ S, int wpr, unsigned char *__restrict__ edges,
-                                                          int nx, int ny, unsigned long long *__restrict__ counts)
+                                                          int nx, int ny, unsigned long long *__restrict__ counts,
+                                                          const unsigned long long *__restrict__ Wm, const unsigned *__restrict__ parents,
+                                                          const unsigned *__restrict__ flags, unsigned last_sweep)
 {
     __shared__ unsigned wsum[4];
     const bool vec = (nx & 15) == 0 && (reinterpret_cast<size_t>(edges) & 15) == 0;
+    const bool united = flags[HY_SWEEPS_MAX + blockIdx.y] == last_sweep;  // workgroup-uniform
+    const unsigned *P = parents + (size_t)blockIdx.y * nx * ny;
     unsigned c = 0;
     for (int y = blockIdx.x; y < ny; y += gridDim.x) {
         for (int x = 16 * (int)threadIdx.x; x < nx; x += 16 * 256) {
-            const unsigned long long word = S[((size_t)blockIdx.y * ny + y) * wpr + (x >> 6)];
+            unsigned long long word = S[((size_t)blockIdx.y * ny + y) * wpr + (x >> 6)];
+            if (united) {
+                const unsigned long long m = Wm[((size_t)blockIdx.y * ny + y) * wpr + (x >> 6)] & ~word;
+                unsigned long long starts = m & ~(m << 1);
+                while (starts) {
+                    const int b = __ffsll((long long)starts) - 1;
+                    starts &= starts - 1ull;
+                    unsigned r = (unsigned)(y * nx + (x >> 6) * 64 + b) + 1u;
+                    while (r != 0u && P[r - 1u] != r) r = P[r - 1u];
+                    if (r == 0u) word |= uf_run_from(m, b);
+                }
+            }
             unsigned bits = (unsigned)(word >> (x & 63)) & 0xffffu;
             if (x + 16 > nx) bits &= (1u << (nx - x)) - 1u;
             c += (unsigned)__popc(bits);
@@ -1050,47 +1012,8 @@ size_t canny_ws_bytes(int nx, int ny, int nf)
     const size_t words = (size_t)ceil_div(nx, 64) * ny * nf;
     return align_up(n * sizeof(double), 256) + align_up(n * sizeof(float), 256) + 2 * align_up(words * 8, 256) +
            align_up(12 * ((size_t)nx + ny), 256) + 512 +  // taps in memory (kernels of more than CANNY_MAX_TAPS taps)
-           align_up(2 * (size_t)nf * ceil_div(nx, 64) * ceil_div(ny, 8), 256) +
+           align_up(4 * ((size_t)HY_SWEEPS_MAX + 2 * (size_t)nf), 256) +  // sweep flags, per-frame flags and counters
            align_up(2 * (size_t)nf * ceil_div(ceil_div(nx, 64), 2) * ceil_div(ny, 64), 256) + 4096;
-}
-
-#define HY_SWEEPS 24  // sweeps queued per batch (the bench frames converge in 10-12); flags[] holds one word per sweep
-// Region geometry: as large as LDS allows (15 words x 540 rows: 147 KB for both planes and the ring) when the batch alone
-// fills the device, smaller regions (more workgroups, more rounds) for small batches.
-HystGeom hyst_geometry(const imgfd_ctx *ctx, int wpr, int ny, int nf, bool small)
-{
-    const int num_cu = ctx->num_cu;
-    HystGeom g;
-    g.wpr = wpr; g.ny = ny;
-    // small: the finishing kernel behind the sweeps -- 8 words x 128 rows = 23 KB of LDS, so that its one workgroup per
-    // frame finds room beside whatever else occupies the CUs.  (The largest regions the LDS holds, 15 x 540, were tried for
-    // it: a single edge snaking through a 4K frame, all of it left to this kernel, took 107 instead of 113 ms -- the cost is
-    // tile rounds along the chain, not region visits.)
-    g.RW = std::min(wpr, small ? 8 : 15);
-    g.RH = std::min(ny, small ? 128 : 540);
-    auto count = [&]() { return (long)ceil_div(wpr, g.RW) * ceil_div(ny, g.RH) * nf; };
-    if (ctx->tune.hyst_region_w >= 1 && ctx->tune.hyst_region_h >= 8) {  // tests: a given region size
-        const int a = std::min(15, ctx->tune.hyst_region_w), b = std::min(540, ctx->tune.hyst_region_h);
-        g.RW = std::min(wpr, a); g.RH = std::min(ny, b);
-    } else if (!small) {
-        while (count() < 2L * num_cu && (g.RH > 128 || g.RW > 4)) {
-            if (g.RH > 128 && g.RH / 64 >= g.RW / 4) g.RH = std::max(128, (g.RH / 2 + 63) / 64 * 64);
-            else if (g.RW > 4) g.RW = std::max(4, (g.RW / 2 + 3) / 4 * 4);
-            else break;
-        }
-    }
-    g.rx = ceil_div(wpr, g.RW);
-    g.ry = ceil_div(ny, g.RH);
-    g.pitch = (g.RW + 2) | 1;
-    return g;
-}
-size_t hyst_lds_bytes(const HystGeom &g) { return 8 * (size_t)g.pitch * ((g.RH + 2) + g.RH) + 16 + 2 * HY_MAXTILES; }
-// rounds queued before the finishing kernel: enough for a component to cross a few regions back and forth; what is left
-// after them (never seen on the test images) is finished by canny_hyst_finish
-int hyst_rounds(const imgfd_ctx *ctx, const HystGeom &g)
-{
-    if (ctx->tune.hyst_rounds >= 1) return ctx->tune.hyst_rounds;
-    return std::min(16, 4 + 2 * std::max(g.rx, g.ry) / 2);
 }
 
 // all device work for nf frames; d_edges / d_counts are device buffers
@@ -1116,14 +1039,12 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
     float *blur = (float *)ws_alloc(ctx, n * sizeof(float));
     unsigned long long *S = (unsigned long long *)ws_alloc(ctx, words * 8);
     unsigned long long *Wm = (unsigned long long *)ws_alloc(ctx, words * 8);
-    unsigned *flags = (unsigned *)ws_alloc(ctx, 256);
+    unsigned *flags = (unsigned *)ws_alloc(ctx, 4 * ((size_t)HY_SWEEPS_MAX + (size_t)nf));
     const size_t act_bytes = 2 * (size_t)nf * ceil_div(wpr, 2) * ceil_div(ny, 64);  // tile activity of the sweeps, two parities (tiles of 2 words at the least)
     unsigned char *act = (unsigned char *)ws_alloc(ctx, act_bytes);
-    const size_t rflag_bytes = 2 * (size_t)nf * wpr * ceil_div(ny, 8);  // region flags, two parities (a region is at least 1 word x 8 rows)
-    unsigned char *rflag = (unsigned char *)ws_alloc(ctx, rflag_bytes);
     const size_t tap_bytes = big ? align_up(12 * (offx.size() + offy.size()), 256) + 256 : 0;
     char *taps_dev = big ? (char *)ws_alloc(ctx, tap_bytes) : nullptr;
-    if ((!fast && !tmp) || !blur || !S || !Wm || !flags || !act || !rflag || (big && !taps_dev)) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    if ((!fast && !tmp) || !blur || !S || !Wm || !flags || !act || (big && !taps_dev)) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
     // the caller's hook (imgfd_detect_dev releases FAST-9 and the Harris chain on its other stream through it) is called
     // with the position reached: 0 before the blur, 1 behind it, 2 behind the gradient/NMS kernel
     auto at = [&](int pos) -> imgfd_status {
@@ -1169,52 +1090,43 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
     IMGFD_TRY(at(1));
     dim3 g2(wpr, ceil_div(ny, GN_TY), nf);
     hipLaunchKernelGGL(canny_grad_nms, g2, dim3(256), 0, ctx->stream, blur, S, Wm, nx, ny, wpr, accGrad, (int)low_thr,
-                       (int)high_thr, (int)(nx % 4 == 0 && (size_t)blur % 16 == 0), flags, HY_SWEEPS);
+                       (int)high_thr, (int)(nx % 4 == 0 && (size_t)blur % 16 == 0), flags, HY_SWEEPS_MAX);
     IMGFD_HIP(ctx, hipGetLastError());
     IMGFD_TRY(at(2));
+    unsigned uf_last_sweep = 0;
     // Hysteresis, terminated on the device -- no host read-back anywhere.  A fixed number of sweeps is queued (a sweep whose
-    // predecessor changed nothing returns at once: an idle launch costs a few microseconds), then the finishing kernel,
-    // which leaves at once when the last sweep was idle and otherwise completes the frames region by region.
+    // predecessor changed nothing returns at once: an idle launch costs a few microseconds), then the union-find kernel, which
+    // leaves at once for every frame the last sweep left alone and otherwise completes the frame whatever its chains look like.
     {
-        const bool region_mode = ctx->tune.hyst_mode == 1;  // experiment switch: LDS-resident region rounds instead of sweeps
-        HystGeom g = hyst_geometry(ctx, wpr, ny, nf, !region_mode);
-        const int regions = g.rx * g.ry;
-        const size_t lds = hyst_lds_bytes(g) + 2 * (size_t)regions;
-        IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)canny_hyst_regions, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)canny_hyst_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (region_mode) {
-            const int rounds = hyst_rounds(ctx, g);
-            for (int r = 0; r < rounds; r++)
-                hipLaunchKernelGGL(canny_hyst_regions, dim3(regions, nf), dim3(HY_NT), lds, ctx->stream, S, Wm, g, rflag, r);
-            hipLaunchKernelGGL(canny_hyst_finish, dim3(nf), dim3(HY_NT), lds, ctx->stream, S, Wm, g, rflag, rounds - 1, (const unsigned *)nullptr,
-                               (unsigned long long *)d_counts);
-        } else {
-            // a small batch has nothing to hide idle launches behind (a single 4K frame: 24 launches were 184 of its 438 us):
-            // fewer sweeps are queued, the finishing kernel completes whatever an unusually long chain of weak pixels leaves
-            // One or two frames: tiles of 2 words instead of 4 -- a sweep's length is its slowest wave's in-register fixpoint
-            // loop, and 510 waves leave half the SIMDs of the chip empty (single 4K frame 0.258 -> 0.228 ms; from four frames
-            // on the wider tile wins again: fewer sweeps until nothing changes).
-            const int hw = ctx->tune.hyst_words == 2 || ctx->tune.hyst_words == 4 ? ctx->tune.hyst_words : (nf <= 2 ? 2 : HY_WORDS);
-            // Batches: 24 (the bench frames need 9-12; an idle launch costs ~5 us, and in imgfd_detect_dev the idle tail runs
-            // beside the structure-tensor kernel, off the critical path: 16 and 24 measure the same there).  The margin is what
-            // keeps images with long chains of weak pixels off the finishing kernel's one workgroup per frame.
-            int sweeps = nf >= 8 ? HY_SWEEPS : (hw == 2 ? 10 : 9);
-            if (ctx->tune.hyst_sweeps >= 1 && ctx->tune.hyst_sweeps <= HY_SWEEPS) sweeps = ctx->tune.hyst_sweeps;  // tests: force the finishing kernel to work
-            const int tiles_x = ceil_div(wpr, hw), tiles_y = ceil_div(ny, 64);
-            dim3 g3(ceil_div(tiles_x * tiles_y, 4), nf);
-            for (int i = 0; i < sweeps; i++) {
-                if (hw == 2) hipLaunchKernelGGL(canny_hyst_bits<2>, g3, dim3(256), 0, ctx->stream, S, Wm, wpr, ny, tiles_x, tiles_y, flags, i, act, i);
-                else hipLaunchKernelGGL(canny_hyst_bits<HY_WORDS>, g3, dim3(256), 0, ctx->stream, S, Wm, wpr, ny, tiles_x, tiles_y, flags, i, act, i);
-            }
-            hipLaunchKernelGGL(canny_hyst_finish, dim3(nf), dim3(HY_NT), lds, ctx->stream, S, Wm, g, rflag, 0, (const unsigned *)(flags + sweeps - 1),
-                               (unsigned long long *)d_counts);
+        // One or two frames: tiles of 2 words instead of 4 -- a sweep's length is its slowest wave's in-register fixpoint
+        // loop, and 510 waves leave half the SIMDs of the chip empty (single 4K frame 0.258 -> 0.228 ms; from four frames
+        // on the wider tile wins again: fewer sweeps until nothing changes).
+        const int hw = ctx->tune.hyst_words == 2 || ctx->tune.hyst_words == 4 ? ctx->tune.hyst_words : (nf <= 2 ? 2 : HY_WORDS);
+        // The bench frames need 7 (one frame, 2-word tiles) to 10 sweeps (a batch); an idle launch costs ~4.5 us.  What an image
+        // with longer chains leaves after the queued sweeps is no cliff any more (the union-find kernels: 0.3-0.9 ms for a 4K
+        // frame), so the margin is three sweeps, not fourteen.
+        int sweeps = nf >= 8 ? HY_SWEEPS : (hw == 2 ? 10 : 9);
+        if (ctx->tune.hyst_sweeps >= 1 && ctx->tune.hyst_sweeps <= HY_SWEEPS_MAX) sweeps = ctx->tune.hyst_sweeps;  // tests: leave the work to the union-find kernel
+        const int tiles_x = ceil_div(wpr, hw), tiles_y = ceil_div(ny, 64);
+        dim3 g3(ceil_div(tiles_x * tiles_y, 4), nf);
+        for (int i = 0; i < sweeps; i++) {
+            if (hw == 2) hipLaunchKernelGGL(canny_hyst_bits<2>, g3, dim3(256), 0, ctx->stream, S, Wm, wpr, ny, tiles_x, tiles_y, flags, i, act, i);
+            else hipLaunchKernelGGL(canny_hyst_bits<HY_WORDS>, g3, dim3(256), 0, ctx->stream, S, Wm, wpr, ny, tiles_x, tiles_y, flags, i, act, i);
         }
+        // the blur plane is dead behind the gradient/NMS kernel: 4 bytes per pixel for the forest.  Workgroups per frame: enough
+        // to spread a frame that needs the kernels over the chip, few enough that the idle case stays one short launch each
+        const int uf_blocks = std::max(1, std::min({2048 / nf, ceil_div(wpr * ny, 2 * UF_NT), 256}));
+        hipLaunchKernelGGL(canny_uf_init, dim3(uf_blocks, nf), dim3(UF_NT), 0, ctx->stream, (const unsigned long long *)S, (const unsigned long long *)Wm, wpr, nx, ny,
+                           reinterpret_cast<unsigned *>(blur), (const unsigned *)flags, (unsigned)sweeps, (unsigned long long *)d_counts);
+        hipLaunchKernelGGL(canny_uf_merge, dim3(uf_blocks, nf), dim3(UF_NT), 0, ctx->stream, S, (const unsigned long long *)Wm, wpr, nx, ny,
+                           reinterpret_cast<unsigned *>(blur), (const unsigned *)flags, (unsigned)sweeps);
+        uf_last_sweep = (unsigned)sweeps;
         IMGFD_HIP(ctx, hipGetLastError());
     }
     // 0/255 bytes and pixels_nonzero in one kernel (the finishing kernel zeroed the counts): round 2 queued a memset, the
     // expansion and a 16-workgroup count -- 25 us of a single frame's critical path
     hipLaunchKernelGGL(canny_expand_count, dim3(std::min(EXP_BLOCKS, ny), nf), dim3(256), 0, ctx->stream, S, wpr, d_edges, nx, ny,
-                       (unsigned long long *)d_counts);
+                       (unsigned long long *)d_counts, (const unsigned long long *)Wm, (const unsigned *)blur, (const unsigned *)flags, uf_last_sweep);
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }

@@ -57,11 +57,8 @@ struct imgfd_ctx {
         int fhog_bands = 0;  // bands a workgroup of fhog_hist8 marches through (0: chosen from the batch size)
         int fhog_threads = 256;  // workgroup size of fhog_hist8 (256 | 512)
         // round-1/2 experiment switches (formerly getenv() at their point of use)
-        int hyst_mode = 0;          // Canny hysteresis: 0 = bit-plane sweeps + finishing kernel, 1 = LDS-resident region rounds
-        int hyst_sweeps = 0;        // sweeps queued before the finishing kernel (0: 24, or 14 for batches under 8 frames)
+        int hyst_sweeps = 0;        // Canny hysteresis: sweeps queued before the union-find kernel (0: 14 for batches, 8-9 for fewer than 8 frames)
         int hyst_words = 0;         // words per sweep tile: 2 or 4 (0: 2 for one or two frames, else 4)
-        int hyst_rounds = 0;        // region mode: rounds queued (0: from the region grid)
-        int hyst_region_w = 0, hyst_region_h = 0;  // region size in words x rows (0: from the batch size)
         int surf_taps = 1;          // SURF octaves 1-3: look-ups as buffer loads with host-made offsets (0: address arithmetic per look-up)
         int gauss_march = 1;        // u8 frames whose width is a multiple of 16: the marching Gaussian + gradient kernel (0: the tile kernel)
         int gauss_march_seg = 0;    // rows per segment of that kernel (0: from the batch)

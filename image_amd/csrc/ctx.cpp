@@ -11,12 +11,8 @@ const std::vector<TuneKey> &tune_keys()
         {"fhog_fused", "IMGFD_FHOG_FUSED", &imgfd_ctx::Tune::fhog_fused},
         {"fhog_bands", "IMGFD_FHOG_BANDS", &imgfd_ctx::Tune::fhog_bands},
         {"fhog_threads", "IMGFD_FHOG_THREADS", &imgfd_ctx::Tune::fhog_threads},
-        {"hyst_mode", "IMGFD_HYST_MODE", &imgfd_ctx::Tune::hyst_mode},
         {"hyst_sweeps", "IMGFD_HYST_SWEEPS", &imgfd_ctx::Tune::hyst_sweeps},
-        {"hyst_rounds", "IMGFD_HYST_ROUNDS", &imgfd_ctx::Tune::hyst_rounds},
         {"hyst_words", "IMGFD_HYST_WORDS", &imgfd_ctx::Tune::hyst_words},
-        {"hyst_region_w", "IMGFD_HYST_REGION_W", &imgfd_ctx::Tune::hyst_region_w},
-        {"hyst_region_h", "IMGFD_HYST_REGION_H", &imgfd_ctx::Tune::hyst_region_h},
         {"canny_gate", "IMGFD_CANNY_GATE", &imgfd_ctx::Tune::canny_gate},
         {"harris_gate", "IMGFD_HARRIS_GATE", &imgfd_ctx::Tune::harris_gate},
         {"gauss_march", "IMGFD_GAUSS_MARCH", &imgfd_ctx::Tune::gauss_march},

@@ -41,7 +41,10 @@
 #include <type_traits>
 
 #ifndef FT_PRIO
-#define FT_PRIO 1
+#define FT_PRIO 2
+#endif
+#ifndef FT_DHIST
+#define FT_DHIST 0  // 1: the column history stays in double (2R conversions fewer per column pass, 2R registers more)
 #endif
 #ifdef FT_PROFILE
 // experiment build only (make EXTRA=-DFT_PROFILE): per-phase shader-clock sums over all waves of fir_tensor
@@ -158,8 +161,8 @@ __device__ __forceinline__ void ft_row_products(const float4 *raw4, int r, int s
 //                    of chunk s-1 from registers (-> global, or -> output buffer)
 // Everything that costs f64 issue slots sits in the big phase, where the 12 waves (three per SIMD) run ~600 independent
 // VALU instructions each without meeting a barrier.
-struct TensorPos {  // a step of a worker's sequence: chunk `chunk` of tile (strip, seg, frame); frame >= n_frames: past the end
-    int strip, seg, frame, chunk;
+struct TensorPos {  // a step of a worker's sequence: chunk `chunk` of the segment rows [y0, y0 + nrows) of (strip, frame); frame >= n_frames: past the end
+    int strip, frame, y0, nrows, chunk;
 };
 
 template <int R, int TW, bool FMA, bool VEC, int OUT>
@@ -186,21 +189,35 @@ __global__ void __launch_bounds__(3 * TW) FT_WAVES_PER_EU(TW) fir_tensor(TensorP
     // geometry of a position, recomputed where needed (a handful of scalar operations; keeping it per pipeline stage in
     // registers spilled the scalar file)
 #define FT_X0(t) ((t).strip * TW)
-#define FT_Y0(t) ((t).seg * p.seg_rows)
-#define FT_NROWS(t) (min(p.ny, FT_Y0(t) + p.seg_rows) - FT_Y0(t))
+#define FT_Y0(t) ((t).y0)
+#define FT_NROWS(t) ((t).nrows)
 #define FT_NCHUNKS(t) ((FT_NROWS(t) + 2 * R + CH - 1) / CH)
-    // the step after `t`: next chunk, or chunk 0 of the worker's next tile = tile + workers, advanced digit by digit
-    // (p.step_* = `workers` decomposed in the mixed radix (strips, segments, frames) by the host: no divisions here)
-    auto next_pos = [&](const TensorPos &t) __attribute__((always_inline)) -> TensorPos {
-        TensorPos n = t;
-        if (t.chunk + 1 < FT_NCHUNKS(t)) { n.chunk++; return n; }
+    // Work split.  A (frame, strip) column of ny rows is C = ceil((ny + 2R) / CH) chunks when one worker marches down all of
+    // it; the columns of the batch, strip fastest, form ONE line of n_frames * nstrips * C chunk units, and worker w owns units
+    // [w * S, (w + 1) * S) of it.  A share that begins k units into a column begins at output row CH * k - 2R -- the row the
+    // column's chunk k would begin with -- and pays one chunk of warm-up for it, so no worker runs more than S + 1 steps.
+    // (Fixed-size tiles dealt round-robin meant 15 tiles = 15 warm-ups per worker for the 480 columns of a 32-frame 4K batch
+    // on 256 workers: 270 steps where this split takes 256.)
+    long lin = (long)worker * p.units_per_worker;  // first chunk unit of the worker's next segment
+    const long lin_end = min(lin + p.units_per_worker, p.total_units);
+    auto next_segment = [&]() __attribute__((always_inline)) -> TensorPos {
+        TensorPos n;
         n.chunk = 0;
-        n.strip += p.step_strip;
-        if (n.strip >= p.nstrips) { n.strip -= p.nstrips; n.seg++; }
-        n.seg += p.step_seg;
-        if (n.seg >= p.nseg) { n.seg -= p.nseg; n.frame++; }
-        n.frame += p.step_frame;
+        if (lin >= lin_end) { n.strip = 0; n.frame = p.n_frames; n.y0 = 0; n.nrows = 0; return n; }
+        const long column = lin / p.units_per_column;
+        const int k = (int)(lin - column * p.units_per_column);
+        const int k_end = (int)min((long)p.units_per_column, lin_end - column * p.units_per_column);
+        n.frame = (int)(column / p.nstrips);
+        n.strip = (int)(column - (long)n.frame * p.nstrips);
+        n.y0 = k == 0 ? 0 : CH * k - 2 * R;
+        n.nrows = (k_end == p.units_per_column ? p.ny : CH * k_end - 2 * R) - n.y0;
+        lin += k_end - k;
         return n;
+    };
+    // the step after `t`: next chunk, or chunk 0 of the worker's next segment
+    auto next_pos = [&](const TensorPos &t) __attribute__((always_inline)) -> TensorPos {
+        if (t.chunk + 1 < FT_NCHUNKS(t)) { TensorPos n = t; n.chunk++; return n; }
+        return next_segment();
     };
 
     // ---- tile staging: slot i = tid + l*NT of a chunk's 2 x CH x W4 float4 slots (plane, row, quad); recomputed where
@@ -278,9 +295,10 @@ __global__ void __launch_bounds__(3 * TW) FT_WAVES_PER_EU(TW) fir_tensor(TensorP
     const int col = idx;                            // column pass: column of the strip
     const int scol = ft_ring_col(col);
     float *const outp = plane == 0 ? p.out0 : plane == 1 ? p.out1 : p.out2;
-    float wo[2 * R];  // the column's last 2R row-filtered values of the previous chunk (kept as floats: 2R registers)
+    using hist_t = std::conditional_t<FT_DHIST != 0, double, float>;
+    hist_t wo[2 * R];  // the column's last 2R row-filtered values of the previous chunk
 #pragma unroll
-    for (int i = 0; i < 2 * R; i++) wo[i] = 0.f;
+    for (int i = 0; i < 2 * R; i++) wo[i] = 0;
     float nv[CH];
 #pragma unroll
     for (int i = 0; i < CH; i++) nv[i] = 0.f;
@@ -339,25 +357,33 @@ __global__ void __launch_bounds__(3 * TW) FT_WAVES_PER_EU(TW) fir_tensor(TensorP
         const unsigned crow0 = (unsigned)(FT_Y0(tp) + oi_base) * (unsigned)p.nx * 4u;  // wraps for rows above the segment: those stores are guarded
         if (DO_COL) {
 #pragma unroll
-            for (int i = 0; i < 2 * R; i++) cw[i] = wo[i];
+            for (int i = 0; i < 2 * R; i++) {
+                if (FT_DHIST) { dcw[i] = wo[i]; cw[i] = 0.f; }
+                else cw[i] = (float)wo[i];
+            }
 #pragma unroll
             for (int r = 0; r < CH; r++) cw[2 * R + r] = nv[r];
+            if (!FT_DHIST) {
 #pragma unroll
-            for (int i = 0; i < 2 * R; i++) wo[i] = nv[CH - 2 * R + i];
+                for (int i = 0; i < 2 * R; i++) wo[i] = nv[CH - 2 * R + i];
+            }
         }
         float4 *rdst = reinterpret_cast<float4 *>(ring + (plane * CH + rr) * RP);
 #pragma unroll
         for (int g = 0; g < NG; g++) {
-            // Progress equalisation.  The SIMD's arbiter serves priority first, then age: left alone, the oldest of a SIMD's three
-            // waves runs the big phase at full speed and then idles at the barrier while the youngest finishes ALONE -- and one wave
-            // issues f64 at little more than half the rate three sustain (profiles/r01/ubench2.txt; FT_PROFILE: 22 % of the wave
-            // cycles waited at barrier 1).  Each wave therefore lowers its own priority as it advances (column groups 3, 3, 2, 2,
-            // row groups 1, 1, 0, 0): whoever is behind is served first, and the three reach the barrier together.
+            // Wave priority.  The SIMD's arbiter serves priority first, then age: left alone, the oldest of a SIMD's three waves runs
+            // the big phase at full speed and idles at the barrier while the youngest finishes alone (FT_PROFILE, round 4: 22 % of
+            // the wave cycles waited at barrier 1).  FT_PRIO 1 lets every wave lower its own priority as it advances (column
+            // groups 3, 3, 2, 2, row groups 1, 1, 0, 0): the barrier wait falls to 13 % -- and the row pass grows from 15 % to 29 %
+            // of the wave cycles: the time is conserved, because the f64 pipe is busy either way (profiles/r04/k3_phase_split.txt,
+            // ubench7.txt: 26-28 T lane-op/s is what three waves per SIMD issue of ANY f64 instruction; the kernel runs 23.7).
+            // FT_PRIO 2 (kept, -2 %): column pass at 1, row pass at 0 -- a wave still storing outranks the ones already in their
+            // row pass, so the stores of the chunk leave early.
             if (FT_PRIO == 1) ft_setprio((DO_COL ? 3 : 1) - (2 * g) / NG);
-            else if (FT_PRIO == 2 && g == 0) ft_setprio(DO_COL ? 1 : 0);  // experiment: two levels
+            else if (FT_PRIO == 2 && g == 0) ft_setprio(DO_COL ? 1 : 0);
             if (DO_COL) {
                 float o[ILP];
-                ft_group<R, FMA, ILP, CH + 2 * R>(cw, dcw, ILP * g, p.B, o);
+                ft_group<R, FMA, ILP, CH + 2 * R, FT_DHIST ? 2 * R : 0>(cw, dcw, ILP * g, p.B, o);
 #pragma unroll
                 for (int e = 0; e < ILP; e++) {
                     const int r = ILP * g + e;
@@ -374,14 +400,14 @@ __global__ void __launch_bounds__(3 * TW) FT_WAVES_PER_EU(TW) fir_tensor(TensorP
                 for (int h = 0; h < ILP / 4; h++) rdst[ft_ring_slot4(rs, g * (ILP / 4) + h)] = make_float4(o[4 * h], o[4 * h + 1], o[4 * h + 2], o[4 * h + 3]);
             }
         }
+        if (DO_COL && FT_DHIST) {
+#pragma unroll
+            for (int i = 0; i < 2 * R; i++) wo[i] = dcw[CH + i];
+        }
     };
 
-    TensorPos cur;  // chunk of the row pass in this step
-    cur.strip = worker % p.nstrips;
-    cur.seg = (worker / p.nstrips) % p.nseg;
-    cur.frame = worker / (p.nstrips * p.nseg);
-    cur.chunk = 0;
-    if (cur.frame >= p.n_frames) return;  // workgroup-uniform (the host launches min(workers, tiles) workgroups)
+    TensorPos cur = next_segment();  // chunk of the row pass in this step
+    if (cur.frame >= p.n_frames) return;  // workgroup-uniform (the host launches no worker without rows)
     TensorPos prev = cur, prev2 = cur;    // chunk of the column pass / of the output phase in this step
     bool have_cur = true, have_prev = false, have_prev2 = false;
 #ifdef FT_PROFILE
@@ -459,37 +485,21 @@ static imgfd_status launch_tensor_r(imgfd_ctx *ctx, TensorParams &p, int n_frame
     using G = TensorGeom<R, TW>;
     const int strips = ceil_div(p.nx, G::TW);
     const size_t lds = G::lds_bytes(OUT);
-    // Workers = the workgroups the chip holds at once (persistent: each walks its share of the tiles).  Segment length: a
-    // tile is (rows + 2R) rows in chunks of CH; the pass takes ceil(tiles / workers) tiles of (chunks per tile) steps per
-    // worker: pick the segment count that minimises that product (ties: fewer, longer segments = less halo work).
-    // One persistent workgroup per CU: 12 waves at 168 registers fill a CU's register file, and the hardware admitted one
-    // workgroup even where LDS (68 KB for the 128-column instance) and the occupancy API promised two
-    // (profiles/r02/k3_log.txt).  (Round 2 asked the occupancy API -- before the dynamic-LDS attribute was raised, cached
-    // across instances and devices -- and fell back to this value.)
+    // Workers = the workgroups the chip holds at once (persistent), each with an equal share of the line of chunks (see the
+    // kernel).  One persistent workgroup per CU: 12 waves at 168 registers fill a CU's register file, and the hardware
+    // admitted one workgroup even where LDS (68 KB for the 128-column instance) and the occupancy API promised two
+    // (profiles/r02/k3_log.txt).
     int per_cu = 1;
     if (ctx->tune.tensor_per_cu > 0) per_cu = ctx->tune.tensor_per_cu;
     const long slots = (long)per_cu * ctx->num_cu;
-    long best_cost = -1;
-    int seg = p.ny;
-    for (int nseg = 1; nseg <= ceil_div(p.ny, G::CH); nseg++) {
-        int m = ceil_div(ceil_div(p.ny, nseg) + 2 * R, G::CH);
-        if (m < 2) m = 2;
-        const int sr = m * G::CH - 2 * R;  // (rows + 2R) fills whole chunks
-        const long tiles = (long)strips * ceil_div(p.ny, sr) * n_frames;
-        const long cost = ((tiles + slots - 1) / slots) * m;
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; seg = sr; }
-    }
-    p.seg_rows = seg;
-    if (ctx->tune.tensor_seg > 0) p.seg_rows = ctx->tune.tensor_seg;
     p.nstrips = strips;
-    p.nseg = ceil_div(p.ny, p.seg_rows);
     p.n_frames = n_frames;
-    const long tiles = (long)p.nstrips * p.nseg * n_frames;
-    long workers = std::min<long>(tiles, slots);
-    if (ctx->tune.tensor_workers > 0) workers = std::min<long>(tiles, ctx->tune.tensor_workers);  // tests: several tiles per worker on small images
-    p.step_strip = (int)(workers % p.nstrips);
-    p.step_seg = (int)((workers / p.nstrips) % p.nseg);
-    p.step_frame = (int)(workers / ((long)p.nstrips * p.nseg));
+    p.units_per_column = ceil_div(p.ny + 2 * R, G::CH);
+    p.total_units = (long)strips * n_frames * p.units_per_column;
+    long workers = std::min<long>(p.total_units, slots);
+    if (ctx->tune.tensor_workers > 0) workers = std::min<long>(p.total_units, ctx->tune.tensor_workers);  // tests: few workers, several segments each
+    p.units_per_worker = (p.total_units + workers - 1) / workers;
+    workers = (p.total_units + p.units_per_worker - 1) / p.units_per_worker;
     dim3 grid((unsigned)workers);
     p.xcd_remap = ctx->tune.xcd_remap;
     auto go = [&](auto kern) -> imgfd_status {

@@ -19,6 +19,8 @@ struct TensorParams {
     int seg_rows;       // output rows per segment
     int nstrips, nseg, n_frames;  // tiles = strips x segments x frames, numbered strip-fastest
     int step_strip, step_seg, step_frame;  // the number of workers as (strips, segments, frames) digits: a worker's next tile
+    long total_units, units_per_worker;  // fir_tensor.hip: the batch as one line of chunk units (columns strip fastest), a worker's share of it
+    int units_per_column;  // fir_tensor.hip: chunks of one (frame, strip) column marched in one piece
     int xcd_remap;
     float k;            // Harris constant (OUT = 2)
     // OUT = 2, optional: one byte per quad of pixels, bit e = "the response of pixel x + e is not below the threshold

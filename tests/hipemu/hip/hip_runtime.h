@@ -381,6 +381,9 @@ static inline hipemu_v4u __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_r
 // wavefront-scope fence: no instruction on the device; wave barrier: on the device a scheduling fence (the wave's lanes run in
 // lock step), here the rendezvous of the wave's 64 fibers that lock step stands for
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+// scoped atomic load: one thread at a time runs here
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) (*(p))
 static inline void __builtin_amdgcn_wave_barrier() { (void)hipemu::wave_exchange(0); }
 static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
     unsigned v;
