@@ -39,6 +39,9 @@ F64_LANE_OPS_HW = 256 * 4 * 16 * 2.4e9   # the hardware's issue peak: 256 CUs x 
 RESPONSE_BYTES_PER_PX = 12.25   # the kernel the product launches: reads Ix, Iy (8 B), writes R (4 B) and a threshold byte per 4 pixels
 TENSOR_BYTES_PER_PX = 20        # read Ix,Iy (8 B), write A,B,C (12 B)
 TENSOR_F64_OPS_PER_PX = 90      # 2 passes x 3 planes x (1 mul + 7 add + 7 fma), the reference's own arithmetic
+TENSOR_F64_RATE_OPS_PER_PX = 107.25   # + the f32<->f64 conversions of the two register windows (3 planes x (30 + 16 + 30 + 16) / 16): they issue at the f64 rate (ubench7)
+F64_LANE_OPS_3_WAVES = 27.0e12  # what three waves per SIMD -- the kernel's occupancy: its 30-value double windows need 150-168 registers -- issue of ANY f64
+                                # instruction with 8 independent destinations each: 25.4-29.0 T lane-op/s (profiles/r04/ubench7_f64_instruction_rates.txt)
 
 
 # ------------------------------------------------------------------------------------------------ CPU legs
@@ -85,7 +88,7 @@ def cpu_harris_fast9_canny(img, want_fast9=True, gpu_frame0=None):
         t_h1 = _median(lambda: oracle.ref_harris(f32, threads=1))   # state the single-thread time too
         if want_fast9:
             t_f = _median(lambda: oracle.ref_fast9(img, 20, True))
-        kind = "reference"
+        kind = "reference+restatement(canny)"   # Harris and FAST-9: the reference's own sources; Canny: the pinned restatement (the reference needs FFTW3)
     else:
         sweep = None
         t_h = _median(lambda: oracle.harris(f32))
@@ -277,6 +280,12 @@ class Detect4K(Workload):
              "f64_hardware_issue_peak": "256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-op/s (34 T measured for dependent add+fmac chains)",
              "f64_issue_roof": f"{TENSOR_F64_OPS_PER_PX} f64 FIR lane-ops/px (the reference's double accumulation) at the {F64_LANE_OPS_PER_S / 1e12:.0f} T lane-op/s "
                                "the vector pipe sustains for add+fmac chains (profiles/r01/ubench2.txt): the kernel is bound by f64 issue, HBM second",
+             "f64_floor": {"f64_rate_lane_ops_per_px": TENSOR_F64_RATE_OPS_PER_PX, "lane_ops_per_s_at_the_kernels_occupancy": F64_LANE_OPS_3_WAVES,
+                           "floor_us_per_launch": round(TENSOR_F64_RATE_OPS_PER_PX * NX * NY * B / F64_LANE_OPS_3_WAVES * 1e6, 1),
+                           "frac": round(TENSOR_F64_RATE_OPS_PER_PX * NX * NY * B / F64_LANE_OPS_3_WAVES * 1e6 / us, 4),
+                           "what": "the kernel's f64-rate instructions alone (90 FIR operations + 17.25 conversions per pixel) at the rate three waves per SIMD issue them on this "
+                                   "part, measured (scripts/ubench/ubench7.hip); the phase split and the barrier-free experiment behind this number: profiles/r04/k3_phase_split.txt, "
+                                   "k3_wave_experiment.txt; DESIGN.md, K3"},
              "avg_launch_us": round(us, 2), "frames_per_launch": B, "algorithmic_bytes_per_launch": k3_bytes,
              "timed": "HIP events on the context's stream around back-to-back launches of the stage doorway on this batch's gradients, after the timed region"}
         tr = traffic_for("fir_tensor", B)
@@ -567,7 +576,7 @@ def traffic_for(kernel, batch):
 def kernel_source_hash():
     import hashlib
     h = hashlib.sha1()
-    for f in ("fir_tensor.hip", "fir_device.h"):
+    for f in ("fir_tensor.hip", "fir_tensor_device.h", "fir_device.h"):
         with open(os.path.join(ROOT, "image_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
@@ -724,6 +733,140 @@ def measure(args, det, rank, world, dist, want_cpu, light=False):
     return res
 
 
+def _pcie_rates(device):
+    """what a plain copy of a host vector achieves on this box (GB/s): pageable and pinned, up and down -- the floor the host
+    entry points are priced against (torch copies: hipMemcpyAsync on the current stream)"""
+    import torch
+    n = 64 << 20
+    out = {}
+    for kind in ("pageable", "pinned"):
+        h = torch.empty(n, dtype=torch.uint8, pin_memory=(kind == "pinned"))
+        h.fill_(7)
+        d = torch.empty(n, dtype=torch.uint8, device=f"cuda:{device}")
+        for name, fn in (("h2d", lambda: d.copy_(h)), ("d2h", lambda: h.copy_(d))):
+            fn(); torch.cuda.synchronize()
+            ts = []
+            for _ in range(5):
+                t = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
+            out[f"{kind}_{name}_GBps"] = round(n / min(ts) / 1e9, 1)
+    return out
+
+
+def host_api_config(device):
+    """configs.host_api: the boundary an R user hits -- the five R-facing entry points of include/imgfd.h on host vectors as
+    the .Call glue passes them (REAL(x) / INTEGER(x): pageable memory), one 3840x2160 frame / one 4096x4096 RGB tile per
+    call, PCIe in both directions included, results in the vectors R would own (the edge map and the fHOG features as
+    doubles, widened on the device).  Reference: rcpp_harris.cpp:19-60, f9_rcpp.cpp:8-35, rcpp_canny.cpp:122-244,
+    rcpp_fhog.cpp:10-46, rcpp_surf.cpp:10-53."""
+    import ctypes as C
+
+    import numpy as np
+
+    from image_amd import _binding, _lib, synth
+    ctx = _lib.Context(device)
+    lib, h = ctx.lib, ctx.handle
+    NX, NY, S = 3840, 2160, 4096
+    img = synth.frame(2, NX, NY)
+    d64 = np.ascontiguousarray(img.astype(np.float64)); i32 = np.ascontiguousarray(img.astype(np.int32))
+    rgb = np.ascontiguousarray(synth.frame_rgb(3, S, S).astype(np.int32))
+    edges = np.zeros((NY, NX), np.float64); nz = C.c_int64(0)
+    nr, nc = C.c_int(0), C.c_int(0)
+    ctx.check(lib.imgfd_fhog_size(S, S, 8, 1, 1, C.byref(nr), C.byref(nc)), "fhog_size")
+    hog = np.zeros((31 * nr.value * nc.value,), np.float64)
+    counts = {}
+
+    def harris():
+        out = _binding.Corners()
+        ctx.check(lib.imgfd_harris_f64(h, d64.ctypes.data_as(C.c_void_p), NX, NY, 0.06, 1.0, 2.5, 130.0, 0, 0, 0, 1, 0, 1, 0, 10, 0, C.byref(out)), "harris_f64")
+        counts["harris_corners"] = int(out.n)
+        if out.n: lib.imgfd_free(out.corners)
+
+    def fast9():
+        out = _binding.Points()
+        ctx.check(lib.imgfd_fast9_i32(h, i32.ctypes.data_as(C.c_void_p), NX, NY, NX, 20, 1, C.byref(out)), "fast9_i32")
+        counts["fast9_points"] = int(out.n)
+        if out.n: lib.imgfd_free(out.points)
+
+    def canny():
+        ctx.check(lib.imgfd_canny_f64out(h, i32.ctypes.data_as(C.c_void_p), NX, NY, 2.0, 3.0, 10.0, 1, edges.ctypes.data_as(C.c_void_p), C.byref(nz)), "canny_f64out")
+        counts["canny_pixels_nonzero"] = int(nz.value)
+
+    def fhog():
+        ctx.check(lib.imgfd_fhog_f64out(h, rgb.ctypes.data_as(C.c_void_p), S, S, 8, 1, 1, hog.ctypes.data_as(C.c_void_p), hog.size, C.byref(nr), C.byref(nc)), "fhog_f64out")
+
+    def surf():
+        o = _binding.SurfOut()
+        ctx.check(lib.imgfd_surf_i32(h, rgb.ctypes.data_as(C.c_void_p), S, S, 1000, 30.0, C.byref(o)), "surf_i32")
+        counts["surf_points"] = int(o.n)
+        if o.n: lib.imgfd_free(o.data)
+
+    rates = _pcie_rates(device)
+    up, down = rates["pageable_h2d_GBps"] * 1e9, rates["pageable_d2h_GBps"] * 1e9
+    px4k, pxt = NX * NY, S * S
+    plan = [("imgfd_harris_f64", harris, px4k, 8 * px4k, 0, "image_harris(): 8 B/px up (the NumericMatrix), a corner list down"),
+            ("imgfd_fast9_i32", fast9, px4k, 4 * px4k, 0, "image_detect_corners(): 4 B/px up (as.integer(x)), a point list down"),
+            ("imgfd_canny_f64out", canny, px4k, 4 * px4k, 8 * px4k, "image_canny_edge_detector(): 4 B/px up, 8 B/px down (the NumericMatrix of edges, widened on the device)"),
+            ("imgfd_fhog_f64out", fhog, pxt, 12 * pxt, 8 * hog.size, "image_fhog(): 12 B/px up (3 ints), 31 doubles per 8x8 cell down (widened on the device)"),
+            ("imgfd_surf_i32", surf, pxt, 12 * pxt, 0, "image_surf(): 12 B/px up, <= 1000 points x 70 doubles down")]
+    out = {"what": "one call per entry point on pageable host vectors, results in host vectors; best and median of 7 calls after 2 warm-up calls",
+           "frame": f"{NX}x{NY} gray", "tile": f"{S}x{S} RGB", "copy_rates_this_box": rates, "calls": {}}
+    for name, fn, px, b_up, b_down, note in plan:
+        fn(); fn()
+        ts = []
+        for _ in range(7):
+            t = time.perf_counter(); fn(); ts.append(time.perf_counter() - t)
+        ts.sort()
+        floor = b_up / up + b_down / down
+        out["calls"][name] = {"ms_best": round(1e3 * ts[0], 3), "ms_median": round(1e3 * ts[len(ts) // 2], 3), "Mpixels_per_s": round(px / ts[0] / 1e6, 1),
+                              "bytes_up": int(b_up), "bytes_down": int(b_down), "pcie_floor_ms": round(1e3 * floor, 3),
+                              "floor_over_best": round(floor / ts[0], 3), "note": note}
+    out["results"] = counts
+    three = sum(out["calls"][k]["ms_best"] for k in ("imgfd_harris_f64", "imgfd_fast9_i32", "imgfd_canny_f64out"))
+    out["harris_fast9_canny_Mpixels_per_s"] = round(px4k / three / 1e3, 1)
+    ctx.close()
+    return out
+
+
+def stream_h2d_config(device, n_batches=12, batch=32):
+    """configs.5_h2d: configs[4] with delivery included -- 3840x2160 u8 frames in PINNED host memory through imgfd_stream_*
+    (upload of batch i+1 overlapped with the kernels of batch i), Harris + Canny as configs[4] runs them; the resident rate
+    of the same stream is configs.5.  Floor: 1 B/px up at the pinned copy rate of this box."""
+    import numpy as np
+
+    from image_amd import _lib, framestream, synth
+    NX, NY = 3840, 2160
+    ctx = _lib.Context(device)
+    base = np.stack([synth.frame(50000 + f, NX, NY) for f in range(4)])
+    pinned = [framestream.PinnedFrames(batch, NY, NX) for _ in range(3)]
+    for p in pinned:
+        for f in range(batch):
+            p.array[f] = base[f % 4]
+    out = {"what": f"{n_batches} batches of {batch} frames {NX}x{NY} from pinned host memory, two batches in flight, Harris + Canny (image_harris() defaults, Canny s=2 3/10 accGrad)"}
+    try:
+        with framestream.FrameStream(NX, NY, batch, ctx=ctx, harris=True, fast9=False, canny=True) as fs:
+            def run():
+                counts = []
+                t = time.perf_counter()
+                for r in fs.run(pinned[i % 3].array for i in range(n_batches)):
+                    counts.append((int(r["harris_counts"].sum()), int(r["canny_counts"].sum())))
+                return time.perf_counter() - t, counts
+            run()
+            ts = []
+            for _ in range(3):
+                t, counts = run(); ts.append(t)
+            px = n_batches * batch * NX * NY
+            rates = _pcie_rates(device)
+            out.update({"s_best_of_3": round(min(ts), 4), "value": round(px / min(ts) / 1e6, 1), "unit": "Mpixels/s", "GBps_up": round(px / min(ts) / 1e9, 2),
+                        "pinned_h2d_GBps_this_box": rates["pinned_h2d_GBps"], "pcie_floor_Mpixels_per_s": round(rates["pinned_h2d_GBps"] * 1e3, 1),
+                        "frac_of_pcie_floor": round(px / min(ts) / 1e9 / rates["pinned_h2d_GBps"], 3),
+                        "counts_per_batch": {"harris": counts[0][0], "canny": counts[0][1]}, "counts_equal_across_batches": len(set(counts)) == 1})
+    finally:
+        for p in pinned:
+            p.free()
+        ctx.close()
+    return out
+
+
 def extra_configs(args, det, dist):
     """The other BASELINE.json configurations at their real sizes, a few steps each, in this same process (N = 1): the
     driver's one line then carries all five.  configs[4] stages 2000 of its 10 000 frames (17 GB instead of 83): the stream
@@ -754,6 +897,14 @@ def extra_configs(args, det, dist):
             keep["config"]["note"] = "2000 of the 10 000 frames staged and streamed (one pass each): the per-frame rate is the stream's"
         keep["wall_s_incl_staging_and_checks"] = round(time.perf_counter() - t0, 1)
         out[name] = keep
+    # the boundary R users hit, and configs[4] with delivery: host vectors, PCIe included
+    for name, fn in (("host_api", lambda: host_api_config(det.device)), ("5_h2d", lambda: stream_h2d_config(det.device))):
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn()
+            out[name]["wall_s"] = round(time.perf_counter() - t0, 1)
+        except Exception as e:
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 

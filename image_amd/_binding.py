@@ -62,6 +62,8 @@ SIGNATURES = {
     "imgfd_harris_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float] + [C.c_int] * 9 + [C.c_void_p]),
     "imgfd_fast9_i32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_ubyte, C.c_int, C.c_void_p]),
     "imgfd_canny_i32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]),
+    "imgfd_canny_f64out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]),
+    "imgfd_fhog_f64out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, c_int_p, c_int_p]),
     "imgfd_fhog_i32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_float_pp, c_int_p, c_int_p]),
     "imgfd_surf_i32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_double, C.POINTER(SurfOut)]),
     "imgfd_surf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_double, C.POINTER(SurfOut)]),

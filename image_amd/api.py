@@ -177,12 +177,14 @@ def image_canny_edge_detector(x, s=2, low_thr=3, high_thr=10, accGrad=True, ctx=
     ctx = _ctx(ctx)
     nx, ny = x.shape  # X = nrow(x), Y = ncol(x)
     img = np.ascontiguousarray(_as_integer(x).T.astype(np.int32))  # as.integer(x); rcpp_canny.cpp:135-136 on the device
-    edges = np.zeros((ny, nx), np.uint8)
+    # NumericMatrix(nx, ny), rcpp_canny.cpp:226-233: allocated here (the glue: Rf_allocMatrix), filled by the library -- the
+    # edge map is widened to doubles on the device (the R matrix is column-major: element (x, y) at x + nx*y)
+    edges = np.zeros((ny, nx), np.float64)
     nonzero = C.c_int64(0)
-    st = ctx.lib.imgfd_canny_i32(ctx.handle, img.ctypes.data_as(C.c_void_p), int(nx), int(ny), float(s), float(low_thr),
-                             float(high_thr), int(bool(accGrad)), edges.ctypes.data_as(C.c_void_p), C.byref(nonzero))
-    ctx.check(st, "imgfd_canny_i32")
-    res = RList(edges=edges.T.astype(np.float64),  # NumericMatrix(nx, ny), rcpp_canny.cpp:226-233
+    st = ctx.lib.imgfd_canny_f64out(ctx.handle, img.ctypes.data_as(C.c_void_p), int(nx), int(ny), float(s), float(low_thr),
+                                float(high_thr), int(bool(accGrad)), edges.ctypes.data_as(C.c_void_p), C.byref(nonzero))
+    ctx.check(st, "imgfd_canny_f64out")
+    res = RList(edges=edges.T,
                 pixels_nonzero=int(nonzero.value), nx=float(nx), ny=float(ny), s=float(s),
                 low_thr=float(low_thr), high_thr=float(high_thr), accGrad=bool(accGrad))
     res.r_class = "image_canny"
@@ -206,17 +208,16 @@ def image_fhog(x, cell_size=8, filter_rows_padding=1, filter_cols_padding=1, ctx
     """image_fhog(): image_fhog.R:35-48 over dlib_fhog(), rcpp_fhog.cpp:10-46."""
     ctx = _ctx(ctx)
     rgb, width, height = _rgb_bytes(x)
-    hog = C.POINTER(C.c_float)()
     nr, nc = C.c_int(0), C.c_int(0)
-    st = ctx.lib.imgfd_fhog_i32(ctx.handle, rgb.ctypes.data_as(C.c_void_p), int(height), int(width), int(cell_size),
-                                int(filter_rows_padding), int(filter_cols_padding), C.byref(hog), C.byref(nr), C.byref(nc))
-    ctx.check(st, "imgfd_fhog_i32")
+    ctx.check(ctx.lib.imgfd_fhog_size(int(height), int(width), int(cell_size), int(filter_rows_padding), int(filter_cols_padding),
+                                      C.byref(nr), C.byref(nc)), "imgfd_fhog_size")
     n = 31 * nr.value * nc.value
+    flat = np.zeros((n,), np.float64)  # the glue: Rf_allocVector(REALSXP, n), filled by the library (widened on the device)
     if n:
-        flat = np.ctypeslib.as_array(hog, shape=(n,)).astype(np.float64)
-        ctx.lib.imgfd_free(hog)
-    else:
-        flat = np.zeros((0,), np.float64)
+        st = ctx.lib.imgfd_fhog_f64out(ctx.handle, rgb.ctypes.data_as(C.c_void_p), int(height), int(width), int(cell_size),
+                                       int(filter_rows_padding), int(filter_cols_padding), flat.ctypes.data_as(C.c_void_p), n,
+                                       C.byref(nr), C.byref(nc))
+        ctx.check(st, "imgfd_fhog_f64out")
     # out$fhog <- array(out$fhog, dim = c(hog_height, hog_width, 31)): column-major fill
     res = RList(hog_height=nr.value, hog_width=nc.value,
                 fhog=flat.reshape((nr.value, nc.value, 31), order="F"),

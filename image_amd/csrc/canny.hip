@@ -1135,21 +1135,26 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
 
 extern "C" {
 
+// edges: nx*ny bytes (0/255), or -- edges_f64 -- nx*ny doubles (0.0/255.0: the NumericMatrix of rcpp_canny.cpp:226-233)
 static imgfd_status canny_host(imgfd_ctx *ctx, const void *img, int kind, int nx, int ny, double s, double low_thr,
-                               double high_thr, int accGrad, uint8_t *edges, int64_t *pixels_nonzero)
+                               double high_thr, int accGrad, uint8_t *edges, double *edges_f64, int64_t *pixels_nonzero)
 {
     if (!ctx) return IMGFD_ERR_INVALID;
-    if (!img || !edges || !pixels_nonzero || nx < 1 || ny < 1)
+    if (!img || (!edges && !edges_f64) || !pixels_nonzero || nx < 1 || ny < 1)
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_canny: bad argument");
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)nx * ny;
-    IMGFD_TRY(ws_reserve(ctx, canny_ws_bytes(nx, ny, 1) + 2 * align_up(n, 256) + upload_stage_bytes(kind, n) + 512));
+    IMGFD_TRY(ws_reserve(ctx, canny_ws_bytes(nx, ny, 1) + 2 * align_up(n, 256) + upload_stage_bytes(kind, n) + (edges_f64 ? align_up(n * sizeof(double), 256) : 0) + 512));
     uint8_t *d_in = (uint8_t *)ws_alloc(ctx, n);
     uint8_t *d_edges = (uint8_t *)ws_alloc(ctx, n);
     int64_t *d_count = (int64_t *)ws_alloc(ctx, sizeof(int64_t));
-    if (!d_in || !d_edges || !d_count) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    double *d_wide = edges_f64 ? (double *)ws_alloc(ctx, n * sizeof(double)) : nullptr;
+    if (!d_in || !d_edges || !d_count || (edges_f64 && !d_wide)) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
     IMGFD_TRY(upload_image(ctx, img, kind, n, d_in));
     IMGFD_TRY(canny_device(ctx, d_in, nx, n, nx, ny, 1, s, low_thr, high_thr, accGrad, d_edges, d_count));
+    if (edges_f64) {
+        IMGFD_TRY(download_widened(ctx, d_edges, true, n, d_wide, edges_f64));
+    } else
     IMGFD_HIP(ctx, hipMemcpyAsync(edges, d_edges, n, hipMemcpyDeviceToHost, ctx->stream));
     IMGFD_HIP(ctx, hipMemcpyAsync(pixels_nonzero, d_count, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1159,13 +1164,19 @@ static imgfd_status canny_host(imgfd_ctx *ctx, const void *img, int kind, int nx
 imgfd_status imgfd_canny(imgfd_ctx *ctx, const uint8_t *img, int nx, int ny, double s, double low_thr,
                          double high_thr, int accGrad, uint8_t *edges, int64_t *pixels_nonzero)
 {
-    return imgfd_guard(ctx, [&] { return canny_host(ctx, img, IMGFD_SRC_U8, nx, ny, s, low_thr, high_thr, accGrad, edges, pixels_nonzero); });
+    return imgfd_guard(ctx, [&] { return canny_host(ctx, img, IMGFD_SRC_U8, nx, ny, s, low_thr, high_thr, accGrad, edges, nullptr, pixels_nonzero); });
 }
 
 imgfd_status imgfd_canny_i32(imgfd_ctx *ctx, const int32_t *image, int nx, int ny, double s, double low_thr,
                              double high_thr, int accGrad, uint8_t *edges, int64_t *pixels_nonzero)
 {
-    return imgfd_guard(ctx, [&] { return canny_host(ctx, image, IMGFD_SRC_I32, nx, ny, s, low_thr, high_thr, accGrad, edges, pixels_nonzero); });
+    return imgfd_guard(ctx, [&] { return canny_host(ctx, image, IMGFD_SRC_I32, nx, ny, s, low_thr, high_thr, accGrad, edges, nullptr, pixels_nonzero); });
+}
+
+imgfd_status imgfd_canny_f64out(imgfd_ctx *ctx, const int32_t *image, int nx, int ny, double s, double low_thr,
+                                double high_thr, int accGrad, double *edges, int64_t *pixels_nonzero)
+{
+    return imgfd_guard(ctx, [&] { return canny_host(ctx, image, IMGFD_SRC_I32, nx, ny, s, low_thr, high_thr, accGrad, nullptr, edges, pixels_nonzero); });
 }
 
 imgfd_status imgfd_canny_dev(imgfd_ctx *ctx, const imgfd_frames *fr, double s, double low_thr,

@@ -195,6 +195,8 @@ imgfd_status prof_mark(imgfd_ctx *ctx);
 enum { IMGFD_SRC_U8 = 0, IMGFD_SRC_I32 = 1, IMGFD_SRC_F32 = 2, IMGFD_SRC_F64 = 3 };
 size_t upload_stage_bytes(int kind, size_t n);
 imgfd_status upload_image(imgfd_ctx *ctx, const void *host, int kind, size_t n, void *d_dst);
+// results widened to R's doubles in HBM (d_stage: n doubles of workspace) and copied into host_out; asynchronous on ctx->stream
+imgfd_status download_widened(imgfd_ctx *ctx, const void *d_src, bool src_is_u8, size_t n, double *d_stage, double *host_out);
 
 // ---- kernel launchers shared between translation units (device pointers, async on ctx->stream)
 struct FrameGeom {

@@ -451,10 +451,14 @@ imgfd_status imgfd_fhog_size(int rows, int cols, int cell_size, int filter_rows_
     return IMGFD_OK;
 }
 
+// hog: library-allocated floats (imgfd_fhog, imgfd_fhog_i32), or -- hog_f64 -- the caller's vector of hog_cap doubles
+// (imgfd_fhog_f64out: what rcpp_fhog.cpp:29-38 fills element by element)
 static imgfd_status fhog_host(imgfd_ctx *ctx, const void *rgb, int kind, int rows, int cols, int cell_size, int filter_rows_padding,
-                              int filter_cols_padding, float **hog, int *hog_nr, int *hog_nc)
+                              int filter_cols_padding, float **hog, int *hog_nr, int *hog_nc, double *hog_f64 = nullptr, int64_t hog_cap = 0)
 {
     if (!ctx) return IMGFD_ERR_INVALID;
+    float *unused_hog = nullptr;
+    if (hog_f64) hog = &unused_hog;
     if (!rgb || !hog || !hog_nr || !hog_nc || rows < 0 || cols < 0 || cell_size < 1 || filter_rows_padding < 1 || filter_cols_padding < 1)
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_fhog: bad argument (DLIB_ASSERT of fhog.h:712-720)");
     *hog = nullptr; *hog_nr = 0; *hog_nc = 0;
@@ -462,13 +466,21 @@ static imgfd_status fhog_host(imgfd_ctx *ctx, const void *rgb, int kind, int row
     if (!fhog_geometry(rows, cols, cell_size, filter_rows_padding, filter_cols_padding, &g)) return IMGFD_OK;  // hog.clear()
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
     const size_t in_bytes = (size_t)3 * rows * cols, out_n = (size_t)31 * g.out_nr * g.out_nc;
+    if (hog_f64 && (int64_t)out_n > hog_cap) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_fhog_f64out: the output vector is too short (imgfd_fhog_size gives 31 * hog_nr * hog_nc)");
     IMGFD_TRY(ws_reserve(ctx, fhog_ws_bytes(g, 1, false) + align_up(in_bytes, 256) + align_up(out_n * sizeof(float), 256) +
-                              upload_stage_bytes(kind, in_bytes)));
+                              upload_stage_bytes(kind, in_bytes) + (hog_f64 ? align_up(out_n * sizeof(double), 256) : 0)));
     uint8_t *d_in = (uint8_t *)ws_alloc(ctx, in_bytes);
     float *d_out = (float *)ws_alloc(ctx, out_n * sizeof(float));
-    if (!d_in || !d_out) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    double *d_wide = hog_f64 ? (double *)ws_alloc(ctx, out_n * sizeof(double)) : nullptr;
+    if (!d_in || !d_out || (hog_f64 && !d_wide)) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
     IMGFD_TRY(upload_image(ctx, rgb, kind, in_bytes, d_in));
     IMGFD_TRY(fhog_device(ctx, d_in, in_bytes, g, 1, d_out));
+    if (hog_f64) {
+        IMGFD_TRY(download_widened(ctx, d_out, false, out_n, d_wide, hog_f64));
+        IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        *hog_nr = g.out_nr; *hog_nc = g.out_nc;
+        return IMGFD_OK;
+    }
     float *h = (float *)malloc(out_n * sizeof(float));
     if (!h) return imgfd_fail(ctx, IMGFD_ERR_OOM, "malloc of the fhog output failed");
     IMGFD_HIP(ctx, hipMemcpyAsync(h, d_out, out_n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -487,6 +499,13 @@ imgfd_status imgfd_fhog_i32(imgfd_ctx *ctx, const int32_t *x, int rows, int cols
                             int filter_cols_padding, float **hog, int *hog_nr, int *hog_nc)
 {
     return imgfd_guard(ctx, [&] { return fhog_host(ctx, x, IMGFD_SRC_I32, rows, cols, cell_size, filter_rows_padding, filter_cols_padding, hog, hog_nr, hog_nc); });
+}
+
+imgfd_status imgfd_fhog_f64out(imgfd_ctx *ctx, const int32_t *x, int rows, int cols, int cell_size, int filter_rows_padding,
+                               int filter_cols_padding, double *hog, int64_t hog_cap, int *hog_nr, int *hog_nc)
+{
+    if (!hog) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_fhog_f64out: no output vector");
+    return imgfd_guard(ctx, [&] { return fhog_host(ctx, x, IMGFD_SRC_I32, rows, cols, cell_size, filter_rows_padding, filter_cols_padding, nullptr, hog_nr, hog_nc, hog, hog_cap); });
 }
 
 imgfd_status imgfd_fhog_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, int rows, int cols, size_t frame_stride_bytes,

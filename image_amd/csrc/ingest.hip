@@ -26,6 +26,37 @@ __global__ void __launch_bounds__(256) narrow_f64_f32(const double *__restrict__
     if (i < n) out[i] = (float)in[i];
 }
 
+// ---- the way back.  The reference glue widens its results into R's doubles one element at a time on the R thread
+// (rcpp_canny.cpp:226-233: 8.3 M stores for a 4K edge map; rcpp_fhog.cpp:29-38); the *_f64out entry points widen in HBM and
+// copy straight into the vector R allocated.
+__global__ void __launch_bounds__(256) widen_u8_f64(const unsigned char *__restrict__ in, double *__restrict__ out, size_t n)
+{
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const uchar4 v = *reinterpret_cast<const uchar4 *>(in + i);
+        double2 *o = reinterpret_cast<double2 *>(out + i);
+        o[0] = double2{(double)v.x, (double)v.y};
+        o[1] = double2{(double)v.z, (double)v.w};
+    } else {
+        for (size_t k = i; k < n; k++) out[k] = (double)in[k];
+    }
+}
+__global__ void __launch_bounds__(256) widen_f32_f64(const float *__restrict__ in, double *__restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (double)in[i];
+}
+// d_src (u8 or f32, n elements, 4-byte aligned) -> d_stage (doubles, 16-byte aligned) -> host_out, asynchronously on the context's stream
+imgfd_status download_widened(imgfd_ctx *ctx, const void *d_src, bool src_is_u8, size_t n, double *d_stage, double *host_out)
+{
+    if (!n) return IMGFD_OK;
+    if (src_is_u8) hipLaunchKernelGGL(widen_u8_f64, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, ctx->stream, (const unsigned char *)d_src, d_stage, n);
+    else hipLaunchKernelGGL(widen_f32_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const float *)d_src, d_stage, n);
+    IMGFD_HIP(ctx, hipGetLastError());
+    IMGFD_HIP(ctx, hipMemcpyAsync(host_out, d_stage, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    return IMGFD_OK;
+}
+
 size_t upload_stage_bytes(int kind, size_t n)
 {
     if (kind == IMGFD_SRC_I32) return align_up(n * sizeof(int), 256);

@@ -264,6 +264,17 @@ IMGFD_API imgfd_status imgfd_fhog_i32(imgfd_ctx *ctx, const int32_t *x, int rows
                             int filter_rows_padding, int filter_cols_padding, float **hog, int *hog_nr, int *hog_nc);
 IMGFD_API imgfd_status imgfd_surf_i32(imgfd_ctx *ctx, const int32_t *x, int rows, int cols, long max_points,
                             double detection_threshold, imgfd_surf_out *out);
+/* The way back, for the two functions whose result is a per-pixel / per-cell array: the reference glue widens it into R's
+ * doubles element by element on the R thread (rcpp_canny.cpp:226-233: NumericMatrix edges(nx, ny), 8.3 M stores for a 4K
+ * frame; rcpp_fhog.cpp:29-38).  These entry points widen in HBM and copy straight into the vector R allocated:
+ *   imgfd_canny_f64out: edges = nx*ny doubles (0.0 / 255.0), e.g. REAL(Rf_allocMatrix(REALSXP, nx, ny));
+ *   imgfd_fhog_f64out:  hog = hog_cap >= 31*hog_nr*hog_nc doubles (sizes from imgfd_fhog_size) in the order of
+ *                       rcpp_fhog.cpp:29-38; an image too small for 3x3 cells gives *hog_nr = *hog_nc = 0. */
+IMGFD_API imgfd_status imgfd_canny_f64out(imgfd_ctx *ctx, const int32_t *image, int nx, int ny, double s, double low_thr,
+                                double high_thr, int accGrad, double *edges, int64_t *pixels_nonzero);
+IMGFD_API imgfd_status imgfd_fhog_f64out(imgfd_ctx *ctx, const int32_t *x, int rows, int cols, int cell_size,
+                               int filter_rows_padding, int filter_cols_padding, double *hog, int64_t hog_cap,
+                               int *hog_nr, int *hog_nc);
 
 /* ------------------------------------------------------------------ device-resident batch path
  * Frames live in HBM: frame f starts at (char*)d_frames + f*frame_stride_bytes, rows are row_stride

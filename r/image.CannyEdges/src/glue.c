@@ -8,12 +8,11 @@ SEXP _image_CannyEdges_canny_edge_detector(SEXP image, SEXP X, SEXP Y, SEXP s, S
     const R_xlen_t n = (R_xlen_t)nx * ny;
     SEXP xi = PROTECT(Rf_coerceVector(image, INTSXP));
     if (XLENGTH(xi) < n) Rf_error("image must hold X*Y values");
-    uint8_t *edges = (uint8_t *)R_alloc(n, 1);
     int64_t nonzero = 0;
-    imgfd_glue_check(imgfd_canny_i32(imgfd_glue_ctx(), INTEGER(xi), nx, ny, Rf_asReal(s), Rf_asReal(low_thr),
-                                     Rf_asReal(high_thr), Rf_asLogical(accGrad), edges, &nonzero));
     SEXP m = PROTECT(Rf_allocMatrix(REALSXP, nx, ny)); /* NumericMatrix(nx, ny), rcpp_canny.cpp:226-233 */
-    for (R_xlen_t i = 0; i < n; i++) REAL(m)[i] = edges[i];
+    /* the edge map is widened to doubles on the device and lands in the matrix itself: no per-element loop on the R thread */
+    imgfd_glue_check(imgfd_canny_f64out(imgfd_glue_ctx(), INTEGER(xi), nx, ny, Rf_asReal(s), Rf_asReal(low_thr),
+                                        Rf_asReal(high_thr), Rf_asLogical(accGrad), REAL(m), &nonzero));
     const char *names[] = {"edges", "pixels_nonzero", "nx", "ny", "s", "low_thr", "high_thr", "accGrad", ""};
     SEXP res = PROTECT(Rf_mkNamed(VECSXP, names)); /* :236-243 */
     SET_VECTOR_ELT(res, 0, m);

@@ -7,13 +7,12 @@ SEXP _image_dlib_dlib_fhog(SEXP x, SEXP rows, SEXP cols, SEXP cell_size, SEXP fr
     SEXP xi = PROTECT(Rf_coerceVector(x, INTSXP)); /* std::vector<int> x: element [ch, c, r] at ch + 3*c + 3*cols*r */
     if (XLENGTH(xi) < (R_xlen_t)3 * nr * nc) Rf_error("x must hold 3*rows*cols values");
     int hr = 0, hc = 0;
-    float *hog = NULL;
-    imgfd_glue_check(imgfd_fhog_i32(imgfd_glue_ctx(), INTEGER(xi), nr, nc, Rf_asInteger(cell_size), Rf_asInteger(frp),
-                                    Rf_asInteger(fcp), &hog, &hr, &hc));
+    imgfd_glue_check(imgfd_fhog_size(nr, nc, Rf_asInteger(cell_size), Rf_asInteger(frp), Rf_asInteger(fcp), &hr, &hc));
     const R_xlen_t n = (R_xlen_t)31 * hr * hc;
-    SEXP f = PROTECT(Rf_allocVector(REALSXP, n)); /* already in the order of rcpp_fhog.cpp:29-38 */
-    for (R_xlen_t i = 0; i < n; i++) REAL(f)[i] = hog[i];
-    imgfd_free(hog);
+    SEXP f = PROTECT(Rf_allocVector(REALSXP, n)); /* filled in the order of rcpp_fhog.cpp:29-38, widened on the device */
+    if (n)
+        imgfd_glue_check(imgfd_fhog_f64out(imgfd_glue_ctx(), INTEGER(xi), nr, nc, Rf_asInteger(cell_size), Rf_asInteger(frp),
+                                           Rf_asInteger(fcp), REAL(f), (int64_t)n, &hr, &hc));
     const char *names[] = {"hog_height", "hog_width", "fhog", "hog_cell_size", "filter_rows_padding", "filter_cols_padding", ""};
     SEXP res = PROTECT(Rf_mkNamed(VECSXP, names)); /* rcpp_fhog.cpp:40-45 */
     SET_VECTOR_ELT(res, 0, Rf_ScalarInteger(hr));

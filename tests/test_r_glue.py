@@ -39,3 +39,14 @@ def test_registered_symbols_and_arity_match_the_reference(pkg):
         rtxt = open(ref).read()
         for name, arity in PKGS[pkg].items():
             assert re.search(r'\{"%s",\s*\(DL_FUNC\)\s*&%s,\s*%d\}' % (name, name, arity), rtxt), name
+
+
+def test_no_per_pixel_loop_on_the_r_thread():
+    """the per-pixel / per-cell results are widened to R's doubles on the device and land in the vector R allocated
+    (imgfd_canny_f64out, imgfd_fhog_f64out): the reference's element-by-element fills (rcpp_canny.cpp:226-233,
+    rcpp_fhog.cpp:29-38) have no counterpart in the glue"""
+    canny = open(os.path.join(ROOT, "r", "image.CannyEdges", "src", "glue.c")).read()
+    assert "imgfd_canny_f64out(" in canny and "REAL(m)" in canny and not re.search(r"for\s*\(", canny)
+    dlib = open(os.path.join(ROOT, "r", "image.dlib", "src", "glue.c")).read()
+    fhog = dlib[dlib.index("_image_dlib_dlib_fhog("):dlib.index("_image_dlib_dlib_surf_points(")]
+    assert "imgfd_fhog_f64out(" in fhog and not re.search(r"for\s*\(", fhog)
