@@ -48,6 +48,7 @@ struct imgfd_ctx {
     long gauss_march_launches = 0;
     long tensor_wave_launches = 0;
     std::string detect_key, detect_seen;  // the call it was recorded for / the call seen last (raw bytes of a DetectKey)
+    std::string detect_unrecordable;  // the key of a launch sequence that refused to be captured: run eagerly, do not try again
     // fHOG: magnitude + orientation of every integer gradient (fhog_fused.hip), built on first use
     unsigned *fhog_lut = nullptr;
     // lab switches (imgfd_set_tuning / IMGFD_* environment variables read ONCE at context creation; include/imgfd.h
@@ -284,6 +285,7 @@ imgfd_status launch_harris_nms_tiled(imgfd_ctx *ctx, const float *d_R, int nx, i
 imgfd_status launch_fast9(imgfd_ctx *ctx, const uint8_t *d_img, int w, int h, int stride,
                           size_t frame_stride, int n_frames, int threshold, int nonmax, const CompactBuffers &cb);
 // canny.hip: imgfd_canny_dev with a hook that runs on the host while the (first chunk of the) batch is being queued --
-// before the blur kernel by default (IMGFD_GATE, canny_device); imgfd_detect_dev queues the other detectors from it
+// called with the position reached (0 before the blur, 1 behind it, 2 behind gradient/NMS; canny_device); imgfd_detect_dev
+// queues the other detectors from it (lab switches "canny_gate" / "harris_gate" choose the position)
 imgfd_status canny_dev_hooked(imgfd_ctx *ctx, const imgfd_frames *fr, double s, double low_thr, double high_thr, int accGrad,
                               uint8_t *d_edges, int64_t *d_counts, const std::function<imgfd_status(int)> *hook);

@@ -101,11 +101,11 @@ void imgfd_ctx_destroy(imgfd_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);  // nothing of this context is in flight when its graph, events and buffers go
     detect_graph_drop(ctx);
     if (ctx->side) imgfd_ctx_destroy(ctx->side);
     for (hipEvent_t e : {ctx->ev_fork, ctx->ev_gate, ctx->ev_gate2, ctx->ev_join})
         if (e) (void)hipEventDestroy(e);
-    (void)hipStreamSynchronize(ctx->stream);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->aux) (void)hipFree(ctx->aux);
@@ -137,7 +137,7 @@ void imgfd_free(void *p) { free(p); }
 imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode)
 {
     if (!ctx || (mode != 0 && mode != 1)) return IMGFD_ERR_INVALID;
-    ctx->fir_mode = mode;
+    for (imgfd_ctx *c = ctx; c; c = c->side) c->fir_mode = mode;  // the whole chain of companions (imgfd_surf_dev runs up to four lanes)
     return IMGFD_OK;
 }
 
@@ -147,8 +147,7 @@ imgfd_status imgfd_set_tuning(imgfd_ctx *ctx, const char *name, int value)
     for (const TuneKey &k : tune_keys())
         if (!strcmp(k.name, name)) {
             if (!k.field) return imgfd_set_fir_mode(ctx, value);
-            ctx->tune.*(k.field) = value;
-            if (ctx->side) ctx->side->tune.*(k.field) = value;
+            for (imgfd_ctx *c = ctx; c; c = c->side) c->tune.*(k.field) = value;  // every companion, not only the first
             return IMGFD_OK;
         }
     return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_set_tuning: unknown switch");

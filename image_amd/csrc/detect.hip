@@ -14,26 +14,28 @@
 
 namespace {
 
-// Everything a recorded launch sequence depends on: the arguments (pointers included: they are baked into the kernel
-// nodes) and the two workspace arenas the kernels were pointed at.
-struct DetectKey {
-    imgfd_frames fr;
-    imgfd_stream_params p;
-    const void *corners, *points, *edges, *counts;
-    const void *ws, *side_ws;
-    size_t ws_size, side_ws_size;
-    int fir_mode;
-    imgfd_ctx::Tune tune;
-};
-
-void make_key(const imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_stream_params *p, const void *c, const void *pt, const void *e,
-              const void *n, DetectKey *k)
+// Everything a recorded launch sequence depends on -- the arguments (pointers included: they are baked into the kernel
+// nodes), the two workspace arenas the kernels were pointed at, the switches -- serialised MEMBER BY MEMBER: the argument
+// structs have padding (imgfd_frames after ny, imgfd_stream_params after accGrad and keep_edges), and padding copied from a
+// caller's struct is indeterminate: a key that compared it would never match, or match by accident.
+std::string make_key(const imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_stream_params *p, const void *c, const void *pt, const void *e,
+                     const void *n)
 {
-    memset(k, 0, sizeof *k);  // padding bytes take part in the comparison
-    k->fr = *fr; k->p = *p; k->corners = c; k->points = pt; k->edges = e; k->counts = n;
-    k->ws = ctx->ws; k->ws_size = ctx->ws_size;
-    if (ctx->side) { k->side_ws = ctx->side->ws; k->side_ws_size = ctx->side->ws_size; }
-    k->fir_mode = ctx->fir_mode; k->tune = ctx->tune;
+    std::string k;
+    auto put = [&k](const auto &v) { k.append(reinterpret_cast<const char *>(&v), sizeof v); };
+    put(fr->d_frames); put(fr->n_frames); put(fr->nx); put(fr->ny); put(fr->frame_stride_bytes); put(fr->row_stride_bytes); put(fr->dtype);
+    put(p->harris); put(p->fast9); put(p->canny); put(p->k); put(p->sigma_d); put(p->sigma_i); put(p->threshold);
+    put(p->gaussian); put(p->gradient); put(p->measure); put(p->fast9_threshold); put(p->suppress_non_max);
+    put(p->s); put(p->low_thr); put(p->high_thr); put(p->accGrad); put(p->corner_cap); put(p->point_cap); put(p->keep_edges);
+    put(c); put(pt); put(e); put(n);
+    put(ctx->ws); put(ctx->ws_size);
+    const void *side_ws = ctx->side ? ctx->side->ws : nullptr;
+    const size_t side_size = ctx->side ? ctx->side->ws_size : 0;
+    put(side_ws); put(side_size);
+    put(ctx->fir_mode);
+    static_assert(sizeof(imgfd_ctx::Tune) % sizeof(int) == 0, "the switches are plain ints: no padding between them");
+    put(ctx->tune);
+    return k;
 }
 
 imgfd_status detect_body(imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_stream_params *p, imgfd_corner *d_corners,
@@ -99,6 +101,7 @@ void detect_graph_drop(imgfd_ctx *ctx)
     ctx->detect_exec = nullptr;
     ctx->detect_key.clear();
     ctx->detect_seen.clear();
+    ctx->detect_unrecordable.clear();
 }
 
 extern "C" {
@@ -119,35 +122,36 @@ try {
     const int limit = ctx->tune.detect_graph;  // batches of fewer frames than this use the graph (0: never)
     if (fr->n_frames < 1 || fr->n_frames >= limit || ctx->prof_on || !ctx->stream)  // (the default stream cannot be captured)
         return detect_body(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
-    DetectKey key;
-    make_key(ctx, fr, p, d_corners, d_points, d_edges, d_counts, &key);
-    const std::string kb(reinterpret_cast<const char *>(&key), sizeof key);
+    const std::string kb = make_key(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
     if (ctx->detect_exec && kb == ctx->detect_key) {
         IMGFD_HIP(ctx, hipGraphLaunch((hipGraphExec_t)ctx->detect_exec, ctx->stream));
         ctx->detect_replays++;
         return IMGFD_OK;
     }
+    if (kb == ctx->detect_unrecordable) return detect_body(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
     if (kb != ctx->detect_seen) {  // first sight
         const imgfd_status st = detect_body(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
-        DetectKey after;  // the run may have grown a workspace: remember the state the NEXT call will see
-        make_key(ctx, fr, p, d_corners, d_points, d_edges, d_counts, &after);
-        ctx->detect_seen.assign(reinterpret_cast<const char *>(&after), sizeof after);
+        // the run may have grown a workspace: remember the state the NEXT call will see
+        ctx->detect_seen = make_key(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
         return st;
     }
     detect_graph_drop(ctx);
     hipGraph_t graph = nullptr;
     if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {  // no capture here: eager from now on
         (void)hipGetLastError();
-        ctx->detect_seen.clear();
+        ctx->detect_unrecordable = kb;
         return detect_body(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
     }
     const imgfd_status st = detect_body(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
     const hipError_t ec = hipStreamEndCapture(ctx->stream, &graph);
-    if (st != IMGFD_OK || ec != hipSuccess || !graph) {  // not recordable (or failed): as before, without a graph from now on
+    if (st != IMGFD_OK || ec != hipSuccess || !graph) {
+        // Not recordable: a call that is illegal under capture (a workspace that grows, taps uploaded for a very large sigma, the
+        // pageable copy of Canny's long-kernel path) fails HERE although it succeeds eagerly.  Drop the capture and its error,
+        // remember the key, and run the call once more the ordinary way: only what that run says is reported.
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
-        ctx->detect_seen.clear();
-        if (st != IMGFD_OK) return st;
+        ctx->err.clear();
+        ctx->detect_unrecordable = kb;
         return detect_body(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
     }
     hipGraphExec_t exec = nullptr;

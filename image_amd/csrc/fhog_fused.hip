@@ -339,17 +339,30 @@ bool fhog_fused_supported(const FhogGeom &g, const uint8_t *d_rgb, size_t frame_
     return g.cs == FH_CS && g.cols % 4 == 0 && (size_t)d_rgb % 4 == 0 && frame_stride % 4 == 0;
 }
 
+// first use on a context: the gradient table and the kernels' LDS attribute.  The context keeps the table only when ALL of
+// it succeeded -- a failure leaves the context as it was, and the next call tries again.
+static imgfd_status fhog_fused_init(imgfd_ctx *ctx)
+{
+    if (ctx->fhog_lut) return IMGFD_OK;
+    void *p = nullptr;
+    if (hipMalloc(&p, FHOG_LUT_BYTES) != hipSuccess) return imgfd_fail(ctx, IMGFD_ERR_OOM, "hipMalloc of the fHOG gradient table failed");
+    hipLaunchKernelGGL(fhog_build_lut, dim3(511), dim3(512), 0, ctx->stream, (unsigned *)p);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)fhog_hist8<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FH_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)fhog_hist8<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FH_LDS);
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(ctx->stream);  // the build kernel may be running on the table
+        (void)hipFree(p);
+        return imgfd_fail(ctx, IMGFD_ERR_HIP, (std::string("fHOG: building the gradient table failed: ") + hipGetErrorString(e)).c_str());
+    }
+    ctx->fhog_lut = (unsigned *)p;
+    return IMGFD_OK;
+}
+
 imgfd_status fhog_fused_hist(imgfd_ctx *ctx, const uint8_t *d_rgb, size_t frame_stride, const FhogGeom &g, int nf, float *hist,
                              float *norm)
 {
-    if (!ctx->fhog_lut) {
-        void *p = nullptr;
-        if (hipMalloc(&p, FHOG_LUT_BYTES) != hipSuccess) return imgfd_fail(ctx, IMGFD_ERR_OOM, "hipMalloc of the fHOG gradient table failed");
-        ctx->fhog_lut = (unsigned *)p;
-        hipLaunchKernelGGL(fhog_build_lut, dim3(511), dim3(512), 0, ctx->stream, ctx->fhog_lut);
-        IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)fhog_hist8<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FH_LDS));
-        IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)fhog_hist8<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FH_LDS));
-    }
+    IMGFD_TRY(fhog_fused_init(ctx));
     const int tiles_x = ceil_div(g.cells_nc, FH_CC), n_bands = ceil_div(g.cells_nr, FH_CR);
     int bpw = ctx->tune.fhog_bands;
     if (bpw <= 0) {  // march as far as the batch leaves >= 8 workgroups per CU
@@ -373,14 +386,7 @@ imgfd_status imgfd_k_fhog_lut(imgfd_ctx *ctx, uint32_t *d_out)
 {
     if (!ctx || !d_out) return IMGFD_ERR_INVALID;
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
-    if (!ctx->fhog_lut) {
-        void *p = nullptr;
-        if (hipMalloc(&p, FHOG_LUT_BYTES) != hipSuccess) return imgfd_fail(ctx, IMGFD_ERR_OOM, "hipMalloc of the fHOG gradient table failed");
-        ctx->fhog_lut = (unsigned *)p;
-        hipLaunchKernelGGL(fhog_build_lut, dim3(511), dim3(512), 0, ctx->stream, ctx->fhog_lut);
-        IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)fhog_hist8<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FH_LDS));
-        IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)fhog_hist8<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FH_LDS));
-    }
+    IMGFD_TRY(fhog_fused_init(ctx));
     IMGFD_HIP(ctx, hipMemcpyAsync(d_out, ctx->fhog_lut, FHOG_LUT_BYTES, hipMemcpyDeviceToDevice, ctx->stream));
     return IMGFD_OK;
 }

@@ -73,14 +73,14 @@ IMGFD_API imgfd_status imgfd_ctx_sync(imgfd_ctx *ctx);
 /* free a buffer returned through an out-parameter of this library */
 IMGFD_API void imgfd_free(void *p);
 IMGFD_API int imgfd_version(void);
+/* number of HIP devices this process sees (0 and IMGFD_ERR_NO_DEVICE when there is none).  The path shards by frame: one
+ * context per device, each with its own share of the frames, no exchange between them (examples/multi_gpu_counts.c). */
+IMGFD_API imgfd_status imgfd_device_count(int *count);
 /* arithmetic mode of the double-accumulated FIR (Harris Gaussians):
  *   0 = strict: the reference's operation sequence, no FMA anywhere (bit-exact planes)
  *   1 = fused-accumulate (default): sum = fma(B[j], pair, sum) inside the f64 accumulation only; the
  *       f32 stages (products, response) never contract.  Results differ from strict only when the
  *       f64 sum sits within ~1e-16 relative of a float rounding boundary. */
-/* number of HIP devices this process sees (0 and IMGFD_ERR_NO_DEVICE when there is none).  The path shards by frame: one
- * context per device, each with its own share of the frames, no exchange between them (examples/multi_gpu_counts.c). */
-IMGFD_API imgfd_status imgfd_device_count(int *count);
 IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
 /* Lab switches.  None changes a result; the defaults are the measured best.  Each can also be given through the
  * environment variable in brackets, which is read ONCE, when the context is created.
@@ -88,10 +88,8 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  *   "fhog_bands" [IMGFD_FHOG_BANDS]  bands of 8 cell rows one workgroup of that kernel marches through (0: from the batch)
  *   "fhog_threads" [IMGFD_FHOG_THREADS]  workgroup size of that kernel, 256 (default) or 512
  *   "fir_mode" [IMGFD_FIR_MODE]  as imgfd_set_fir_mode
- *   "hyst_mode" [IMGFD_HYST_MODE]  Canny hysteresis: 0 (default) bit-plane sweeps + finishing kernel, 1 LDS-resident region rounds
- *   "hyst_sweeps" [IMGFD_HYST_SWEEPS], "hyst_rounds" [IMGFD_HYST_ROUNDS]  sweeps / rounds queued before the finishing kernel
+ *   "hyst_sweeps" [IMGFD_HYST_SWEEPS]  Canny hysteresis: sweeps queued before the union-find kernels (0: 14 for batches, 9-10 below 8 frames)
  *   "hyst_words" [IMGFD_HYST_WORDS]  words per tile of a sweep, 2 or 4 (0: 2 for one or two frames, else 4)
- *   "hyst_region_w", "hyst_region_h" [IMGFD_HYST_REGION_W / _H]  region size of the finishing kernel (words x rows)
  *   "canny_gate" [IMGFD_CANNY_GATE]  imgfd_detect_dev: where Canny releases the second stream (0 before the blur, 1, 2)
  *   "harris_gate" [IMGFD_HARRIS_GATE]  imgfd_detect_dev: 1 (default) the Harris chain starts behind Canny's gradient/NMS kernel
  *                                      (FAST-9 starts with the blur); 2: behind the blur; 0: together with FAST-9
@@ -101,6 +99,7 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  *   "fused_response" [IMGFD_FUSED_RESPONSE]  1 (default): corner response in the structure-tensor kernel's epilogue
  *   "nms_tiled" [IMGFD_NMS_TILED]  1: the tiled Harris NMS kernel instead of the sparse one
  *   "tensor_per_cu", "tensor_seg", "tensor_workers", "tensor_tw" [IMGFD_TENSOR_*]  launch geometry of fir_tensor (0: chosen)
+ *   "tensor_wave" [IMGFD_TENSOR_WAVE]  1: the wave-autonomous structure-tensor kernel (fir_tensor_wave.hip: measured slower, kept as an experiment); 0 (default)
  *   "surf_residue" [IMGFD_SURF_RESIDUE]  SURF octaves 1-3: modulus of the residue layout (4; 0 = plain table, 16)
  *   "max_chunk_frames" [IMGFD_MAX_CHUNK_FRAMES]  frames per sub-batch of the *_dev entry points (0: from the memory budgets)
  *   "tile_run" [IMGFD_TILE_RUN]  tiles per workgroup of the u8 tile kernels (0: from the batch size)
@@ -319,12 +318,12 @@ IMGFD_API imgfd_status imgfd_k_gradient(imgfd_ctx *ctx, const float *d_I, float 
 /* K1 + K2 as the batch path runs them on u8 frames: discrete Gaussian of radius 3 (sigma_d in [1, 4/3)) and the gradient of
  * the smoothed frame in one kernel (gaussian.cpp:289-395 + gradient.cpp:17-106); the smoothed plane is not written.
  * d_u8: ny rows of nx bytes (pitch nx).  IMGFD_ERR_UNSUPPORTED for another radius. */
+IMGFD_API imgfd_status imgfd_k_gauss_grad_u8(imgfd_ctx *ctx, const uint8_t *d_u8, float *d_Ix, float *d_Iy, int nx, int ny,
+                                             float sigma_d, int grad_type);
 /* the gradient table of the fused fHOG kernel: 511 x 512 words, entry [(ty + 255) * 512 + tx + 255] for the integer gradient
  * (tx, ty): bits 0..26 = sqrtf(tx^2 + ty^2) with the exponent field lowered by 126 (0 for a zero gradient), bits 27..31 = the
  * orientation bin (fhog.h:846-859) */
 IMGFD_API imgfd_status imgfd_k_fhog_lut(imgfd_ctx *ctx, uint32_t *d_out);
-IMGFD_API imgfd_status imgfd_k_gauss_grad_u8(imgfd_ctx *ctx, const uint8_t *d_u8, float *d_Ix, float *d_Iy, int nx, int ny,
-                                             float sigma_d, int grad_type);
 /* K3: the structure-tensor pass, compute_autocorrelation_matrix harris.cpp:44-70:
  * reads Ix,Iy (8 B/px), writes the smoothed A,B,C (12 B/px) */
 IMGFD_API imgfd_status imgfd_k_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_A,
