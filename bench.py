@@ -167,6 +167,23 @@ class Detect4K(Workload):
         for f0 in range(0, self.n_local, gen):   # pre-stage every frame of this rank in HBM (untimed)
             n = min(gen, self.n_local - f0)
             self.frames[f0:f0 + n] = det.synth_frames(n, NX, NY, seed0=stream.frame_seed(50000, self.first + f0))
+        self.h2d = bool(getattr(a, "h2d", False))
+        if self.h2d:
+            # delivery included: a ring of up to 4 batches in pinned host memory (distinct frames; a longer stream re-reads the
+            # ring -- what is measured is the rate of upload + kernels, the per-frame counts are those of the ring's frames), two
+            # device input buffers, a copy stream of its own
+            # the whole share of this rank when it fits 12 GB of pinned memory (a 10 000-frame stream on 8 ranks: 10.4 GB each),
+            # else a ring of four batches that a longer stream re-reads (the rate is upload + kernels either way; with a re-read ring
+            # the per-frame counts are the ring's, and the sampled parity check compares only frames that were streamed as themselves)
+            ring = self.n_local if self.n_local * NX * NY <= (12 << 30) else min(4 * B, self.n_local)
+            self.host_ring = torch.empty((ring, NY, NX), dtype=torch.uint8, pin_memory=True)
+            self.host_ring.copy_(self.frames[:ring])
+            self.dev_in = [torch.empty((B, NY, NX), dtype=torch.uint8, device="cuda") for _ in range(2)]
+            self.copy_stream = torch.cuda.Stream()
+            self.ev_copied = [torch.cuda.Event() for _ in range(2)]
+            self.ev_done = [torch.cuda.Event() for _ in range(2)]
+            self.h2d_pass = 0
+            self.h2d_pending = None
         self.cap_h, self.cap_f = (0, 0) if self.stream_mode else (65536, 262144)
         dev = "cuda"
         self.corners = torch.empty((B, max(1, self.cap_h), 3), dtype=torch.float32, device=dev)
@@ -191,6 +208,38 @@ class Detect4K(Workload):
             return min(self.n_local, steps * self.B) * self.NX * self.NY
         return steps * self.px_per_step()
 
+    # ---- --h2d: batch `f0 .. f0+n` of the host ring into device buffer `slot`, on the copy stream, behind the kernels that last read that buffer
+    def _upload(self, slot, f0, n):
+        import torch
+        ring = self.host_ring.shape[0]
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(self.ev_done[slot])
+            k = 0
+            while k < n:   # the ring may wrap inside a batch
+                r0 = (f0 + k) % ring
+                m = min(n - k, ring - r0)
+                self.dev_in[slot][k:k + m].copy_(self.host_ring[r0:r0 + m], non_blocking=True)
+                k += m
+            self.ev_copied[slot].record(self.copy_stream)
+
+    def _delivered(self, f0, n, next_f0=None, next_n=0):
+        """the device buffer holding frames f0 .. f0+n of the stream (uploaded if nobody queued it yet), with the NEXT batch's
+        upload queued before this batch's kernels so that the two overlap"""
+        import torch
+        p = self.h2d_pass
+        if self.h2d_pending != (p, f0, n):
+            self._upload(p % 2, f0, n)
+        if next_n > 0:
+            self._upload((p + 1) % 2, next_f0, next_n)
+            self.h2d_pending = (p + 1, next_f0, next_n)
+        torch.cuda.current_stream().wait_event(self.ev_copied[p % 2])
+        return self.dev_in[p % 2][:n]
+
+    def _consumed(self):
+        import torch
+        self.ev_done[self.h2d_pass % 2].record(torch.cuda.current_stream())
+        self.h2d_pass += 1
+
     def reset(self):
         self.cursor = 0
         # BASELINE.md section 3 asks for a median over >= 100 event-timed iterations: an event pair around EVERY pass of the timed
@@ -208,8 +257,15 @@ class Detect4K(Workload):
             if c is None:
                 import torch
                 c = self._counts_n[n] = torch.zeros((3, n), dtype=torch.int64, device="cuda")
-            det.detect_all(self.frames[f0:f0 + n], self.corners, self.points, self.edges[:n], c, corner_cap=self.cap_h,
+            if self.h2d:
+                n2 = min(self.B, self.n_local - (f0 + n))
+                src = self._delivered(f0, n, f0 + n, n2)
+            else:
+                src = self.frames[f0:f0 + n]
+            det.detect_all(src, self.corners, self.points, self.edges[:n], c, corner_cap=self.cap_h,
                            point_cap=self.cap_f, **self.params)
+            if self.h2d:
+                self._consumed()
             self.frame_counts[0, f0:f0 + n] = c[0]
             self.frame_counts[1, f0:f0 + n] = c[2]
             self.cursor += n
@@ -218,13 +274,16 @@ class Detect4K(Workload):
         pe = getattr(self, "pass_ev", None)
         if pe is not None:
             e0 = torch.cuda.Event(enable_timing=True); e0.record(); pe.append(e0)
-        for _ in range(self.inner):
+        for it in range(self.inner):
+            frames = self._delivered(0, self.B, 0, self.B) if self.h2d else self.frames
             if self.args.no_overlap:
-                det.harris(self.frames, out=(self.corners, self.counts[0]))
-                det.fast9(self.frames, threshold=20, suppress_non_max=True, out=(self.points, self.counts[1]))
-                det.canny(self.frames, out=(self.edges, self.counts[2]))
+                det.harris(frames, out=(self.corners, self.counts[0]))
+                det.fast9(frames, threshold=20, suppress_non_max=True, out=(self.points, self.counts[1]))
+                det.canny(frames, out=(self.edges, self.counts[2]))
             else:
-                det.detect_all(self.frames, self.corners, self.points, self.edges, self.counts, **self.params)
+                det.detect_all(frames, self.corners, self.points, self.edges, self.counts, **self.params)
+            if self.h2d:
+                self._consumed()
             if pe is not None:
                 e1 = torch.cuda.Event(enable_timing=True); e1.record(); pe.append(e1)
 
@@ -248,7 +307,9 @@ class Detect4K(Workload):
         a = self.args
         c = {"workload": ("configs[1]+Canny: image_harris() defaults + FAST-9 thr 20 nonmax + Canny s=2 3/10 accGrad" if not self.stream_mode else
                           f"configs[4]: {a.frames}-frame stream, image_harris() defaults + Canny s=2 3/10 accGrad, contiguous blocks of frames per rank") +
-             f" on {self.NX}x{self.NY} u8 frames resident in HBM",
+             f" on {self.NX}x{self.NY} u8 frames " + ("resident in HBM" if not self.h2d else
+                                                         f"in pinned host memory (ring of {self.host_ring.shape[0]} frames), every batch uploaded (1 B/px) on a copy stream beside the kernels of the batch before"),
+             "delivery": "h2d (PCIe included)" if self.h2d else "resident",
              "frames_per_step_per_gpu": self.B, "passes_per_step": self.inner,
              "schedule": "one stream" if a.no_overlap else "two streams (imgfd_detect_dev)",
              "fir_mode": "fused-accumulate" if a.fir_mode else "strict",
@@ -339,10 +400,11 @@ def stream_sample_check(wl, want_cpu):
     import torch
 
     from image_amd import stream
-    n_s = min(wl.cursor, max(1, round(0.01 * wl.cursor)), wl.args.max_parity_frames)
+    limit = min(wl.cursor, wl.host_ring.shape[0]) if getattr(wl, "h2d", False) else wl.cursor   # --h2d: frames beyond a re-read ring were not streamed as themselves
+    n_s = min(limit, max(1, round(0.01 * limit)), wl.args.max_parity_frames)
     if n_s <= 0:
         return None
-    idx = np.unique(np.linspace(0, wl.cursor - 1, n_s).round().astype(int))
+    idx = np.unique(np.linspace(0, limit - 1, n_s).round().astype(int))
     cap = 65536
     res = {"frames_checked": int(len(idx)), "frame_indices": [int(wl.first + i) for i in idx[:8]] + (["..."] if len(idx) > 8 else [])}
     t0 = time.perf_counter()
@@ -434,7 +496,7 @@ class Canny1080p(Workload):
 
         import oracle
         from image_amd import stream, synth
-        idx = sorted({0, self.F // 2, self.F - 1})[: self.args.max_parity_frames]
+        idx = sorted(set(np.linspace(0, self.F - 1, max(3, -(-self.F // 100))).astype(int).tolist()))[: self.args.max_parity_frames]   # >= 1 % of the batch
         mism = 0
         cnt_ok = True
         ts = []
@@ -533,24 +595,35 @@ class DlibTiles(Workload):
         import oracle
         from image_amd import synth
         S = self.S
-        rgb = synth.frame_rgb(3 + self.first, S, S)
-        assert np.array_equal(self.tiles[0].cpu().numpy(), rgb), "device and host tile generators diverged"
         use_ref = oracle.have_ref("dlib")
-        t = time.perf_counter(); rh = oracle.ref_fhog(rgb) if use_ref else oracle.fhog(rgb); t_h = time.perf_counter() - t
-        t = time.perf_counter(); rs = oracle.surf(rgb, 1000, 30.0, use_ref=use_ref); t_s = time.perf_counter() - t
-        gh = np.ascontiguousarray(self.hog[0].cpu().numpy().transpose(2, 1, 0))
-        n = int(self.counts[0])
-        gs = self.feat[0, :n].cpu().numpy()
-        # exact score ties (the synthetic tiles have them) may come in a different order: the reference leaves it to std::sort
         key = lambda x, y, sc: sorted(zip(sc.tolist(), x.tolist(), y.tolist()))
-        same_pts = n == len(rs["x"]) and bool(np.array_equal(gs[:, 4], rs["score"])) and key(gs[:, 0], gs[:, 1], gs[:, 4]) == key(rs["x"], rs["y"], rs["score"])
-        desc_err = None
-        if same_pts and n:
-            order_g = np.lexsort((gs[:, 1], gs[:, 0], gs[:, 4])); order_r = np.lexsort((rs["y"], rs["x"], rs["score"]))
-            desc_err = float(np.max(np.abs(gs[order_g, 6:] - np.nan_to_num(rs["surf"])[order_r])))
-        out = {"parity_sample": {"tile": int(self.first), "fhog_max_abs_err": float(np.max(np.abs(gh - rh))) if gh.shape == rh.shape else None,
-                                 "fhog_bit_equal": bool(gh.shape == rh.shape and np.array_equal(gh, rh)), "surf_points": n, "surf_points_equal": same_pts,
-                                 "surf_descriptor_max_abs_err": desc_err}}
+        sample = sorted(set(np.linspace(0, self.T - 1, max(1, -(-self.T // 100))).astype(int).tolist()))   # >= 1 % of the batch (3 of 256 tiles)
+        per_tile, t_h, t_s = [], None, None
+        for ti in sample:
+            rgb = synth.frame_rgb(3 + self.first + ti, S, S)
+            assert np.array_equal(self.tiles[ti].cpu().numpy(), rgb), "device and host tile generators diverged"
+            t = time.perf_counter(); rh = oracle.ref_fhog(rgb) if use_ref else oracle.fhog(rgb); th_ = time.perf_counter() - t
+            t = time.perf_counter(); rs = oracle.surf(rgb, 1000, 30.0, use_ref=use_ref); ts_ = time.perf_counter() - t
+            if t_h is None:
+                t_h, t_s = th_, ts_
+            gh = np.ascontiguousarray(self.hog[ti].cpu().numpy().transpose(2, 1, 0))
+            n = int(self.counts[ti])
+            gs = self.feat[ti, :n].cpu().numpy()
+            # exact score ties (the synthetic tiles have them) may come in a different order: the reference leaves it to std::sort
+            same_pts = n == len(rs["x"]) and bool(np.array_equal(gs[:, 4], rs["score"])) and key(gs[:, 0], gs[:, 1], gs[:, 4]) == key(rs["x"], rs["y"], rs["score"])
+            desc_err = None
+            if same_pts and n:
+                order_g = np.lexsort((gs[:, 1], gs[:, 0], gs[:, 4])); order_r = np.lexsort((rs["y"], rs["x"], rs["score"]))
+                desc_err = float(np.max(np.abs(gs[order_g, 6:] - np.nan_to_num(rs["surf"])[order_r])))
+            per_tile.append({"tile": int(self.first + ti), "fhog_bit_equal": bool(gh.shape == rh.shape and np.array_equal(gh, rh)),
+                             "fhog_max_abs_err": float(np.max(np.abs(gh - rh))) if gh.shape == rh.shape else None,
+                             "surf_points": n, "surf_points_equal": same_pts, "surf_descriptor_max_abs_err": desc_err})
+        errs = [p["surf_descriptor_max_abs_err"] for p in per_tile if p["surf_descriptor_max_abs_err"] is not None]
+        out = {"parity_sample": {"tiles_checked": len(per_tile), "tiles": [p["tile"] for p in per_tile],
+                                 "fhog_bit_equal": all(p["fhog_bit_equal"] for p in per_tile),
+                                 "fhog_max_abs_err": max((p["fhog_max_abs_err"] for p in per_tile if p["fhog_max_abs_err"] is not None), default=None),
+                                 "surf_points": [p["surf_points"] for p in per_tile], "surf_points_equal": all(p["surf_points_equal"] for p in per_tile),
+                                 "surf_descriptor_max_abs_err": max(errs) if errs else None}}
         if want_cpu:
             out.update({"value": round(S * S / (t_h + t_s) / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "reference" if use_ref else "port",
                         "sample": f"1 tile {S}x{S}, one run each: dlib's own extract_fhog_features ({1e3 * t_h:.0f} ms) and get_surf_points ({1e3 * t_s:.0f} ms) "
@@ -583,6 +656,30 @@ def kernel_source_hash():
 
 
 # ------------------------------------------------------------------------------------------------ launch
+def pin_to_gpu_numa(local):
+    """Bind this rank's host threads (the launch thread, the staging copies of --h2d) to the CPUs of the NUMA node its GPU hangs
+    off: eight ranks that all run on node 0 share one memory controller and one PCIe root for their uploads.  Best effort:
+    returns a description for the per-rank table, never fails the run."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(local)
+        bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read().strip())
+        if node < 0:
+            return {"gpu_pci": bdf, "numa_node": None, "pinned": False, "note": "the platform reports no NUMA node for this device"}
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return {"gpu_pci": bdf, "numa_node": node, "pinned": False, "note": "none of that node's CPUs is in this process's affinity mask"}
+        os.sched_setaffinity(0, cpus)
+        return {"gpu_pci": bdf, "numa_node": node, "pinned": True, "cpus": len(cpus)}
+    except Exception as e:
+        return {"pinned": False, "note": f"{type(e).__name__}: {e}"}
+
+
 def free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return p
@@ -644,6 +741,9 @@ def parse(argv):
                     help="run the three detectors back to back on one stream instead of imgfd_detect_dev's two-stream schedule")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; nccl (= RCCL) is the product path, gloo is a functional check")
+    ap.add_argument("--h2d", action="store_true",
+                    help="config 2 / 5: the frames live in PINNED HOST memory and every pass uploads its batch (double-buffered on a copy stream, "
+                         "overlapped with the kernels of the previous batch): the rate with delivery included (SURVEY.md 8e asks for both)")
     ap.add_argument("--share-device", action="store_true",
                     help="test hook: every rank uses cuda:0 (functional check of the N>1 path on a 1-GPU box; not a measurement)")
     ap.add_argument("--dry-run", action="store_true",
@@ -689,7 +789,17 @@ def measure(args, det, rank, world, dist, want_cpu, light=False):
     pass_ms = sorted(wl.pass_times_ms()) if hasattr(wl, "pass_times_ms") else []
 
     # the path's only collectives: feature counts (sum; per-frame vectors are gathered in stream mode) and the elapsed time (max)
+    dt_local = dt
     counts, dt = stream.reduce_counts(wl.count_vector(), dt, dist if on else None)
+    # the per-rank table (host objects over the process group's gloo side: no device collective needed)
+    mine = {"rank": rank, "device": int(torch.cuda.current_device()), "pixels": int(wl.px_total(steps)), "s": round(dt_local, 4),
+            "Mpixels_per_s": round(wl.px_total(steps) / dt_local / 1e6, 1), "numa": getattr(args, "numa_note", None)}
+    if hasattr(wl, "n_local"):
+        mine["frames"] = int(wl.n_local)
+    per_rank = [mine]
+    if on and world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     px_local = torch.tensor([wl.px_total(steps)], dtype=torch.int64, device="cuda")
     px_all, _ = stream.reduce_counts(px_local, 0.0, dist if on else None)
     per_frame = None
@@ -711,12 +821,15 @@ def measure(args, det, rank, world, dist, want_cpu, light=False):
             "config": {**({"note": "functional check only: ranks share one device / gloo collectives"} if (args.share_device or (world > 1 and args.backend != "nccl")) else {}),
                        **wl.describe(counts)},
         }
+        res["config"]["per_rank"] = per_rank
         if pass_ms:
             res["ms_per_pass_median_hip_events"] = round(pass_ms[len(pass_ms) // 2], 4)
             res["passes_event_timed"] = len(pass_ms)
         if on:
             be = stream.device_backend(dist)
-            res["config"]["collectives"] = f"{be} ({'RCCL' if be == 'nccl' else 'functional check'}) for the device tensors, world size {dist.get_world_size()}"
+            res["config"]["collectives"] = (f"{be} ({'RCCL' if be == 'nccl' else 'functional check'}) for the device tensors, world size {dist.get_world_size()}; the communicator is "
+                                            "created by the first device collective, AFTER the timed region (a live RCCL communicator costs the kernels 12 % at N = 1, "
+                                            "profiles/r03; a stream that keeps one alive pays that), the barriers of the timed region are host barriers (gloo)")
         if per_frame is not None:
             res["config"]["per_frame_counts_gathered"] = int(per_frame.shape[1])
             res["config"]["per_frame_counts_checksum"] = {"harris": int(per_frame[0].sum()), "canny": int(per_frame[1].sum())}
@@ -955,6 +1068,7 @@ def main(argv=None):
         raise SystemExit(f"bench.py: rank {rank} needs GPU {local} but only {torch.cuda.device_count()} are visible: --gpus {world} is more than this node has "
                          "(--share-device runs a functional check of the N>1 path on one GPU)")
     torch.cuda.set_device(local)
+    args.numa_note = pin_to_gpu_numa(local) if world > 1 or os.environ.get("IMGFD_BENCH_PIN") else {"pinned": False, "note": "one rank: left to the scheduler"}
     dist_note = None
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     # The process group serves host tensors through gloo and device tensors through RCCL.  The RCCL communicator is created by

@@ -10,7 +10,7 @@
  *
  * Pinning: the reference has no known-answer test for FAST-9; this restatement
  * is pinned against f9.cpp itself compiled in place (oracle/_ref/libref_f9.so)
- * in tests/test_oracle_vs_ref.py and against tests/golden/ vectors produced by
+ * in tests/test_oracle.py and against tests/golden/ vectors produced by
  * that build (chairs.pgm thr 80 -> 926 corners / 347 after NMS).
  */
 #include <stdlib.h>

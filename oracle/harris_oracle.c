@@ -15,7 +15,7 @@
  * Pinning: the reference ships no known-answer test for this path; the
  * restatement is pinned against the reference sources compiled in place
  * (oracle/_ref/libref_harris.so, see oracle/Makefile) on the repository
- * fixtures and on seeded synthetic frames -- tests/test_oracle_vs_ref.py -- and
+ * fixtures and on seeded synthetic frames -- tests/test_oracle.py -- and
  * against the committed vectors in tests/golden/ generated from that build.
  */
 #include <math.h>

@@ -142,6 +142,8 @@ def main():
     canny_golden("canny_chairs", np.ascontiguousarray(chairs.T))
     canny_golden("canny_synth_320x240_seed7", synth.frame(7, 320, 240, n_rect=20), tuple(CANNY_CASES))
     fhog_dlib_kat()
+    fhog_golden()   # tests/golden/fhog_cruise_boat.npz
+    surf_golden()   # tests/golden/surf_cruise_boat.npz
 
 
 if __name__ == "__main__":

@@ -40,6 +40,28 @@ def test_two_ranks_equal_one_rank_over_the_same_frames():
     assert two["config"]["feature_counts"] == one["config"]["feature_counts"]
     assert all(v > 0 for v in one["config"]["feature_counts"].values())
     assert two["metric"] == one["metric"] and "roofline" in two
+    # the per-rank table: one row per rank, its frames, seconds and rate, and what the NUMA pinning did
+    rows = two["config"]["per_rank"]
+    assert [r["rank"] for r in rows] == [0, 1] and all(r["frames"] == 3 and r["s"] > 0 and r["Mpixels_per_s"] > 0 and "pinned" in r["numa"] for r in rows)
+    assert sum(r["pixels"] for r in rows) == 6 * 3840 * 2160
+    assert len(one["config"]["per_rank"]) == 1 and one["config"]["delivery"] == "resident"
+
+
+@pytest.mark.gpu
+def test_h2d_delivery_gives_the_same_counts():
+    """--h2d: the frames come from pinned host memory, every pass uploads its batch on a copy stream beside the kernels of the
+    batch before -- same feature counts as the resident run, in the default workload and in the stream (ragged last batch, two
+    ranks), and the line says how the frames were delivered"""
+    common = ["--no-cpu", "--steps", "2", "--warmup", "1", "--inner", "3", "--batch", "3"]
+    res = run_bench("--gpus", "1", *common)
+    h2d = run_bench("--gpus", "1", "--h2d", *common)
+    assert h2d["config"]["feature_counts"] == res["config"]["feature_counts"] and h2d["config"]["delivery"].startswith("h2d")
+    s_common = ["--config", "5", "--frames", "10", "--batch", "4", "--warmup", "1", "--no-cpu"]
+    s_res = run_bench("--gpus", "1", *s_common)
+    s_h2d = run_bench("--gpus", "2", "--share-device", "--h2d", *s_common)
+    assert s_h2d["config"]["per_frame_counts_checksum"] == s_res["config"]["per_frame_counts_checksum"]
+    assert s_h2d["config"]["feature_counts"] == s_res["config"]["feature_counts"]
+    assert [r["frames"] for r in s_h2d["config"]["per_rank"]] == [5, 5]
 
 
 @pytest.mark.gpu

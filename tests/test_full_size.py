@@ -43,7 +43,7 @@ def test_harris_4k_strict_bit_exact_and_default_within_tolerance(gpu, frame4k):
     assert int((bits(got[:, 2]) != bits(ref[:, 2])).sum()) <= 2                  # in fact (almost) the same bits
 
 
-@pytest.mark.parametrize("thr,nms", [(50, False), (20, False), (20, True)])
+@pytest.mark.parametrize("thr,nms", [(50, False), (50, True), (20, False), (20, True)])   # thr 50 / 20, with and without NMS
 def test_fast9_4k_bit_exact(gpu, frame4k, thr, nms):
     ref = oracle.fast9(frame4k, thr, nms)
     lists, counts = gpu.fast9_dev(frame4k[None], thr, nms, cap=1 << 20)
@@ -84,6 +84,16 @@ def test_fhog_tile_4096(gpu):
     assert np.array_equal(g2[2:-2, 2:-2].view(np.uint32), got[8 + 2:8 + 126 - 2, 16 + 2:16 + 126 - 2].view(np.uint32))
 
 
+def test_fhog_tile_4096_gray_replicated(gpu):
+    """config 4's second input variant: a gray tile replicated into the three channels -- every channel ties in
+    the gradient pick (fhog.h:821-845 keeps the first of equal magnitudes); whole tile against the oracle"""
+    gray = synth.frame(4, 4096, 4096)
+    tile = np.ascontiguousarray(np.repeat(gray[:, :, None], 3, axis=2))
+    got = gpu.fhog_dev(tile[None], 8, 1, 1)[0]
+    ref = oracle.fhog(tile, 8, 1, 1)
+    assert got.shape == ref.shape == (510, 510, 31) and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
 def test_surf_tile_4096(gpu):
     """config 4 shape: interest points of a 4096x4096 tile, exact against the oracle (int32/f64 arithmetic)"""
     from test_surf import blobs
@@ -92,10 +102,12 @@ def test_surf_tile_4096(gpu):
     got = gpu.surf_interest_points(tile, 30.0)
     ref = oracle.surf_interest_points(tile, 30.0)
     assert len(ref) > 200 and got.shape == ref.shape and np.array_equal(got, ref)
-    s = gpu.surf(tile, 1000, 30.0)
-    r = oracle.surf(tile, 1000, 30.0)
-    for k in r:
-        assert s[k].shape == r[k].shape and np.array_equal(s[k], r[k]), k
+    for max_points in (1000, 10000):   # both caps (10000 keeps every point of this tile)
+        s = gpu.surf(tile, max_points, 30.0)
+        r = oracle.surf(tile, max_points, 30.0)
+        assert 0 < len(r["x"]) <= min(max_points, len(ref))   # (points too close to the border for a descriptor are dropped)
+        for k in r:
+            assert s[k].shape == r[k].shape and np.array_equal(s[k], r[k]), (k, max_points)
 
 
 def test_config5_stream_of_4k_frames_sampled_against_the_oracle():
