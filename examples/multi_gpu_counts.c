@@ -11,12 +11,14 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "imgfd.h"
 
 typedef struct {
     int device, nx, ny, first, count;  /* this device's block of the stream: frames first .. first + count - 1 */
     long long harris, fast9, canny;    /* feature totals of the block */
+    double seconds;                    /* this device's block, first submit to last collect (frame drawing included) */
     int status;
     char err[256];
 } shard;
@@ -57,6 +59,8 @@ static void *run(void *arg)
     {
         imgfd_stream_result r;
         int submitted = 0, pending = 0, b = 0;
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
         while (submitted < s->count || pending) {
             if (submitted < s->count && pending < 2) {
                 const int m = s->count - submitted < batch ? s->count - submitted : batch;
@@ -71,6 +75,8 @@ static void *run(void *arg)
                 s->harris += r.harris_counts[f]; s->fast9 += r.fast9_counts[f]; s->canny += r.canny_counts[f];
             }
         }
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        s->seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
     }
 done:
     for (int i = 0; i < 3; i++) if (buf[i]) imgfd_host_free(buf[i]);
@@ -104,8 +110,9 @@ int main(int argc, char **argv)
     for (int d = 0; d < ndev; d++) {
         pthread_join(th[d], NULL);
         if (sh[d].status) { fprintf(stderr, "%s\n", sh[d].err); bad = 1; }
-        printf("device %d: frames %d..%d: harris %lld fast9 %lld canny %lld\n", d, sh[d].first, sh[d].first + sh[d].count - 1,
-               sh[d].harris, sh[d].fast9, sh[d].canny);
+        printf("device %d: frames %d..%d: harris %lld fast9 %lld canny %lld  (%.3f s, %.1f Mpixel/s incl. drawing and upload)\n", d, sh[d].first,
+               sh[d].first + sh[d].count - 1, sh[d].harris, sh[d].fast9, sh[d].canny, sh[d].seconds,
+               sh[d].seconds > 0 ? 1e-6 * (double)sh[d].count * nx * ny / sh[d].seconds : 0.0);
         h += sh[d].harris; f9 += sh[d].fast9; c += sh[d].canny;
     }
     printf("total over %d device(s), %d frames: harris %lld fast9 %lld canny %lld\n", ndev, n, h, f9, c);

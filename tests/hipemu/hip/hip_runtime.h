@@ -384,6 +384,7 @@ static inline hipemu_v4u __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_r
 // scoped atomic load: one thread at a time runs here
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 static inline void __builtin_amdgcn_wave_barrier() { (void)hipemu::wave_exchange(0); }
 static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
     unsigned v;
