@@ -385,6 +385,8 @@ static inline hipemu_v4u __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_r
 #define __HIP_MEMORY_SCOPE_AGENT 4
 #define __hip_atomic_load(p, order, scope) (*(p))
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __hip_atomic_fetch_add(p, v, order, scope) atomicAdd((p), (v))
+#define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 static inline void __builtin_amdgcn_wave_barrier() { (void)hipemu::wave_exchange(0); }
 static inline unsigned __builtin_amdgcn_raw_buffer_load_b32(__amdgpu_buffer_rsrc_t r, int voffset, int soffset, int) {
     unsigned v;
@@ -401,6 +403,7 @@ enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDevice
 struct hipDeviceProp_t {
     char name[256]; char gcnArchName[256]; int multiProcessorCount; size_t totalGlobalMem; int warpSize;
     size_t sharedMemPerBlock; int maxThreadsPerBlock; int clockRate;
+    int cooperativeLaunch;  // 0: the emulator runs the blocks of a launch one after another -- they cannot wait for each other
 };
 #define hipHostMallocDefault 0
 #define hipStreamNonBlocking 1
