@@ -550,6 +550,9 @@ __device__ __forceinline__ unsigned long long lane_below(unsigned long long v)
 #ifndef HY_WORDS
 #define HY_WORDS 4
 #endif
+#ifndef HY_EXP
+#define HY_EXP 0  // timing experiments only (wrong results): 1 no S stores, 4 no tile loads, 8 no halo-row loads
+#endif
 // a wave turns its own LDS patch round (written lane = (row, word), read lane = row): program order inside the wave is the
 // only synchronisation; the fences keep the compiler from moving one lane's read over another lane's write
 __device__ __forceinline__ void hyst_wave_sync()
@@ -558,132 +561,12 @@ __device__ __forceinline__ void hyst_wave_sync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// the rows above / below a tile, held by lanes 0 .. HW+1 (words w0-1 .. w0+HW): dilated along x, as wave-uniform values
-// (readlane: scalar registers; a border lane picks its row per use)
-template <int HW>
-__device__ __forceinline__ void hyst_halo_rows(unsigned long long trow, unsigned long long brow, unsigned long long (&top_d)[HW], unsigned long long (&bot_d)[HW])
-{
-    unsigned long long t[HW + 2], b[HW + 2];
-#pragma unroll
-    for (int q = 0; q < HW + 2; q++) {
-        t[q] = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(trow >> 32), q) << 32) |
-               (unsigned)__builtin_amdgcn_readlane((int)(unsigned)trow, q);
-        b[q] = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(brow >> 32), q) << 32) |
-               (unsigned)__builtin_amdgcn_readlane((int)(unsigned)brow, q);
-    }
-#pragma unroll
-    for (int q = 0; q < HW; q++) {
-        top_d[q] = dilate_h(t[q + 1], t[q], t[q + 2]);
-        bot_d[q] = dilate_h(b[q + 1], b[q], b[q + 2]);
-    }
-}
-
-// ---- a wave's tile: HW words x 64 rows (lane = row) of S and W in registers, the words left / right of it (s[0], s[HW + 1]) and
-// the dilated rows above / below it (wave-uniform) as its halo
-template <int HW>
-struct HystTile {
-    static constexpr int LPR = HW + 2 <= 4 ? 4 : 8, LPW = HW <= 2 ? 2 : 4;      // lanes per row of the (row, word) load patterns
-    static constexpr int SP = (HW + 2) | 1, WP = HW | 1;                          // odd LDS pitches: lane = row reads hit distinct banks
-    static constexpr int LDS_WORDS = 64 * (SP + WP);
-    unsigned long long s[HW + 2], w[HW];
-    unsigned long long trow, brow;        // the rows above / below, words w0-1 .. w0+HW in lanes 0 .. HW+1
-    unsigned long long top_d[HW], bot_d[HW];
-
-    // The tile comes in through the wave's LDS patch.  In registers a lane owns a ROW, and rows lie wpr * 8 bytes apart: loaded
-    // lane = row, every 8-byte load of a wave touches 64 different 128-byte lines.  Loaded lane = (row, word) -- LPR lanes per
-    // row, 64 / LPR rows per instruction -- an instruction touches one line per row; the LDS patch turns the tile round.
-    // Returns false (wave-uniform) when the tile holds no marked-but-not-strong pixel.
-    __device__ __forceinline__ bool load(const unsigned long long *Sf, const unsigned long long *Wf, int wpr, int ny, int w0, int y0, int lane,
-                                         unsigned long long *ls, unsigned long long *lw)
-    {
-        {
-            const int c = lane % LPR, rsub = lane / LPR;
-#pragma unroll
-            for (int i = 0; i < LPR; i++) {
-                const int r = i * (64 / LPR) + rsub, yy = y0 + r, wi = w0 - 1 + c;
-                if (c < HW + 2) ls[r * SP + c] = (yy < ny && wi >= 0 && wi < wpr) ? Sf[(size_t)yy * wpr + wi] : 0ull;
-            }
-            const int cw_ = lane % LPW, rw_ = lane / LPW;
-#pragma unroll
-            for (int i = 0; i < LPW; i++) {
-                const int r = i * (64 / LPW) + rw_, yy = y0 + r, wi = w0 + cw_;
-                if (cw_ < HW) lw[r * WP + cw_] = (yy < ny && wi < wpr) ? Wf[(size_t)yy * wpr + wi] : 0ull;
-            }
-        }
-        hyst_wave_sync();
-#pragma unroll
-        for (int q = 0; q < HW + 2; q++) s[q] = ls[lane * SP + q];
-        bool todo = false;
-#pragma unroll
-        for (int q = 0; q < HW; q++) {
-            w[q] = lw[lane * WP + q];
-            todo = todo || (w[q] & ~s[q + 1]) != 0ull;
-        }
-        return __any(todo) != 0;
-    }
-    // halo rows above / below: lanes 0 .. HW+1 fetch the words, the dilated rows are kept wave-uniform
-    __device__ __forceinline__ void load_halo_rows(const unsigned long long *Sf, int wpr, int ny, int w0, int y0, int lane)
-    {
-        trow = 0ull; brow = 0ull;
-        const int wi = w0 - 1 + lane, yt = y0 - 1, yb = y0 + 64;
-        if (lane < HW + 2 && wi >= 0 && wi < wpr) {
-            if (yt >= 0) trow = Sf[(size_t)yt * wpr + wi];
-            if (yb < ny) brow = Sf[(size_t)yb * wpr + wi];
-        }
-        hyst_halo_rows<HW>(trow, brow, top_d, bot_d);
-    }
-    // the tile to its fixpoint under the current halo; returns whether it changed (wave-uniform).
-    // Only words whose neighbourhood moved are visited again: bit q of `prev` / `cur` = "word q of some row changed in the
-    // previous / in this pass" (scalar tests): a chain that climbs through one word no longer drags the others through every pass.
-    __device__ __forceinline__ bool fixpoint(int lane)
-    {
-        const bool first = lane == 0, last = lane == 63;
-        bool moved = false;
-        unsigned prev = (1u << HW) - 1u;
-        for (;;) {
-            unsigned cur = 0;
-#pragma unroll
-            for (int q = 0; q < HW; q++) {
-                const unsigned around = ((7u << q) >> 1) & ((1u << HW) - 1u);  // words q-1, q, q+1
-                if (!((prev & around) || (q > 0 && (cur & (1u << (q - 1)))))) continue;
-                // a word's dilation is taken when the word is visited (words to its left already hold this pass's additions: the
-                // fixpoint is the same, reached no later).  lane_above / lane_below give 0 to lanes 0 / 63: their neighbours are
-                // the halo rows
-                const unsigned long long d = dilate_h(s[q + 1], s[q], s[q + 2]);
-                const unsigned long long halo = first ? top_d[q] : (last ? bot_d[q] : 0ull);
-                const unsigned long long cand = w[q] & ~s[q + 1] & (d | lane_above(d) | lane_below(d) | halo);
-                if (__any(cand != 0ull)) {
-                    s[q + 1] |= flood_runs(w[q], cand);  // flood_runs(m, 0) = 0: lanes without a candidate keep their word
-                    cur |= 1u << q;
-                }
-            }
-            if (!cur) break;
-            moved = true;
-            prev = cur;
-        }
-        return moved;
-    }
-    // the tile's own words back the way they came: rows to the LDS patch, then lane = (row, word) stores
-    __device__ __forceinline__ void store(unsigned long long *Sf, int wpr, int ny, int w0, int y0, int lane, unsigned long long *lw) const
-    {
-        hyst_wave_sync();
-#pragma unroll
-        for (int q = 0; q < HW; q++) lw[lane * WP + q] = s[q + 1];
-        hyst_wave_sync();
-        const int cw_ = lane % LPW, rw_ = lane / LPW;
-#pragma unroll
-        for (int i = 0; i < LPW; i++) {
-            const int r = i * (64 / LPW) + rw_, yy = y0 + r, wi = w0 + cw_;
-            if (cw_ < HW && yy < ny && wi < wpr) Sf[(size_t)yy * wpr + wi] = lw[r * WP + cw_];
-        }
-    }
-};
-
+// HY_WORDS: a wave's tile: 4 words (256 columns) x 64 rows (lane = row), iterated to a fixpoint in registers
 // One sweep over all tiles of all frames (a wave per tile, the tile iterated to its fixpoint in registers).  flags[sweep]
 // is raised when any tile changed; a sweep whose predecessor was idle returns at once, so the host queues a fixed number
-// of sweeps without ever reading a flag back.  act[] holds one byte per tile and sweep parity: "this tile changed in that
-// sweep"; a tile can only change if itself or one of its 8 neighbours changed in the previous sweep (its inputs are its
-// own words and their halo), so all others leave at once.
+// of sweeps without ever reading a flag back.  act[] holds one byte per
+// tile and sweep parity: "this tile changed in that sweep"; a tile can only change if itself or one of its 8
+// neighbours changed in the previous sweep (its inputs are its own words and their halo), so all others leave at once.
 template <int HW>  // words per tile: HY_WORDS for batches (throughput), 2 for one or two frames (twice the waves, shorter sweeps)
 __global__ void __launch_bounds__(256) canny_hyst_bits(unsigned long long *__restrict__ S,
                                                        const unsigned long long *__restrict__ Wm, int wpr, int ny,
@@ -709,30 +592,129 @@ __global__ void __launch_bounds__(256) canny_hyst_bits(unsigned long long *__res
             return;
         }
     }
-    const int w0 = tx * HW, y0 = ty * 64;
+    const int w0 = tx * HW;
     unsigned long long *Sf = S + (size_t)blockIdx.y * ny * wpr;
     const unsigned long long *Wf = Wm + (size_t)blockIdx.y * ny * wpr;
-    using T = HystTile<HW>;
-    __shared__ unsigned long long hb_lds[4][T::LDS_WORDS];
-    unsigned long long *ls = hb_lds[threadIdx.x >> 6], *lw = ls + 64 * T::SP;
-    T t;
-    if (!t.load(Sf, Wf, wpr, ny, w0, y0, lane, ls, lw)) {  // no marked-but-not-strong pixel in the tile
+    unsigned long long s[HW + 2], w[HW];  // s[0] / s[HW+1]: halo words left / right
+    // The tile comes in through LDS.  In registers a lane owns a ROW (its HW + 2 words of S, HW of W), and rows lie wpr * 8
+    // bytes apart: loaded lane = row, every 8-byte load of a wave touched 64 different 128-byte lines and the twelve loads of
+    // a tile fetched 96 KB from L2 for 5 KB of bits -- PMC, round 4: 69 % of the sweep's wave cycles waited for them (215 us
+    // for the first sweep over 32 4K frames, 75 us of VALU work in it).  Loaded lane = (row, word) -- LPR lanes per row, 64 /
+    // LPR rows per instruction -- an instruction touches one line per row; the wave's own LDS patch turns the tile round.
+    constexpr int LPR = HW + 2 <= 4 ? 4 : 8, SP = (HW + 2) | 1, WP = HW | 1;  // lanes per row; odd pitches: lane = row reads hit distinct banks
+    __shared__ unsigned long long hb_lds[4][64 * (SP + WP)];
+    unsigned long long *ls = hb_lds[threadIdx.x >> 6], *lw = ls + 64 * SP;
+    {
+        const int c = lane % LPR, rsub = lane / LPR;
+#pragma unroll
+        for (int i = 0; i < LPR; i++) {
+            const int r = i * (64 / LPR) + rsub, yy = ty * 64 + r, wi = w0 - 1 + c;
+            if (c < HW + 2) ls[r * SP + c] = (!(HY_EXP & 4) && yy < ny && wi >= 0 && wi < wpr) ? Sf[(size_t)yy * wpr + wi] : (HY_EXP & 4 ? 0x0101010101010101ull * (unsigned)(lane & 1) : 0ull);
+        }
+        constexpr int LPW = HW <= 2 ? 2 : 4;
+        const int cw_ = lane % LPW, rw_ = lane / LPW;
+#pragma unroll
+        for (int i = 0; i < LPW; i++) {
+            const int r = i * (64 / LPW) + rw_, yy = ty * 64 + r, wi = w0 + cw_;
+            if (cw_ < HW) lw[r * WP + cw_] = (!(HY_EXP & 4) && yy < ny && wi < wpr) ? Wf[(size_t)yy * wpr + wi] : (HY_EXP & 4 ? 0x0303030303030303ull : 0ull);
+        }
+    }
+    hyst_wave_sync();
+#pragma unroll
+    for (int q = 0; q < HW + 2; q++) s[q] = ls[lane * SP + q];
+    bool todo = false;
+#pragma unroll
+    for (int q = 0; q < HW; q++) {
+        w[q] = lw[lane * WP + q];
+        todo = todo || (w[q] & ~s[q + 1]) != 0ull;
+    }
+    if (!__any(todo)) {  // no marked-but-not-strong pixel in the tile
         if (lane == 0) act_w[tile] = 0;
         return;
     }
-    t.load_halo_rows(Sf, wpr, ny, w0, y0, lane);
-    const bool any = t.fixpoint(lane);
+    // halo rows above / below: lanes 0..5 fetch the six words, then everybody gets them by shuffle
+    unsigned long long trow = 0ull, brow = 0ull;
+    {
+        const int wi = w0 - 1 + lane;
+        const int yt = ty * 64 - 1, yb = ty * 64 + 64;
+        if (!(HY_EXP & 8) && lane < HW + 2 && wi >= 0 && wi < wpr) {
+            if (yt >= 0) trow = Sf[(size_t)yt * wpr + wi];
+            if (yb < ny) brow = Sf[(size_t)yb * wpr + wi];
+        }
+    }
+    // the dilated halo rows are wave-uniform: kept in scalar registers (readlane), a border lane picks its row per use
+    unsigned long long top_d[HW], bot_d[HW];
+    {
+        unsigned long long t[HW + 2], b[HW + 2];
+#pragma unroll
+        for (int q = 0; q < HW + 2; q++) {
+            t[q] = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(trow >> 32), q) << 32) |
+                   (unsigned)__builtin_amdgcn_readlane((int)(unsigned)trow, q);
+            b[q] = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(brow >> 32), q) << 32) |
+                   (unsigned)__builtin_amdgcn_readlane((int)(unsigned)brow, q);
+        }
+#pragma unroll
+        for (int q = 0; q < HW; q++) {
+            top_d[q] = dilate_h(t[q + 1], t[q], t[q + 2]);
+            bot_d[q] = dilate_h(b[q + 1], b[q], b[q + 2]);
+        }
+    }
+    const bool first = lane == 0, last = lane == 63;
+    bool any = false;
+    // Only words whose neighbourhood moved are visited again: bit q of `prev` / `cur` = "word q of some row changed in the
+    // previous / in this pass" (wave-uniform, scalar tests).  A chain that climbs through one word of the tile no longer
+    // drags the other three through every pass.
+#ifdef HY_MAXITER
+    int hy_it = 0;
+#endif
+    unsigned prev = (1u << HW) - 1u;
+    for (;;) {
+        unsigned cur = 0;
+#pragma unroll
+        for (int q = 0; q < HW; q++) {
+            const unsigned around = ((7u << q) >> 1) & ((1u << HW) - 1u);  // words q-1, q, q+1
+            if (!((prev & around) || (q > 0 && (cur & (1u << (q - 1)))))) continue;
+            // a word's dilation is taken when the word is visited (words to its left already hold this pass's additions: the
+            // fixpoint is the same, reached no later).  lane_above / lane_below give 0 to lanes 0 / 63: their neighbours are
+            // the halo rows
+            const unsigned long long d = dilate_h(s[q + 1], s[q], s[q + 2]);
+            const unsigned long long halo = first ? top_d[q] : (last ? bot_d[q] : 0ull);
+            const unsigned long long cand = w[q] & ~s[q + 1] & (d | lane_above(d) | lane_below(d) | halo);
+            if (__any(cand != 0ull)) {
+                s[q + 1] |= flood_runs(w[q], cand);  // flood_runs(m, 0) = 0: lanes without a candidate keep their word
+                cur |= 1u << q;
+            }
+        }
+        if (!cur) break;
+        any = true;
+        prev = cur;
+#ifdef HY_MAXITER
+        if (++hy_it >= HY_MAXITER) break;  // timing experiment only (wrong results)
+#endif
+    }
     if (any) {  // wave-uniform
-        t.store(Sf, wpr, ny, w0, y0, lane, lw);
+        // back the way it came: rows to the LDS patch, then lane = (row, word) stores
+        hyst_wave_sync();
+#pragma unroll
+        for (int q = 0; q < HW; q++) lw[lane * WP + q] = s[q + 1];
+        hyst_wave_sync();
+        constexpr int LPW = HW <= 2 ? 2 : 4;
+        const int cw_ = lane % LPW, rw_ = lane / LPW;
+#pragma unroll
+        for (int i = 0; i < LPW; i++) {
+            const int r = i * (64 / LPW) + rw_, yy = ty * 64 + r, wi = w0 + cw_;
+            if (!(HY_EXP & 1) && cw_ < HW && yy < ny && wi < wpr) Sf[(size_t)yy * wpr + wi] = lw[r * WP + cw_];
+        }
         // a plain store: every writer stores the same 1.  (An atomicOr here -- sixteen thousand waves of a 32-frame sweep on ONE
         // address -- WAS the first two sweeps: 215 and 190 us, against 43 and 38 with the store; round 4, scripts/gpu_canny_variants.sh.)
         if (lane == 0) {
             flags[sweep] = 1u;
-            flags[HY_SWEEPS_MAX + blockIdx.y] = (unsigned)sweep + 1u;  // frame blockIdx.y moved in this sweep (the union-find kernels ask about the last one)
+            flags[HY_SWEEPS_MAX + blockIdx.y] = (unsigned)sweep + 1u;  // frame blockIdx.y moved in this sweep (the union-find kernel asks about the last one)
         }
     }
     if (lane == 0) act_w[tile] = any ? 1 : 0;
 }
+
 
 // ---- what the queued sweeps leave: union-find
 // A sweep carries the strong label across one tile outline, so a chain of weak pixels that winds through the frame can outlast
