@@ -137,6 +137,7 @@ struct BlurMarchParams {
     int row_stride;       // bytes between input rows
     long frame_stride;    // bytes between input frames
     int seg_rows;
+    int strips, xcd_order;  // strips per frame row (grid.x = strips x segments); 1: XCD-aware order of the (segment, strip) tiles
     int aligned4;         // base, strides and nx are multiples of 4: dword tile loads
     double wx[33];        // wx[j], j = 0..R: normalised taps along x (zero padded up to the template radius)
     double wy[33];
@@ -170,13 +171,18 @@ __global__ void __launch_bounds__(BM_NT) canny_blur_march(BlurMarchParams p)
     unsigned *raw = reinterpret_cast<unsigned *>(smem_d + RING * BM_RP);  // [BM_CH][PITCH]
 
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * BM_TW;
-    const int y0 = blockIdx.y * p.seg_rows;
+    // grid = (strips x segments of a frame, frames); XCD-aware order inside the frame (imgfd_xcd_tile): the strips left and right
+    // of a strip, which share the 128-byte lines at its edges and its 2R halo columns, march on the same XCD (the kernel
+    // fetched 4.1 B/px for 1 algorithmic when they were dealt round-robin)
+    const int in_frame = (int)(p.xcd_order ? imgfd_xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x);
+    const int seg_i = in_frame / p.strips, strip_i = in_frame - seg_i * p.strips;
+    const int x0 = strip_i * BM_TW;
+    const int y0 = seg_i * p.seg_rows;
     const int nrows = min(p.ny, y0 + p.seg_rows) - y0;
     const int nchunks = (nrows + 2 * R + BM_CH - 1) / BM_CH;
     const int ybase = y0 - R;
-    const unsigned char *in = p.in + (size_t)blockIdx.z * p.frame_stride;
-    float *out = p.out + (size_t)blockIdx.z * p.nx * p.ny;
+    const unsigned char *in = p.in + (size_t)blockIdx.y * p.frame_stride;
+    float *out = p.out + (size_t)blockIdx.y * p.nx * p.ny;
 
     // tile loads: slot l of a thread is always dword q[l] of tile row r[l]; only the image row moves (by BM_CH rows per
     // chunk, wrapping around the image), so the column offset and the LDS address are fixed up front and the row index
@@ -359,12 +365,12 @@ template <bool INSIDE>
 __device__ __forceinline__ void canny_grad_nms_tile(double (*sb)[GN_TX + 2 * GN_XO + 4], double (*sg)[GN_TX + 2 + 1],
                                                     const float *__restrict__ blur, unsigned long long *__restrict__ S,
                                                     unsigned long long *__restrict__ Wm, int nx, int ny, int words_per_row,
-                                                    int accGrad, int low_thr, int high_thr)
+                                                    int accGrad, int low_thr, int high_thr, int bx, int by, int bz)
 {
     constexpr int LW = GN_TX + 2 * GN_XO;  // 72 columns: x0-4 .. x0+67
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * GN_TX, y0 = blockIdx.y * GN_TY;
-    const float *pl = blur + (size_t)blockIdx.z * nx * ny;
+    const int x0 = bx * GN_TX, y0 = by * GN_TY;
+    const float *pl = blur + (size_t)bz * nx * ny;
     // INSIDE tiles see x0-4 >= 0, x0+68 <= nx, y0-2 >= 0, y0+18 <= ny and a 16-byte aligned plane
     if (INSIDE) {
         for (int i = tid; i < (GN_TY + 4) * (LW / 4); i += 256) {
@@ -486,7 +492,7 @@ __device__ __forceinline__ void canny_grad_nms_tile(double (*sb)[GN_TX + 2 * GN_
         }
         const unsigned long long strong = __ballot(o == 2), marked = __ballot(o >= 1);
         if (c == 0 && (INSIDE || gy < ny)) {
-            const size_t w = ((size_t)blockIdx.z * ny + gy) * words_per_row + blockIdx.x;
+            const size_t w = ((size_t)bz * ny + gy) * words_per_row + bx;
             S[w] = strong;
             Wm[w] = marked;
         }
@@ -496,19 +502,25 @@ __device__ __forceinline__ void canny_grad_nms_tile(double (*sb)[GN_TX + 2 * GN_
 __global__ void __launch_bounds__(256) canny_grad_nms(const float *__restrict__ blur, unsigned long long *__restrict__ S,
                                                       unsigned long long *__restrict__ Wm, int nx, int ny,
                                                       int words_per_row, int accGrad, int low_thr, int high_thr, int vec4,
-                                                      unsigned *__restrict__ sweep_flags, int n_sweep_flags)
+                                                      unsigned *__restrict__ sweep_flags, int n_sweep_flags, int tiles_x, int xcd_order)
 {
     __shared__ __attribute__((aligned(16))) double sb[GN_TY + 4][GN_TX + 2 * GN_XO + 4];
     __shared__ double sg[GN_TY + 2][GN_TX + 2 + 1];
-    const int x0 = blockIdx.x * GN_TX, y0 = blockIdx.y * GN_TY;
+    // grid = (tiles of a frame, frames), XCD-aware tile order inside the frame (imgfd_xcd_tile; tile = row * tiles_x + column).
+    // The 72 floats a tile row needs straddle three or four 128-byte lines, two of them shared with the neighbours left and
+    // right: dealt round-robin to the XCDs, every tile fetched them from HBM itself -- 9.9 B/px for 4 algorithmic; 4.00 now
+    // (round 4, profiles/r04/xcd_tile_order.txt)
+    const int in_frame = (int)(xcd_order ? imgfd_xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x), bz = blockIdx.y;
+    const int by = in_frame / tiles_x, bx = in_frame - by * tiles_x;
+    const int x0 = bx * GN_TX, y0 = by * GN_TY;
     // the hysteresis sweeps behind this kernel start from cleared "changed" words (a memset of their own was 5 us of a
     // single frame's critical path)
-    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (int)threadIdx.x < n_sweep_flags) sweep_flags[threadIdx.x] = 0;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sweep_flags[n_sweep_flags + blockIdx.z] = 0;  // per frame: the last sweep that changed it
+    if (in_frame == 0 && bz == 0 && (int)threadIdx.x < n_sweep_flags) sweep_flags[threadIdx.x] = 0;
+    if (in_frame == 0 && threadIdx.x == 0) sweep_flags[n_sweep_flags + bz] = 0;  // per frame: the last sweep that changed it
     // workgroup-uniform: interior tiles skip every clamp and fetch the blurred tile as float4s
     const bool inside = vec4 && x0 - GN_XO >= 0 && x0 + GN_TX + GN_XO <= nx && y0 - 2 >= 0 && y0 + GN_TY + 2 <= ny;
-    if (inside) canny_grad_nms_tile<true>(sb, sg, blur, S, Wm, nx, ny, words_per_row, accGrad, low_thr, high_thr);
-    else canny_grad_nms_tile<false>(sb, sg, blur, S, Wm, nx, ny, words_per_row, accGrad, low_thr, high_thr);
+    if (inside) canny_grad_nms_tile<true>(sb, sg, blur, S, Wm, nx, ny, words_per_row, accGrad, low_thr, high_thr, bx, by, bz);
+    else canny_grad_nms_tile<false>(sb, sg, blur, S, Wm, nx, ny, words_per_row, accGrad, low_thr, high_thr, bx, by, bz);
 }
 
 // ------------------------------------------------------------------ K12
@@ -998,7 +1010,9 @@ imgfd_status launch_blur_march(imgfd_ctx *ctx, BlurMarchParams &p, int nf)
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; seg = sr; }
     }
     p.seg_rows = seg;
-    dim3 grid(strips, ceil_div(p.ny, seg), nf);
+    p.strips = strips;
+    p.xcd_order = ctx->tune.xcd_remap;
+    dim3 grid((unsigned)strips * (unsigned)ceil_div(p.ny, seg), nf);
     IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)canny_blur_march<R>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)G::LDS_BYTES));
     hipLaunchKernelGGL((canny_blur_march<R>), grid, dim3(BM_NT), G::LDS_BYTES, ctx->stream, p);
@@ -1088,9 +1102,9 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
         hipLaunchKernelGGL(canny_blur_cols, g1, dim3(256), 0, ctx->stream, tmp, blur, nx, ny, ty);
     }
     IMGFD_TRY(at(1));
-    dim3 g2(wpr, ceil_div(ny, GN_TY), nf);
+    dim3 g2((unsigned)wpr * (unsigned)ceil_div(ny, GN_TY), nf);
     hipLaunchKernelGGL(canny_grad_nms, g2, dim3(256), 0, ctx->stream, blur, S, Wm, nx, ny, wpr, accGrad, (int)low_thr,
-                       (int)high_thr, (int)(nx % 4 == 0 && (size_t)blur % 16 == 0), flags, HY_SWEEPS_MAX);
+                       (int)high_thr, (int)(nx % 4 == 0 && (size_t)blur % 16 == 0), flags, HY_SWEEPS_MAX, wpr, ctx->tune.xcd_remap);
     IMGFD_HIP(ctx, hipGetLastError());
     IMGFD_TRY(at(2));
     unsigned uf_last_sweep = 0;

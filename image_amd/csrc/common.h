@@ -157,6 +157,16 @@ typedef unsigned short imgfd_u16x2 __attribute__((ext_vector_type(2)));  // two 
 #define IMGFD_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
 #endif
 
+// ---- XCD-aware tile order.  Workgroup ids are dealt round-robin to the 8 XCDs, each with an L2 of its own: with the natural
+// order, the tiles to the left and right of a tile (and the tile rows above and below it) run on OTHER XCDs and fetch the
+// 128-byte lines they share with it from HBM again.  Workgroup `id` of `total` takes tile xcd * (total / 8) + ... instead: an
+// XCD owns a contiguous run of the tile order, walked in step by its CUs, so shared lines are L2 hits.
+__device__ __forceinline__ unsigned imgfd_xcd_tile(unsigned id, unsigned total)
+{
+    const unsigned q = total >> 3, r = total & 7u, xcd = id & 7u, local = id >> 3;
+    return xcd * q + (xcd < r ? xcd : r) + local;
+}
+
 // ---- tile runs: the 2-D tile kernels over u8 frames (fast9_tile, gauss_grad_tile) walk `run` consecutive tiles of one
 // band of rows per workgroup instead of one tile.  A 64-pixel tile row with its halo straddles two 128-byte lines; with
 // one tile per workgroup the x-neighbour (another workgroup, dealt to another XCD with its own L2) fetched both lines

@@ -98,7 +98,7 @@ template <int NONMAX>
 __global__ void __launch_bounds__(256) fast9_tile(const unsigned char *__restrict__ img, int w, int h, int stride,
                                                   size_t frame_stride, int b, int aligned4, int aligned16,
                                                   unsigned long long *__restrict__ mask,
-                                                  unsigned *__restrict__ rowcount, int words_per_row, TileRuns runs)
+                                                  unsigned *__restrict__ rowcount, int words_per_row, TileRuns runs, int xcd_order)
 {
     // LDS tile: rows y0-4 .. y0+TY+3; columns x0-16 .. x0+79 (the left margin of 16 keeps the first column 16-byte
     // aligned in the frame, so interior tiles are staged with 16-byte loads; only x0-4 .. x0+67 are ever looked at)
@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256) fast9_tile(const unsigned char *__restric
     // the score tile is cleared once; every tile puts back to 0 the cells its candidates wrote (far fewer than the tile)
     for (int i = tid; i < SR * (SCW / 4); i += 256) (&sc32[0][0])[i] = 0u;
     {  // one run of tiles per workgroup (TileRuns, common.h)
-    const unsigned run_id = blockIdx.x;
+    const unsigned run_id = xcd_order ? imgfd_xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x;  // an XCD owns neighbouring runs and bands: their shared lines are L2 hits
     const int frame = (int)(run_id / (unsigned)(runs.runs_per_band * runs.bands));
     const int in_frame = (int)(run_id - (unsigned)frame * (unsigned)(runs.runs_per_band * runs.bands));
     const int band = in_frame / runs.runs_per_band, tile0 = (in_frame - band * runs.runs_per_band) * runs.run;
@@ -250,10 +250,10 @@ imgfd_status launch_fast9(imgfd_ctx *ctx, const uint8_t *d_img, int w, int h, in
     const int aligned16 = ((size_t)d_img % 16 == 0) && stride % 16 == 0 && frame_stride % 16 == 0;
     if (!nonmax)
         hipLaunchKernelGGL(fast9_tile<0>, grid, dim3(256), 0, ctx->stream, d_img, w, h, stride, frame_stride, threshold,
-                           aligned4, aligned16, cb.mask, cb.rowcount, cb.words_per_row, runs);
+                           aligned4, aligned16, cb.mask, cb.rowcount, cb.words_per_row, runs, ctx->tune.xcd_remap);
     else
         hipLaunchKernelGGL(fast9_tile<1>, grid, dim3(256), 0, ctx->stream, d_img, w, h, stride, frame_stride, threshold,
-                           aligned4, aligned16, cb.mask, cb.rowcount, cb.words_per_row, runs);
+                           aligned4, aligned16, cb.mask, cb.rowcount, cb.words_per_row, runs, ctx->tune.xcd_remap);
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }

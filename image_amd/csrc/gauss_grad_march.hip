@@ -40,6 +40,7 @@ struct GaussMarchParams {
     int nx, ny, in_pitch;
     long in_frame_stride;
     int seg_rows, nstrips, nseg;
+    int xcd_order;       // 1: XCD-aware order of the tiles (imgfd_xcd_tile): neighbouring strips march on one XCD
     unsigned *rowcount;  // optional: ny counters per frame, cleared by the workgroups of strip 0 (for the NMS kernel two launches on:
                          // a fill of its own, queued behind the structure-tensor kernel, sat 20 us on the chain's critical path)
     double B[8];
@@ -80,7 +81,7 @@ __global__ void __launch_bounds__(GM_NT) IMGFD_WAVES_PER_EU(4, 4) gauss_grad_mar
     __shared__ __attribute__((aligned(16))) float obuf[GM_OBR * GM_OBP];
     const int tid = threadIdx.x;
     // tile = (strip, segment, frame), strip fastest
-    int t = blockIdx.x;
+    int t = (int)(p.xcd_order ? imgfd_xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x);
     const int strip = t % p.nstrips; t /= p.nstrips;
     const int seg = t % p.nseg;
     const int frame = t / p.nseg;
@@ -307,6 +308,7 @@ imgfd_status launch_gauss_grad_march(imgfd_ctx *ctx, const void *d_in, int in_pi
     while (seg < ny && ny - (ceil_div(ny, seg) - 1) * seg < 2) seg++;
     p.seg_rows = seg;
     p.nseg = ceil_div(ny, seg);
+    p.xcd_order = ctx->tune.xcd_remap;
     const dim3 grid((unsigned)((long)p.nstrips * p.nseg * n_frames));
     const bool sobel = grad_type == IMGFD_SOBEL_OPERATOR;
 #define GM_LAUNCH(G, F) hipLaunchKernelGGL((gauss_grad_march<R, G, F>), grid, dim3(GM_NT), 0, ctx->stream, p)
