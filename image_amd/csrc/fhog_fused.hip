@@ -211,7 +211,7 @@ __device__ __forceinline__ void fh_vote_row(float *bins, const unsigned (&pw)[16
 template <int NT>
 __global__ void __launch_bounds__(NT) fhog_hist8(const unsigned char *__restrict__ rgb, size_t frame_stride,
                                                          const unsigned *__restrict__ lut, float *__restrict__ hist,
-                                                         float *__restrict__ norm, FhogGeom g, int bands_per_wg)
+                                                         float *__restrict__ norm, FhogGeom g, int bands_per_wg, int tiles_x, int xcd_order)
 {
     HIP_DYNAMIC_SHARED(unsigned, lds)
     unsigned *V = lds;
@@ -223,16 +223,20 @@ __global__ void __launch_bounds__(NT) fhog_hist8(const unsigned char *__restrict
                                         // window row may be scheduled across the bin stores
 
     const int tid = threadIdx.x;
-    const int f = blockIdx.z;
+    // grid = (windows of a frame, frames); XCD-aware order of the windows inside the frame (imgfd_xcd_tile): the windows left and
+    // right of a window share the 128-byte lines at its edges with it
+    const int in_frame = (int)(xcd_order ? imgfd_xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x);
+    const int wy = in_frame / tiles_x, wx = in_frame - wy * tiles_x;
+    const int f = blockIdx.y;
     const unsigned *img = reinterpret_cast<const unsigned *>(rgb + (size_t)f * frame_stride);
     const int rd = 3 * g.cols / 4;
     const int n_bands = (g.cells_nr + FH_CR - 1) / FH_CR;
-    const int k0 = blockIdx.y * bands_per_wg, k1 = min(k0 + bands_per_wg, n_bands);
-    const int hc0 = 1 + FH_CC * blockIdx.x;
+    const int k0 = wy * bands_per_wg, k1 = min(k0 + bands_per_wg, n_bands);
+    const int hc0 = 1 + FH_CC * wx;
     const int x0 = FH_CS * hc0 - 12;        // image column of window column 0 (128 bx - 4)
     const int Y0 = FH_CS * (1 + FH_CR * k0) - 12;  // image row of window row 0 (64 k0 - 4)
     // the two waves that run phase 2 alternate between workgroups (a workgroup's waves go to the four SIMDs in turn)
-    const int role = (blockIdx.x + blockIdx.y) & (NT / 128 - 1);
+    const int role = (wx + wy) & (NT / 128 - 1);
     const bool cols_inside = x0 >= 4 && x0 + FH_WX + 1 <= min(g.visible_nc, g.body_end);
     const bool tail_window = x0 + FH_WX > g.body_end;
 
@@ -370,11 +374,11 @@ imgfd_status fhog_fused_hist(imgfd_ctx *ctx, const uint8_t *d_rgb, size_t frame_
         bpw = (int)std::min<long>(8, std::max<long>(1, band_tiles / (8L * ctx->num_cu)));
     }
     bpw = std::min(bpw, n_bands);
-    const dim3 grid(tiles_x, ceil_div(n_bands, bpw), nf);
+    const dim3 grid((unsigned)tiles_x * (unsigned)ceil_div(n_bands, bpw), nf);
     if (ctx->tune.fhog_threads == 512)
-        hipLaunchKernelGGL(fhog_hist8<512>, grid, dim3(512), FH_LDS, ctx->stream, d_rgb, frame_stride, ctx->fhog_lut, hist, norm, g, bpw);
+        hipLaunchKernelGGL(fhog_hist8<512>, grid, dim3(512), FH_LDS, ctx->stream, d_rgb, frame_stride, ctx->fhog_lut, hist, norm, g, bpw, tiles_x, ctx->tune.xcd_remap);
     else
-        hipLaunchKernelGGL(fhog_hist8<256>, grid, dim3(256), FH_LDS, ctx->stream, d_rgb, frame_stride, ctx->fhog_lut, hist, norm, g, bpw);
+        hipLaunchKernelGGL(fhog_hist8<256>, grid, dim3(256), FH_LDS, ctx->stream, d_rgb, frame_stride, ctx->fhog_lut, hist, norm, g, bpw, tiles_x, ctx->tune.xcd_remap);
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }

@@ -443,12 +443,15 @@ __device__ __forceinline__ double surf_lds_interval(const unsigned *__restrict__
 
 template <int O>
 __global__ void __launch_bounds__(256) surf_pyramid_lds(const unsigned *__restrict__ I, double *__restrict__ pyr, SurfGeom g,
-                                                        unsigned long long *__restrict__ mask, double thr)
+                                                        unsigned long long *__restrict__ mask, double thr, int blocks_x, int xcd_order)
 {
     using G = SurfPyrLds<O>;
     HIP_DYNAMIC_SHARED(unsigned, win)  // [G::H][G::P]
     const int tid = threadIdx.x;
-    const int lc0 = blockIdx.x * G::LX, lr0 = blockIdx.y * G::LY;
+    // 1-D grid, XCD-aware order of the blocks (imgfd_xcd_tile): the windows of neighbouring blocks overlap by their halo
+    const int blk = (int)(xcd_order ? imgfd_xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x);
+    const int blk_y = blk / blocks_x, blk_x = blk - blk_y * blocks_x;
+    const int lc0 = blk_x * G::LX, lr0 = blk_y * G::LY;
     const int x0 = G::STEP * lc0 - G::HL, y0 = G::STEP * lr0 - G::HL;
     const int cols = g.cols, rows = g.rows;
     if (x0 >= 0 && y0 >= 0 && x0 + G::P <= cols && y0 + G::H <= rows && (cols & 3) == 0) {  // workgroup-uniform; x0 % 4 == 0
@@ -505,7 +508,8 @@ static imgfd_status launch_surf_pyramid_lds(imgfd_ctx *ctx, const unsigned *d_I,
     using G = SurfPyrLds<O>;
     const size_t lds = sizeof(unsigned) * (size_t)G::H * G::P;
     IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)surf_pyramid_lds<O>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(surf_pyramid_lds<O>, dim3(ceil_div(g.nc[O], G::LX), ceil_div(g.nr[O], G::LY)), dim3(256), lds, ctx->stream, d_I, d_pyr, g, d_mask, thr);
+    const int bx = ceil_div(g.nc[O], G::LX), by = ceil_div(g.nr[O], G::LY);
+    hipLaunchKernelGGL(surf_pyramid_lds<O>, dim3((unsigned)bx * (unsigned)by), dim3(256), lds, ctx->stream, d_I, d_pyr, g, d_mask, thr, bx, ctx->tune.xcd_remap);
     return IMGFD_OK;
 }
 
