@@ -90,7 +90,7 @@ def test_batch_surf_dev_descriptors_on_the_device(be):
     assert len(few["x"]) <= 7 and np.array_equal(few["score"], np.sort(few["score"])[::-1])
 
 
-@pytest.mark.parametrize("w,h", [(384, 256), (400, 304), (640, 272)])
+@pytest.mark.parametrize("w,h", [(384, 256), (400, 304), (640, 272), (528, 162)])
 def test_upper_octaves_both_gather_forms(be, w, h):
     """octaves 1-3: the look-ups as buffer loads with host-made offsets (surf_pyramid_taps, the default) and with per-look-up
     address arithmetic (surf_pyramid<2>, "surf_taps" 0) give the reference's interest points, bit for bit"""
