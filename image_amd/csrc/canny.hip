@@ -1158,7 +1158,7 @@ static imgfd_status canny_host(imgfd_ctx *ctx, const void *img, int kind, int nx
                                double high_thr, int accGrad, uint8_t *edges, double *edges_f64, int64_t *pixels_nonzero)
 {
     if (!ctx) return IMGFD_ERR_INVALID;
-    if (!img || (!edges && !edges_f64) || !pixels_nonzero || nx < 1 || ny < 1)
+    if (!img || (!edges && !edges_f64) || !pixels_nonzero || nx < 1 || ny < 1 || !frame_fits(nx, ny))
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_canny: bad argument");
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)nx * ny;
@@ -1208,7 +1208,8 @@ imgfd_status imgfd_canny_dev(imgfd_ctx *ctx, const imgfd_frames *fr, double s, d
 imgfd_status canny_dev_hooked(imgfd_ctx *ctx, const imgfd_frames *fr, double s, double low_thr, double high_thr, int accGrad,
                               uint8_t *d_edges, int64_t *d_counts, const std::function<imgfd_status(int)> *hook)
 try {
-    if (!ctx || !fr || !fr->d_frames || !d_edges || !d_counts || fr->n_frames < 0 || fr->dtype != 0 || fr->nx < 1 || fr->ny < 1)
+    if (!ctx || !fr || !fr->d_frames || !d_edges || !d_counts || fr->n_frames < 0 || fr->dtype != 0 || fr->nx < 1 || fr->ny < 1 ||
+        !frame_fits(fr->nx, fr->ny))
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_canny_dev: bad argument (frames must be u8)");
     if (!fr->n_frames) {
         for (int pos = 0; hook && pos < 3; pos++) IMGFD_TRY((*hook)(pos));

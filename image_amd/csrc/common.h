@@ -126,6 +126,10 @@ static inline imgfd_status imgfd_guard(imgfd_ctx *ctx, F &&body) noexcept
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+// The kernels index the pixels (RGB: the bytes) of one frame with 32-bit integers, like the reference's own loops (an R
+// matrix holds at most 2^31 - 1 elements); larger frames are refused at the boundary instead of wrapping inside a kernel.
+constexpr int64_t IMGFD_MAX_FRAME_ELEMS = ((int64_t)1 << 31) - ((int64_t)1 << 24);
+static inline bool frame_fits(int64_t nx, int64_t ny, int64_t channels = 1) { return nx * ny * channels <= IMGFD_MAX_FRAME_ELEMS; }
 // frames per sub-batch of a *_dev entry point: as many as fit `budget` bytes of stage planes, at least one.
 // The lab switch "max_chunk_frames" (tests) lowers it so that small batches cross sub-batch boundaries too.
 static inline int sub_batch_frames(const imgfd_ctx *ctx, int n_frames, size_t per_frame_bytes, size_t budget)

@@ -13,7 +13,7 @@ static imgfd_status fast9_host(imgfd_ctx *ctx, const void *img, int kind, int wi
     if (!ctx || !out) return IMGFD_ERR_INVALID;
     out->points = nullptr;
     out->n = 0;
-    if (!img || width < 0 || height < 0 || bytes_per_row < width)
+    if (!img || width < 0 || height < 0 || bytes_per_row < width || !frame_fits(bytes_per_row, height))
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_fast9: bad image geometry");
     if (width < 7 || height < 7) return IMGFD_OK;  // empty search domain, f9.cpp:2959-2960
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
@@ -65,7 +65,7 @@ imgfd_status imgfd_fast9_dev(imgfd_ctx *ctx, const imgfd_frames *fr, uint8_t thr
 {
     if (!ctx || !fr || !fr->d_frames || (!d_points && cap > 0) || !d_counts || cap < 0 || fr->n_frames < 0 || fr->dtype != 0)
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_fast9_dev: bad argument (frames must be u8)");
-    if (fr->nx < 1 || fr->ny < 1 || fr->row_stride_bytes < fr->nx)
+    if (fr->nx < 1 || fr->ny < 1 || fr->row_stride_bytes < fr->nx || !frame_fits(fr->nx, fr->ny))
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_fast9_dev: bad frame geometry");
     if (fr->n_frames == 0) return IMGFD_OK;
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));

@@ -459,7 +459,8 @@ static imgfd_status fhog_host(imgfd_ctx *ctx, const void *rgb, int kind, int row
     if (!ctx) return IMGFD_ERR_INVALID;
     float *unused_hog = nullptr;
     if (hog_f64) hog = &unused_hog;
-    if (!rgb || !hog || !hog_nr || !hog_nc || rows < 0 || cols < 0 || cell_size < 1 || filter_rows_padding < 1 || filter_cols_padding < 1)
+    if (!rgb || !hog || !hog_nr || !hog_nc || rows < 0 || cols < 0 || cell_size < 1 || filter_rows_padding < 1 || filter_cols_padding < 1 ||
+        !frame_fits(rows, cols, 3))
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_fhog: bad argument (DLIB_ASSERT of fhog.h:712-720)");
     *hog = nullptr; *hog_nr = 0; *hog_nc = 0;
     FhogGeom g;
@@ -512,7 +513,8 @@ imgfd_status imgfd_fhog_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, 
                             int cell_size, int filter_rows_padding, int filter_cols_padding, float *d_hog)
 {
     if (!ctx) return IMGFD_ERR_INVALID;
-    if (!d_rgb || !d_hog || n_frames < 0 || rows < 0 || cols < 0 || cell_size < 1 || filter_rows_padding < 1 || filter_cols_padding < 1)
+    if (!d_rgb || !d_hog || n_frames < 0 || rows < 0 || cols < 0 || cell_size < 1 || filter_rows_padding < 1 || filter_cols_padding < 1 ||
+        !frame_fits(rows, cols, 3))
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_fhog_dev: bad argument");
     FhogGeom g;
     if (!n_frames || !fhog_geometry(rows, cols, cell_size, filter_rows_padding, filter_cols_padding, &g)) return IMGFD_OK;

@@ -179,7 +179,7 @@ imgfd_status imgfd_stream_open(imgfd_ctx *ctx, int nx, int ny, int batch_frames,
 {
     if (out) *out = nullptr;
     if (!ctx || !out || !params || nx < 1 || ny < 1 || batch_frames < 1 || params->corner_cap < 0 || params->point_cap < 0 ||
-        params->fast9_threshold < 0 || params->fast9_threshold > 255)
+        params->fast9_threshold < 0 || params->fast9_threshold > 255 || !frame_fits(nx, ny))
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_stream_open: bad argument");
     if (!params->harris && !params->fast9 && !params->canny)
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_stream_open: no detector selected");

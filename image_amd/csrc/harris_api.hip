@@ -290,7 +290,7 @@ static imgfd_status harris_host(imgfd_ctx *ctx, const void *img, int kind, int n
     out->corners = nullptr;
     out->n = 0;
     memset(out->stage_seconds, 0, sizeof out->stage_seconds);
-    if (!img || nx < 0 || ny < 0) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_harris: bad image");
+    if (!img || nx < 0 || ny < 0 || !frame_fits(nx, ny)) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_harris: bad image");
     if (nx < 3 || ny < 3) return IMGFD_OK;  // harris.cpp:493 (harris_scale falls through to harris for small images)
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
     // arena: the input plane, a half-size pyramid for the scale check, and one set of stage planes
@@ -338,7 +338,8 @@ imgfd_status imgfd_harris_dev(imgfd_ctx *ctx, const imgfd_frames *fr, float k, f
                               float sigma_i, float threshold, int gaussian, int gradient, int measure,
                               imgfd_corner *d_corners, int64_t cap, int64_t *d_counts)
 {
-    if (!ctx || !fr || !fr->d_frames || (!d_corners && cap > 0) || !d_counts || cap < 0 || fr->n_frames < 0)
+    if (!ctx || !fr || !fr->d_frames || (!d_corners && cap > 0) || !d_counts || cap < 0 || fr->n_frames < 0 ||
+        fr->nx < 0 || fr->ny < 0 || !frame_fits(fr->nx, fr->ny))
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_harris_dev: bad argument");
     const int nx = fr->nx, ny = fr->ny;
     if (fr->n_frames == 0) return IMGFD_OK;

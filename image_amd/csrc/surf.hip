@@ -1394,7 +1394,7 @@ imgfd_status imgfd_surf_interest_points(imgfd_ctx *ctx, const uint8_t *rgb, int 
                                         double *points, int64_t cap, int64_t *n)
 try {
     if (!ctx) return IMGFD_ERR_INVALID;
-    if (!rgb || !n || rows < 0 || cols < 0 || cap < 0 || (cap && !points) || !(detection_threshold >= 0))
+    if (!rgb || !n || rows < 0 || cols < 0 || cap < 0 || (cap && !points) || !(detection_threshold >= 0) || !frame_fits(rows, cols, 3))
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_surf_interest_points: bad argument");
     std::vector<SurfRecord> pts;
     IMGFD_TRY(surf_points_host(ctx, rgb, IMGFD_SRC_U8, rows, cols, detection_threshold, pts, nullptr));
@@ -1415,7 +1415,8 @@ imgfd_status imgfd_surf_points_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_f
                                    int64_t cap, int64_t *d_counts)
 {
     if (!ctx) return IMGFD_ERR_INVALID;
-    if (!d_rgb || !d_points || !d_counts || n_frames < 0 || rows < 1 || cols < 1 || cap < 1 || !(detection_threshold >= 0))
+    if (!d_rgb || !d_points || !d_counts || n_frames < 0 || rows < 1 || cols < 1 || cap < 1 || !(detection_threshold >= 0) ||
+        !frame_fits(rows, cols, 3))
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_surf_points_dev: bad argument");
     static_assert(sizeof(imgfd_surf_point) == sizeof(SurfRecord), "record layout");
     if (!n_frames) return IMGFD_OK;
@@ -1445,7 +1446,7 @@ imgfd_status imgfd_surf_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, 
 try {
     if (!ctx) return IMGFD_ERR_INVALID;
     if (!d_rgb || !d_features || !d_counts || n_frames < 0 || rows < 1 || cols < 1 || cap < 1 || !(max_points > 0) ||
-        !(detection_threshold >= 0))
+        !(detection_threshold >= 0) || !frame_fits(rows, cols, 3))
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_surf_dev: bad argument");
     if (!n_frames) return IMGFD_OK;
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
@@ -1554,7 +1555,7 @@ static imgfd_status surf_host(imgfd_ctx *ctx, const void *rgb, int kind, int row
 {
     if (!ctx || !out) return IMGFD_ERR_INVALID;
     memset(out, 0, sizeof *out);
-    if (!rgb || rows < 0 || cols < 0 || !(max_points > 0) || !(detection_threshold >= 0))
+    if (!rgb || rows < 0 || cols < 0 || !(max_points > 0) || !(detection_threshold >= 0) || !frame_fits(rows, cols, 3))
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_surf: bad argument (DLIB_ASSERT of surf.h:243-248)");
     std::vector<SurfRecord> pts;
     const unsigned *d_I = nullptr;

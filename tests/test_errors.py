@@ -123,3 +123,26 @@ def test_counts_only_batch_calls_accept_null_record_buffers(be):
     fr0 = be.frames(d, 0, 96, 72, 0)
     p.corner_cap = 0
     assert be.lib.imgfd_detect_dev(be.ctx, C.byref(fr0), C.byref(p), None, None, be.ptr(edges), be.ptr(cnt)) == OK, msg(be)
+
+
+def test_frames_beyond_32_bit_indexing_are_refused(be):
+    """a frame of 2^31 pixels (RGB: bytes) or more would wrap the kernels' 32-bit pixel indices: refused at the boundary
+    before anything is read (the pointers here are far too small for such a frame)"""
+    big = 46400   # 46400^2 > 2^31
+    img = np.zeros((16, 16), np.uint8)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    n = C.c_int64(0)
+    assert be.lib.imgfd_canny(be.ctx, p(img), big, big, 2.0, 3.0, 10.0, 1, p(img), C.byref(n)) == INVALID
+    out = _binding.Corners()
+    assert be.lib.imgfd_harris(be.ctx, p(img), big, big, 0.06, 1.0, 2.5, 130.0, 0, 0, 0, 1, 0, 1, 0, 10, 0, C.byref(out)) == INVALID
+    pts = _binding.Points()
+    assert be.lib.imgfd_fast9(be.ctx, p(img), big, big, big, 20, 0, C.byref(pts)) == INVALID
+    hog = C.POINTER(C.c_float)(); nr = C.c_int(0); nc = C.c_int(0)
+    assert be.lib.imgfd_fhog(be.ctx, p(img), 26800, 26800, 8, 1, 1, C.byref(hog), C.byref(nr), C.byref(nc)) == INVALID   # x 3 bytes
+    d = be.to_dev(np.zeros((1, 16, 16), np.uint8))
+    cnt = be.empty((1,), np.int64)
+    fr = _binding.Frames(be.ptr(d), 1, big, big, big * big, big, 0)
+    assert be.lib.imgfd_canny_dev(be.ctx, C.byref(fr), 2.0, 3.0, 10.0, 1, be.ptr(d), be.ptr(cnt)) == INVALID
+    assert be.lib.imgfd_fast9_dev(be.ctx, C.byref(fr), 20, 0, None, 0, be.ptr(cnt)) == INVALID
+    e, k = be.canny(synth.frame(2, 40, 30))   # the context still works
+    assert k == np.count_nonzero(e)
