@@ -45,7 +45,8 @@ extern "C" {
 
 typedef enum {
     IMGFD_OK = 0,
-    IMGFD_ERR_INVALID = 1,   /* bad argument */
+    IMGFD_ERR_INVALID = 1,   /* bad argument; also a frame of more than 2^31 - 2^24 pixels (RGB: bytes): the kernels index one
+                              * frame with 32 bits, as the reference's own int loops do (an R matrix holds < 2^31 elements) */
     IMGFD_ERR_NO_DEVICE = 2, /* no usable gfx950 device / HIP runtime failure at init */
     IMGFD_ERR_HIP = 3,       /* a HIP call failed; see imgfd_last_error */
     IMGFD_ERR_OOM = 4,
