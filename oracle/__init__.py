@@ -135,7 +135,8 @@ def harris_stage(which: str, *arrays, use_ref: bool = False, **kw):
                                      C.c_float(kw.get("k", 0.06)))
         return R
     if which == "nms":
-        fn = getattr(L, pre + "nms"); fn.restype = C.c_long
+        # rows_independent: the OpenMP schedule in which no row sees another row's skip marks (restatement only)
+        fn = lib().orc_nms_rows_independent if kw.get("rows_independent") else getattr(L, pre + "nms"); fn.restype = C.c_long
         cap = nx * ny // 4 + 16
         out = np.zeros((cap, 3), np.float32)
         n = fn(vp(a[0]), nx, ny, C.c_float(kw["Th"]), int(kw["radius"]), vp(out), C.c_long(cap))

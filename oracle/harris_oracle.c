@@ -243,7 +243,7 @@ ORC_API void orc_response(const float *A, const float *B, const float *C, float 
  * Output: xyR triples in raster order.  Returns the corner count (which may
  * exceed cap; only the first cap are stored).
  */
-ORC_API long orc_nms(const float *R, int nx, int ny, float Th, int radius, float *xyR, long cap)
+static long nms_scan(const float *R, int nx, int ny, float Th, int radius, float *xyR, long cap, int carry)
 {
     if (ny <= 2 * radius + 1 || nx <= 2 * radius + 1) return 0;
     if (radius < 1) radius = 1;
@@ -271,7 +271,7 @@ ORC_API long orc_nms(const float *R, int nx, int ny, float Th, int radius, float
                             int l = j + radius;
                             while (!found && l >= j - radius) {
                                 if (R[k * nx + l] > R[i * nx + j]) found = 1;
-                                else skip[k * nx + l] = 1;
+                                else if (carry) skip[k * nx + l] = 1;
                                 l--;
                             }
                             k--;
@@ -301,6 +301,19 @@ ORC_API long orc_nms(const float *R, int nx, int ny, float Th, int radius, float
     }
     free(skip);
     return n;
+}
+ORC_API long orc_nms(const float *R, int nx, int ny, float Th, int radius, float *xyR, long cap)
+{
+    return nms_scan(R, nx, ny, Th, radius, xyR, cap, 1);
+}
+/* The row loop of harris.cpp:169-172 is an OpenMP parallel-for in the reference's build (src/Makevars: SHLIB_OPENMP_CXXFLAGS),
+ * and the marks of harris.cpp:218 are written into rows BELOW the candidate -- rows another thread may be scanning, or have
+ * finished.  Which of them a later row observes depends on the schedule: orc_nms is the one-thread schedule (every mark of
+ * the rows above is seen); this is the other extreme, no row sees a mark another row made.  The two differ only when exact
+ * ties in adjacent rows meet (tests/test_harris_stages.py). */
+ORC_API long orc_nms_rows_independent(const float *R, int nx, int ny, float Th, int radius, float *xyR, long cap)
+{
+    return nms_scan(R, nx, ny, Th, radius, xyR, cap, 0);
 }
 
 /* ---------------------------------------------------------------- H10 -----
