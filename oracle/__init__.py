@@ -200,6 +200,22 @@ def canny(img, s: float = 2.0, low_thr: float = 3.0, high_thr: float = 10.0, acc
     return edges, int(n)
 
 
+def canny_from_blur(blur, low_thr: float = 3.0, high_thr: float = 10.0, accGrad: bool = True):
+    """The stages behind the blur (gradient, maxima, hysteresis: rcpp_canny.cpp:153-215) on a given blurred plane (ny, nx) of
+    float values -- lets a test swap the blur's FFT for another implementation (FFTW3 itself is not in this image).
+    Returns (edges uint8 (ny,nx) of 0/255, pixels_nonzero)."""
+    data = np.ascontiguousarray(np.asarray(blur, dtype=np.float32), dtype=np.float64)   # data[] holds floats (crealf, tools.c:126)
+    ny, nx = data.shape
+    L = lib()
+    vp = lambda x: x.ctypes.data_as(C.c_void_p)
+    grad, theta, edges = np.zeros((ny, nx)), np.zeros((ny, nx)), np.zeros((ny, nx), np.uint8)
+    L.orc_canny_gradient(vp(data), vp(grad), vp(theta), nx, ny, int(bool(accGrad)))
+    L.orc_canny_maxima(vp(grad), vp(theta), vp(edges), nx, ny, int(low_thr), int(high_thr))
+    L.orc_canny_hysteresis.restype = C.c_long
+    n = L.orc_canny_hysteresis(vp(edges), nx, ny)
+    return edges, int(n)
+
+
 def ref_canny(img, s: float = 2.0, low_thr: float = 3.0, high_thr: float = 10.0, accGrad: bool = True):
     """The reference's own canny_edge_detector() (rcpp_canny.cpp:122-244 + tools.c + adsf.c compiled in place into
     oracle/_ref/libref_canny.so; FFTW3 replaced by the plain DFT of oracle/fftw_stub.c).  Slow: O(n^3) transforms.

@@ -25,7 +25,9 @@
  * and because g is an outer product, as two 1-D circular convolutions with the
  * FULL-length wrapped kernels (no truncation), accumulated in double, rounded
  * to float once at the end like crealf does (tools.c:129).
- * tests/test_oracle.py also cross-checks this against a literal numpy fft2/ifft2 restatement (pocketfft).
+ * tests/test_oracle.py also cross-checks this against a literal numpy fft2/ifft2 restatement (pocketfft): at 640x480,
+ * 1000x700 and 4K no float of the blur and no edge pixel differs (test_canny_edges_through_an_independent_fft) -- an FFT's
+ * ~1e-13 error can flip a float only within that distance of a rounding boundary, ~1e-8 of the pixels.
  */
 #include <math.h>
 #include <stdlib.h>
