@@ -209,8 +209,10 @@ def image_fhog(x, cell_size=8, filter_rows_padding=1, filter_cols_padding=1, ctx
     ctx = _ctx(ctx)
     rgb, width, height = _rgb_bytes(x)
     nr, nc = C.c_int(0), C.c_int(0)
-    ctx.check(ctx.lib.imgfd_fhog_size(int(height), int(width), int(cell_size), int(filter_rows_padding), int(filter_cols_padding),
-                                      C.byref(nr), C.byref(nc)), "imgfd_fhog_size")
+    # (a context-free call: it leaves no message in the context for ctx.check to report)
+    if ctx.lib.imgfd_fhog_size(int(height), int(width), int(cell_size), int(filter_rows_padding), int(filter_cols_padding),
+                               C.byref(nr), C.byref(nc)) != 0:
+        raise ValueError("image_fhog: cell_size, filter_rows_padding and filter_cols_padding must be >= 1 (DLIB_ASSERT of fhog.h:712-720)")
     n = 31 * nr.value * nc.value
     flat = np.zeros((n,), np.float64)  # the glue: Rf_allocVector(REALSXP, n), filled by the library (widened on the device)
     if n:

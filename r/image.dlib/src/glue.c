@@ -7,7 +7,10 @@ SEXP _image_dlib_dlib_fhog(SEXP x, SEXP rows, SEXP cols, SEXP cell_size, SEXP fr
     SEXP xi = PROTECT(Rf_coerceVector(x, INTSXP)); /* std::vector<int> x: element [ch, c, r] at ch + 3*c + 3*cols*r */
     if (XLENGTH(xi) < (R_xlen_t)3 * nr * nc) Rf_error("x must hold 3*rows*cols values");
     int hr = 0, hc = 0;
-    imgfd_glue_check(imgfd_fhog_size(nr, nc, Rf_asInteger(cell_size), Rf_asInteger(frp), Rf_asInteger(fcp), &hr, &hc));
+    /* (a context-free call: it leaves no message behind for imgfd_glue_check) */
+    if (imgfd_fhog_size(nr, nc, Rf_asInteger(cell_size), Rf_asInteger(frp), Rf_asInteger(fcp), &hr, &hc) != IMGFD_OK)
+        Rf_error("imgfd: dlib_fhog: rows, cols >= 0 and cell_size, filter_rows_padding, filter_cols_padding >= 1 "
+                 "(DLIB_ASSERT of fhog.h:712-720)");
     const R_xlen_t n = (R_xlen_t)31 * hr * hc;
     SEXP f = PROTECT(Rf_allocVector(REALSXP, n)); /* filled in the order of rcpp_fhog.cpp:29-38, widened on the device */
     if (n)
