@@ -900,8 +900,9 @@ __global__ void __launch_bounds__(NMS_WORDS) surf_nms_masked(const double *__res
 // point get_interest_points emitted first comes first (what a stable sort would do; the reference's std::sort over
 // reverse iterators leaves the order of exact ties to the library's introsort).  As a 128-bit value: (score bits, ~key),
 // larger = better (scores are non-negative doubles: their bit patterns order like the values; keys are unique).
-//   1. radix select, up to 16 passes of 8 bits from the top over shrinking candidate lists: the lim best records
-//   2. they are ranked among themselves (bitonic sort of up to 2048 composites in LDS; all pairs beyond)
+//   1. radix select, passes of 8 bits from the top over shrinking candidate lists, until the winners and the candidates still
+//      open fit the LDS sort (lim > 2048: until the lim best records are known, at most 16 passes)
+//   2. they are ranked among themselves (bitonic sort of up to 2048 composites in LDS; all pairs beyond); the lim best stay
 //   3. in rank order: drop the points whose 32*scale box leaves the image (:271-285), compact with a block scan, write
 //      x, y, scale for K19 and the head of the feature record (x, y, -, pyramid_scale, score, laplacian)
 // counts_out[0] = points kept (or -candidates when the record buffer overflowed: nothing is written then).
@@ -939,12 +940,20 @@ __device__ __forceinline__ bool surf_better(unsigned long long sa, unsigned long
     return sa > sb || (sa == sb && ka < kb);
 }
 
+// LDS written by some lanes of a wave, read by others: program order inside the wave is the synchronisation; the fences keep
+// the compiler from moving a read over another lane's write
+__device__ __forceinline__ void sr_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __global__ void __launch_bounds__(SR_NT) surf_rank_select(SurfRankParams q)
 {
     __shared__ unsigned hist[256];
-    __shared__ unsigned want, nsel, ncand, cut, scan[SR_NT], carry;
+    __shared__ unsigned want, nsel, ncand, cut, scan[SR_NT / 64], wtot[4], carry;
     __shared__ unsigned long long st_s[SR_SORT], st_k[SR_SORT];
-    __shared__ unsigned perm[SR_SORT];
+    __shared__ unsigned sidx[SR_SORT];
     const int tid = threadIdx.x;
     const unsigned long long cnt = *q.count;
     if (cnt > q.cap) {  // more candidates than the record buffer holds: report, leave the feature rows alone
@@ -972,8 +981,13 @@ __global__ void __launch_bounds__(SR_NT) surf_rank_select(SurfRankParams q)
         if (tid == 0) nsel = n;
         mc = 0;
     }
+    const unsigned sort_limit = min((unsigned)SR_SORT, q.sort_cap);
     for (int pass = 0; pass < 16 && mc > 0; pass++) {
+        // Winners so far + the candidates still open fit the LDS sort: it settles the rest (the later passes -- few candidates,
+        // two dependent loads and seven barriers each -- were 8 x ~4 us for one workgroup)
+        if (nsel + mc <= sort_limit) break;
         for (int i = tid; i < 256; i += SR_NT) hist[i] = 0;
+        if (tid == 0) cut = 0;  // (want <= mc always: some bin takes it)
         __syncthreads();
         for (unsigned i0 = 0; i0 < mc; i0 += SR_NT) {  // every lane makes every trip (wave intrinsics inside)
             const unsigned i = i0 + tid;
@@ -994,15 +1008,21 @@ __global__ void __launch_bounds__(SR_NT) surf_rank_select(SurfRankParams q)
             }
         }
         __syncthreads();
-        if (tid == 0) {  // walk the bins from the top: the bin in which the `want`-th best candidate lies
-            unsigned w = want, b = 255;
-            for (;; b--) {
-                if (hist[b] >= w) break;
-                w -= hist[b];
-                if (b == 0) break;
-            }
-            want = w; cut = b; ncand = 0;
+        // the bin in which the `want`-th best candidate lies: suffix sums of the histogram from the top, four waves (one thread
+        // walking the bins -- up to 256 dependent LDS reads in each of the 8-16 passes -- was half of this kernel's 64 us)
+        const unsigned want_in = want;  // read by every thread before the barrier, rewritten behind it
+        unsigned hb = 0, incl = 0;
+        if (tid < 256) {
+            hb = hist[255 - tid];
+            incl = si_wave_incl(hb, tid & 63);
+            if ((tid & 63) == 63) wtot[tid >> 6] = incl;
         }
+        __syncthreads();
+        if (tid < 256) {
+            for (int w = 0; w < (tid >> 6); w++) incl += wtot[w];
+            if (incl >= want_in && incl - hb < want_in) { cut = 255u - (unsigned)tid; want = want_in - (incl - hb); }
+        }
+        if (tid == 0) ncand = 0;
         __syncthreads();
         const unsigned cb = cut, keep_all = hist[cb] == want ? 1u : 0u;  // the whole bin is needed: no further pass
         if (!keep_all && hist[cb] == mc) {  // every candidate holds this byte (sign / exponent): nothing to part
@@ -1031,29 +1051,42 @@ __global__ void __launch_bounds__(SR_NT) surf_rank_select(SurfRankParams q)
         __syncthreads();
     }
     __syncthreads();
-    const unsigned m = min(nsel, lim);  // == lim
-    if (m <= min((unsigned)SR_SORT, q.sort_cap)) {
-        // up to SR_SORT selected records: bitonic sort of their positions in LDS, better first (all pairs -- below -- cost
+    // the records to rank: the winners (every one of them better than every open candidate) and, if the select stopped early,
+    // the open candidates; the best `m` of them in rank order are the result
+    const unsigned ns = nsel, m_all = ns + mc, m = min(m_all, lim);
+    if (m_all <= sort_limit) {
+        // up to SR_SORT records: bitonic sort of (score bits, key, record index) in LDS, better first (all pairs -- below -- cost
         // 10^6 comparisons in this one workgroup for the R default of 1000 points: ~80 us of the kernel's 140)
         unsigned N = 2;
-        while (N < m) N <<= 1;
+        while (N < m_all) N <<= 1;
         for (unsigned i = tid; i < N; i += SR_NT) {
-            if (i < m) { const SurfRecord &r = q.rec[q.sel[i]]; st_s[i] = surf_score_bits(r.score); st_k[i] = r.key; }
-            else { st_s[i] = 0ull; st_k[i] = ~0ull; }  // padding ranks after every record
-            perm[i] = i;
+            if (i < m_all) {
+                const unsigned idx = i < ns ? q.sel[i] : (ident ? i - ns : cur[i - ns]);
+                const SurfRecord &r = q.rec[idx];
+                sidx[i] = idx; st_s[i] = surf_score_bits(r.score); st_k[i] = r.key;
+            } else { sidx[i] = 0u; st_s[i] = 0ull; st_k[i] = ~0ull; }  // padding ranks after every record
         }
         __syncthreads();
+        // A thread's pair (lo, hi) lies in the block of 2j elements around it: for j <= 64 the 64 threads of a wave work on 128
+        // elements no other wave touches in that step -- and in every later step of the same merge -- so those steps need
+        // no workgroup barrier (program order inside the wave + a wave-scope fence); 10 barriers instead of 55 for 1024 records
         for (unsigned k = 2; k <= N; k <<= 1)
             for (unsigned j = k >> 1; j > 0; j >>= 1) {
                 for (unsigned t = tid; t < N / 2; t += SR_NT) {
                     const unsigned lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
-                    const unsigned a = perm[lo], b = perm[hi];
-                    const bool a_first = surf_better(st_s[a], st_k[a], st_s[b], st_k[b]);
-                    if (a_first != ((lo & k) == 0)) { perm[lo] = b; perm[hi] = a; }
+                    const unsigned long long sa = st_s[lo], sb = st_s[hi], ka = st_k[lo], kb = st_k[hi];
+                    if (surf_better(sa, ka, sb, kb) != ((lo & k) == 0)) {  // the composites themselves move (sorting positions
+                        st_s[lo] = sb; st_s[hi] = sa;                      // instead put two dependent, bank-conflicting reads
+                        st_k[lo] = kb; st_k[hi] = ka;                      // into every step)
+                        const unsigned ia = sidx[lo];
+                        sidx[lo] = sidx[hi]; sidx[hi] = ia;
+                    }
                 }
-                __syncthreads();
+                if (j > 64 || (j == 1 && k >= 128) || N / 2 > SR_NT) __syncthreads();  // (the merge after k = 128 starts with other waves' elements)
+                else sr_wave_sync();
             }
-        for (unsigned i = tid; i < m; i += SR_NT) q.order[i] = q.sel[perm[i]];
+        __syncthreads();
+        for (unsigned i = tid; i < m; i += SR_NT) q.order[i] = sidx[i];
     } else
     for (unsigned base = 0; base < m; base += SR_NT) {
         const unsigned i = base + tid;
@@ -1085,22 +1118,25 @@ __global__ void __launch_bounds__(SR_NT) surf_rank_select(SurfRankParams q)
             const long l = px - (long)bs / 2, t = py - (long)bs / 2, rr = l + (long)bs - 1, b = t + (long)bs - 1;
             keep = l >= 0 && t >= 0 && rr <= q.cols - 1 && b <= q.rows - 1;
         }
-        scan[tid] = keep ? 1u : 0u;
+        // positions: ballot inside the wave, the 16 wave totals through LDS (a Hillis-Steele scan over 1024 words took 20 barriers)
+        const unsigned long long km = __ballot(keep);
+        const int lane = (int)__lane_id(), wave = tid >> 6;
+        if (lane == 0) scan[wave] = (unsigned)__popcll(km);
         __syncthreads();
-        for (int d = 1; d < SR_NT; d <<= 1) {  // inclusive Hillis-Steele scan
-            const unsigned v = tid >= d ? scan[tid - d] : 0u;
-            __syncthreads();
-            scan[tid] += v;
-            __syncthreads();
+        unsigned before = carry, total = 0;
+        for (int w = 0; w < SR_NT / 64; w++) {
+            const unsigned c = scan[w];
+            if (w < wave) before += c;
+            total += c;
         }
         if (keep) {
-            const unsigned pos = carry + scan[tid] - 1;
+            const unsigned pos = before + (unsigned)__popcll(km & ((1ull << lane) - 1ull));
             q.pts[3 * pos] = r.x; q.pts[3 * pos + 1] = r.y; q.pts[3 * pos + 2] = r.scale;
             double *h = q.feat + (size_t)pos * 70;
             h[0] = r.x; h[1] = r.y; h[2] = 0.0; h[3] = r.scale; h[4] = r.score; h[5] = r.laplacian;
         }
         __syncthreads();
-        if (tid == SR_NT - 1) carry += scan[tid];
+        if (tid == 0) carry += total;
         __syncthreads();
     }
     if (tid == 0) { *q.count_out = (long long)carry; *q.m_out = carry; }

@@ -107,13 +107,15 @@ def test_upper_octaves_both_gather_forms(be, w, h):
 
 
 @pytest.mark.parametrize("max_points", [1, 9, 25])
-@pytest.mark.parametrize("sort_cap", [2048, 4])
+@pytest.mark.parametrize("sort_cap", [2048, 48, 4])
 def test_surf_dev_ranks_and_cuts_on_the_device(be, max_points, sort_cap):
     """imgfd_surf_dev orders the candidates on the device (radix select of the max_points best, rank, box test, compaction):
-    with fewer slots than candidates the strongest survive, in the reference's order"""
+    with fewer slots than candidates the strongest survive, in the reference's order.  sort_cap 2048: every candidate of these
+    frames goes straight into the LDS sort; 48: the radix select runs until winners + open candidates fit 48 slots, then the
+    sort ranks both together (what a 4096^2 tile does at 2048); 4: the select runs to the end, all-pairs ranking"""
     frames = np.stack([blobs(140 + f, 384, 256) for f in range(2)])
     try:
-        be.set_tuning("surf_sort_cap", sort_cap)   # 4: more than 4 selected records take the all-pairs ranking instead of the LDS sort
+        be.set_tuning("surf_sort_cap", sort_cap)
         got = be.surf_dev(frames, max_points=max_points, threshold=5.0)
     finally:
         be.set_tuning("surf_sort_cap", 2048)
