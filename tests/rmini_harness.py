@@ -30,7 +30,10 @@ class RPackage:
                                    "-I", os.path.join(ROOT, "r", "stub"), "-I", os.path.join(ROOT, "include"), *srcs,
                                    imgfd_lib_path, f"-Wl,-rpath,{os.path.dirname(imgfd_lib_path)}", "-lm", "-o", tmp])
             os.replace(tmp, so)
-        self.dll = d = C.CDLL(so)
+        # DEEPBIND: the glue's imgfd_* references bind to the library it was linked with, whatever else the process has loaded
+        # globally by then (a session that touched the product library first would otherwise hand the emulator's glue the
+        # product's imgfd_ctx_create)
+        self.dll = d = C.CDLL(so, mode=os.RTLD_NOW | os.RTLD_LOCAL | os.RTLD_DEEPBIND)
         vp = C.c_void_p
         for name, res, args in [("rmini_int_vector", vp, [vp, C.c_long]), ("rmini_real_vector", vp, [vp, C.c_long]),
                                 ("rmini_logical", vp, [C.c_int]), ("rmini_type", C.c_uint, [vp]), ("rmini_length", C.c_long, [vp]),
