@@ -89,6 +89,7 @@ SIGNATURES = {
     "imgfd_set_tuning": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "imgfd_get_counter": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
     "imgfd_k_fhog_lut": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "imgfd_k_fhog_lut_arith": (C.c_int, [C.c_void_p, C.c_void_p]),
     "imgfd_harris": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float,
                                C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_int, C.POINTER(Corners)]),

@@ -57,6 +57,7 @@ struct imgfd_ctx {
         int fhog_fused = 1;  // 1: cell_size 8 through fhog_hist8; 0: the three stage kernels
         int fhog_bands = 0;  // bands a workgroup of fhog_hist8 marches through (0: chosen from the batch size)
         int fhog_threads = 256;  // workgroup size of fhog_hist8 (256 | 512)
+        int fhog_arith = 32;     // fhog_hist8: a wave with >= this many lanes outside the table's LDS centre computes their words (0: always gathers)
         // round-1/2 experiment switches (formerly getenv() at their point of use)
         int hyst_sweeps = 0;        // Canny hysteresis: sweeps queued before the union-find kernel (0: 14 for batches, 8-9 for fewer than 8 frames)
         int hyst_words = 0;         // words per sweep tile: 2 or 4 (0: 2 for one or two frames, else 4)

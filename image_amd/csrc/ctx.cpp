@@ -11,6 +11,7 @@ const std::vector<TuneKey> &tune_keys()
         {"fhog_fused", "IMGFD_FHOG_FUSED", &imgfd_ctx::Tune::fhog_fused},
         {"fhog_bands", "IMGFD_FHOG_BANDS", &imgfd_ctx::Tune::fhog_bands},
         {"fhog_threads", "IMGFD_FHOG_THREADS", &imgfd_ctx::Tune::fhog_threads},
+        {"fhog_arith", "IMGFD_FHOG_ARITH", &imgfd_ctx::Tune::fhog_arith},
         {"hyst_sweeps", "IMGFD_HYST_SWEEPS", &imgfd_ctx::Tune::hyst_sweeps},
         {"hyst_words", "IMGFD_HYST_WORDS", &imgfd_ctx::Tune::hyst_words},
         {"canny_gate", "IMGFD_CANNY_GATE", &imgfd_ctx::Tune::canny_gate},

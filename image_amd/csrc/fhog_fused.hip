@@ -60,6 +60,19 @@ constexpr float FH_2P126 = 0x1p126f;
 constexpr int FH_CEN = 16;  // the LDS copy of the table covers gradients -16 .. 15 per axis (32 x 32 words)
 __device__ __forceinline__ unsigned fh_pack(float v, unsigned o) { return (max(__float_as_uint(v), FH_EXP_SHIFT) - FH_EXP_SHIFT) | (o << 27); }
 
+// The packed word of the gradient (tx, ty) without the table: the float chain of fhog_best_orientation decides like integer
+// arithmetic does -- k = the number of the four boundaries between neighbouring directions of the first quadrant that
+// (|tx|, |ty|) lies beyond (|ty| D_k > |tx| N_k with N_k / D_k = the differences of the 4-digit direction literals x 10^4),
+// mirrored into the other quadrants; ties and zero gradients fall where the chain's strict comparisons put them.  Equal to
+// the table for all 511 x 511 gradients (tests/test_fhog.py::test_fused_gradient_word_arithmetic_exhaustive).
+__device__ __forceinline__ unsigned fh_word_arith(int tx, int ty, int len)
+{
+    const unsigned ax = (unsigned)abs(tx), ay = (unsigned)abs(ty);  // <= 255: the products fit 24 bits
+    int k = (int)(ay * 3420u > ax * 603u) + (int)(ay * 3008u > ax * 1737u) + (int)(ay * 2232u > ax * 2660u) + (int)(ay * 1188u > ax * 3264u);
+    const int o = ty >= 0 ? (tx >= 0 ? k : 9 - k) : (tx > 0 ? (k ? 18 - k : 0) : 9 + k);
+    return fh_pack(sqrtf((float)len), (unsigned)o);
+}
+
 struct FhRows {
     int x;      // image column of the group's first pixel (multiple of 4, may lie outside the image)
     int col;    // its window column
@@ -73,7 +86,7 @@ struct FhRows {
 // [1, visible) vote 0, tail columns use the scalar colour rule.
 template <bool EDGE>
 __device__ __forceinline__ void fh_phase1(const unsigned *__restrict__ img, const unsigned *__restrict__ lut, const unsigned *lut_c,
-                                          unsigned *V, const FhogGeom &g, int rd, const FhRows it)
+                                          unsigned *V, const FhogGeom &g, int rd, const FhRows it, int arith_lanes)
 {
     const int d0 = 3 * (it.x / 4);  // dword of the group's first byte in its row
     int di[5];
@@ -109,7 +122,7 @@ __device__ __forceinline__ void fh_phase1(const unsigned *__restrict__ img, cons
     auto row = [&](const unsigned(&up)[5], const unsigned(&cen)[5], const unsigned(&dn)[5], int y) {
         const bool rowvalid = !EDGE || (y >= 1 && y < g.visible_nr);
         unsigned nw[4];
-        int txs[4], tys[4];
+        int txs[4], tys[4], lens[4];
         unsigned span = 0;
 #pragma unroll
         for (int p = 0; p < 4; p++) {
@@ -126,7 +139,7 @@ __device__ __forceinline__ void fh_phase1(const unsigned *__restrict__ img, cons
                 const bool take = ch == 0 || len > t - b;
                 tx = take ? gx : tx; ty = take ? gy : ty; t = take ? len : t;
             }
-            txs[p] = tx + FH_CEN; tys[p] = ty + FH_CEN;
+            txs[p] = tx + FH_CEN; tys[p] = ty + FH_CEN; lens[p] = t;
             span |= (unsigned)txs[p] | (unsigned)tys[p];
         }
         // a lane whose four gradients lie inside the table's centre reads them from LDS (masked indices: always in bounds);
@@ -135,7 +148,16 @@ __device__ __forceinline__ void fh_phase1(const unsigned *__restrict__ img, cons
 #pragma unroll
         for (int p = 0; p < 4; p++)
             nw[p] = lut_c[((unsigned)tys[p] & (2u * FH_CEN - 1u)) * (2 * FH_CEN) + ((unsigned)txs[p] & (2u * FH_CEN - 1u))];
-        if (span >= 2u * FH_CEN && it.live) {
+        const bool far = span >= 2u * FH_CEN && it.live;
+        // A wave with at least arith_lanes such lanes (switch "fhog_arith", 32) computes their words: the arithmetic (~40 VALU
+        // instructions per pixel) costs the same for one lane or 64, a gather's cost in the texture unit follows its lanes.
+        // Uniform noise, where every lane is outside: 112 -> 86.5 us per 4096^2 tile; the synthetic tile (75 us) takes the gathers.
+        if (arith_lanes > 0 && (int)__popcll(__ballot(far)) >= arith_lanes) {
+            if (far) {
+#pragma unroll
+                for (int p = 0; p < 4; p++) nw[p] = fh_word_arith(txs[p] - FH_CEN, tys[p] - FH_CEN, lens[p]);
+            }
+        } else if (far) {
 #pragma unroll
             for (int p = 0; p < 4; p++) nw[p] = lut[(unsigned)((tys[p] + 255 - FH_CEN) * 512 + (txs[p] + 255 - FH_CEN))];
         }
@@ -211,7 +233,8 @@ __device__ __forceinline__ void fh_vote_row(float *bins, const unsigned (&pw)[16
 template <int NT>
 __global__ void __launch_bounds__(NT) fhog_hist8(const unsigned char *__restrict__ rgb, size_t frame_stride,
                                                          const unsigned *__restrict__ lut, float *__restrict__ hist,
-                                                         float *__restrict__ norm, FhogGeom g, int bands_per_wg, int tiles_x, int xcd_order)
+                                                         float *__restrict__ norm, FhogGeom g, int bands_per_wg, int tiles_x, int xcd_order,
+                                                         int arith_lanes)
 {
     HIP_DYNAMIC_SHARED(unsigned, lds)
     unsigned *V = lds;
@@ -256,8 +279,8 @@ __global__ void __launch_bounds__(NT) fhog_hist8(const unsigned char *__restrict
             const int grp = tid & 31, seg = tid >> 5;
             it.x = x0 + 4 * grp; it.col = 4 * grp;
             it.wr = wr_main + seg * SEG_ROWS; it.y = Y0 + it.wr; it.nrows = SEG_ROWS;
-            if (edge) fh_phase1<true>(img, lut, lut_c, V, g, rd, it);
-            else fh_phase1<false>(img, lut, lut_c, V, g, rd, it);
+            if (edge) fh_phase1<true>(img, lut, lut_c, V, g, rd, it, arith_lanes);
+            else fh_phase1<false>(img, lut, lut_c, V, g, rd, it, arith_lanes);
             const int n_left = 2 * FH_NEW + (i ? 0 : FH_CS * (FH_WX / 4));
 #pragma unroll 1
             for (int first = 0; first < n_left; first += NT) {
@@ -266,8 +289,8 @@ __global__ void __launch_bounds__(NT) fhog_hist8(const unsigned char *__restrict
                 if (item < 2 * FH_NEW) { it.col = 128 + 4 * (item & 1); it.wr = wr_main + (item >> 1); }
                 else { const int u = item - 2 * FH_NEW; it.col = 4 * (u % (FH_WX / 4)); it.wr = u / (FH_WX / 4); }
                 it.x = x0 + it.col; it.y = Y0 + it.wr; it.nrows = 1;
-                if (edge) fh_phase1<true>(img, lut, lut_c, V, g, rd, it);
-                else fh_phase1<false>(img, lut, lut_c, V, g, rd, it);
+                if (edge) fh_phase1<true>(img, lut, lut_c, V, g, rd, it, arith_lanes);
+                else fh_phase1<false>(img, lut, lut_c, V, g, rd, it, arith_lanes);
             }
         }
         __syncthreads();
@@ -328,11 +351,12 @@ __global__ void __launch_bounds__(NT) fhog_hist8(const unsigned char *__restrict
 
 // lut[(ty + 255) * 512 + tx + 255] = the packed word of the gradient (tx, ty): v = sqrtf(tx^2 + ty^2) (the compiler's correctly
 // rounded sqrtf, fhog.h:871 / :929), o by the reference's float chain
-__global__ void __launch_bounds__(512) fhog_build_lut(unsigned *__restrict__ lut)
+// (arith: the same words from fh_word_arith -- the doorway imgfd_k_fhog_lut_arith, for the exhaustive comparison)
+__global__ void __launch_bounds__(512) fhog_build_lut(unsigned *__restrict__ lut, int arith)
 {
     const int tx = (int)threadIdx.x - 255, ty = (int)blockIdx.x - 255;
     unsigned w = 0;
-    if (tx <= 255) w = fh_pack(sqrtf((float)(tx * tx + ty * ty)), (unsigned)fhog_best_orientation(tx, ty));
+    if (tx <= 255) w = arith ? fh_word_arith(tx, ty, tx * tx + ty * ty) : fh_pack(sqrtf((float)(tx * tx + ty * ty)), (unsigned)fhog_best_orientation(tx, ty));
     lut[blockIdx.x * 512 + threadIdx.x] = w;
 }
 
@@ -350,7 +374,7 @@ static imgfd_status fhog_fused_init(imgfd_ctx *ctx)
     if (ctx->fhog_lut) return IMGFD_OK;
     void *p = nullptr;
     if (hipMalloc(&p, FHOG_LUT_BYTES) != hipSuccess) return imgfd_fail(ctx, IMGFD_ERR_OOM, "hipMalloc of the fHOG gradient table failed");
-    hipLaunchKernelGGL(fhog_build_lut, dim3(511), dim3(512), 0, ctx->stream, (unsigned *)p);
+    hipLaunchKernelGGL(fhog_build_lut, dim3(511), dim3(512), 0, ctx->stream, (unsigned *)p, 0);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)fhog_hist8<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FH_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void *)fhog_hist8<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FH_LDS);
@@ -376,9 +400,9 @@ imgfd_status fhog_fused_hist(imgfd_ctx *ctx, const uint8_t *d_rgb, size_t frame_
     bpw = std::min(bpw, n_bands);
     const dim3 grid((unsigned)tiles_x * (unsigned)ceil_div(n_bands, bpw), nf);
     if (ctx->tune.fhog_threads == 512)
-        hipLaunchKernelGGL(fhog_hist8<512>, grid, dim3(512), FH_LDS, ctx->stream, d_rgb, frame_stride, ctx->fhog_lut, hist, norm, g, bpw, tiles_x, ctx->tune.xcd_remap);
+        hipLaunchKernelGGL(fhog_hist8<512>, grid, dim3(512), FH_LDS, ctx->stream, d_rgb, frame_stride, ctx->fhog_lut, hist, norm, g, bpw, tiles_x, ctx->tune.xcd_remap, ctx->tune.fhog_arith);
     else
-        hipLaunchKernelGGL(fhog_hist8<256>, grid, dim3(256), FH_LDS, ctx->stream, d_rgb, frame_stride, ctx->fhog_lut, hist, norm, g, bpw, tiles_x, ctx->tune.xcd_remap);
+        hipLaunchKernelGGL(fhog_hist8<256>, grid, dim3(256), FH_LDS, ctx->stream, d_rgb, frame_stride, ctx->fhog_lut, hist, norm, g, bpw, tiles_x, ctx->tune.xcd_remap, ctx->tune.fhog_arith);
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }
@@ -392,6 +416,16 @@ imgfd_status imgfd_k_fhog_lut(imgfd_ctx *ctx, uint32_t *d_out)
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
     IMGFD_TRY(fhog_fused_init(ctx));
     IMGFD_HIP(ctx, hipMemcpyAsync(d_out, ctx->fhog_lut, FHOG_LUT_BYTES, hipMemcpyDeviceToDevice, ctx->stream));
+    return IMGFD_OK;
+}
+
+// the same 511 x 512 words computed by fh_word_arith (integer orientation rule): must equal imgfd_k_fhog_lut's bit for bit
+imgfd_status imgfd_k_fhog_lut_arith(imgfd_ctx *ctx, uint32_t *d_out)
+{
+    if (!ctx || !d_out) return IMGFD_ERR_INVALID;
+    IMGFD_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(fhog_build_lut, dim3(511), dim3(512), 0, ctx->stream, d_out, 1);
+    IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }
 

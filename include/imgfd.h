@@ -88,6 +88,9 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  *   "fhog_fused" [IMGFD_FHOG_FUSED]  1 (default): cell_size 8 runs the fused gradient + histogram kernel; 0: stage kernels
  *   "fhog_bands" [IMGFD_FHOG_BANDS]  bands of 8 cell rows one workgroup of that kernel marches through (0: from the batch)
  *   "fhog_threads" [IMGFD_FHOG_THREADS]  workgroup size of that kernel, 256 (default) or 512
+ *   "fhog_arith" [IMGFD_FHOG_ARITH]  a wave of that kernel with at least this many lanes whose gradients lie outside the
+ *                  table's LDS centre computes their (magnitude, bin) words instead of gathering them (default 32; 0: always
+ *                  gathers; same bits either way)
  *   "fir_mode" [IMGFD_FIR_MODE]  as imgfd_set_fir_mode
  *   "hyst_sweeps" [IMGFD_HYST_SWEEPS]  Canny hysteresis: sweeps queued before the union-find kernels (0: 14 for batches, 9-10 below 8 frames)
  *   "hyst_words" [IMGFD_HYST_WORDS]  words per tile of a sweep, 2 or 4 (0: 2 for one or two frames, else 4)
@@ -325,6 +328,9 @@ IMGFD_API imgfd_status imgfd_k_gauss_grad_u8(imgfd_ctx *ctx, const uint8_t *d_u8
  * (tx, ty): bits 0..26 = sqrtf(tx^2 + ty^2) with the exponent field lowered by 126 (0 for a zero gradient), bits 27..31 = the
  * orientation bin (fhog.h:846-859) */
 IMGFD_API imgfd_status imgfd_k_fhog_lut(imgfd_ctx *ctx, uint32_t *d_out);
+/* the same table computed without the float chain (integer orientation rule of fhog_fused.hip's fh_word_arith, what the
+ * fused kernel evaluates for waves with many large gradients, switch "fhog_arith"): equal to imgfd_k_fhog_lut's bit for bit */
+IMGFD_API imgfd_status imgfd_k_fhog_lut_arith(imgfd_ctx *ctx, uint32_t *d_out);
 /* K3: the structure-tensor pass, compute_autocorrelation_matrix harris.cpp:44-70:
  * reads Ix,Iy (8 B/px), writes the smoothed A,B,C (12 B/px) */
 IMGFD_API imgfd_status imgfd_k_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy, float *d_A,

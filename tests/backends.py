@@ -40,9 +40,10 @@ class _Base:
         self.check(self.lib.imgfd_get_counter(self.ctx, name.encode(), C.byref(v)), "imgfd_get_counter")
         return int(v.value)
 
-    def k_fhog_lut(self):
+    def k_fhog_lut(self, arith=False):
         out = self.empty((511, 512), np.uint32)
-        self.check(self.lib.imgfd_k_fhog_lut(self.ctx, self.ptr(out)), "k_fhog_lut")
+        fn = self.lib.imgfd_k_fhog_lut_arith if arith else self.lib.imgfd_k_fhog_lut
+        self.check(fn(self.ctx, self.ptr(out)), "k_fhog_lut")
         self.sync()
         return self.to_host(out)
 

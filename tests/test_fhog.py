@@ -102,6 +102,31 @@ def test_fused_gradient_table_exhaustive(be):
     assert want.max() < (1 << 27) and np.all((want >> 23)[v != 0] >= 1)  # a normal float after masking, never a denormal
 
 
+def test_fused_gradient_word_arithmetic_exhaustive(be):
+    """fh_word_arith (integer orientation rule + sqrtf: what the fused kernel evaluates for waves with many large gradients) gives the table's word
+    for every one of the 511 x 511 gradients"""
+    assert np.array_equal(be.k_fhog_lut(arith=True), be.k_fhog_lut())
+
+
+@pytest.mark.parametrize("lanes", [1, 24, 64])
+def test_fused_kernel_arithmetic_fallback(be, lanes):
+    """switch fhog_arith (default 32): waves with >= `lanes` lanes outside the table's LDS centre compute their words -- same bits
+    as the gathers (0), on noise (nearly every lane outside), a half-noise frame and the synthetic frame"""
+    rng = np.random.default_rng(77)
+    noise = rng.integers(0, 256, (200, 264, 3), dtype=np.uint8)
+    half = noise.copy(); half[100:] = 100 + (half[100:] & 7)
+    try:
+        for rgb in (noise, half, synth.frame_rgb(78, 264, 200)):
+            be.set_tuning("fhog_arith", 0)
+            want = be.fhog_dev(rgb[None], 8, 1, 1)[0]
+            be.set_tuning("fhog_arith", lanes)
+            got = be.fhog_dev(rgb[None], 8, 1, 1)[0]
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+            assert np.array_equal(want.view(np.uint32), oracle.fhog(rgb, 8, 1, 1).view(np.uint32))
+    finally:
+        be.set_tuning("fhog_arith", 32)
+
+
 @pytest.mark.parametrize("bands,nt", [(1, 256), (2, 512), (3, 256), (0, 512)])
 @pytest.mark.parametrize("w,h", [(264, 200), (1032, 520), (136, 72), (264, 1100), (252, 131)])
 def test_fused_kernel_shapes(be, w, h, bands, nt):
