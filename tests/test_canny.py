@@ -95,6 +95,16 @@ def test_thresholds_are_int_truncated(be):
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("low,high", [(0, 0), (3, 3), (10, 3), (-5, 2), (-3.7, -1.2), (0.9, 0.9), (200, 300), (0, 1e9)])
+def test_unusual_thresholds_follow_the_reference(be, low, high):
+    """thresholds the R interface does not forbid: equal, crossed (low > high), negative (truncated toward zero like the int
+    cast of rcpp_canny.cpp:180), zero, beyond every magnitude -- `now <= low` rejects, `now >= high` marks strong (:98-104)"""
+    img = synth.frame(23, 150, 110)
+    edges, n = be.canny(img, low_thr=low, high_thr=high)
+    ref, rn = oracle.canny(img, low_thr=low, high_thr=high)
+    assert n == rn and np.array_equal(edges, ref), (low, high, n, rn)
+
+
 def test_hysteresis_long_chain(be):
     """a weak edge across many 64-pixel words must light up from its strong left end: the contrast of a (slightly
     slanted) step decays smoothly along x -- one unbroken line whose left end alone is above the high threshold.  The step

@@ -112,7 +112,11 @@ needs_ref_canny = pytest.mark.skipif(not oracle.have_ref("canny"), reason="oracl
 @needs_ref_canny
 @pytest.mark.parametrize("nx,ny,kw", [(160, 120, {}), (200, 131, dict(accGrad=False)), (97, 64, dict(s=3.5)),
                                       (131, 90, dict(s=1.0, low_thr=2, high_thr=6)), (64, 64, dict(s=0.7, low_thr=0, high_thr=1)),
-                                      (33, 47, dict(s=5.0, low_thr=0.5, high_thr=2.5)), (16, 9, {})])
+                                      (33, 47, dict(s=5.0, low_thr=0.5, high_thr=2.5)), (16, 9, {}),
+                                      # thresholds the interface does not forbid: crossed, negative, equal, beyond every magnitude
+                                      (90, 70, dict(low_thr=10, high_thr=3)), (90, 70, dict(low_thr=-5, high_thr=2)),
+                                      (90, 70, dict(low_thr=-3.7, high_thr=-1.2)), (90, 70, dict(low_thr=3, high_thr=3)),
+                                      (90, 70, dict(low_thr=200, high_thr=300))])
 def test_canny_restatement_matches_reference(nx, ny, kw):
     img = synth.frame(60 + nx, max(nx, 16), max(ny, 16), n_rect=9)[:ny, :nx]
     ref_e, ref_n = oracle.ref_canny(img, **kw)
