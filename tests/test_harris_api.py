@@ -131,3 +131,25 @@ def test_batch_dev_tile_borders(be):
         lists, counts = be.harris_dev(img[None], threshold=1.0)
         ref = oracle.harris(img.astype(np.float32), threshold=1.0)
         assert counts[0] == len(ref) and np.array_equal(bits(lists[0]), bits(ref)), (nx, ny)
+
+
+UNUSUAL = [dict(k=0.0, threshold=1.0), dict(k=-0.05, threshold=1.0), dict(k=0.25, threshold=0.0), dict(threshold=-10.0),
+           dict(sigma_i=0.5, threshold=1.0), dict(sigma_i=0.3, threshold=1.0), dict(sigma_d=0.3, threshold=1.0), dict(sigma_d=0.0, threshold=1.0),
+           dict(strategy=2, Nselect=100000, threshold=1.0), dict(strategy=2, Nselect=0, threshold=1.0), dict(strategy=1, Nselect=3, threshold=1.0),
+           dict(strategy=3, Nselect=7, cells=1, threshold=1.0), dict(strategy=3, Nselect=500, cells=200, threshold=1.0),
+           dict(strategy=3, Nselect=0, cells=4, threshold=1.0),
+           dict(Nscales=6, threshold=1.0), dict(Nscales=6, gaussian=1, precision=2, threshold=1.0), dict(Nscales=0, threshold=1.0),
+           dict(gaussian=2, gradient=1, measure=1, precision=1, threshold=0.5), dict(gaussian=1, gradient=1, measure=2, precision=2, threshold=0.1),
+           dict(measure=2, threshold=0.0), dict(gaussian=1, sigma_d=3.0, sigma_i=6.0, threshold=0.01)]
+
+
+@pytest.mark.parametrize("kw", UNUSUAL, ids=[",".join(f"{k}={v}" for k, v in d.items()) for d in UNUSUAL])
+def test_unusual_parameters_follow_the_reference(be, kw):
+    """parameter values at and beyond the edges of what image_harris() documents -- zero / negative k and threshold, sigmas
+    that give the smallest Gaussian radius, selections that ask for more corners or cells than there are, more scales than
+    the frame has octaves -- through imgfd_harris in strict mode: the restated reference's list, bit for bit"""
+    img = synth.frame(41, 96, 72).astype(np.float32)
+    be.set_fir_mode(0)
+    got = be.harris(img, **kw)
+    ref = oracle.harris(img, **kw)
+    assert got.shape == ref.shape and np.array_equal(bits(got), bits(ref)), (kw, len(got), len(ref))

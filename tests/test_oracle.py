@@ -205,3 +205,15 @@ def test_canny_hysteresis_is_connected_components():
     keep[0] = False
     assert np.array_equal(edges > 0, keep[lab])
     assert n == int(np.count_nonzero(edges))
+
+
+@pytest.mark.skipif(not oracle.have_ref("harris"), reason="oracle/_ref/libref_harris.so not built (needs /root/reference)")
+def test_harris_restatement_matches_reference_on_unusual_parameters():
+    """the parameter sets of tests/test_harris_api.py::test_unusual_parameters_follow_the_reference (zero / negative k and
+    threshold, minimal sigmas, selections larger than the corner list, more scales than octaves ...) through the reference
+    compiled in place and through its restatement: the same lists, bit for bit"""
+    from test_harris_api import UNUSUAL
+    img = synth.frame(41, 96, 72).astype(np.float32)
+    for kw in UNUSUAL:
+        a, b = oracle.harris(img, **kw), oracle.ref_harris(img, threads=1, **kw)
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), kw
