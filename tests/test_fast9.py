@@ -56,3 +56,19 @@ def test_batch_dev(be):
         for f in range(4):
             ref = oracle.fast9(frames[f], 20, nms)
             assert counts[f] == len(ref) and np.array_equal(lists[f], ref)
+
+
+@pytest.mark.parametrize("kind", ["zeros", "full", "checker", "noise", "steps"])
+def test_extreme_images(be, kind):
+    """flat black / white frames (no corner, whatever the threshold), a one-pixel checkerboard, uniform noise at the lowest
+    thresholds (a corner at nearly every pixel: the candidate lists fill up) and saturated steps: the reference's points in
+    the reference's order"""
+    w, h = 150, 97
+    rng = np.random.default_rng(5)
+    img = {"zeros": np.zeros((h, w), np.uint8), "full": np.full((h, w), 255, np.uint8),
+           "checker": ((np.add.outer(np.arange(h), np.arange(w)) & 1) * 255).astype(np.uint8),
+           "noise": rng.integers(0, 256, (h, w)).astype(np.uint8),
+           "steps": np.repeat(np.repeat(rng.integers(0, 2, (h // 8 + 1, w // 8 + 1)) * 255, 8, 0), 8, 1)[:h, :w].astype(np.uint8)}[kind]
+    for thr in (0, 1, 127, 254, 255):
+        for nms in (False, True):
+            assert np.array_equal(be.fast9(img, thr, nms), oracle.fast9(img, thr, nms)), (kind, thr, nms)

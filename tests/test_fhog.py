@@ -25,6 +25,18 @@ def test_matches_oracle(be, w, h, cs, pr, pc):
     check(be.fhog(rgb, cs, pr, pc), oracle.fhog(rgb, cs, pr, pc))
 
 
+@pytest.mark.parametrize("w,h,cs,pr,pc", [(96, 80, 32, 1, 1), (96, 80, 40, 1, 1), (96, 80, 64, 1, 1), (71, 53, 3, 1, 1), (71, 53, 7, 9, 9),
+                                          (64, 64, 8, 12, 1), (33, 90, 11, 2, 5)])
+def test_unusual_cell_sizes_and_paddings(be, w, h, cs, pr, pc):
+    """cells as large as the image allows (and larger: an empty array, fhog.h:780-790), odd cell sizes, paddings wider than the
+    feature map -- on noise (every orientation, colour ties)"""
+    rgb = np.random.default_rng(w + cs).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    got, ref = be.fhog(rgb, cs, pr, pc), oracle.fhog(rgb, cs, pr, pc)
+    assert got.shape == ref.shape
+    if ref.size:
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
 @pytest.mark.parametrize("w,h,pr,pc", [(64, 48, 1, 1), (67, 35, 1, 1), (40, 30, 3, 2), (3, 3, 1, 1), (130, 17, 1, 1)])
 def test_cell_size_1(be, w, h, pr, pc):
     """dlib's special case impl_extract_fhog_features_cell_size_1 (fhog.h:499-694)"""

@@ -103,6 +103,21 @@ def test_fast9_against_compiled_reference():
                 assert np.array_equal(oracle.fast9(img, thr, nms), oracle.ref_fast9(img, thr, nms)), (i, thr, nms)
 
 
+@needs_ref
+def test_fast9_extreme_images_against_compiled_reference():
+    """the frames of tests/test_fast9.py::test_extreme_images (flat, checkerboard, noise, saturated steps) at thresholds 0, 1,
+    127, 254, 255"""
+    w, h = 150, 97
+    rng = np.random.default_rng(5)
+    imgs = [np.zeros((h, w), np.uint8), np.full((h, w), 255, np.uint8),
+            ((np.add.outer(np.arange(h), np.arange(w)) & 1) * 255).astype(np.uint8), rng.integers(0, 256, (h, w)).astype(np.uint8),
+            np.repeat(np.repeat(rng.integers(0, 2, (h // 8 + 1, w // 8 + 1)) * 255, 8, 0), 8, 1)[:h, :w].astype(np.uint8)]
+    for i, img in enumerate(imgs):
+        for thr in (0, 1, 127, 254, 255):
+            for nms in (False, True):
+                assert np.array_equal(oracle.fast9(img, thr, nms), oracle.ref_fast9(img, thr, nms)), (i, thr, nms)
+
+
 # ------------------------------------------------------------------ Canny
 # pinned by the reference's own rcpp_canny.cpp + tools.c + adsf.c compiled in place (oracle/_ref/libref_canny.so); FFTW3,
 # which the reference links but does not vendor, is replaced by the plain DFT of oracle/fftw_stub.c

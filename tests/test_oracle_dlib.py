@@ -20,6 +20,16 @@ def test_fhog_restatement_is_bit_identical_to_dlib(w, h, cs, pr, pc):
 
 
 @needs_ref
+@pytest.mark.parametrize("w,h,cs,pr,pc", [(96, 80, 32, 1, 1), (96, 80, 40, 1, 1), (96, 80, 64, 1, 1), (71, 53, 3, 1, 1), (71, 53, 7, 9, 9),
+                                          (64, 64, 8, 12, 1), (33, 90, 11, 2, 5)])
+def test_fhog_restatement_unusual_cell_sizes_and_paddings(w, h, cs, pr, pc):
+    """the parameter sets of tests/test_fhog.py::test_unusual_cell_sizes_and_paddings, on the same noise"""
+    rgb = np.random.default_rng(w + cs).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    a, b = oracle.ref_fhog(rgb, cs, pr, pc), oracle.fhog(rgb, cs, pr, pc)
+    assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@needs_ref
 @pytest.mark.parametrize("w,h,pr,pc", [(64, 48, 1, 1), (67, 35, 1, 1), (40, 30, 3, 2), (3, 3, 1, 1), (2, 5, 1, 1), (130, 17, 1, 1)])
 def test_fhog_cell_size_1_restatement_is_bit_identical_to_dlib(w, h, pr, pc):
     rgb = synth.frame_rgb(4, max(w, 16), max(h, 16))[:h, :w]
