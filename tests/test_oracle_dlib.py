@@ -73,6 +73,25 @@ def test_surf_restatement_is_bit_identical_to_dlib(seed, w, h, thr):
             assert x[k].shape == y[k].shape and np.array_equal(x[k], y[k]), (k, mp)
 
 
+@needs_ref
+@pytest.mark.parametrize("kind", ["zeros", "full", "noise", "checker8", "gray_ramp"])
+def test_surf_restatement_on_extreme_images(kind):
+    """the frames of tests/test_surf.py::test_extreme_images through dlib compiled in place and through the restatement"""
+    w, h = 200, 152
+    rng = np.random.default_rng(6)
+    ramp = np.clip(np.add.outer(np.arange(h), np.arange(w)) // 2, 0, 255).astype(np.uint8)
+    rgb = {"zeros": np.zeros((h, w, 3), np.uint8), "full": np.full((h, w, 3), 255, np.uint8),
+           "noise": rng.integers(0, 256, (h, w, 3), dtype=np.uint8),
+           "checker8": np.repeat(((np.add.outer(np.arange(h) // 8, np.arange(w) // 8) & 1) * 255).astype(np.uint8)[:, :, None], 3, axis=2),
+           "gray_ramp": np.repeat(ramp[:, :, None], 3, axis=2)}[kind]
+    for thr, max_points in ((0.0, 10000), (30.0, 7), (1e9, 1000)):
+        a, b = oracle.surf_interest_points(rgb, thr), oracle.surf_interest_points(rgb, thr, use_ref=True)
+        assert a.shape == b.shape and np.array_equal(a, b), (kind, thr)
+        x, y = oracle.surf(rgb, max_points, thr), oracle.surf(rgb, max_points, thr, use_ref=True)
+        for k in y:
+            assert x[k].shape == y[k].shape and np.array_equal(x[k], y[k], equal_nan=True), (kind, thr, k)
+
+
 def test_surf_golden(golden):
     g = golden("surf_cruise_boat")
     got = oracle.surf(g["image"], 1000, 30.0)

@@ -65,6 +65,26 @@ def test_surf_points_and_descriptors_exact(be, max_points, thr):
         assert np.array_equal(got[k], ref[k]), k
 
 
+@pytest.mark.parametrize("kind", ["zeros", "full", "noise", "checker8", "gray_ramp"])
+def test_extreme_images(be, kind):
+    """flat frames (no interest point at any threshold), uniform noise at threshold 0 (every local maximum of the determinant
+    is a point: thousands on a small frame), an 8-pixel checkerboard (exact ties everywhere), a gray ramp: points and
+    descriptors as the restated reference has them"""
+    w, h = 200, 152
+    rng = np.random.default_rng(6)
+    ramp = np.clip(np.add.outer(np.arange(h), np.arange(w)) // 2, 0, 255).astype(np.uint8)
+    rgb = {"zeros": np.zeros((h, w, 3), np.uint8), "full": np.full((h, w, 3), 255, np.uint8),
+           "noise": rng.integers(0, 256, (h, w, 3), dtype=np.uint8),
+           "checker8": np.repeat(((np.add.outer(np.arange(h) // 8, np.arange(w) // 8) & 1) * 255).astype(np.uint8)[:, :, None], 3, axis=2),
+           "gray_ramp": np.repeat(ramp[:, :, None], 3, axis=2)}[kind]
+    for thr, max_points in ((0.0, 10000), (30.0, 7), (1e9, 1000)):
+        p, rp = be.surf_interest_points(rgb, thr), oracle.surf_interest_points(rgb, thr)
+        assert p.shape == rp.shape and np.array_equal(p, rp), (kind, thr)
+        got, ref = be.surf(rgb, max_points, thr), oracle.surf(rgb, max_points, thr)
+        for k in ("x", "y", "pyramid_scale", "score", "laplacian", "angle", "surf"):
+            assert got[k].shape == ref[k].shape and np.array_equal(got[k], ref[k], equal_nan=True), (kind, thr, k)
+
+
 def test_batch_points_dev(be):
     frames = np.stack([blobs(95 + f, 256, 192) for f in range(3)])
     lists, counts = be.surf_points_dev(frames, 10.0)
