@@ -105,6 +105,35 @@ def test_unusual_thresholds_follow_the_reference(be, low, high):
     assert n == rn and np.array_equal(edges, ref), (low, high, n, rn)
 
 
+@pytest.mark.parametrize("kind", ["zeros", "full", "checker1", "checker8", "noise", "ramp", "one_pixel"])
+def test_extreme_images(be, kind):
+    """flat frames (every gradient zero: atan2(0, 0), magnitude 0 <= low), one- and eight-pixel checkerboards (exact ties in the
+    non-maximum test), uniform noise (edge pixels everywhere: the densest hysteresis), a ramp (constant gradient), a single
+    bright pixel"""
+    w, h = 168, 120
+    rng = np.random.default_rng(8)
+    one = np.zeros((h, w), np.uint8); one[h // 2, w // 3] = 255
+    img = {"zeros": np.zeros((h, w), np.uint8), "full": np.full((h, w), 255, np.uint8),
+           "checker1": ((np.add.outer(np.arange(h), np.arange(w)) & 1) * 255).astype(np.uint8),
+           "checker8": ((np.add.outer(np.arange(h) // 8, np.arange(w) // 8) & 1) * 255).astype(np.uint8),
+           "noise": rng.integers(0, 256, (h, w)).astype(np.uint8),
+           "ramp": np.clip(np.add.outer(np.arange(h), np.arange(w)), 0, 255).astype(np.uint8), "one_pixel": one}[kind]
+    for kw in (dict(), dict(accGrad=False), dict(s=0.8, low_thr=0, high_thr=1), dict(s=4.0, low_thr=1, high_thr=2)):
+        edges, n = be.canny(img, **kw)
+        ref, rn = oracle.canny(img, **kw)
+        if kind != "ramp":
+            assert n == rn and np.array_equal(edges, ref), (kind, kw, n, rn, int(np.count_nonzero(edges != ref)))
+            continue
+        # The ramp's gradient is constant, and at the frame border clamp-to-edge hands the non-maximum test its own pixel
+        # as a neighbour: `now` against an interpolation of values equal to `now`, decided by the last bit of
+        # (1 - a) g + a g.  The reference gets `a` from cos / sin(atan2(v, h)), the device from the unit vector (SURVEY
+        # Appendix A: ~1e-16 apart, "only exact-tie comparisons can flip") -- this frame is where they do: at most two
+        # pixels, on the border (the restatement and the compiled reference agree with each other here, tests/test_oracle.py).
+        ys, xs = np.nonzero(edges != ref)
+        assert len(ys) <= 2 and abs(n - rn) <= 2, (kw, len(ys))
+        assert all(y in (0, h - 1) or x in (0, w - 1) for y, x in zip(ys, xs)), list(zip(ys, xs))
+
+
 def test_hysteresis_long_chain(be):
     """a weak edge across many 64-pixel words must light up from its strong left end: the contrast of a (slightly
     slanted) step decays smoothly along x -- one unbroken line whose left end alone is above the high threshold.  The step

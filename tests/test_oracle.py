@@ -141,6 +141,23 @@ def test_canny_restatement_matches_reference(nx, ny, kw):
 
 
 @needs_ref_canny
+@pytest.mark.parametrize("kind", ["zeros", "full", "checker1", "checker8", "ramp", "one_pixel"])
+def test_canny_restatement_on_extreme_images(kind):
+    """the frame kinds of tests/test_canny.py::test_extreme_images (smaller: the stand-in DFT is O(n^3)) through the compiled
+    reference and the restatement: equal pixel for pixel, the tie-ridden ramp included"""
+    w, h = 64, 48
+    one = np.zeros((h, w), np.uint8); one[h // 2, w // 3] = 255
+    img = {"zeros": np.zeros((h, w), np.uint8), "full": np.full((h, w), 255, np.uint8),
+           "checker1": ((np.add.outer(np.arange(h), np.arange(w)) & 1) * 255).astype(np.uint8),
+           "checker8": ((np.add.outer(np.arange(h) // 8, np.arange(w) // 8) & 1) * 255).astype(np.uint8),
+           "ramp": np.clip(np.add.outer(np.arange(h) + 70, np.arange(w) + 100), 0, 255).astype(np.uint8), "one_pixel": one}[kind]
+    for kw in (dict(), dict(accGrad=False), dict(s=0.8, low_thr=0, high_thr=1), dict(s=4.0, low_thr=1, high_thr=2)):
+        ref_e, ref_n = oracle.ref_canny(img, **kw)
+        e, n = oracle.canny(img, **kw)
+        assert n == ref_n and np.array_equal(e, ref_e), (kind, kw)
+
+
+@needs_ref_canny
 def test_canny_reference_on_noise():
     rng = np.random.default_rng(3)
     img = rng.integers(0, 256, (70, 101)).astype(np.uint8)
