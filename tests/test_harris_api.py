@@ -153,3 +153,29 @@ def test_unusual_parameters_follow_the_reference(be, kw):
     got = be.harris(img, **kw)
     ref = oracle.harris(img, **kw)
     assert got.shape == ref.shape and np.array_equal(bits(got), bits(ref)), (kw, len(got), len(ref))
+
+
+def extreme_frames(w=160, h=120):
+    rng = np.random.default_rng(9)
+    return {"zeros": np.zeros((h, w), np.float32), "full": np.full((h, w), 255, np.float32),
+            "checker8": ((np.add.outer(np.arange(h) // 8, np.arange(w) // 8) & 1) * 255).astype(np.float32),
+            "checker1": ((np.add.outer(np.arange(h), np.arange(w)) & 1) * 255).astype(np.float32),
+            "noise": rng.integers(0, 256, (h, w)).astype(np.float32),
+            "ramp": np.clip(np.add.outer(np.arange(h), np.arange(w)), 0, 255).astype(np.float32),
+            "steps": np.repeat(np.repeat(rng.integers(0, 2, (h // 8, w // 8)) * 255, 8, 0), 8, 1).astype(np.float32)}
+
+
+EXTREME_KW = (dict(threshold=1.0), dict(threshold=1.0, gaussian=1, precision=1), dict(threshold=0.001, measure=1))
+
+
+@pytest.mark.parametrize("kind", ["zeros", "full", "checker8", "checker1", "noise", "ramp", "steps"])
+def test_extreme_images(be, kind):
+    """flat frames and a ramp (no corner), a one-pixel checkerboard (the smoothing erases it), an 8-pixel checkerboard and random
+    8-pixel steps (a lattice of equally strong corners: exact ties of the response in rows and columns), noise: the restated
+    reference's corners, bit for bit, in strict mode"""
+    img = extreme_frames()[kind]
+    be.set_fir_mode(0)
+    for kw in EXTREME_KW:
+        got, ref = be.harris(img, **kw), oracle.harris(img, **kw)
+        assert got.shape == ref.shape and np.array_equal(bits(got), bits(ref)), (kind, kw, len(got), len(ref))
+    assert kind not in ("checker8", "steps", "noise") or len(ref) > 50

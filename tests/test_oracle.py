@@ -249,3 +249,14 @@ def test_harris_restatement_matches_reference_on_unusual_parameters():
     for kw in UNUSUAL:
         a, b = oracle.harris(img, **kw), oracle.ref_harris(img, threads=1, **kw)
         assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), kw
+
+
+@pytest.mark.skipif(not oracle.have_ref("harris"), reason="oracle/_ref/libref_harris.so not built (needs /root/reference)")
+def test_harris_restatement_matches_reference_on_extreme_images():
+    """the frames of tests/test_harris_api.py::test_extreme_images (flat, checkerboards, steps, ramp, noise) through the
+    reference compiled in place (one thread: its NMS is schedule-dependent on ties) and through its restatement"""
+    from test_harris_api import EXTREME_KW, extreme_frames
+    for kind, img in extreme_frames().items():
+        for kw in EXTREME_KW:
+            a, b = oracle.harris(img, **kw), oracle.ref_harris(img, threads=1, **kw)
+            assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (kind, kw)
