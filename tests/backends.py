@@ -345,8 +345,10 @@ class EmuBackend(_Base):
     name = "emu"
 
     def __init__(self):
-        path = os.path.join(ROOT, "tests", "hipemu", "libimgfd_emu.so")
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "image_amd", "csrc"), "emu"])
+        path = os.environ.get("IMGFD_EMU_LIB")   # e.g. a sanitizer build of the same sources (scripts/asan_emu.sh)
+        if not path:
+            path = os.path.join(ROOT, "tests", "hipemu", "libimgfd_emu.so")
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "image_amd", "csrc"), "emu"])
         super().__init__(_binding.bind(C.CDLL(path), strict=False))
 
     def to_dev(self, a):
