@@ -65,7 +65,7 @@ struct imgfd_ctx {
         int gauss_march = 1;        // u8 frames whose width is a multiple of 16: the marching Gaussian + gradient kernel (0: the tile kernel)
         int gauss_march_seg = 0;    // rows per segment of that kernel (0: from the batch)
         int harris_gate = 1;        // imgfd_detect_dev: the Harris chain is released behind Canny's gradient/NMS kernel (1), behind its blur (2), or together with FAST-9 (0)
-        int canny_gate = 0;         // imgfd_detect_dev: where Canny releases the second stream (0 before the blur, 1 after it, 2 after gradient/NMS)
+        int canny_gate = -1;        // imgfd_detect_dev: where Canny releases FAST-9 on the other stream (0 before the blur, 1 after it, 2 after gradient/NMS; -1: 2 for a single frame, else 0)
         int xcd_remap = 1;          // marching FIR kernels: workers of one XCD own neighbouring tiles
         int fused_response = 1;     // Harris: corner response in the structure-tensor kernel's epilogue
         int nms_tiled = 0;          // Harris batch path: 1 = the tiled NMS kernel instead of the sparse one

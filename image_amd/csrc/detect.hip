@@ -67,7 +67,10 @@ imgfd_status detect_body(imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_str
     // (Round 2 got this order by accident: the 16-wave rows_scan workgroup of FAST-9's compaction found no CU with 16 free
     // wave slots until the gradient/NMS kernel had drained.  Released together with FAST-9: 43.5 instead of 40.3 ms per
     // 10 passes of 32 4K frames, profiles/r03/experiments_log.txt.)
-    const int fast_at = ctx->tune.canny_gate == 1 ? 1 : (ctx->tune.canny_gate == 0 ? 0 : 2);
+    // (a single frame: FAST-9 too waits for gradient/NMS -- beside the blur it only delays the frame's critical path, the Canny
+    // chain: 0.236 -> 0.230 ms per 4K frame; from two frames on it fills the blur's gaps: profiles/r04/xcd_tile_order.txt)
+    const int cg = ctx->tune.canny_gate < 0 ? (B == 1 ? 2 : 0) : ctx->tune.canny_gate;
+    const int fast_at = cg == 1 ? 1 : (cg == 0 ? 0 : 2);
     const int harris_at = ctx->tune.harris_gate == 0 ? fast_at : (ctx->tune.harris_gate == 2 ? 1 : 2);
     const std::function<imgfd_status(int)> hook = [&](int pos) -> imgfd_status {  // pos: 0 before Canny's blur, 1 behind it, 2 behind gradient/NMS
         if (pos == fast_at) {

@@ -94,7 +94,8 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  *   "fir_mode" [IMGFD_FIR_MODE]  as imgfd_set_fir_mode
  *   "hyst_sweeps" [IMGFD_HYST_SWEEPS]  Canny hysteresis: sweeps queued before the union-find kernels (0: 14 for batches, 9-10 below 8 frames)
  *   "hyst_words" [IMGFD_HYST_WORDS]  words per tile of a sweep, 2 or 4 (0: 2 for one or two frames, else 4)
- *   "canny_gate" [IMGFD_CANNY_GATE]  imgfd_detect_dev: where Canny releases the second stream (0 before the blur, 1, 2)
+ *   "canny_gate" [IMGFD_CANNY_GATE]  imgfd_detect_dev: where Canny releases FAST-9 on the other stream (0 before the blur,
+ *                  1 behind it, 2 behind gradient/NMS; -1, default: 2 for a single frame, else 0)
  *   "harris_gate" [IMGFD_HARRIS_GATE]  imgfd_detect_dev: 1 (default) the Harris chain starts behind Canny's gradient/NMS kernel
  *                                      (FAST-9 starts with the blur); 2: behind the blur; 0: together with FAST-9
  *   "gauss_march" [IMGFD_GAUSS_MARCH]  1 (default): u8 frames whose width is a multiple of 16 (>= 256) take the marching
