@@ -24,6 +24,8 @@
 //                carry-propagation trick (m & ~(m+p)).  Tiles iterate to a local fixpoint in registers;
 //                launches repeat until a whole sweep changes nothing (later sweeps of a round exit at
 //                once when the previous one was idle, so one host read-back covers a round).
+// the blurred plane and the edge map go out with streaming stores (imgfd_canny_dev on 32 4K frames: 1.916 -> 1.904 ms)
+#define IMGFD_NT_OUT 1
 #include "common.h"
 
 #include <math.h>
@@ -292,7 +294,7 @@ __global__ void __launch_bounds__(BM_NT) canny_blur_march(BlurMarchParams p)
 #pragma unroll
                     for (int o = 0; o < BM_PX; o++) {
                         const int oi = oi0 + o;
-                        if (oi >= 0 && oi < nrows) out[(size_t)(y0 + oi) * p.nx + gx] = (float)acc[o];
+                        if (oi >= 0 && oi < nrows) IMGFD_OUT_STORE((float)acc[o], &out[(size_t)(y0 + oi) * p.nx + gx]);
                     }
                 }
             }
@@ -908,7 +910,8 @@ __global__ void __launch_bounds__(256) canny_expand_count(const unsigned long lo
             for (int k = 0; k < 4; k++) v[k] = ((((bits >> (4 * k)) & 0xfu) * 0x00204081u) & 0x01010101u) * 0xffu;
             unsigned char *dst = edges + ((size_t)blockIdx.y * ny + y) * nx + x;
             if (vec) {
-                *reinterpret_cast<uint4 *>(dst) = make_uint4(v[0], v[1], v[2], v[3]);
+                typedef unsigned v4u __attribute__((vector_size(16)));
+                IMGFD_OUT_STORE((v4u{v[0], v[1], v[2], v[3]}), reinterpret_cast<v4u *>(dst));
             } else {
                 for (int k = 0; k < 16 && x + k < nx; k++) dst[k] = (unsigned char)(v[k >> 2] >> (8 * (k & 3)));
             }

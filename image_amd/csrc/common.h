@@ -146,6 +146,16 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 // streaming (non-temporal) store: data the kernel itself will not read again
 #define IMGFD_STREAM_STORE(value, ptr) __builtin_nontemporal_store((value), (ptr))
+// a kernel's big output plane (read next by another kernel, from HBM: a batch's planes exceed every cache): streaming when
+// IMGFD_NT_OUT is set for the translation unit
+#ifndef IMGFD_NT_OUT
+#define IMGFD_NT_OUT 0
+#endif
+#if IMGFD_NT_OUT
+#define IMGFD_OUT_STORE(value, ptr) __builtin_nontemporal_store((value), (ptr))
+#else
+#define IMGFD_OUT_STORE(value, ptr) (*(ptr) = (value))
+#endif
 // The one place where the device build and the host-side emulator build of the tests (HIPEMU, tests/hipemu: the same
 // sources compiled by g++) part over compiler-specific syntax; gfx950 builtins are emulated in tests/hipemu/hip/hip_runtime.h.
 #ifdef HIPEMU
