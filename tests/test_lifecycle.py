@@ -47,3 +47,39 @@ def test_context_cycles_leave_no_device_memory_behind():
     assert before - after < 8 << 20, f"{(before - after) / 2**20:.1f} MiB of device memory lost over 25 context cycles"
     # host side: result vectors (imgfd_free), pinned staging buffers, companion contexts
     assert rss1 - rss0 < 64 << 20, f"{(rss1 - rss0) / 2**20:.1f} MiB of host memory gained over 25 context cycles"
+
+
+def test_contexts_on_concurrent_host_threads():
+    """a context is thread-compatible: four host threads, each with its own context, run the five functions at once (ctypes
+    drops the GIL inside the calls) -- every result as if it had run alone"""
+    import threading
+    import oracle
+    from image_amd import api, _lib
+    imgs = [synth.frame(20 + t, 320 + 16 * t, 240) for t in range(4)]
+    rgbs = [synth.frame_rgb(30 + t, 264, 200 + 8 * t) for t in range(4)]
+    errors = []
+
+    def work(t):
+        try:
+            ctx = _lib.Context(0)
+            ctx.set_fir_mode(0)
+            for rep in range(3):
+                g = imgs[t]
+                h = api.detect_corners(g.astype(np.float64), g.shape[1], g.shape[0], threshold=1.0, gaussian=1, precision=1, verbose=0, ctx=ctx)
+                ref = oracle.harris(g.astype(np.float32), threshold=1.0, gaussian=1, precision=1)
+                assert np.array_equal(np.asarray(h["x"], np.float32), ref[:, 0]) and np.array_equal(np.asarray(h["strength"], np.float32), ref[:, 2])
+                c = api.image_canny_edge_detector(g.T, ctx=ctx)
+                assert c["pixels_nonzero"] == oracle.canny(g)[1]
+                f = api.image_detect_corners(g.T, threshold=20, suppress_non_max=True, ctx=ctx)
+                assert len(f["x"]) == len(oracle.fast9(g, 20, True))
+                x = np.ascontiguousarray(rgbs[t].transpose(2, 1, 0)).astype(np.int32)
+                fh = api.image_fhog(x, ctx=ctx)
+                assert np.array_equal(fh["fhog"].astype(np.float32).view(np.uint32), oracle.fhog(rgbs[t], 8, 1, 1).view(np.uint32))
+            ctx.close()
+        except Exception as e:   # noqa: BLE001 -- reported by the main thread
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads: th.start()
+    for th in threads: th.join()
+    assert not errors, errors
