@@ -101,8 +101,10 @@ def _harris_args(p, x, w, h, **kw):
 
 
 def test_harris_list_as_the_r_wrapper_gets_it(be):
-    """image_harris(x): detect_corners(x, w = nrow(x), h = ncol(x), ...) with the wrapper's defaults
-    (gaussian "fast Gaussian" = 1, precision "quadratic approximation" = 1: pkg.R:70-74)"""
+    """detect_corners(x, nx = nrow(x), ny = ncol(x), ...) with the codes of the Rcpp-level defaults (gaussian 1 = fast Gaussian,
+    precision 1 = quadratic approximation, RcppExports.R), then with the codes image_harris() itself always sends -- pkg.R:70-74
+    evaluates `which(arg %in% match.arg(arg)) - 1L`, which is 0 for the default vector and for every single string: precise
+    Gaussian, no sub-pixel step (the verbose call below)"""
     p = package(be, "image.CornerDetectionHarris")
     w, h = 128, 96
     frame = synth.frame(24, w, h)
