@@ -136,3 +136,20 @@ def test_config5_stream_of_4k_frames_sampled_against_the_oracle():
     assert np.array_equal(points[sample, :len(ref_f)].cpu().numpy(), ref_f)
     assert np.array_equal(edges[sample].cpu().numpy(), ref_e)
     assert np.all(c > 0)                                               # every frame of the stream produced features
+
+
+def test_one_8192x6000_frame_through_the_batch_entry_points(gpu):
+    """index arithmetic beyond 2^25 pixels per frame (49 Mpixel: mask words, tile counts, union-find labels, candidate lists):
+    FAST-9, Harris (strict) and Canny on one frame against the oracle"""
+    nx, ny = 8192, 6000
+    img = synth.frame(77, nx, ny, n_rect=900)
+    gpu.set_fir_mode(0)
+    pts, pc = gpu.fast9_dev(img[None], 20, True)
+    ref = oracle.fast9(img, 20, True)
+    assert int(pc[0]) == len(ref) and np.array_equal(pts[0], ref)
+    lists, counts = gpu.harris_dev(img[None])
+    ref = oracle.harris(img.astype(np.float32))
+    assert int(counts[0]) == len(ref) > 1000 and np.array_equal(bits(lists[0]), bits(ref))
+    edges, ec = gpu.canny_dev(img[None])
+    ref, n = oracle.canny(img)
+    assert int(np.count_nonzero(edges[0] != ref)) <= 1e-5 * ref.size and abs(int(ec[0]) - n) <= 1e-5 * ref.size
