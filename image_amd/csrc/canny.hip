@@ -19,11 +19,9 @@
 //                marked pixels contains a strong one.  The NMS kernel publishes two bit planes per frame
 //                (S = strong, W = marked; one 64-bit __ballot word per 64 pixels of a row).  Propagation
 //                S |= W & dilate3x3(S) is monotone with a unique fixpoint, so scheduling cannot change the
-//                result.  One WAVE owns a 256x64 tile: lane = row, 4 words per lane; the 3x3 dilation is
-//                shifts + two lane shuffles, and runs of W inside a word are flooded in O(1) with the
-//                carry-propagation trick (m & ~(m+p)).  Tiles iterate to a local fixpoint in registers;
-//                launches repeat until a whole sweep changes nothing (later sweeps of a round exit at
-//                once when the previous one was idle, so one host read-back covers a round).
+//                result.  canny_hyst_block: a wave per tile, a block of tiles per workgroup iterated to the
+//                block's fixpoint through LDS, a fixed number of launches queued (no host read-back);
+//                canny_finish: union-find over whatever the launches left, then the 0/255 bytes and the count.
 // the blurred plane and the edge map go out with streaming stores (imgfd_canny_dev on 32 4K frames: 1.916 -> 1.904 ms)
 #define IMGFD_NT_OUT 1
 #include "common.h"
@@ -504,7 +502,8 @@ __device__ __forceinline__ void canny_grad_nms_tile(double (*sb)[GN_TX + 2 * GN_
 __global__ void __launch_bounds__(256) canny_grad_nms(const float *__restrict__ blur, unsigned long long *__restrict__ S,
                                                       unsigned long long *__restrict__ Wm, int nx, int ny,
                                                       int words_per_row, int accGrad, int low_thr, int high_thr, int vec4,
-                                                      unsigned *__restrict__ sweep_flags, int n_sweep_flags, int tiles_x, int xcd_order)
+                                                      unsigned *__restrict__ sweep_flags, int n_sweep_flags, int tiles_x, int xcd_order,
+                                                      unsigned long long *__restrict__ counts)
 {
     __shared__ __attribute__((aligned(16))) double sb[GN_TY + 4][GN_TX + 2 * GN_XO + 4];
     __shared__ double sg[GN_TY + 2][GN_TX + 2 + 1];
@@ -518,7 +517,11 @@ __global__ void __launch_bounds__(256) canny_grad_nms(const float *__restrict__ 
     // the hysteresis sweeps behind this kernel start from cleared "changed" words (a memset of their own was 5 us of a
     // single frame's critical path)
     if (in_frame == 0 && bz == 0 && (int)threadIdx.x < n_sweep_flags) sweep_flags[threadIdx.x] = 0;
-    if (in_frame == 0 && threadIdx.x == 0) sweep_flags[n_sweep_flags + bz] = 0;  // per frame: the last sweep that changed it
+    if (in_frame == 0 && threadIdx.x == 0) {
+        sweep_flags[n_sweep_flags + bz] = 0;              // per frame: the last sweep that changed it
+        sweep_flags[n_sweep_flags + gridDim.y + bz] = 0;  // ... and the arrival counter of canny_finish's frame barriers
+        counts[bz] = 0;                                   // pixels_nonzero: the expansion adds to it
+    }
     // workgroup-uniform: interior tiles skip every clamp and fetch the blurred tile as float4s
     const bool inside = vec4 && x0 - GN_XO >= 0 && x0 + GN_TX + GN_XO <= nx && y0 - 2 >= 0 && y0 + GN_TY + 2 <= ny;
     if (inside) canny_grad_nms_tile<true>(sb, sg, blur, S, Wm, nx, ny, words_per_row, accGrad, low_thr, high_thr, bx, by, bz);
@@ -559,14 +562,7 @@ __device__ __forceinline__ unsigned long long lane_below(unsigned long long v)
     return ((unsigned long long)hi << 32) | lo;
 }
 
-#define HY_SWEEPS 14      // sweeps queued per batch of 8 frames or more (the bench frames converge in 10)
-#define HY_SWEEPS_MAX 32  // flags[]: one word per sweep, one word per frame ("the last sweep that changed this frame" + 1), one more per frame (union-find)
-#ifndef HY_WORDS
-#define HY_WORDS 4
-#endif
-#ifndef HY_EXP
-#define HY_EXP 0  // timing experiments only (wrong results): 1 no S stores, 4 no tile loads, 8 no halo-row loads
-#endif
+#define HY_SWEEPS_MAX 32  // flags[]: one word per sweep, one word per frame ("the last sweep that changed this frame" + 1), one more per frame (arrivals at canny_finish's frame barriers)
 // a wave turns its own LDS patch round (written lane = (row, word), read lane = row): program order inside the wave is the
 // only synchronisation; the fences keep the compiler from moving one lane's read over another lane's write
 __device__ __forceinline__ void hyst_wave_sync()
@@ -575,91 +571,113 @@ __device__ __forceinline__ void hyst_wave_sync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// HY_WORDS: a wave's tile: 4 words (256 columns) x 64 rows (lane = row), iterated to a fixpoint in registers
-// One sweep over all tiles of all frames (a wave per tile, the tile iterated to its fixpoint in registers).  flags[sweep]
-// is raised when any tile changed; a sweep whose predecessor was idle returns at once, so the host queues a fixed number
-// of sweeps without ever reading a flag back.  act[] holds one byte per
-// tile and sweep parity: "this tile changed in that sweep"; a tile can only change if itself or one of its 8
-// neighbours changed in the previous sweep (its inputs are its own words and their halo), so all others leave at once.
-template <int HW>  // words per tile: HY_WORDS for batches (throughput), 2 for one or two frames (twice the waves, shorter sweeps)
-__global__ void __launch_bounds__(256) canny_hyst_bits(unsigned long long *__restrict__ S,
-                                                       const unsigned long long *__restrict__ Wm, int wpr, int ny,
-                                                       int tiles_x, int tiles_y, unsigned *__restrict__ flags, int sweep,
-                                                       unsigned char *__restrict__ act, int gsweep)
+
+// ---- sweeps.  A wave owns a tile of HW words x 64 rows (lane = row, HW words of S and W per lane + the halo words left and
+// right) and iterates it to its fixpoint in registers: the 3x3 dilation is shifts + two DPP wave shifts, runs of W inside a
+// word are flooded in O(1) by carry propagation (flood_runs), only words whose neighbourhood moved in the previous pass are
+// visited.  A WORKGROUP owns BX x BY such tiles (a wave each) and iterates them to the fixpoint of the whole block inside one
+// launch: what crosses a tile outline inside the block travels through LDS -- a "board" on which a wave that changed posts
+// its first and last row and its first and last column -- and costs one workgroup barrier per round; what crosses the block's
+// outline waits for the next launch.  Launches alternate between two groupings of the same tiles (the second starts half a
+// block up and left), so every tile outline lies inside a block in one of them: a chain that wobbles along an outline of one
+// grouping is an LDS matter in the other (the single 4K bench frame: 8 working launches with a tile per wave and no exchange,
+// round 4 -> 3-5; profiles/r05/canny_block_sweeps.txt).  S only grows and every value on the board is a lower bound of its
+// owner's state, so a reader that meets a newer posting than the barrier promises is only better informed; the block stops when
+// a whole round posted nothing (then every wave has read a complete board and found nothing to add: the block's fixpoint under
+// its outer halo).  flags[sweep] is raised when any tile changed; a launch whose predecessor changed nothing returns at once,
+// so the host queues a fixed number of launches without ever reading a flag back.  act[] holds one byte per tile and sweep
+// parity, "this tile changed in that sweep": a tile can only change if itself or one of its 8 neighbours changed in the
+// previous sweep, so a block none of whose tiles (and the ring of tiles around them) changed leaves at once.
+// The tile comes in through LDS: in registers a lane owns a ROW, and rows lie wpr * 8 bytes apart -- loaded lane = row, every
+// 8-byte load of a wave touched 64 different 128-byte lines (PMC, round 4: 69 % of a sweep's wave cycles waited for them);
+// loaded lane = (row, word) an instruction touches one line per row, and the wave's own LDS patch turns the tile round.
+template <int HW>
+struct HystBoard {
+    unsigned long long top[HW], bot[HW];  // rows 0 and 63 of the tile
+    unsigned long long lm, rm;            // bit r: pixel (row r, first column) / (row r, last column)
+};
+template <int HW, int BX, int BY>
+__global__ void __launch_bounds__(64 * BX * BY) canny_hyst_block(unsigned long long *__restrict__ S, const unsigned long long *__restrict__ Wm, int wpr,
+                                                                 int ny, int tiles_x, int tiles_y, int blocks_x, int shift_x, int shift_y,
+                                                                 unsigned *__restrict__ flags, int sweep, unsigned char *__restrict__ act, int prio)
 {
-    if (sweep > 0 && flags[sweep - 1] == 0) return;
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (sweep > 0 && flags[sweep - 1] == 0) return;  // the sweep before changed nothing anywhere
+    // a sweep is a chain of dependent instructions in a few waves: where it shares a SIMD with another kernel's waves (the
+    // Harris chain on the other stream) it goes first -- it asks for a fraction of the issue slots and is the frame's critical path
+    if (prio) __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int ntiles = tiles_x * tiles_y;
-    if (tile >= ntiles) return;  // whole wave leaves together
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
-    unsigned char *act_w = act + ((size_t)(gsweep & 1) * gridDim.y + blockIdx.y) * ntiles;            // written by this sweep
-    const unsigned char *act_r = act + ((size_t)((gsweep + 1) & 1) * gridDim.y + blockIdx.y) * ntiles;  // previous sweep
-    if (gsweep > 0) {
+    // The block grid of this launch starts (shift_x, shift_y) tiles up and left of the frame's corner: launches alternate
+    // between two groupings of the same tiles, so that every tile outline lies INSIDE a block in one of them -- a chain that
+    // wobbles along an outline of one grouping (one launch per crossing) is an LDS matter in the other.
+    const int bx0 = (int)(blockIdx.x % blocks_x) * BX - shift_x, by0 = (int)(blockIdx.x / blocks_x) * BY - shift_y;
+    const int wx = wv % BX, wy = wv / BX;
+    const int tx = bx0 + wx, ty = by0 + wy, tile = ty * tiles_x + tx;
+    const bool live = tx >= 0 && tx < tiles_x && ty >= 0 && ty < tiles_y;  // wave-uniform; a wave without a tile still keeps the barriers
+    unsigned char *act_w = act + ((size_t)(sweep & 1) * gridDim.y + blockIdx.y) * ntiles;            // written by this sweep
+    const unsigned char *act_r = act + ((size_t)((sweep + 1) & 1) * gridDim.y + blockIdx.y) * ntiles;  // previous sweep
+    if (sweep > 0) {  // a tile can only change if itself or one of its 8 neighbours changed in the previous sweep: the block's tiles and the ring around them
+        static_assert((BX + 2) * (BY + 2) <= 64, "one lane per tile of the neighbourhood");
         bool near = false;
-        if (lane < 9) {
-            const int nx_ = tx + lane % 3 - 1, ny_ = ty + lane / 3 - 1;
+        if (lane < (BX + 2) * (BY + 2)) {
+            const int nx_ = bx0 - 1 + lane % (BX + 2), ny_ = by0 - 1 + lane / (BX + 2);
             near = nx_ >= 0 && nx_ < tiles_x && ny_ >= 0 && ny_ < tiles_y && act_r[ny_ * tiles_x + nx_] != 0;
         }
-        if (!__any(near)) {
-            if (lane == 0) act_w[tile] = 0;
+        if (!__any(near)) {  // the same answer in every wave of the workgroup
+            if (live && lane == 0) act_w[tile] = 0;
             return;
         }
     }
     const int w0 = tx * HW;
     unsigned long long *Sf = S + (size_t)blockIdx.y * ny * wpr;
     const unsigned long long *Wf = Wm + (size_t)blockIdx.y * ny * wpr;
-    unsigned long long s[HW + 2], w[HW];  // s[0] / s[HW+1]: halo words left / right
-    // The tile comes in through LDS.  In registers a lane owns a ROW (its HW + 2 words of S, HW of W), and rows lie wpr * 8
-    // bytes apart: loaded lane = row, every 8-byte load of a wave touched 64 different 128-byte lines and the twelve loads of
-    // a tile fetched 96 KB from L2 for 5 KB of bits -- PMC, round 4: 69 % of the sweep's wave cycles waited for them (215 us
-    // for the first sweep over 32 4K frames, 75 us of VALU work in it).  Loaded lane = (row, word) -- LPR lanes per row, 64 /
-    // LPR rows per instruction -- an instruction touches one line per row; the wave's own LDS patch turns the tile round.
-    constexpr int LPR = HW + 2 <= 4 ? 4 : 8, SP = (HW + 2) | 1, WP = HW | 1;  // lanes per row; odd pitches: lane = row reads hit distinct banks
-    __shared__ unsigned long long hb_lds[4][64 * (SP + WP)];
-    unsigned long long *ls = hb_lds[threadIdx.x >> 6], *lw = ls + 64 * SP;
-    {
+    constexpr int LPR = HW + 2 <= 4 ? 4 : 8, SP = (HW + 2) | 1, WP = HW | 1;  // lanes per row of a load instruction; odd pitches: the lane = row reads hit distinct banks
+    HIP_DYNAMIC_SHARED(unsigned long long, hb_dyn)
+    unsigned long long *ls = hb_dyn + (size_t)wv * 64 * (SP + WP), *lw = ls + 64 * SP;
+    __shared__ HystBoard<HW> board[BX * BY];
+    __shared__ unsigned rflag[3];
+    unsigned long long s[HW + 2], w[HW];
+    if (live) {
         const int c = lane % LPR, rsub = lane / LPR;
 #pragma unroll
         for (int i = 0; i < LPR; i++) {
             const int r = i * (64 / LPR) + rsub, yy = ty * 64 + r, wi = w0 - 1 + c;
-            if (c < HW + 2) ls[r * SP + c] = (!(HY_EXP & 4) && yy < ny && wi >= 0 && wi < wpr) ? Sf[(size_t)yy * wpr + wi] : (HY_EXP & 4 ? 0x0101010101010101ull * (unsigned)(lane & 1) : 0ull);
+            if (c < HW + 2) ls[r * SP + c] = (yy < ny && wi >= 0 && wi < wpr) ? Sf[(size_t)yy * wpr + wi] : 0ull;
         }
         constexpr int LPW = HW <= 2 ? 2 : 4;
         const int cw_ = lane % LPW, rw_ = lane / LPW;
 #pragma unroll
         for (int i = 0; i < LPW; i++) {
             const int r = i * (64 / LPW) + rw_, yy = ty * 64 + r, wi = w0 + cw_;
-            if (cw_ < HW) lw[r * WP + cw_] = (!(HY_EXP & 4) && yy < ny && wi < wpr) ? Wf[(size_t)yy * wpr + wi] : (HY_EXP & 4 ? 0x0303030303030303ull : 0ull);
+            if (cw_ < HW) lw[r * WP + cw_] = (yy < ny && wi < wpr) ? Wf[(size_t)yy * wpr + wi] : 0ull;
         }
     }
-    hyst_wave_sync();
+    if (threadIdx.x < 3) rflag[threadIdx.x] = 0;
+    if (lane == 0) {
 #pragma unroll
-    for (int q = 0; q < HW + 2; q++) s[q] = ls[lane * SP + q];
+        for (int q = 0; q < HW; q++) board[wv].top[q] = board[wv].bot[q] = 0ull;
+        board[wv].lm = board[wv].rm = 0ull;
+    }
+    hyst_wave_sync();
     bool todo = false;
 #pragma unroll
+    for (int q = 0; q < HW + 2; q++) s[q] = live ? ls[lane * SP + q] : 0ull;
+#pragma unroll
     for (int q = 0; q < HW; q++) {
-        w[q] = lw[lane * WP + q];
+        w[q] = live ? lw[lane * WP + q] : 0ull;
         todo = todo || (w[q] & ~s[q + 1]) != 0ull;
     }
-    if (!__any(todo)) {  // no marked-but-not-strong pixel in the tile
-        if (lane == 0) act_w[tile] = 0;
-        return;
-    }
-    // halo rows above / below: lanes 0..5 fetch the six words, then everybody gets them by shuffle
-    unsigned long long trow = 0ull, brow = 0ull;
+    todo = __any(todo) != 0;  // a tile without a marked-but-unlit pixel never changes: its outline is what memory holds
+    // halo rows above / below as the launch finds them in memory: lanes 0..HW+1 fetch the words, kept wave-uniform
+    unsigned long long t[HW + 2], b[HW + 2];
     {
+        unsigned long long trow = 0ull, brow = 0ull;
         const int wi = w0 - 1 + lane;
         const int yt = ty * 64 - 1, yb = ty * 64 + 64;
-        if (!(HY_EXP & 8) && lane < HW + 2 && wi >= 0 && wi < wpr) {
+        if (todo && lane < HW + 2 && wi >= 0 && wi < wpr) {
             if (yt >= 0) trow = Sf[(size_t)yt * wpr + wi];
             if (yb < ny) brow = Sf[(size_t)yb * wpr + wi];
         }
-    }
-    // the dilated halo rows are wave-uniform: kept in scalar registers (readlane), a border lane picks its row per use
-    unsigned long long top_d[HW], bot_d[HW];
-    {
-        unsigned long long t[HW + 2], b[HW + 2];
 #pragma unroll
         for (int q = 0; q < HW + 2; q++) {
             t[q] = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(trow >> 32), q) << 32) |
@@ -667,47 +685,104 @@ __global__ void __launch_bounds__(256) canny_hyst_bits(unsigned long long *__res
             b[q] = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(brow >> 32), q) << 32) |
                    (unsigned)__builtin_amdgcn_readlane((int)(unsigned)brow, q);
         }
-#pragma unroll
-        for (int q = 0; q < HW; q++) {
-            top_d[q] = dilate_h(t[q + 1], t[q], t[q + 2]);
-            bot_d[q] = dilate_h(b[q + 1], b[q], b[q + 2]);
-        }
     }
     const bool first = lane == 0, last = lane == 63;
-    bool any = false;
-    // Only words whose neighbourhood moved are visited again: bit q of `prev` / `cur` = "word q of some row changed in the
-    // previous / in this pass" (wave-uniform, scalar tests).  A chain that climbs through one word of the tile no longer
-    // drags the other three through every pass.
-#ifdef HY_MAXITER
-    int hy_it = 0;
-#endif
-    unsigned prev = (1u << HW) - 1u;
-    for (;;) {
-        unsigned cur = 0;
+    bool any = false, run = todo;
+    int round = 0;
+    __syncthreads();  // board and round flags are cleared
+    for (;; round++) {
+        bool changed = false;
+        if (run) {  // wave-uniform
+            unsigned long long top_d[HW], bot_d[HW];
 #pragma unroll
-        for (int q = 0; q < HW; q++) {
-            const unsigned around = ((7u << q) >> 1) & ((1u << HW) - 1u);  // words q-1, q, q+1
-            if (!((prev & around) || (q > 0 && (cur & (1u << (q - 1)))))) continue;
-            // a word's dilation is taken when the word is visited (words to its left already hold this pass's additions: the
-            // fixpoint is the same, reached no later).  lane_above / lane_below give 0 to lanes 0 / 63: their neighbours are
-            // the halo rows
-            const unsigned long long d = dilate_h(s[q + 1], s[q], s[q + 2]);
-            const unsigned long long halo = first ? top_d[q] : (last ? bot_d[q] : 0ull);
-            const unsigned long long cand = w[q] & ~s[q + 1] & (d | lane_above(d) | lane_below(d) | halo);
-            if (__any(cand != 0ull)) {
-                s[q + 1] |= flood_runs(w[q], cand);  // flood_runs(m, 0) = 0: lanes without a candidate keep their word
-                cur |= 1u << q;
+            for (int q = 0; q < HW; q++) {
+                top_d[q] = dilate_h(t[q + 1], t[q], t[q + 2]);
+                bot_d[q] = dilate_h(b[q + 1], b[q], b[q + 2]);
+            }
+            unsigned prev = (1u << HW) - 1u;
+            // the tile's own fixpoint under its present halo.  Bit q of `prev` / `cur` = "word q of some row changed in the previous /
+            // in this pass" (wave-uniform): a chain that climbs through one word does not drag the others through every pass.  A
+            // word's dilation is taken when the word is visited (words to its left already hold this pass's additions: the same
+            // fixpoint, reached no later); lane_above / lane_below give 0 to lanes 0 / 63, whose neighbours are the halo rows
+            for (;;) {
+                unsigned cur = 0;
+#pragma unroll
+                for (int q = 0; q < HW; q++) {
+                    const unsigned around = ((7u << q) >> 1) & ((1u << HW) - 1u);
+                    if (!((prev & around) || (q > 0 && (cur & (1u << (q - 1)))))) continue;
+                    const unsigned long long d = dilate_h(s[q + 1], s[q], s[q + 2]);
+                    const unsigned long long halo = first ? top_d[q] : (last ? bot_d[q] : 0ull);
+                    const unsigned long long cand = w[q] & ~s[q + 1] & (d | lane_above(d) | lane_below(d) | halo);
+                    if (__any(cand != 0ull)) {
+                        s[q + 1] |= flood_runs(w[q], cand);
+                        cur |= 1u << q;
+                    }
+                }
+                if (!cur) break;
+                changed = true;
+                prev = cur;
             }
         }
-        if (!cur) break;
-        any = true;
-        prev = cur;
-#ifdef HY_MAXITER
-        if (++hy_it >= HY_MAXITER) break;  // timing experiment only (wrong results)
-#endif
+        if (changed) {  // post the outline
+            any = true;
+            const unsigned long long lm = __ballot((s[1] & 1ull) != 0ull), rm = __ballot((s[HW] >> 63) != 0ull);
+            if (first) {
+#pragma unroll
+                for (int q = 0; q < HW; q++) board[wv].top[q] = s[q + 1];
+                board[wv].lm = lm;
+                board[wv].rm = rm;
+                rflag[round % 3] = 1u;
+            }
+            if (last) {
+#pragma unroll
+                for (int q = 0; q < HW; q++) board[wv].bot[q] = s[q + 1];
+            }
+        }
+        if (threadIdx.x == 0) rflag[(round + 1) % 3] = 0u;  // read last behind the barrier of round - 2: nobody is still there
+        __syncthreads();
+        if (rflag[round % 3] == 0u) break;  // a whole round without a posting
+        run = false;
+        if (todo) {
+            // what the neighbours inside the block have posted, OR-ed onto the halo
+            bool grew = false;
+            auto merge = [&grew](unsigned long long &dst, unsigned long long v) {
+                v |= dst;
+                grew = grew || v != dst;
+                dst = v;
+            };
+            auto uni = [](unsigned long long v) {  // every lane read the same LDS word: keep it in scalar registers
+                return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) |
+                       (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+            };
+            if (wy > 0) {
+                const HystBoard<HW> *nb = &board[wv - BX];
+#pragma unroll
+                for (int q = 0; q < HW; q++) merge(t[q + 1], uni(nb->bot[q]));
+                if (wx > 0) merge(t[0], uni(nb[-1].bot[HW - 1]) & (1ull << 63));
+                if (wx < BX - 1) merge(t[HW + 1], uni(nb[1].bot[0]) & 1ull);
+            }
+            if (wy < BY - 1) {
+                const HystBoard<HW> *nb = &board[wv + BX];
+#pragma unroll
+                for (int q = 0; q < HW; q++) merge(b[q + 1], uni(nb->top[q]));
+                if (wx > 0) merge(b[0], uni(nb[-1].top[HW - 1]) & (1ull << 63));
+                if (wx < BX - 1) merge(b[HW + 1], uni(nb[1].top[0]) & 1ull);
+            }
+            bool side = false;
+            if (wx > 0) {
+                const unsigned long long add = ((uni(board[wv - 1].rm) >> lane) & 1ull) << 63;
+                side = side || (add & ~s[0]) != 0ull;
+                s[0] |= add;
+            }
+            if (wx < BX - 1) {
+                const unsigned long long add = (uni(board[wv + 1].lm) >> lane) & 1ull;
+                side = side || (add & ~s[HW + 1]) != 0ull;
+                s[HW + 1] |= add;
+            }
+            run = grew || __any(side);
+        }
     }
-    if (any) {  // wave-uniform
-        // back the way it came: rows to the LDS patch, then lane = (row, word) stores
+    if (any) {  // wave-uniform: rows back to the LDS patch, then lane = (row, word) stores
         hyst_wave_sync();
 #pragma unroll
         for (int q = 0; q < HW; q++) lw[lane * WP + q] = s[q + 1];
@@ -717,18 +792,15 @@ __global__ void __launch_bounds__(256) canny_hyst_bits(unsigned long long *__res
 #pragma unroll
         for (int i = 0; i < LPW; i++) {
             const int r = i * (64 / LPW) + rw_, yy = ty * 64 + r, wi = w0 + cw_;
-            if (!(HY_EXP & 1) && cw_ < HW && yy < ny && wi < wpr) Sf[(size_t)yy * wpr + wi] = lw[r * WP + cw_];
-        }
-        // a plain store: every writer stores the same 1.  (An atomicOr here -- sixteen thousand waves of a 32-frame sweep on ONE
-        // address -- WAS the first two sweeps: 215 and 190 us, against 43 and 38 with the store; round 4, scripts/gpu_canny_variants.sh.)
-        if (lane == 0) {
-            flags[sweep] = 1u;
-            flags[HY_SWEEPS_MAX + blockIdx.y] = (unsigned)sweep + 1u;  // frame blockIdx.y moved in this sweep (the union-find kernel asks about the last one)
+            if (cw_ < HW && yy < ny && wi < wpr) Sf[(size_t)yy * wpr + wi] = lw[r * WP + cw_];
         }
     }
-    if (lane == 0) act_w[tile] = any ? 1 : 0;
+    if (live && lane == 0) act_w[tile] = any ? 1 : 0;
+    if (threadIdx.x == 0 && round > 0) {  // the loop left in round r: rounds 0 .. r-1 posted
+        flags[sweep] = 1u;  // plain stores: every writer stores the same value
+        flags[HY_SWEEPS_MAX + blockIdx.y] = (unsigned)sweep + 1u;
+    }
 }
-
 
 // ---- what the queued sweeps leave: union-find
 // A sweep carries the strong label across one tile outline, so a chain of weak pixels that winds through the frame can outlast
@@ -793,7 +865,7 @@ __device__ __forceinline__ unsigned long long uf_run_from(unsigned long long m, 
     return zeros_above ? (((zeros_above & (0ull - zeros_above)) - 1ull) & ~((1ull << b) - 1ull)) : (~0ull << b);
 }
 struct UfFrame {  // the planes of one frame
-    unsigned long long *Sf;
+    const unsigned long long *Sf;
     const unsigned long long *Wf;
     unsigned *P;
     int wpr, nx, ny;
@@ -810,17 +882,14 @@ struct UfFrame {  // the planes of one frame
     }
 };
 // flags layout (see HY_SWEEPS_MAX): [sweep flags][per frame: last sweep that changed it + 1]
-__global__ void __launch_bounds__(UF_NT) canny_uf_init(const unsigned long long *__restrict__ S, const unsigned long long *__restrict__ Wm,
-                                                      int wpr, int nx, int ny, unsigned *__restrict__ parents, const unsigned *__restrict__ flags,
-                                                      unsigned last_sweep, unsigned long long *__restrict__ counts)
+// every run of W & ~S of frame `frame` becomes its own root (workgroup `bid` of `nblk` shares the frame's words)
+__device__ __forceinline__ void uf_init_frame(const unsigned long long *__restrict__ S, const unsigned long long *__restrict__ Wm, int wpr, int nx, int ny,
+                                              unsigned *__restrict__ parents, int frame, int bid, int nblk)
 {
-    const int frame = blockIdx.y;
-    if (blockIdx.x == 0 && threadIdx.x == 0) counts[frame] = 0;  // pixels_nonzero of this frame: canny_expand_count adds to it
-    if (flags[HY_SWEEPS_MAX + frame] != last_sweep) return;  // the last queued sweep left this frame alone: converged
     const size_t plane = (size_t)ny * wpr;
     const unsigned long long *Sf = S + frame * plane, *Wf = Wm + frame * plane;
     unsigned *P = parents + (size_t)frame * nx * ny;
-    for (long i = (long)blockIdx.x * UF_NT + threadIdx.x; i < (long)plane; i += (long)gridDim.x * UF_NT) {
+    for (long i = (long)bid * UF_NT + threadIdx.x; i < (long)plane; i += (long)nblk * UF_NT) {
         const unsigned long long m = Wf[i] & ~Sf[i];
         if (!m) continue;
         const int y = (int)(i / wpr), wi = (int)(i - (long)y * wpr);
@@ -833,17 +902,21 @@ __global__ void __launch_bounds__(UF_NT) canny_uf_init(const unsigned long long 
         }
     }
 }
-__global__ void __launch_bounds__(UF_NT) canny_uf_merge(unsigned long long *__restrict__ S, const unsigned long long *__restrict__ Wm,
-                                                       int wpr, int nx, int ny, unsigned *__restrict__ parents, const unsigned *__restrict__ flags,
-                                                       unsigned last_sweep)
+__global__ void __launch_bounds__(UF_NT) canny_uf_init(const unsigned long long *__restrict__ S, const unsigned long long *__restrict__ Wm,
+                                                      int wpr, int nx, int ny, unsigned *__restrict__ parents, const unsigned *__restrict__ flags,
+                                                      unsigned last_sweep)
 {
-    const int frame = blockIdx.y;
-    if (flags[HY_SWEEPS_MAX + frame] != last_sweep) return;
+    if (flags[HY_SWEEPS_MAX + blockIdx.y] != last_sweep) return;  // the last queued sweep left this frame alone: converged
+    uf_init_frame(S, Wm, wpr, nx, ny, parents, blockIdx.y, blockIdx.x, gridDim.x);
+}
+// unite what touches (8-neighbourhood): the run to the left in the row, the runs of the row above, and LIT
+__device__ __forceinline__ void uf_merge_frame(const unsigned long long *__restrict__ S, const unsigned long long *__restrict__ Wm, int wpr, int nx, int ny,
+                                               unsigned *__restrict__ parents, int frame, int bid, int nblk)
+{
     const size_t plane = (size_t)ny * wpr;
     UfFrame f{S + frame * plane, Wm + frame * plane, parents + (size_t)frame * nx * ny, wpr, nx, ny};
     unsigned *P = f.P;
-    // unite what touches (8-neighbourhood): the run to the left in the row, the runs of the row above, and LIT
-    for (long i = (long)blockIdx.x * UF_NT + threadIdx.x; i < (long)plane; i += (long)gridDim.x * UF_NT) {
+    for (long i = (long)bid * UF_NT + threadIdx.x; i < (long)plane; i += (long)nblk * UF_NT) {
         const unsigned long long m = f.Wf[i] & ~f.Sf[i];
         if (!m) continue;
         const int y = (int)(i / wpr), wi = (int)(i - (long)y * wpr);
@@ -873,26 +946,32 @@ __global__ void __launch_bounds__(UF_NT) canny_uf_merge(unsigned long long *__re
     }
 }
 
+__global__ void __launch_bounds__(UF_NT) canny_uf_merge(const unsigned long long *__restrict__ S, const unsigned long long *__restrict__ Wm,
+                                                       int wpr, int nx, int ny, unsigned *__restrict__ parents, const unsigned *__restrict__ flags,
+                                                       unsigned last_sweep)
+{
+    if (flags[HY_SWEEPS_MAX + blockIdx.y] != last_sweep) return;
+    uf_merge_frame(S, Wm, wpr, nx, ny, parents, blockIdx.y, blockIdx.x, gridDim.x);
+}
+
 #define EXP_BLOCKS 128
 // rcpp_canny.cpp:226-243: the edge map as 0/255 bytes and its number of non-zero pixels; a workgroup walks every
 // EXP_BLOCKS-th row and adds its count once
 // A frame that went through the union-find kernels (uf != nullptr and its flag says so): the runs of W & ~S whose root is LIT
 // count as strong (plain loads of the forest: it was finished by the previous kernel).
-__global__ void __launch_bounds__(256) canny_expand_count(const unsigned long long *__restrict__ S, int wpr, unsigned char *__restrict__ edges,
-                                                          int nx, int ny, unsigned long long *__restrict__ counts,
-                                                          const unsigned long long *__restrict__ Wm, const unsigned *__restrict__ parents,
-                                                          const unsigned *__restrict__ flags, unsigned last_sweep)
+__device__ __forceinline__ void expand_count_frame(const unsigned long long *__restrict__ S, int wpr, unsigned char *__restrict__ edges, int nx, int ny,
+                                                   unsigned long long *__restrict__ counts, const unsigned long long *__restrict__ Wm,
+                                                   const unsigned *__restrict__ parents, bool united, int frame, int bid, int nblk)
 {
     __shared__ unsigned wsum[4];
     const bool vec = (nx & 15) == 0 && (reinterpret_cast<size_t>(edges) & 15) == 0;
-    const bool united = flags[HY_SWEEPS_MAX + blockIdx.y] == last_sweep;  // workgroup-uniform
-    const unsigned *P = parents + (size_t)blockIdx.y * nx * ny;
+    const unsigned *P = parents + (size_t)frame * nx * ny;
     unsigned c = 0;
-    for (int y = blockIdx.x; y < ny; y += gridDim.x) {
+    for (int y = bid; y < ny; y += nblk) {
         for (int x = 16 * (int)threadIdx.x; x < nx; x += 16 * 256) {
-            unsigned long long word = S[((size_t)blockIdx.y * ny + y) * wpr + (x >> 6)];
+            unsigned long long word = S[((size_t)frame * ny + y) * wpr + (x >> 6)];
             if (united) {
-                const unsigned long long m = Wm[((size_t)blockIdx.y * ny + y) * wpr + (x >> 6)] & ~word;
+                const unsigned long long m = Wm[((size_t)frame * ny + y) * wpr + (x >> 6)] & ~word;
                 unsigned long long starts = m & ~(m << 1);
                 while (starts) {
                     const int b = __ffsll((long long)starts) - 1;
@@ -908,7 +987,7 @@ __global__ void __launch_bounds__(256) canny_expand_count(const unsigned long lo
             unsigned v[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) v[k] = ((((bits >> (4 * k)) & 0xfu) * 0x00204081u) & 0x01010101u) * 0xffu;
-            unsigned char *dst = edges + ((size_t)blockIdx.y * ny + y) * nx + x;
+            unsigned char *dst = edges + ((size_t)frame * ny + y) * nx + x;
             if (vec) {
                 typedef unsigned v4u __attribute__((vector_size(16)));
                 IMGFD_OUT_STORE((v4u{v[0], v[1], v[2], v[3]}), reinterpret_cast<v4u *>(dst));
@@ -923,28 +1002,50 @@ __global__ void __launch_bounds__(256) canny_expand_count(const unsigned long lo
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (t) atomicAdd(&counts[blockIdx.y], (unsigned long long)t);
+        if (t) atomicAdd(&counts[frame], (unsigned long long)t);
     }
 }
-#define CNT_BLOCKS 16
-__global__ void __launch_bounds__(256) canny_count_bits(const unsigned long long *__restrict__ S, size_t words_per_frame,
-                                                        unsigned long long *__restrict__ counts)
+__global__ void __launch_bounds__(256) canny_expand_count(const unsigned long long *__restrict__ S, int wpr, unsigned char *__restrict__ edges,
+                                                          int nx, int ny, unsigned long long *__restrict__ counts,
+                                                          const unsigned long long *__restrict__ Wm, const unsigned *__restrict__ parents,
+                                                          const unsigned *__restrict__ flags, unsigned last_sweep)
 {
-    __shared__ unsigned wsum[4];
-    const unsigned long long *Sf = S + (size_t)blockIdx.y * words_per_frame;
-    unsigned c = 0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words_per_frame; i += (size_t)CNT_BLOCKS * 256)
-        c += (unsigned)__popcll(Sf[i]);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    const bool united = flags[HY_SWEEPS_MAX + blockIdx.y] == last_sweep;  // workgroup-uniform
+    expand_count_frame(S, wpr, edges, nx, ny, counts, Wm, parents, united, blockIdx.y, blockIdx.x, gridDim.x);
+}
+// The three kernels above as ONE launch (round 5; a single 4K frame spent 10 us of its critical chain in the two union-find
+// launches that find nothing to do).  A frame the last sweep left alone -- the case in practice -- is expanded at once.  A frame
+// it did not finish takes the same three steps with two barriers between them, each across the workgroups of THAT FRAME only
+// (a counter in the flags block, cleared by the gradient/NMS kernel): workgroups are dispatched in order, a frame's
+// EXP_BLOCKS workgroups are consecutive and wait for nobody else, so they become resident together whatever else runs.
+// Needs workgroups that can wait for each other (not the one-block-at-a-time emulator of the tests: the host asks the device).
+__device__ __forceinline__ void frame_barrier(unsigned *counter, unsigned target)
+{
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (t) atomicAdd(&counts[blockIdx.y], (unsigned long long)t);
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(8);
     }
+    __syncthreads();
+    __threadfence();  // what the other workgroups wrote before they arrived
 }
-
+__global__ void __launch_bounds__(256) canny_finish(const unsigned long long *__restrict__ S, int wpr, unsigned char *__restrict__ edges, int nx, int ny,
+                                                    unsigned long long *__restrict__ counts, const unsigned long long *__restrict__ Wm,
+                                                    unsigned *__restrict__ parents, unsigned *__restrict__ flags, unsigned last_sweep, int n_frames)
+{
+    const int frame = blockIdx.y;
+    const bool united = flags[HY_SWEEPS_MAX + frame] == last_sweep;  // workgroup-uniform
+    if (united) {
+        unsigned *bar = flags + HY_SWEEPS_MAX + n_frames + frame;
+        uf_init_frame(S, Wm, wpr, nx, ny, parents, frame, blockIdx.x, gridDim.x);
+        __threadfence();
+        frame_barrier(bar, gridDim.x);
+        uf_merge_frame(S, Wm, wpr, nx, ny, parents, frame, blockIdx.x, gridDim.x);
+        __threadfence();
+        frame_barrier(bar, 2u * gridDim.x);
+    }
+    expand_count_frame(S, wpr, edges, nx, ny, counts, Wm, parents, united, frame, blockIdx.x, gridDim.x);
+}
 namespace {
 
 // Wrapped, normalised 1-D kernel (tools.c:146-163) reduced to the taps >= 1e-17, in the oracle's order.  The oracle keeps
@@ -1023,6 +1124,36 @@ imgfd_status launch_blur_march(imgfd_ctx *ctx, BlurMarchParams &p, int nf)
     return IMGFD_OK;
 }
 
+template <int HW, int BX, int BY>
+imgfd_status launch_hyst_block(imgfd_ctx *ctx, unsigned long long *S, const unsigned long long *Wm, int wpr, int ny, int tiles_x, int tiles_y,
+                               int nf, unsigned *flags, unsigned char *act, int sweeps)
+{
+    constexpr int SP = (HW + 2) | 1, WP = HW | 1;
+    constexpr size_t lds = (size_t)BX * BY * 64 * (SP + WP) * sizeof(unsigned long long);
+    if (lds > 48 * 1024)
+        IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)canny_hyst_block<HW, BX, BY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int i = 0; i < sweeps; i++) {
+        // odd launches group the tiles half a block up and left ("hyst_shift" 0: every launch the same grouping)
+        const int sx = (i & 1) && ctx->tune.hyst_shift ? BX / 2 : 0, sy = (i & 1) && ctx->tune.hyst_shift ? BY / 2 : 0;
+        const int blocks_x = ceil_div(tiles_x + sx, BX), blocks_y = ceil_div(tiles_y + sy, BY);
+        hipLaunchKernelGGL((canny_hyst_block<HW, BX, BY>), dim3(blocks_x * blocks_y, nf), dim3(64 * BX * BY), lds, ctx->stream, S, Wm, wpr, ny, tiles_x,
+                           tiles_y, blocks_x, sx, sy, flags, i, act, ctx->tune.hyst_prio);
+    }
+    IMGFD_HIP(ctx, hipGetLastError());
+    return IMGFD_OK;
+}
+imgfd_status launch_hyst_blocks(imgfd_ctx *ctx, int hw, int shape, unsigned long long *S, const unsigned long long *Wm, int wpr, int ny, int tiles_x,
+                                int tiles_y, int nf, unsigned *flags, unsigned char *act, int sweeps)
+{
+#define HY_CASE(W, X, Y) \
+    if (hw == W && shape == 10 * X + Y) return launch_hyst_block<W, X, Y>(ctx, S, Wm, wpr, ny, tiles_x, tiles_y, nf, flags, act, sweeps);
+    HY_CASE(1, 2, 2) HY_CASE(1, 4, 2) HY_CASE(1, 2, 4) HY_CASE(1, 4, 4)
+    HY_CASE(2, 2, 2) HY_CASE(2, 4, 2) HY_CASE(2, 2, 4) HY_CASE(2, 4, 4)
+    HY_CASE(4, 2, 2) HY_CASE(4, 4, 2) HY_CASE(4, 2, 4) HY_CASE(4, 4, 4)
+#undef HY_CASE
+    return imgfd_fail(ctx, IMGFD_ERR_INVALID, "hyst_block: 22, 42, 24 or 44 (tiles per workgroup, 10 * across + down)");
+}
+
 size_t canny_ws_bytes(int nx, int ny, int nf)
 {
     const size_t n = (size_t)nx * ny * nf;
@@ -1030,7 +1161,7 @@ size_t canny_ws_bytes(int nx, int ny, int nf)
     return align_up(n * sizeof(double), 256) + align_up(n * sizeof(float), 256) + 2 * align_up(words * 8, 256) +
            align_up(12 * ((size_t)nx + ny), 256) + 512 +  // taps in memory (kernels of more than CANNY_MAX_TAPS taps)
            align_up(4 * ((size_t)HY_SWEEPS_MAX + 2 * (size_t)nf), 256) +  // sweep flags, per-frame flags and counters
-           align_up(2 * (size_t)nf * ceil_div(ceil_div(nx, 64), 2) * ceil_div(ny, 64), 256) + 4096;
+           align_up(2 * (size_t)nf * ceil_div(nx, 64) * ceil_div(ny, 64), 256) + 4096;
 }
 
 // all device work for nf frames; d_edges / d_counts are device buffers
@@ -1043,11 +1174,28 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
     const size_t n = (size_t)nx * ny * nf;
     const int wpr = ceil_div(nx, 64);
     const size_t words = (size_t)wpr * ny * nf;
-    BlurTaps tx, ty;
-    std::vector<int> offx, offy;
-    std::vector<double> wtx, wty;
-    make_taps(nx, s, offx, wtx, &tx);
-    make_taps(ny, s, offy, wty, &ty);
+    // the taps of this (nx, ny, s): kept on the context between calls
+    struct TapsCache {
+        int nx = -1, ny = -1;
+        double s = 0;
+        BlurTaps tx, ty;
+        std::vector<int> offx, offy;
+        std::vector<double> wtx, wty;
+    };
+    if (!ctx->canny_taps) {
+        ctx->canny_taps = new TapsCache();
+        ctx->canny_taps_free = [](void *p) { delete static_cast<TapsCache *>(p); };
+    }
+    TapsCache &tc = *static_cast<TapsCache *>(ctx->canny_taps);
+    if (tc.nx != nx || tc.ny != ny || tc.s != s) {
+        tc.nx = -1;  // stays invalid if an allocation below throws
+        make_taps(nx, s, tc.offx, tc.wtx, &tc.tx);
+        make_taps(ny, s, tc.offy, tc.wty, &tc.ty);
+        tc.nx = nx; tc.ny = ny; tc.s = s;
+    }
+    const BlurTaps &tx = tc.tx, &ty = tc.ty;
+    const std::vector<int> &offx = tc.offx, &offy = tc.offy;
+    const std::vector<double> &wtx = tc.wtx, &wty = tc.wty;
     const bool big = tx.n == 0 || ty.n == 0;  // more than CANNY_MAX_TAPS taps along an axis
     const int Rx = big ? -1 : symmetric_radius(tx, nx), Ry = big ? -1 : symmetric_radius(ty, ny);
     const int R = std::max(Rx, Ry);
@@ -1056,8 +1204,8 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
     float *blur = (float *)ws_alloc(ctx, n * sizeof(float));
     unsigned long long *S = (unsigned long long *)ws_alloc(ctx, words * 8);
     unsigned long long *Wm = (unsigned long long *)ws_alloc(ctx, words * 8);
-    unsigned *flags = (unsigned *)ws_alloc(ctx, 4 * ((size_t)HY_SWEEPS_MAX + (size_t)nf));
-    const size_t act_bytes = 2 * (size_t)nf * ceil_div(wpr, 2) * ceil_div(ny, 64);  // tile activity of the sweeps, two parities (tiles of 2 words at the least)
+    unsigned *flags = (unsigned *)ws_alloc(ctx, 4 * ((size_t)HY_SWEEPS_MAX + 2 * (size_t)nf));
+    const size_t act_bytes = 2 * (size_t)nf * wpr * ceil_div(ny, 64);  // tile activity of the sweeps, two parities (tiles of one word at the least)
     unsigned char *act = (unsigned char *)ws_alloc(ctx, act_bytes);
     const size_t tap_bytes = big ? align_up(12 * (offx.size() + offy.size()), 256) + 256 : 0;
     char *taps_dev = big ? (char *)ws_alloc(ctx, tap_bytes) : nullptr;
@@ -1107,7 +1255,8 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
     IMGFD_TRY(at(1));
     dim3 g2((unsigned)wpr * (unsigned)ceil_div(ny, GN_TY), nf);
     hipLaunchKernelGGL(canny_grad_nms, g2, dim3(256), 0, ctx->stream, blur, S, Wm, nx, ny, wpr, accGrad, (int)low_thr,
-                       (int)high_thr, (int)(nx % 4 == 0 && (size_t)blur % 16 == 0), flags, HY_SWEEPS_MAX, wpr, ctx->tune.xcd_remap);
+                       (int)high_thr, (int)(nx % 4 == 0 && (size_t)blur % 16 == 0), flags, HY_SWEEPS_MAX, wpr, ctx->tune.xcd_remap,
+                       (unsigned long long *)d_counts);
     IMGFD_HIP(ctx, hipGetLastError());
     IMGFD_TRY(at(2));
     unsigned uf_last_sweep = 0;
@@ -1115,39 +1264,42 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
     // predecessor changed nothing returns at once: an idle launch costs a few microseconds), then the union-find kernel, which
     // leaves at once for every frame the last sweep left alone and otherwise completes the frame whatever its chains look like.
     {
-        // One or two frames: tiles of 2 words instead of 4 -- a sweep's length is its slowest wave's in-register fixpoint
-        // loop, and 510 waves leave half the SIMDs of the chip empty (single 4K frame 0.258 -> 0.228 ms; from four frames
-        // on the wider tile wins again: fewer sweeps until nothing changes).
-        const int hw = ctx->tune.hyst_words == 2 || ctx->tune.hyst_words == 4 ? ctx->tune.hyst_words : (nf <= 2 ? 2 : HY_WORDS);
-        // The bench frames need 7 (one frame, 2-word tiles) to 10 sweeps (a batch); an idle launch costs ~4.5 us.  What an image
-        // with longer chains leaves after the queued sweeps is no cliff any more (the union-find kernels: 0.3-0.9 ms for a 4K
-        // frame), so the margin is three sweeps, not fourteen.
-        int sweeps = nf >= 8 ? HY_SWEEPS : (hw == 2 ? 10 : 9);
-        if (ctx->tune.hyst_sweeps >= 1 && ctx->tune.hyst_sweeps <= HY_SWEEPS_MAX) sweeps = ctx->tune.hyst_sweeps;  // tests: leave the work to the union-find kernel
+        // Tile width and tiles per workgroup by batch size (imgfd_canny_dev alone on 4K frames, us per frame, scripts/canny_shapes_probe.py,
+        // profiles/r05/canny_block_sweeps.txt): up to a dozen frames one-word tiles in blocks of 2 x 4 (one frame 134, against 154 / 172
+        // with two- / four-word tiles: a sweep's length is its slowest wave's fixpoint loop, and a pass over a tile costs its words);
+        // batches four-word tiles in blocks of 2 x 2 (56.5 per frame at 32 frames, one-word tiles 59).
+        const bool few = nf <= 12;
+        const int hw = ctx->tune.hyst_words == 1 || ctx->tune.hyst_words == 2 || ctx->tune.hyst_words == 4 ? ctx->tune.hyst_words : (few ? 1 : 4);
+        const int shape = ctx->tune.hyst_block > 0 ? ctx->tune.hyst_block : (few ? 24 : 22);
+        // The bench frames need 4 (one frame) to 6 launches (a batch) and one more that finds nothing; a launch that returns at
+        // once costs ~1.5 us, a frame the queued launches do not finish 0.3-0.9 ms in the union-find part of canny_finish: the
+        // margin is three launches.
+        int sweeps = few ? 8 : 9;
+        if (ctx->tune.hyst_sweeps >= 1 && ctx->tune.hyst_sweeps <= HY_SWEEPS_MAX) sweeps = ctx->tune.hyst_sweeps;  // tests: leave the work to the union-find part
         const int tiles_x = ceil_div(wpr, hw), tiles_y = ceil_div(ny, 64);
-        dim3 g3(ceil_div(tiles_x * tiles_y, 4), nf);
-        // (One persistent kernel for one or two frames -- every tile resident, a grid barrier between the rounds instead of a launch --
-        // was built and measured in round 4: 167-181 us for the frame that takes 94 us as ten launches.  A round needs five hops
-        // through agent-scope memory across the eight XCDs -- publish, arrive, poll, flag, halo -- at ~2.5 us each; a launch
-        // boundary costs 4.5.  profiles/r04/canny_hysteresis.txt.)
-        for (int i = 0; i < sweeps; i++) {
-            if (hw == 2) hipLaunchKernelGGL(canny_hyst_bits<2>, g3, dim3(256), 0, ctx->stream, S, Wm, wpr, ny, tiles_x, tiles_y, flags, i, act, i);
-            else hipLaunchKernelGGL(canny_hyst_bits<HY_WORDS>, g3, dim3(256), 0, ctx->stream, S, Wm, wpr, ny, tiles_x, tiles_y, flags, i, act, i);
-        }
-        // the blur plane is dead behind the gradient/NMS kernel: 4 bytes per pixel for the forest.  Workgroups per frame: enough
-        // to spread a frame that needs the kernels over the chip, few enough that the idle case stays one short launch each
-        const int uf_blocks = std::max(1, std::min({2048 / nf, ceil_div(wpr * ny, 2 * UF_NT), 256}));
-        hipLaunchKernelGGL(canny_uf_init, dim3(uf_blocks, nf), dim3(UF_NT), 0, ctx->stream, (const unsigned long long *)S, (const unsigned long long *)Wm, wpr, nx, ny,
-                           reinterpret_cast<unsigned *>(blur), (const unsigned *)flags, (unsigned)sweeps, (unsigned long long *)d_counts);
-        hipLaunchKernelGGL(canny_uf_merge, dim3(uf_blocks, nf), dim3(UF_NT), 0, ctx->stream, S, (const unsigned long long *)Wm, wpr, nx, ny,
-                           reinterpret_cast<unsigned *>(blur), (const unsigned *)flags, (unsigned)sweeps);
+        IMGFD_TRY(launch_hyst_blocks(ctx, hw, shape, S, Wm, wpr, ny, tiles_x, tiles_y, nf, flags, act, sweeps));
         uf_last_sweep = (unsigned)sweeps;
+        ctx->canny_flags = flags; ctx->canny_sweeps = sweeps; ctx->canny_frames = nf;
         IMGFD_HIP(ctx, hipGetLastError());
     }
-    // 0/255 bytes and pixels_nonzero in one kernel (the finishing kernel zeroed the counts): round 2 queued a memset, the
-    // expansion and a 16-workgroup count -- 25 us of a single frame's critical path
-    hipLaunchKernelGGL(canny_expand_count, dim3(std::min(EXP_BLOCKS, ny), nf), dim3(256), 0, ctx->stream, S, wpr, d_edges, nx, ny,
-                       (unsigned long long *)d_counts, (const unsigned long long *)Wm, (const unsigned *)blur, (const unsigned *)flags, uf_last_sweep);
+    // the blur plane is dead behind the gradient/NMS kernel: 4 bytes per pixel for the union-find forest
+    const int exp_blocks = std::min(EXP_BLOCKS, ny);
+    if (ctx->coop && ctx->tune.canny_finish) {
+        // union-find (frames the sweeps did not finish only), 0/255 bytes and pixels_nonzero in ONE launch
+        hipLaunchKernelGGL(canny_finish, dim3(exp_blocks, nf), dim3(256), 0, ctx->stream, (const unsigned long long *)S, wpr, d_edges, nx, ny,
+                           (unsigned long long *)d_counts, (const unsigned long long *)Wm, reinterpret_cast<unsigned *>(blur), flags, uf_last_sweep, nf);
+    } else {
+        // Workgroups per frame of the union-find kernels: enough to spread a frame that needs them over the chip, few enough
+        // that the idle case stays one short launch each
+        const int uf_blocks = std::max(1, std::min({2048 / nf, ceil_div(wpr * ny, 2 * UF_NT), 256}));
+        hipLaunchKernelGGL(canny_uf_init, dim3(uf_blocks, nf), dim3(UF_NT), 0, ctx->stream, (const unsigned long long *)S, (const unsigned long long *)Wm, wpr, nx, ny,
+                           reinterpret_cast<unsigned *>(blur), (const unsigned *)flags, uf_last_sweep);
+        hipLaunchKernelGGL(canny_uf_merge, dim3(uf_blocks, nf), dim3(UF_NT), 0, ctx->stream, (const unsigned long long *)S, (const unsigned long long *)Wm, wpr, nx, ny,
+                           reinterpret_cast<unsigned *>(blur), (const unsigned *)flags, uf_last_sweep);
+        // 0/255 bytes and pixels_nonzero in one kernel (the gradient/NMS kernel zeroed the counts)
+        hipLaunchKernelGGL(canny_expand_count, dim3(exp_blocks, nf), dim3(256), 0, ctx->stream, S, wpr, d_edges, nx, ny,
+                           (unsigned long long *)d_counts, (const unsigned long long *)Wm, (const unsigned *)blur, (const unsigned *)flags, uf_last_sweep);
+    }
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }

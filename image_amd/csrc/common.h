@@ -23,6 +23,7 @@ struct imgfd_ctx {
     bool own_stream = true;
     int fir_mode = 1;  // 1 = fused accumulate, 0 = strict
     int num_cu = 256;
+    bool coop = false;  // workgroups of one launch can wait for each other (hipDeviceProp_t::cooperativeLaunch; false on the tests' emulator)
     std::string err;
     // grow-only device workspace arena (bump-allocated per call, reset at call entry; when it has to grow, the stream is
     // drained and the old arena freed on the spot)
@@ -46,6 +47,14 @@ struct imgfd_ctx {
     void *detect_exec = nullptr;          // hipGraphExec_t
     long detect_replays = 0, detect_records = 0;  // statistics (imgfd_get_counter)
     long gauss_march_launches = 0;
+    // Canny hysteresis, last call on this context: where its sweep flags live (workspace), sweeps queued, frames (diagnostic
+    // counters "canny_frames_unconverged" / "canny_sweeps_working": imgfd_get_counter waits for the stream and reads them back)
+    // Canny: the wrapped Gaussian taps of the last (nx, ny, s) -- making them costs nx + ny calls of exp(), ~80 us of host time
+    // for a 4K frame, more than a single frame's kernels leave idle (canny.hip owns the object and its destructor)
+    void *canny_taps = nullptr;
+    void (*canny_taps_free)(void *) = nullptr;
+    const unsigned *canny_flags = nullptr;
+    int canny_sweeps = 0, canny_frames = 0;
     long tensor_wave_launches = 0;
     std::string detect_key, detect_seen;  // the call it was recorded for / the call seen last (raw bytes of a DetectKey)
     std::string detect_unrecordable;  // the key of a launch sequence that refused to be captured: run eagerly, do not try again
@@ -59,8 +68,13 @@ struct imgfd_ctx {
         int fhog_threads = 256;  // workgroup size of fhog_hist8 (256 | 512)
         int fhog_arith = 32;     // fhog_hist8: a wave with >= this many lanes outside the table's LDS centre computes their words (0: always gathers)
         // round-1/2 experiment switches (formerly getenv() at their point of use)
-        int hyst_sweeps = 0;        // Canny hysteresis: sweeps queued before the union-find kernel (0: 14 for batches, 8-9 for fewer than 8 frames)
-        int hyst_words = 0;         // words per sweep tile: 2 or 4 (0: 2 for one or two frames, else 4)
+        int hyst_sweeps = 0;        // Canny hysteresis: sweeps queued before the union-find step (0: 8 up to 12 frames, 9 for batches)
+        int hyst_words = 0;         // words per sweep tile: 1, 2 or 4 (0: 1 up to 12 frames, else 4)
+        int hyst_block = 0;         // tiles per workgroup of a sweep, 10 * across + down: 22, 42, 24, 44 (0: 24 up to 12 frames, else 22)
+        int canny_finish = 1;       // 1: union-find + expansion + count as one launch (canny_finish) where workgroups can wait for each other; 0: three launches
+        int hyst_prio = 1;          // block sweeps run at wave priority 3 (0: default priority)
+        int hyst_shift = 1;         // block sweeps: odd launches group the tiles half a block up and left (0: the same grouping in every launch)
+        int detect_defer = -1;      // imgfd_detect_dev: 1 = FAST-9 and the Harris chain are QUEUED only after the whole Canny chain (their release point on the device stays where canny_gate / harris_gate put it); 0 = queued where they are released; -1: 1 below 8 frames
         int surf_taps = 1;          // SURF octaves 1-3: look-ups as buffer loads with host-made offsets (0: address arithmetic per look-up)
         int gauss_march = 1;        // u8 frames whose width is a multiple of 16: the marching Gaussian + gradient kernel (0: the tile kernel)
         int gauss_march_seg = 0;    // rows per segment of that kernel (0: from the batch)

@@ -5,9 +5,12 @@
 // part of what the R functions return.  The detector kernels therefore do not append with atomics;
 // they publish one bit per pixel (a 64-bit __ballot word per wave) plus integer per-row counts.  This
 // file turns that into the ordered list:
-//   rows_scan : one workgroup per frame, exclusive scan of the ny row counts -> row offsets + total
 //   scatter   : one wave per row, lane l owns mask word l (+64k): wave-level prefix of popcounts, then
-//               each lane walks its set bits and writes records at rowoff + prefix + k.
+//               each lane walks its set bits and writes records at (offset of the row) + prefix + k.  The offset of a
+//               workgroup's first row is the sum of the counts of all rows above it, which the workgroup adds up itself
+//               (ny <= SCATTER_SELF_SCAN_MAX_ROWS: a few KB from L2 -- one launch less per detector, round 5);
+//   rows_scan : one workgroup per frame, exclusive scan of the ny row counts -> row offsets + total (taller frames, and
+//               calls that want the counts only)
 // Integer-only bookkeeping: the output is deterministic and identical to a sequential scan.
 #include "common.h"
 #include "harris_device.h"
@@ -77,11 +80,13 @@ struct AbcSource {  // KIND 2..4: strength recomputed from the structure tensor 
 };
 
 // KIND 0: imgfd_corner {x, y, R[y*nx+x]};  KIND 1: imgfd_point {x, y};  KIND 2+m: imgfd_corner with R = response_m(A,B,C)
-template <int KIND>
+// SELF_SCAN: `rowoff` holds the row COUNTS and the workgroup derives its rows' offsets (and, the last one, the frame's total)
+#define SCATTER_SELF_SCAN_MAX_ROWS 16384
+template <int KIND, bool SELF_SCAN>
 __global__ void __launch_bounds__(256) scatter_rows(const unsigned long long *__restrict__ mask,
                                                     const unsigned *__restrict__ rowoff, int words_per_row,
                                                     int nx, int ny, const float *__restrict__ R, AbcSource abc,
-                                                    void *__restrict__ out, long long cap)
+                                                    void *__restrict__ out, long long cap, long long *__restrict__ counts)
 {
     const int lane = threadIdx.x & 63;
     const int y = blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per row
@@ -89,7 +94,23 @@ __global__ void __launch_bounds__(256) scatter_rows(const unsigned long long *__
     const bool row_ok = y < ny;
     const int yy = row_ok ? y : 0;
     const unsigned long long *mrow = mask + ((size_t)frame * ny + yy) * words_per_row;
-    unsigned running = row_ok ? rowoff[(size_t)frame * ny + yy] : 0u;
+    unsigned running;
+    if (SELF_SCAN) {
+        __shared__ unsigned part[4];
+        const unsigned *rc = rowoff + (size_t)frame * ny;
+        const int y0 = blockIdx.x * 4;
+        unsigned sum = 0;
+        for (int i = threadIdx.x; i < y0; i += 256) sum += rc[i];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+        if (lane == 0) part[threadIdx.x >> 6] = sum;
+        __syncthreads();
+        running = part[0] + part[1] + part[2] + part[3];
+        for (int r = y0; r < y; r++) running += rc[r];  // the rows of the waves before this one (at most three, wave-uniform)
+        if (y == ny - 1 && lane == 0) counts[frame] = (long long)(running + rc[y]);
+    } else {
+        running = row_ok ? rowoff[(size_t)frame * ny + yy] : 0u;
+    }
     for (int w0 = 0; w0 < words_per_row; w0 += 64) {
         const int w = w0 + lane;
         unsigned long long m = (row_ok && w < words_per_row) ? mrow[w] : 0ull;
@@ -129,14 +150,24 @@ __global__ void __launch_bounds__(256) scatter_rows(const unsigned long long *__
 static imgfd_status compact_emit_impl(imgfd_ctx *ctx, const CompactBuffers &cb, int nx, int ny, int n_frames, int kind,
                                       const float *d_R, const AbcSource &abc, void *d_out, int64_t cap, int64_t *d_counts)
 {
-    hipLaunchKernelGGL(rows_scan, dim3(n_frames), dim3(SCAN_NT), 0, ctx->stream, cb.rowcount, cb.rowoff, ny,
-                       (long long *)d_counts);
+    const bool self_scan = cap > 0 && ny <= SCATTER_SELF_SCAN_MAX_ROWS;
+    if (!self_scan)
+        hipLaunchKernelGGL(rows_scan, dim3(n_frames), dim3(SCAN_NT), 0, ctx->stream, cb.rowcount, cb.rowoff, ny,
+                           (long long *)d_counts);
     if (cap <= 0) {  // counts only: nothing to emit
         IMGFD_HIP(ctx, hipGetLastError());
         return IMGFD_OK;
     }
     dim3 grid(ceil_div(ny, 4), n_frames);
-#define SC_LAUNCH(K) hipLaunchKernelGGL(scatter_rows<K>, grid, dim3(256), 0, ctx->stream, cb.mask, cb.rowoff, cb.words_per_row, nx, ny, d_R, abc, d_out, (long long)cap)
+#define SC_LAUNCH(K)                                                                                                                      \
+    do {                                                                                                                                  \
+        if (self_scan)                                                                                                                    \
+            hipLaunchKernelGGL((scatter_rows<K, true>), grid, dim3(256), 0, ctx->stream, cb.mask, (const unsigned *)cb.rowcount, cb.words_per_row, nx, ny, \
+                               d_R, abc, d_out, (long long)cap, (long long *)d_counts);                                                   \
+        else                                                                                                                              \
+            hipLaunchKernelGGL((scatter_rows<K, false>), grid, dim3(256), 0, ctx->stream, cb.mask, (const unsigned *)cb.rowoff, cb.words_per_row, nx, ny,  \
+                               d_R, abc, d_out, (long long)cap, (long long *)d_counts);                                                   \
+    } while (0)
     switch (kind) {
         case 0: SC_LAUNCH(0); break;
         case 1: SC_LAUNCH(1); break;

@@ -3,6 +3,8 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
+
 namespace {
 struct TuneKey { const char *name, *env; int imgfd_ctx::Tune::*field; };
 const std::vector<TuneKey> &tune_keys()
@@ -14,6 +16,11 @@ const std::vector<TuneKey> &tune_keys()
         {"fhog_arith", "IMGFD_FHOG_ARITH", &imgfd_ctx::Tune::fhog_arith},
         {"hyst_sweeps", "IMGFD_HYST_SWEEPS", &imgfd_ctx::Tune::hyst_sweeps},
         {"hyst_words", "IMGFD_HYST_WORDS", &imgfd_ctx::Tune::hyst_words},
+        {"hyst_block", "IMGFD_HYST_BLOCK", &imgfd_ctx::Tune::hyst_block},
+        {"hyst_shift", "IMGFD_HYST_SHIFT", &imgfd_ctx::Tune::hyst_shift},
+        {"hyst_prio", "IMGFD_HYST_PRIO", &imgfd_ctx::Tune::hyst_prio},
+        {"canny_finish", "IMGFD_CANNY_FINISH", &imgfd_ctx::Tune::canny_finish},
+        {"detect_defer", "IMGFD_DETECT_DEFER", &imgfd_ctx::Tune::detect_defer},
         {"canny_gate", "IMGFD_CANNY_GATE", &imgfd_ctx::Tune::canny_gate},
         {"harris_gate", "IMGFD_HARRIS_GATE", &imgfd_ctx::Tune::harris_gate},
         {"gauss_march", "IMGFD_GAUSS_MARCH", &imgfd_ctx::Tune::gauss_march},
@@ -57,8 +64,10 @@ static imgfd_status ctx_init(int device, void *stream, bool own, imgfd_ctx **out
     if (!ctx) return IMGFD_ERR_OOM;
     ctx->device = device;
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
         ctx->num_cu = prop.multiProcessorCount;
+        ctx->coop = prop.cooperativeLaunch != 0;
+    }
     if (own) {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
             delete ctx;
@@ -112,6 +121,7 @@ void imgfd_ctx_destroy(imgfd_ctx *ctx)
     if (ctx->aux) (void)hipFree(ctx->aux);
     if (ctx->fhog_lut) (void)hipFree(ctx->fhog_lut);
     if (ctx->taps_dev) (void)hipFree(ctx->taps_dev);
+    if (ctx->canny_taps && ctx->canny_taps_free) ctx->canny_taps_free(ctx->canny_taps);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -161,6 +171,21 @@ imgfd_status imgfd_get_counter(imgfd_ctx *ctx, const char *name, int64_t *value)
     if (!strcmp(name, "detect_graph_records")) { *value = ctx->detect_records; return IMGFD_OK; }
     if (!strcmp(name, "gauss_march_launches")) { *value = ctx->gauss_march_launches; return IMGFD_OK; }
     if (!strcmp(name, "tensor_wave_launches")) { *value = ctx->tensor_wave_launches; return IMGFD_OK; }
+    if (!strcmp(name, "canny_frames_unconverged") || !strcmp(name, "canny_sweeps_working")) {
+        // diagnostics of the last Canny call on this context (its companion's, for imgfd_detect_dev): frames the queued sweeps
+        // did not finish (the union-find kernels did), and the number of the last sweep that changed anything.  Waits for the stream.
+        const imgfd_ctx *c = ctx->canny_flags ? ctx : (ctx->side && ctx->side->canny_flags ? ctx->side : nullptr);
+        *value = 0;
+        if (!c) return IMGFD_OK;
+        IMGFD_HIP(ctx, hipStreamSynchronize(c->stream));
+        std::vector<unsigned> f(32 + (size_t)c->canny_frames);  // HY_SWEEPS_MAX sweep flags, then one word per frame
+        IMGFD_HIP(ctx, hipMemcpy(f.data(), c->canny_flags, 4 * f.size(), hipMemcpyDeviceToHost));
+        for (int i = 0; i < c->canny_frames; i++) {
+            if (!strcmp(name, "canny_frames_unconverged")) *value += f[32 + i] == (unsigned)c->canny_sweeps;
+            else *value = std::max<int64_t>(*value, f[32 + i]);
+        }
+        return IMGFD_OK;
+    }
     for (const TuneKey &k : tune_keys())
         if (!strcmp(k.name, name)) { *value = k.field ? ctx->tune.*(k.field) : ctx->fir_mode; return IMGFD_OK; }
     return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_get_counter: unknown name");

@@ -69,19 +69,33 @@ imgfd_status detect_body(imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_str
     // 10 passes of 32 4K frames, profiles/r03/experiments_log.txt.)
     // (a single frame: FAST-9 too waits for gradient/NMS -- beside the blur it only delays the frame's critical path, the Canny
     // chain: 0.236 -> 0.230 ms per 4K frame; from two frames on it fills the blur's gaps: profiles/r04/xcd_tile_order.txt)
-    const int cg = ctx->tune.canny_gate < 0 ? (B == 1 ? 2 : 0) : ctx->tune.canny_gate;
+    const int cg = ctx->tune.canny_gate < 0 ? 0 : ctx->tune.canny_gate;
     const int fast_at = cg == 1 ? 1 : (cg == 0 ? 0 : 2);
     const int harris_at = ctx->tune.harris_gate == 0 ? fast_at : (ctx->tune.harris_gate == 2 ? 1 : 2);
+    // Small batches are bound by Canny's chain of dependent kernels, and the HOST queues launches at 4-8 us each: with the other
+    // detectors queued from inside the hook, a single 4K frame's first hysteresis sweep reached its queue 39 us after
+    // gradient/NMS had finished (profiles/r04/f_single_frame_timeline.txt: the ten launches of FAST-9 and the Harris chain sat in
+    // between).  "detect_defer": the hook only RECORDS the release events where they belong in Canny's stream; the waits and the
+    // other detectors' launches are queued after the last Canny launch.  Same dependencies on the device, the critical chain
+    // first on the host.
+    const bool defer = ctx->tune.detect_defer < 0 ? B < 8 : ctx->tune.detect_defer != 0;
+    bool fast_due = false, harris_due = false;
     const std::function<imgfd_status(int)> hook = [&](int pos) -> imgfd_status {  // pos: 0 before Canny's blur, 1 behind it, 2 behind gradient/NMS
         if (pos == fast_at) {
             IMGFD_HIP(ctx, hipEventRecord(ctx->ev_gate, side->stream));
-            IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gate, 0));
-            IMGFD_TRY(fast9());
+            if (defer) fast_due = true;
+            else {
+                IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gate, 0));
+                IMGFD_TRY(fast9());
+            }
         }
         if (pos == harris_at) {
             IMGFD_HIP(ctx, hipEventRecord(ctx->ev_gate2, side->stream));
-            IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gate2, 0));
-            IMGFD_TRY(harris());
+            if (defer) harris_due = true;
+            else {
+                IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gate2, 0));
+                IMGFD_TRY(harris());
+            }
         }
         return IMGFD_OK;
     };
@@ -89,6 +103,14 @@ imgfd_status detect_body(imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_str
     if (st != IMGFD_OK) {
         if (ctx->err.empty() || !side->err.empty()) ctx->err = side->err.empty() ? ctx->err : side->err;
         return st;
+    }
+    if (fast_due) {
+        IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gate, 0));
+        IMGFD_TRY(fast9());
+    }
+    if (harris_due) {
+        IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gate2, 0));
+        IMGFD_TRY(harris());
     }
     // whoever waits for the context's stream waits for the edges too
     IMGFD_HIP(ctx, hipEventRecord(ctx->ev_join, side->stream));

@@ -92,10 +92,16 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  *                  table's LDS centre computes their (magnitude, bin) words instead of gathering them (default 32; 0: always
  *                  gathers; same bits either way)
  *   "fir_mode" [IMGFD_FIR_MODE]  as imgfd_set_fir_mode
- *   "hyst_sweeps" [IMGFD_HYST_SWEEPS]  Canny hysteresis: sweeps queued before the union-find kernels (0: 14 for batches, 9-10 below 8 frames)
- *   "hyst_words" [IMGFD_HYST_WORDS]  words per tile of a sweep, 2 or 4 (0: 2 for one or two frames, else 4)
+ *   "hyst_sweeps" [IMGFD_HYST_SWEEPS]  Canny hysteresis: sweep launches queued before the union-find step (0: 8 up to 12 frames, 9 for batches)
+ *   "hyst_words" [IMGFD_HYST_WORDS]  words per tile of a sweep: 1, 2 or 4 (0: 1 up to 12 frames, else 4)
+ *   "hyst_block" [IMGFD_HYST_BLOCK]  tiles per workgroup of a sweep, 10 * across + down: 22, 42, 24 or 44 (0: 24 up to 12 frames, else 22)
+ *   "hyst_shift" [IMGFD_HYST_SHIFT]  1 (default): odd sweep launches group the tiles half a block up and left; 0: one grouping
+ *   "hyst_prio" [IMGFD_HYST_PRIO]  1 (default): the sweeps run at wave priority 3
+ *   "canny_finish" [IMGFD_CANNY_FINISH]  1 (default): union-find, 0/255 expansion and count in one launch; 0: three launches
  *   "canny_gate" [IMGFD_CANNY_GATE]  imgfd_detect_dev: where Canny releases FAST-9 on the other stream (0 before the blur,
- *                  1 behind it, 2 behind gradient/NMS; -1, default: 2 for a single frame, else 0)
+ *                  1 behind it, 2 behind gradient/NMS; -1, default: 0)
+ *   "detect_defer" [IMGFD_DETECT_DEFER]  imgfd_detect_dev: 1: FAST-9 and the Harris chain are QUEUED after Canny's last launch
+ *                  (released on the device where the gates say); 0: queued where they are released; -1 (default): 1 below 8 frames
  *   "harris_gate" [IMGFD_HARRIS_GATE]  imgfd_detect_dev: 1 (default) the Harris chain starts behind Canny's gradient/NMS kernel
  *                                      (FAST-9 starts with the blur); 2: behind the blur; 0: together with FAST-9
  *   "gauss_march" [IMGFD_GAUSS_MARCH]  1 (default): u8 frames whose width is a multiple of 16 (>= 256) take the marching
@@ -109,7 +115,7 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  *   "max_chunk_frames" [IMGFD_MAX_CHUNK_FRAMES]  frames per sub-batch of the *_dev entry points (0: from the memory budgets)
  *   "tile_run" [IMGFD_TILE_RUN]  tiles per workgroup of the u8 tile kernels (0: from the batch size)
  *   "detect_graph" [IMGFD_DETECT_GRAPH]  imgfd_detect_dev replays a recorded hipGraph for repeating calls on fewer frames than this
- *                                        (0 = never, the default: a single 4K frame took 0.259 ms either way)
+ *                                        (0 = never, the default: a single 4K frame takes the same time either way, 0.20 ms in round 5)
  *   "surf_taps" [IMGFD_SURF_TAPS]  1 (default): SURF octaves 1-3 look their 32 table words up with buffer loads and host-made offsets
  *   "surf_lanes" [IMGFD_SURF_LANES]  4 (default): imgfd_surf_dev deals the tiles round-robin to this many HIP streams (1..4)
  *   "surf_async" [IMGFD_SURF_ASYNC]  0 (default): imgfd_surf_dev reads the tile counts back once per call and redoes tiles
@@ -120,7 +126,8 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
 IMGFD_API imgfd_status imgfd_set_tuning(imgfd_ctx *ctx, const char *name, int value);
 /* reads a switch back, or a statistic: "detect_graph_records" / "detect_graph_replays" (launch sequences imgfd_detect_dev
  * recorded into a hipGraph / replayed from one on this context), "gauss_march_launches" (launches of the marching
- * Gaussian + gradient kernel) */
+ * Gaussian + gradient kernel), "canny_sweeps_working" / "canny_frames_unconverged" (last Canny call on this context: the last
+ * sweep launch that changed a frame; frames the queued launches did not finish -- these two wait for the stream) */
 IMGFD_API imgfd_status imgfd_get_counter(imgfd_ctx *ctx, const char *name, int64_t *value);
 
 /* ------------------------------------------------------------------ Harris */

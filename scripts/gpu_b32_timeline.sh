@@ -19,6 +19,6 @@ for s, e, k, q in rows[i0 - 1:i1 + 2]:
     if 'hyst_bits' in k:
         hy.append((s, e)); continue
     if hy:
-        print(f"{(hy[0][0] - t0) / 1e3:9.1f} {(hy[-1][1] - hy[0][0]) / 1e3:7.1f}  {'':>5s}  canny_hyst_bits x {len(hy)} (sum of durations {sum(b - a for a, b in hy) / 1e3:.1f})"); hy = []
+        print(f"{(hy[0][0] - t0) / 1e3:9.1f} {(hy[-1][1] - hy[0][0]) / 1e3:7.1f}  {'':>5s}  canny_hyst_block x {len(hy)} (sum of durations {sum(b - a for a, b in hy) / 1e3:.1f})"); hy = []
     print(f"{(s - t0) / 1e3:9.1f} {(e - s) / 1e3:7.1f}  {q:>5s}  {k}")
 PY

@@ -1,5 +1,5 @@
 #!/bin/bash
-# hysteresis: duration of every canny_hyst_bits launch of one imgfd_canny_dev call, in launch order (32 frames 4K)
+# hysteresis: duration of every canny_hyst_block launch of one imgfd_canny_dev call, in launch order (32 frames 4K)
 cd "$GRAFT_REPO_ROOT"; R="$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 python scripts/canny_time.py 2>/dev/null | grep canny_ms
 cd /tmp; rm -rf /tmp/ph
