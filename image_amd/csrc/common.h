@@ -55,7 +55,6 @@ struct imgfd_ctx {
     void (*canny_taps_free)(void *) = nullptr;
     const unsigned *canny_flags = nullptr;
     int canny_sweeps = 0, canny_frames = 0;
-    long tensor_wave_launches = 0;
     std::string detect_key, detect_seen;  // the call it was recorded for / the call seen last (raw bytes of a DetectKey)
     std::string detect_unrecordable;  // the key of a launch sequence that refused to be captured: run eagerly, do not try again
     // fHOG: magnitude + orientation of every integer gradient (fhog_fused.hip), built on first use
@@ -83,8 +82,7 @@ struct imgfd_ctx {
         int xcd_remap = 1;          // marching FIR kernels: workers of one XCD own neighbouring tiles
         int fused_response = 1;     // Harris: corner response in the structure-tensor kernel's epilogue
         int nms_tiled = 0;          // Harris batch path: 1 = the tiled NMS kernel instead of the sparse one
-        int tensor_per_cu = 0, tensor_seg = 0, tensor_workers = 0, tensor_tw = 0;  // fir_tensor launch geometry (0: chosen)
-        int tensor_wave = 0;        // structure tensor: 1 = the wave-autonomous kernel (fir_tensor_wave.hip) where it applies, 0 = the workgroup-marching one
+        int tensor_per_cu = 0, tensor_workers = 0, tensor_tw = 0;  // fir_tensor launch geometry (0: chosen)
         int surf_residue = 4;       // SURF octaves 1-3: modulus of the residue layout (0: plain table, 4, 16)
         int max_chunk_frames = 0;   // frames per sub-batch of the *_dev entry points (0: from the 12 GiB / 1 GiB budgets)
         int tile_run = 0;           // tiles per workgroup of the u8 tile kernels (0: from the batch size)

@@ -29,10 +29,8 @@ const std::vector<TuneKey> &tune_keys()
         {"fused_response", "IMGFD_FUSED_RESPONSE", &imgfd_ctx::Tune::fused_response},
         {"nms_tiled", "IMGFD_NMS_TILED", &imgfd_ctx::Tune::nms_tiled},
         {"tensor_per_cu", "IMGFD_TENSOR_PER_CU", &imgfd_ctx::Tune::tensor_per_cu},
-        {"tensor_seg", "IMGFD_TENSOR_SEG", &imgfd_ctx::Tune::tensor_seg},
         {"tensor_workers", "IMGFD_TENSOR_WORKERS", &imgfd_ctx::Tune::tensor_workers},
         {"tensor_tw", "IMGFD_TENSOR_TW", &imgfd_ctx::Tune::tensor_tw},
-        {"tensor_wave", "IMGFD_TENSOR_WAVE", &imgfd_ctx::Tune::tensor_wave},
         {"surf_residue", "IMGFD_SURF_RESIDUE", &imgfd_ctx::Tune::surf_residue},
         {"max_chunk_frames", "IMGFD_MAX_CHUNK_FRAMES", &imgfd_ctx::Tune::max_chunk_frames},
         {"tile_run", "IMGFD_TILE_RUN", &imgfd_ctx::Tune::tile_run},
@@ -170,7 +168,6 @@ imgfd_status imgfd_get_counter(imgfd_ctx *ctx, const char *name, int64_t *value)
     if (!strcmp(name, "detect_graph_replays")) { *value = ctx->detect_replays; return IMGFD_OK; }
     if (!strcmp(name, "detect_graph_records")) { *value = ctx->detect_records; return IMGFD_OK; }
     if (!strcmp(name, "gauss_march_launches")) { *value = ctx->gauss_march_launches; return IMGFD_OK; }
-    if (!strcmp(name, "tensor_wave_launches")) { *value = ctx->tensor_wave_launches; return IMGFD_OK; }
     if (!strcmp(name, "canny_frames_unconverged") || !strcmp(name, "canny_sweeps_working")) {
         // diagnostics of the last Canny call on this context (its companion's, for imgfd_detect_dev): frames the queued sweeps
         // did not finish (the union-find kernels did), and the number of the last sweep that changed anything.  Waits for the stream.

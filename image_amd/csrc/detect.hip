@@ -21,6 +21,8 @@ namespace {
 std::string make_key(const imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_stream_params *p, const void *c, const void *pt, const void *e,
                      const void *n)
 {
+    // a member added to either struct must be added below: the sizes pin the layouts this list was written for
+    static_assert(sizeof(imgfd_frames) == 40 && sizeof(imgfd_stream_params) == 104, "imgfd_frames / imgfd_stream_params changed: extend make_key");
     std::string k;
     auto put = [&k](const auto &v) { k.append(reinterpret_cast<const char *>(&v), sizeof v); };
     put(fr->d_frames); put(fr->n_frames); put(fr->nx); put(fr->ny); put(fr->frame_stride_bytes); put(fr->row_stride_bytes); put(fr->dtype);

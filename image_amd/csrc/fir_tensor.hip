@@ -149,9 +149,10 @@ __device__ __forceinline__ void ft_row_products(const float4 *raw4, int r, int s
 // OUT 1: A, B, C staged through LDS and stored as float4 rows
 // OUT 2: corner response (Harris measure) computed from the staged A, B, C; only R is stored (float4 rows)
 //
-// Schedule.  The workgroup is persistent: it walks a list of (frame, strip, segment) tiles -- tile t of worker w is
-// w + t * workers -- as ONE sequence of steps (a step = one 16-row chunk of a tile), so consecutive tiles overlap like
-// consecutive chunks do and no CU idles between workgroups.  Step s, pipelined over three consecutive chunks:
+// Schedule.  The workgroup is persistent: the batch's (frame, strip) columns form ONE line of 16-row chunk units, worker w owns
+// the units [w * units_per_worker, (w + 1) * units_per_worker) and marches them as ONE sequence of steps (a step = one chunk;
+// one warm-up chunk where its share begins inside a column), so consecutive columns overlap like consecutive chunks do and
+// no CU idles between workgroups.  Step s, pipelined over three consecutive chunks:
 //     barrier 1
 //       small phase: every thread pulls its column's 16 row-filtered values of chunk s-1 out of the ring into registers,
 //                    writes the Ix/Iy tile of chunk s (fetched into registers during step s-1) to LDS, and -- OUT 1/2 --
@@ -476,7 +477,6 @@ __global__ void __launch_bounds__(3 * TW) FT_WAVES_PER_EU(TW) fir_tensor(TensorP
 }
 
 // ------------------------------------------------------------------ host side
-imgfd_status launch_tensor_wave(imgfd_ctx *ctx, TensorParams &p, int n_frames, int R, int out_mode);  // fir_tensor_wave.hip
 bool tensor_fast_path(int R) { return R == 7 || R == 3 || R == 1; }
 
 template <int R, int TW, int OUT>
@@ -524,6 +524,10 @@ imgfd_status launch_tensor_march(imgfd_ctx *ctx, const float *d_Ix, const float 
                                  unsigned char *d_tq, float Th)
 {
     if (!tensor_fast_path(R)) return IMGFD_ERR_UNSUPPORTED;
+    // the kernel addresses a frame's f32 plane with 32-bit BYTE offsets (buffer resources, row offsets in scalar registers): a
+    // plane of 4 GiB or more is not its business (frame_fits admits up to 2^31 - 2^24 ELEMENTS; the caller falls back to the
+    // generic two-pass FIR, which indexes with size_t)
+    if ((size_t)nx * (size_t)ny * sizeof(float) >= ((size_t)1 << 32)) return IMGFD_ERR_UNSUPPORTED;
     TensorParams p;
     memset(&p, 0, sizeof p);
     p.ix = d_Ix; p.iy = d_Iy; p.out0 = d_A; p.out1 = d_B; p.out2 = d_C; p.nx = nx; p.ny = ny;
@@ -536,10 +540,6 @@ imgfd_status launch_tensor_march(imgfd_ctx *ctx, const float *d_Ix, const float 
                      (out_mode == 2 || ((size_t)d_B % 16 == 0 && (size_t)d_C % 16 == 0));
     if (out_mode != 0 && out_mode != 2) return IMGFD_ERR_UNSUPPORTED;
     if (out_mode != 0 && !vec) return IMGFD_ERR_UNSUPPORTED;
-    if (vec && ctx->tune.tensor_wave) {  // the wave-autonomous kernel (fir_tensor_wave.hip) where it applies
-        const imgfd_status st = launch_tensor_wave(ctx, p, n_frames, R, out_mode);
-        if (st != IMGFD_ERR_UNSUPPORTED) return st;
-    }
     // 256-column strips (12 waves: every SIMD carries three) unless the image is narrow
     const int tw = ctx->tune.tensor_tw == 128 ? 128 : ctx->tune.tensor_tw == 256 ? 256 : (nx > 384 ? 256 : 128);
 #define FT_GO(RR)                                                                                          \

@@ -1,5 +1,6 @@
-// image_amd/csrc/fir_tensor_device.h -- what the two structure-tensor kernels (fir_tensor.hip: workgroup-marching,
-// fir_tensor_wave.hip: wave-autonomous) share: launch parameters, buffer-addressed stores, the interleaved tap chains.
+// image_amd/csrc/fir_tensor_device.h -- device helpers of the structure-tensor kernel (fir_tensor.hip): launch parameters,
+// buffer-addressed stores, the interleaved tap chains.  (Also included by the measured-and-rejected wave-autonomous variant,
+// scripts/experiments/fir_tensor_wave.hip, which is not part of the library.)
 // compute_autocorrelation_matrix(), image.CornerDetectionHarris/src/harris.cpp:44-70; gaussian.cpp:289-395.
 #pragma once
 #include "common.h"
@@ -16,11 +17,9 @@ struct TensorParams {
     float *out0, *out1, *out2;  // A, B, C -- or R in out0 (OUT = 2)
     int nx, ny;
     long frame_stride;  // elements between frames (planes are packed: pitch nx)
-    int seg_rows;       // output rows per segment
-    int nstrips, nseg, n_frames;  // tiles = strips x segments x frames, numbered strip-fastest
-    int step_strip, step_seg, step_frame;  // the number of workers as (strips, segments, frames) digits: a worker's next tile
-    long total_units, units_per_worker;  // fir_tensor.hip: the batch as one line of chunk units (columns strip fastest), a worker's share of it
-    int units_per_column;  // fir_tensor.hip: chunks of one (frame, strip) column marched in one piece
+    int nstrips, n_frames;
+    long total_units, units_per_worker;  // the batch as one line of chunk units (columns strip fastest), a worker's share of it
+    int units_per_column;  // chunks of one (frame, strip) column marched in one piece
     int xcd_remap;
     float k;            // Harris constant (OUT = 2)
     // OUT = 2, optional: one byte per quad of pixels, bit e = "the response of pixel x + e is not below the threshold

@@ -109,8 +109,8 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  *   "xcd_remap" [IMGFD_XCD_REMAP]  1 (default): workers of one XCD own neighbouring tiles in the marching FIR kernels
  *   "fused_response" [IMGFD_FUSED_RESPONSE]  1 (default): corner response in the structure-tensor kernel's epilogue
  *   "nms_tiled" [IMGFD_NMS_TILED]  1: the tiled Harris NMS kernel instead of the sparse one
- *   "tensor_per_cu", "tensor_seg", "tensor_workers", "tensor_tw" [IMGFD_TENSOR_*]  launch geometry of fir_tensor (0: chosen)
- *   "tensor_wave" [IMGFD_TENSOR_WAVE]  1: the wave-autonomous structure-tensor kernel (fir_tensor_wave.hip: measured slower, kept as an experiment); 0 (default)
+ *   "tensor_per_cu", "tensor_workers", "tensor_tw" [IMGFD_TENSOR_*]  launch geometry of fir_tensor: workgroups per CU, workers
+ *                  (each takes an equal share of the batch's line of 16-row chunk units), strip width 128 | 256 (0: chosen)
  *   "surf_residue" [IMGFD_SURF_RESIDUE]  SURF octaves 1-3: modulus of the residue layout (4; 0 = plain table, 16)
  *   "max_chunk_frames" [IMGFD_MAX_CHUNK_FRAMES]  frames per sub-batch of the *_dev entry points (0: from the memory budgets)
  *   "tile_run" [IMGFD_TILE_RUN]  tiles per workgroup of the u8 tile kernels (0: from the batch size)

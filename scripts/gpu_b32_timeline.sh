@@ -16,7 +16,7 @@ print("offset_us  dur_us  queue  kernel   (one pass of the timed region, 32 fram
 hy = []
 for s, e, k, q in rows[i0 - 1:i1 + 2]:
     k = re.sub(r'^void ', '', k); k = re.split(r'\(', k)[0][:50]
-    if 'hyst_bits' in k:
+    if 'canny_hyst_' in k:
         hy.append((s, e)); continue
     if hy:
         print(f"{(hy[0][0] - t0) / 1e3:9.1f} {(hy[-1][1] - hy[0][0]) / 1e3:7.1f}  {'':>5s}  canny_hyst_block x {len(hy)} (sum of durations {sum(b - a for a, b in hy) / 1e3:.1f})"); hy = []

@@ -14,8 +14,8 @@ for fn in glob.glob('/tmp/ct/**/*kernel_trace.csv', recursive=True):
 rows.sort()
 idx = [i for i, r in enumerate(rows) if 'canny_blur_march' in r[2]]
 i0, i1 = idx[-2], idx[-1]
-hy = [(e - s) / 1e3 for s, e, k in rows[i0:i1] if 'hyst_bits' in k]
-oth = [(re.split(r'\(', re.sub(r'^void ', '', k))[0][:30], round((e - s) / 1e3, 1)) for s, e, k in rows[i0:i1] if 'hyst_bits' not in k]
+hy = [(e - s) / 1e3 for s, e, k in rows[i0:i1] if 'canny_hyst_' in k]
+oth = [(re.split(r'\(', re.sub(r'^void ', '', k))[0][:30], round((e - s) / 1e3, 1)) for s, e, k in rows[i0:i1] if 'canny_hyst_' not in k]
 print("  sweeps:", " ".join(f"{d:.1f}" for d in hy[:12]), f"... sum {sum(hy):.1f} us over {len(hy)}")
 print("  others:", oth)
 PY

@@ -5,7 +5,7 @@ cd "$GRAFT_REPO_ROOT"; R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/k3p"; mkdir -p "$O
 export TMPDIR=/tmp
 {
 echo "=== pytest (harris stages + api)"
-timeout 600 python -m pytest tests/test_harris_stages.py tests/test_harris_api.py tests/test_tensor_wave.py -m gpu -x -q 2>&1 | tail -3
+timeout 600 python -m pytest tests/test_harris_stages.py tests/test_harris_api.py -m gpu -x -q 2>&1 | tail -3
 echo "=== doorway (20 B/px), HIP events: product library (FT_PRIO 1), then variants"
 for v in "" scripts/variants/lib_p*.so; do
   VARIANT_LIB=$v BATCHES=1,32 timeout 200 python scripts/k3_variants.py 2>&1 | grep structure_tensor

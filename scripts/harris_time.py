@@ -16,4 +16,4 @@ it = int(os.environ.get("ITERS", 10))
 e0.record()
 for _ in range(it): det.harris(frames, out=out)
 e1.record(); e1.synchronize()
-print(json.dumps({"harris_ms_per_batch": round(e0.elapsed_time(e1) / it, 4), "corners": int(out[1].sum()), "variant": os.environ.get("VARIANT_LIB", "default"), "tensor_wave": os.environ.get("IMGFD_TENSOR_WAVE", "default")}))
+print(json.dumps({"harris_ms_per_batch": round(e0.elapsed_time(e1) / it, 4), "corners": int(out[1].sum()), "variant": os.environ.get("VARIANT_LIB", "default")}))

@@ -187,14 +187,15 @@ def test_structure_tensor_rows_that_are_no_whole_quads(be, nx, ny):
         assert_bits_equal(g, r, f"structure tensor {nm} {nx}x{ny}")
 
 
-@pytest.mark.parametrize("workers", [1, 3, 7])
+@pytest.mark.parametrize("workers", [1, 3, 7, 11])
 @pytest.mark.parametrize("out", ["abc", "response"])
 def test_tensor_kernel_workers_walk_several_tiles(be, workers, out):
-    """the structure-tensor workgroups are persistent: each walks a list of (frame, strip, segment) tiles as one
-    pipelined sequence of chunks.  Few workers and short segments: every worker crosses tile boundaries (strip change,
-    segment change, last short segment)."""
+    """the structure-tensor workgroups are persistent: the batch's (frame, strip) columns form ONE line of 16-row chunk units
+    and a worker marches its equal share of it as one pipelined sequence.  520 x 77 with sigma 2.5: 3 strips x 6 units = 18
+    units -- 7 and 11 workers get 3 and 2 units each, so shares begin and end in the middle of a column (a warm-up chunk
+    where a share begins), 3 workers get one whole column each, one worker walks all three."""
     try:
-        be.set_tuning("tensor_workers", workers); be.set_tuning("tensor_seg", 18)
+        be.set_tuning("tensor_workers", workers)
         nx, ny = 520, 77
         ix, iy = _gradients(26, nx, ny)
         be.set_fir_mode(0)
@@ -206,7 +207,7 @@ def test_tensor_kernel_workers_walk_several_tiles(be, workers, out):
             ref = oracle.harris_stage("response", A, B, Cc, measure=0, k=0.06)
             assert_bits_equal(be.k_tensor_response(ix, iy, 2.5, 0.06), ref, f"tensor+response, {workers} workers")
     finally:
-        be.set_tuning("tensor_workers", 0); be.set_tuning("tensor_seg", 0)
+        be.set_tuning("tensor_workers", 0)
 
 
 def test_tensor_response_unsupported_shapes_are_refused(be):
