@@ -26,14 +26,22 @@ def device_backend(dist) -> str:
     return "nccl" if "nccl" in str(dist.get_backend()) else "gloo"
 
 
-def reduce_counts(counts, elapsed_s: float, dist=None, device=None):
+def has_host_side(dist) -> bool:
+    """the process group serves HOST tensors through gloo ("gloo" alone, or the mixed "cpu:gloo,cuda:nccl" group bench.py forms)"""
+    return "gloo" in str(dist.get_backend())
+
+
+def reduce_counts(counts, elapsed_s: float, dist=None, device=None, on_host: bool = False):
     """Sum the per-rank feature counts and take the max elapsed time over ranks.
 
-    counts: 1-D int64 torch tensor on the rank's device.  Returns (total_counts tensor, max elapsed float)."""
+    counts: 1-D int64 torch tensor on the rank's device.  Returns (total_counts tensor, max elapsed float).
+    on_host: reduce copies of the few bytes over the group's gloo side when it has one -- no RCCL communicator has to exist
+    (a live one costs the kernels beside it ~12 % on this hardware, profiles/r03); rccl_gather_counts() is the device-side
+    collective north_star asks for, run once when every clock has stopped."""
     import torch
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=counts.device if device is None else device)
-    if dist is not None and dist.is_initialized():   # one rank included: the reductions of N = 1 run through the communicator too
-        if device_backend(dist) == "gloo" and counts.is_cuda:  # functional checks: gloo reduces host tensors
+    if dist is not None and dist.is_initialized():   # one rank included: the reductions of N = 1 run through the group too
+        if counts.is_cuda and (device_backend(dist) == "gloo" or (on_host and has_host_side(dist))):
             c, tt = counts.cpu(), t.cpu()
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -43,14 +51,26 @@ def reduce_counts(counts, elapsed_s: float, dist=None, device=None):
     return counts, float(t.item())
 
 
-def gather_frame_counts(frame_counts, dist=None):
+def rccl_gather_counts(counts, dist):
+    """ONE all_gather of every rank's feature-count vector on DEVICE tensors ("RCCL only to gather feature counts"); returns the
+    [world, k] tensor on the host, or None where the group has no device backend (ranks sharing one device: gloo only)."""
+    import torch
+    if dist is None or not dist.is_initialized() or device_backend(dist) != "nccl" or not counts.is_cuda:
+        return None
+    parts = [torch.zeros_like(counts) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, counts.contiguous())
+    return torch.stack(parts).cpu()
+
+
+def gather_frame_counts(frame_counts, dist=None, on_host: bool = False):
     """configs[4]: every rank holds a [k, n_local] int64 tensor of per-frame counts of its contiguous block of the
-    stream; returns the [k, n_total] tensor in stream order on every rank (one all_gather of padded blocks)."""
+    stream; returns the [k, n_total] tensor in stream order on every rank (one all_gather of padded blocks).
+    on_host: as reduce_counts."""
     import torch
     if dist is None or not dist.is_initialized():
         return frame_counts
     world = dist.get_world_size()
-    use_host = device_backend(dist) == "gloo" and frame_counts.is_cuda
+    use_host = frame_counts.is_cuda and (device_backend(dist) == "gloo" or (on_host and has_host_side(dist)))
     fc = frame_counts.cpu() if use_host else frame_counts
     n = torch.tensor([fc.shape[1]], dtype=torch.int64, device=fc.device)
     ns = [torch.zeros_like(n) for _ in range(world)]

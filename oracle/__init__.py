@@ -200,6 +200,25 @@ def canny(img, s: float = 2.0, low_thr: float = 3.0, high_thr: float = 10.0, acc
     return edges, int(n)
 
 
+def fft_gblur(img, s: float = 2.0):
+    """gblur() as the reference computes it (tools.c:146-185): y = float(ifft2(fft2(x) * fft2(g)) / (w h)) with the wrapped
+    Gaussian -- three 2-D FFTs, here through numpy's pocketfft (the reference calls FFTW3, which this image does not have)."""
+    img = np.asarray(img)
+    h, w = img.shape
+    xs = np.where(np.arange(w) < w // 2, np.arange(w), np.arange(w) - w).astype(np.float64)
+    ys = np.where(np.arange(h) < h // 2, np.arange(h), np.arange(h) - h).astype(np.float64)
+    g = np.exp(-(xs[None, :] ** 2 + ys[:, None] ** 2) / (s * s))
+    g /= g.sum()
+    y = np.fft.ifft2(np.fft.fft2(img.astype(np.float64)) * np.fft.fft2(g))
+    return y.real.astype(np.float32)
+
+
+def canny_fft(img, s: float = 2.0, low_thr: float = 3.0, high_thr: float = 10.0, accGrad: bool = True):
+    """canny_edge_detector() with the reference's ALGORITHM for the blur (FFT product) instead of the restatement's direct
+    circular sums: the CPU leg a timing baseline should quote (bench.py).  Same edge map (tests/test_oracle.py)."""
+    return canny_from_blur(fft_gblur(img, s), low_thr, high_thr, accGrad)
+
+
 def canny_from_blur(blur, low_thr: float = 3.0, high_thr: float = 10.0, accGrad: bool = True):
     """The stages behind the blur (gradient, maxima, hysteresis: rcpp_canny.cpp:153-215) on a given blurred plane (ny, nx) of
     float values -- lets a test swap the blur's FFT for another implementation (FFTW3 itself is not in this image).

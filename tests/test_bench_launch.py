@@ -108,10 +108,11 @@ def test_more_ranks_than_gpus_is_an_error_not_a_hang():
 
 @pytest.mark.gpu
 def test_nccl_world1_collectives():
-    """N = 1 creates a one-rank RCCL communicator and sends the path's three collectives through it: all_reduce(sum) of the
-    feature counts, all_reduce(max) of the elapsed time, all_gather of the per-frame count vectors (configs[4])"""
+    """N = 1 forms the group of N > 1 (gloo for host tensors, RCCL for device tensors): the counts are reduced over gloo, and ONE
+    RCCL all_gather of the count vectors runs after every clock has stopped -- the line says how many ranks it saw.  The three
+    collectives of image_amd/stream.py also run on device tensors over a plain nccl group."""
     out = run_bench("--config", "5", "--frames", "6", "--batch", "4", "--warmup", "1", "--no-cpu")
-    assert out["config"]["collectives"].startswith("nccl (RCCL) for the device tensors, world size 1"), out["config"].get("collectives")
+    assert out["config"]["rccl_ranks_seen"] == 1 and "ONE RCCL all_gather" in out["config"]["collectives"] and "sums equal" in out["config"]["collectives"], out["config"].get("collectives")
     assert out["config"]["per_frame_counts_gathered"] == 6
     # the same reductions directly, on device tensors
     import torch
@@ -128,3 +129,18 @@ def test_nccl_world1_collectives():
         assert torch.equal(stream.gather_frame_counts(fc, dist), fc)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_scale_run_sheet_on_one_device(tmp_path):
+    """scripts/scale_8gpu.sh end to end in miniature: N = 1 and 2 (the two ranks share device 0, so no RCCL communicator can
+    form: the sheet records 0 ranks seen), resident and --h2d, the default workload and the stream; the sheet's own assertions
+    (N = 1 against a plain line, stream counts independent of the sharding) must hold and the JSON carry every run"""
+    out = tmp_path / "scale.json"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(GPUS="1 2", SHARE="1", FRAMES="12", BATCH="3", STEPS="2", INNER="2")
+    p = subprocess.run(["bash", os.path.join(ROOT, "scripts", "scale_8gpu.sh"), str(out)], env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    sheet = json.loads(out.read_text())
+    assert len(sheet["runs"]) == 8 and {r["n_gpus"] for r in sheet["runs"]} == {1, 2} and {r["delivery"] for r in sheet["runs"]} == {"resident", "h2d"}
+    assert all(len(r["per_rank"]) == r["n_gpus"] and r["value"] > 0 for r in sheet["runs"])

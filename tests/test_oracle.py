@@ -180,15 +180,7 @@ def test_canny_restatement_matches_reference_golden(golden, fixture, cases):
         assert np.array_equal(np.packbits(e > 0), g[f"edges_bits_{case}"]), case
 
 
-def _numpy_gblur(img, s):
-    """tools.c:146-185 literally: y = float(ifft2(fft2(x) * fft2(g)) / (w h)) with the wrapped Gaussian."""
-    h, w = img.shape
-    xs = np.where(np.arange(w) < w // 2, np.arange(w), np.arange(w) - w).astype(np.float64)
-    ys = np.where(np.arange(h) < h // 2, np.arange(h), np.arange(h) - h).astype(np.float64)
-    g = np.exp(-(xs[None, :] ** 2 + ys[:, None] ** 2) / (s * s))
-    g /= g.sum()
-    y = np.fft.ifft2(np.fft.fft2(img.astype(np.float64)) * np.fft.fft2(g))
-    return y.real.astype(np.float32)
+_numpy_gblur = oracle.fft_gblur   # tools.c:146-185 literally, through numpy's FFT
 
 
 @pytest.mark.parametrize("nx,ny,s", [(64, 48, 2.0), (128, 100, 2.0), (90, 61, 1.0), (75, 40, 3.0)])
