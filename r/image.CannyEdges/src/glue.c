@@ -1,6 +1,6 @@
 /* Replaces image.CannyEdges/src/{RcppExports.cpp, rcpp_canny.cpp, tools.c, adsf.c} and drops the FFTW3 / libpng
  * system requirements (src/Makevars:1). */
-#include "../../imgfd_glue.h"
+#include "imgfd_glue.h"
 
 SEXP _image_CannyEdges_canny_edge_detector(SEXP image, SEXP X, SEXP Y, SEXP s, SEXP low_thr, SEXP high_thr, SEXP accGrad)
 {

@@ -1,5 +1,5 @@
 /* Replaces image.CornerDetectionF9/src/{RcppExports.cpp, f9_rcpp.cpp, f9.cpp}. */
-#include "../../imgfd_glue.h"
+#include "imgfd_glue.h"
 
 SEXP _image_CornerDetectionF9_detect_corners(SEXP x, SEXP width, SEXP height, SEXP bytes_per_row, SEXP suppress_non_max,
                                              SEXP threshold)

@@ -1,6 +1,6 @@
 /* Replaces image.CornerDetectionHarris/src/{RcppExports.cpp, rcpp_harris.cpp} and the bundled algorithm sources.
  * R/RcppExports.R stays as it is: .Call('_image_CornerDetectionHarris_detect_corners', ...16 args...). */
-#include "../../imgfd_glue.h"
+#include "imgfd_glue.h"
 
 SEXP _image_CornerDetectionHarris_detect_corners(SEXP x, SEXP nx, SEXP ny, SEXP k, SEXP sigma_d, SEXP sigma_i,
         SEXP threshold, SEXP gaussian, SEXP gradient, SEXP strategy, SEXP Nselect, SEXP measure, SEXP Nscales,

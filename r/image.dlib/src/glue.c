@@ -1,5 +1,5 @@
 /* Replaces image.dlib/src/{RcppExports.cpp, rcpp_fhog.cpp, rcpp_surf.cpp, dlib-core.cpp} (no dlib unity build). */
-#include "../../imgfd_glue.h"
+#include "imgfd_glue.h"
 
 SEXP _image_dlib_dlib_fhog(SEXP x, SEXP rows, SEXP cols, SEXP cell_size, SEXP frp, SEXP fcp)
 {

@@ -27,7 +27,7 @@ class RPackage:
         if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
             tmp = f"{so}.{os.getpid()}.tmp"   # (xdist workers may build the same object)
             subprocess.check_call(["gcc", "-O1", "-g", "-Wall", "-Wextra", "-Werror", "-Wno-cast-function-type", "-shared", "-fPIC",
-                                   "-I", os.path.join(ROOT, "r", "stub"), "-I", os.path.join(ROOT, "include"), *srcs,
+                                   "-I", os.path.join(ROOT, "r", "stub"), "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "r"), *srcs,
                                    imgfd_lib_path, f"-Wl,-rpath,{os.path.dirname(imgfd_lib_path)}", "-lm", "-o", tmp])
             os.replace(tmp, so)
         # DEEPBIND: the glue's imgfd_* references bind to the library it was linked with, whatever else the process has loaded

@@ -20,7 +20,7 @@ PKGS = {
 def test_glue_compiles_against_the_c_abi(pkg):
     src = os.path.join(ROOT, "r", pkg, "src", "glue.c")
     cmd = ["gcc", "-std=gnu99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "r", "stub"),
-           "-I", os.path.join(ROOT, "include"), src]
+           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "r"), src]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
 
@@ -50,3 +50,26 @@ def test_no_per_pixel_loop_on_the_r_thread():
     dlib = open(os.path.join(ROOT, "r", "image.dlib", "src", "glue.c")).read()
     fhog = dlib[dlib.index("_image_dlib_dlib_fhog("):dlib.index("_image_dlib_dlib_surf_points(")]
     assert "imgfd_fhog_f64out(" in fhog and not re.search(r"for\s*\(", fhog)
+
+
+def test_r_check_kit_is_complete_and_current():
+    """r/check/*.R (the scripts a maintainer with R runs, r/README.md) name their expected values through gold("file"): every such file
+    exists under r/check/golden/, and the Harris / FAST-9 tables there are what tests/golden/*.npz hold (scripts/export_golden_for_r.py)"""
+    import glob
+    import re
+
+    import numpy as np
+    gdir = os.path.join(ROOT, "r", "check", "golden")
+    named = set()
+    for f in glob.glob(os.path.join(ROOT, "r", "check", "check_*.R")):
+        txt = open(f).read()
+        named |= set(re.findall(r'gold\("([^"%]+)"\)', txt))
+    assert len(named) >= 12
+    for n in named:
+        assert os.path.exists(os.path.join(gdir, n)), n
+    g = np.load(os.path.join(ROOT, "tests", "golden", "harris_building.npz"))
+    t = np.loadtxt(os.path.join(gdir, "harris_building_default.csv"), delimiter=",", skiprows=1)
+    assert t.shape == (251, 3) and np.array_equal(t.astype(np.float32), g["xyR_default"])
+    f9 = np.load(os.path.join(ROOT, "tests", "golden", "fast9_chairs.npz"))
+    t = np.loadtxt(os.path.join(gdir, "fast9_chairs_t80_n1.csv"), delimiter=",", skiprows=1)
+    assert np.array_equal(t[:, 0], f9["xy_t80_n1"][:, 1]) and np.array_equal(t[:, 1], 512 - f9["xy_t80_n1"][:, 0])   # f9_rcpp.cpp:29-30
