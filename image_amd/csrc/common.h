@@ -71,13 +71,14 @@ struct imgfd_ctx {
         int hyst_words = 0;         // words per sweep tile: 1, 2 or 4 (0: 1 up to 12 frames, else 4)
         int hyst_block = 0;         // tiles per workgroup of a sweep, 10 * across + down: 22, 42, 24, 44 (0: 24 up to 12 frames, else 22)
         int canny_finish = 1;       // 1: union-find + expansion + count as one launch (canny_finish) where workgroups can wait for each other; 0: three launches
+        int detect_swap = -1;       // imgfd_detect_dev: 1 = Canny's chain on the context's own stream, FAST-9 and the Harris chain on the companion's; 0: the other way round; -1: 1 below 8 frames
         int hyst_prio = 1;          // block sweeps run at wave priority 3 (0: default priority)
         int hyst_shift = 1;         // block sweeps: odd launches group the tiles half a block up and left (0: the same grouping in every launch)
         int detect_defer = -1;      // imgfd_detect_dev: 1 = FAST-9 and the Harris chain are QUEUED only after the whole Canny chain (their release point on the device stays where canny_gate / harris_gate put it); 0 = queued where they are released; -1: 1 below 8 frames
         int surf_taps = 1;          // SURF octaves 1-3: look-ups as buffer loads with host-made offsets (0: address arithmetic per look-up)
         int gauss_march = 1;        // u8 frames whose width is a multiple of 16: the marching Gaussian + gradient kernel (0: the tile kernel)
         int gauss_march_seg = 0;    // rows per segment of that kernel (0: from the batch)
-        int harris_gate = 1;        // imgfd_detect_dev: the Harris chain is released behind Canny's gradient/NMS kernel (1), behind its blur (2), or together with FAST-9 (0)
+        int harris_gate = -1;       // imgfd_detect_dev: the Harris chain is released behind Canny's gradient/NMS kernel (1), behind its blur (2), or together with FAST-9 (0); -1: 2 below 8 frames, else 1
         int canny_gate = -1;        // imgfd_detect_dev: where Canny releases FAST-9 on the other stream (0 before the blur, 1 after it, 2 after gradient/NMS; -1: 2 for a single frame, else 0)
         int xcd_remap = 1;          // marching FIR kernels: workers of one XCD own neighbouring tiles
         int fused_response = 1;     // Harris: corner response in the structure-tensor kernel's epilogue

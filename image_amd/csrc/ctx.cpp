@@ -21,6 +21,7 @@ const std::vector<TuneKey> &tune_keys()
         {"hyst_prio", "IMGFD_HYST_PRIO", &imgfd_ctx::Tune::hyst_prio},
         {"canny_finish", "IMGFD_CANNY_FINISH", &imgfd_ctx::Tune::canny_finish},
         {"detect_defer", "IMGFD_DETECT_DEFER", &imgfd_ctx::Tune::detect_defer},
+        {"detect_swap", "IMGFD_DETECT_SWAP", &imgfd_ctx::Tune::detect_swap},
         {"canny_gate", "IMGFD_CANNY_GATE", &imgfd_ctx::Tune::canny_gate},
         {"harris_gate", "IMGFD_HARRIS_GATE", &imgfd_ctx::Tune::harris_gate},
         {"gauss_march", "IMGFD_GAUSS_MARCH", &imgfd_ctx::Tune::gauss_march},
@@ -191,25 +192,32 @@ imgfd_status imgfd_get_counter(imgfd_ctx *ctx, const char *name, int64_t *value)
 imgfd_status imgfd_profile_k3(imgfd_ctx *ctx, int enable)
 {
     if (!ctx) return IMGFD_ERR_INVALID;
-    ctx->prof_on = enable != 0;
-    ctx->prof_used = 0;
+    // the whole chain of companions: imgfd_detect_dev runs the Harris chain on the companion's stream for small batches
+    for (imgfd_ctx *c = ctx; c; c = c->side) {
+        c->prof_on = enable != 0;
+        c->prof_used = 0;
+    }
     return IMGFD_OK;
 }
 
 imgfd_status imgfd_profile_k3_read(imgfd_ctx *ctx, double *total_us, int *launches)
 {
     if (!ctx || !total_us || !launches) return IMGFD_ERR_INVALID;
-    IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     double tot = 0;
-    const size_t pairs = ctx->prof_used / 2;
-    for (size_t i = 0; i < pairs; i++) {
-        float ms = 0;
-        IMGFD_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
-        tot += 1e3 * (double)ms;
+    size_t all = 0;
+    for (imgfd_ctx *c = ctx; c; c = c->side) {  // each context's pairs were recorded on its own stream
+        IMGFD_HIP(ctx, hipStreamSynchronize(c->stream));
+        const size_t pairs = c->prof_used / 2;
+        for (size_t i = 0; i < pairs; i++) {
+            float ms = 0;
+            IMGFD_HIP(ctx, hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+            tot += 1e3 * (double)ms;
+        }
+        all += pairs;
+        c->prof_used = 0;
     }
     *total_us = tot;
-    *launches = (int)pairs;
-    ctx->prof_used = 0;
+    *launches = (int)all;
     return IMGFD_OK;
 }
 
@@ -279,6 +287,7 @@ imgfd_status ctx_side(imgfd_ctx *ctx, imgfd_ctx **side)
         if (st != IMGFD_OK) return imgfd_fail(ctx, st, "could not create the companion context");
         s->fir_mode = ctx->fir_mode;
         s->tune = ctx->tune;
+        s->prof_on = ctx->prof_on;
         // the three events first; the companion is published only when everything it needs exists
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
         for (int i = 0; i < 4; i++) {

@@ -44,22 +44,34 @@ imgfd_status detect_body(imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_str
                          imgfd_point *d_points, uint8_t *d_edges, int64_t *d_counts)
 {
     const int B = fr->n_frames;
-    auto fast9 = [&]() -> imgfd_status {
-        if (!p->fast9) return IMGFD_OK;
-        return imgfd_fast9_dev(ctx, fr, (uint8_t)p->fast9_threshold, p->suppress_non_max, d_points, p->point_cap, d_counts + B);
-    };
-    auto harris = [&]() -> imgfd_status {
-        if (!p->harris) return IMGFD_OK;
-        return imgfd_harris_dev(ctx, fr, p->k, p->sigma_d, p->sigma_i, p->threshold, p->gaussian, p->gradient, p->measure, d_corners,
-                                p->corner_cap, d_counts);
-    };
     if (!p->canny) {
-        IMGFD_TRY(fast9());
-        return harris();
+        if (p->fast9) IMGFD_TRY(imgfd_fast9_dev(ctx, fr, (uint8_t)p->fast9_threshold, p->suppress_non_max, d_points, p->point_cap, d_counts + B));
+        if (p->harris) IMGFD_TRY(imgfd_harris_dev(ctx, fr, p->k, p->sigma_d, p->sigma_i, p->threshold, p->gaussian, p->gradient, p->measure, d_corners, p->corner_cap, d_counts));
+        return IMGFD_OK;
     }
     if (!p->harris && !p->fast9) return imgfd_canny_dev(ctx, fr, p->s, p->low_thr, p->high_thr, p->accGrad, d_edges, d_counts + 2 * B);
     imgfd_ctx *side = nullptr;
     IMGFD_TRY(ctx_side(ctx, &side));
+    // Two streams: `cs` runs Canny's chain, `os` FAST-9 and the Harris chain.  By default Canny takes the companion's stream;
+    // "detect_swap" 1 gives it the context's own: then nothing stands between the caller's previous work on that stream and the blur
+    // -- no fork event to cross -- and the join at the end is a wait that has usually been satisfied already.
+    const bool swap = ctx->tune.detect_swap < 0 ? B < 8 : ctx->tune.detect_swap == 1;
+    imgfd_ctx *cc = swap ? ctx : side, *oc = swap ? side : ctx;   // Canny's context / the other detectors'
+    auto fail_from = [&](imgfd_ctx *c, imgfd_status st) -> imgfd_status {
+        if (c != ctx && !c->err.empty()) ctx->err = c->err;
+        return st;
+    };
+    auto fast9 = [&]() -> imgfd_status {
+        if (!p->fast9) return IMGFD_OK;
+        const imgfd_status st = imgfd_fast9_dev(oc, fr, (uint8_t)p->fast9_threshold, p->suppress_non_max, d_points, p->point_cap, d_counts + B);
+        return st == IMGFD_OK ? st : fail_from(oc, st);
+    };
+    auto harris = [&]() -> imgfd_status {
+        if (!p->harris) return IMGFD_OK;
+        const imgfd_status st = imgfd_harris_dev(oc, fr, p->k, p->sigma_d, p->sigma_i, p->threshold, p->gaussian, p->gradient, p->measure, d_corners,
+                                                 p->corner_cap, d_counts);
+        return st == IMGFD_OK ? st : fail_from(oc, st);
+    };
     // the frames (and anything else queued on the context's stream) come first
     IMGFD_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     IMGFD_HIP(ctx, hipStreamWaitEvent(side->stream, ctx->ev_fork, 0));
@@ -69,12 +81,13 @@ imgfd_status detect_body(imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_str
     // (Round 2 got this order by accident: the 16-wave rows_scan workgroup of FAST-9's compaction found no CU with 16 free
     // wave slots until the gradient/NMS kernel had drained.  Released together with FAST-9: 43.5 instead of 40.3 ms per
     // 10 passes of 32 4K frames, profiles/r03/experiments_log.txt.)
-    // (a single frame: FAST-9 too waits for gradient/NMS -- beside the blur it only delays the frame's critical path, the Canny
-    // chain: 0.236 -> 0.230 ms per 4K frame; from two frames on it fills the blur's gaps: profiles/r04/xcd_tile_order.txt)
     const int cg = ctx->tune.canny_gate < 0 ? 0 : ctx->tune.canny_gate;
     const int fast_at = cg == 1 ? 1 : (cg == 0 ? 0 : 2);
-    const int harris_at = ctx->tune.harris_gate == 0 ? fast_at : (ctx->tune.harris_gate == 2 ? 1 : 2);
-    // Small batches are bound by Canny's chain of dependent kernels, and the HOST queues launches at 4-8 us each: with the other
+    // (small batches: behind the blur already -- the chain then ends before Canny's does, and the join below is a wait that has been
+    // satisfied by the time the stream reaches it: 182 against 190 us for a single 4K frame, profiles/r05/single_frame_variants.txt)
+    const int hg = ctx->tune.harris_gate < 0 ? (B < 8 ? 2 : 1) : ctx->tune.harris_gate;
+    const int harris_at = hg == 0 ? fast_at : (hg == 2 ? 1 : 2);
+    // Small batches are bound by Canny's chain of dependent kernels, and the HOST queues launches at 3-8 us each: with the other
     // detectors queued from inside the hook, a single 4K frame's first hysteresis sweep reached its queue 39 us after
     // gradient/NMS had finished (profiles/r04/f_single_frame_timeline.txt: the ten launches of FAST-9 and the Harris chain sat in
     // between).  "detect_defer": the hook only RECORDS the release events where they belong in Canny's stream; the waits and the
@@ -84,37 +97,34 @@ imgfd_status detect_body(imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_str
     bool fast_due = false, harris_due = false;
     const std::function<imgfd_status(int)> hook = [&](int pos) -> imgfd_status {  // pos: 0 before Canny's blur, 1 behind it, 2 behind gradient/NMS
         if (pos == fast_at) {
-            IMGFD_HIP(ctx, hipEventRecord(ctx->ev_gate, side->stream));
+            IMGFD_HIP(ctx, hipEventRecord(ctx->ev_gate, cc->stream));
             if (defer) fast_due = true;
             else {
-                IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gate, 0));
+                IMGFD_HIP(ctx, hipStreamWaitEvent(oc->stream, ctx->ev_gate, 0));
                 IMGFD_TRY(fast9());
             }
         }
         if (pos == harris_at) {
-            IMGFD_HIP(ctx, hipEventRecord(ctx->ev_gate2, side->stream));
+            IMGFD_HIP(ctx, hipEventRecord(ctx->ev_gate2, cc->stream));
             if (defer) harris_due = true;
             else {
-                IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gate2, 0));
+                IMGFD_HIP(ctx, hipStreamWaitEvent(oc->stream, ctx->ev_gate2, 0));
                 IMGFD_TRY(harris());
             }
         }
         return IMGFD_OK;
     };
-    const imgfd_status st = canny_dev_hooked(side, fr, p->s, p->low_thr, p->high_thr, p->accGrad, d_edges, d_counts + 2 * B, &hook);
-    if (st != IMGFD_OK) {
-        if (ctx->err.empty() || !side->err.empty()) ctx->err = side->err.empty() ? ctx->err : side->err;
-        return st;
-    }
+    const imgfd_status st = canny_dev_hooked(cc, fr, p->s, p->low_thr, p->high_thr, p->accGrad, d_edges, d_counts + 2 * B, &hook);
+    if (st != IMGFD_OK) return fail_from(cc, st);
     if (fast_due) {
-        IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gate, 0));
+        IMGFD_HIP(ctx, hipStreamWaitEvent(oc->stream, ctx->ev_gate, 0));
         IMGFD_TRY(fast9());
     }
     if (harris_due) {
-        IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gate2, 0));
+        IMGFD_HIP(ctx, hipStreamWaitEvent(oc->stream, ctx->ev_gate2, 0));
         IMGFD_TRY(harris());
     }
-    // whoever waits for the context's stream waits for the edges too
+    // whoever waits for the context's stream waits for the companion's work too
     IMGFD_HIP(ctx, hipEventRecord(ctx->ev_join, side->stream));
     IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     return IMGFD_OK;

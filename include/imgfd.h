@@ -102,8 +102,10 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  *                  1 behind it, 2 behind gradient/NMS; -1, default: 0)
  *   "detect_defer" [IMGFD_DETECT_DEFER]  imgfd_detect_dev: 1: FAST-9 and the Harris chain are QUEUED after Canny's last launch
  *                  (released on the device where the gates say); 0: queued where they are released; -1 (default): 1 below 8 frames
- *   "harris_gate" [IMGFD_HARRIS_GATE]  imgfd_detect_dev: 1 (default) the Harris chain starts behind Canny's gradient/NMS kernel
- *                                      (FAST-9 starts with the blur); 2: behind the blur; 0: together with FAST-9
+ *   "harris_gate" [IMGFD_HARRIS_GATE]  imgfd_detect_dev: 1: the Harris chain starts behind Canny's gradient/NMS kernel
+ *                                      (FAST-9 starts with the blur); 2: behind the blur; 0: together with FAST-9; -1 (default): 2 below 8 frames, else 1
+ *   "detect_swap" [IMGFD_DETECT_SWAP]  imgfd_detect_dev: 1: Canny's chain runs on the context's own stream, the other detectors on the
+ *                                      companion's; 0: the other way round; -1 (default): 1 below 8 frames
  *   "gauss_march" [IMGFD_GAUSS_MARCH]  1 (default): u8 frames whose width is a multiple of 16 (>= 256) take the marching
  *                                      Gaussian + gradient kernel; 0: the tile kernel.  "gauss_march_seg": its rows per segment
  *   "xcd_remap" [IMGFD_XCD_REMAP]  1 (default): workers of one XCD own neighbouring tiles in the marching FIR kernels
