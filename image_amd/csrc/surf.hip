@@ -381,6 +381,11 @@ __global__ void __launch_bounds__(256) surf_int_apply(const unsigned char *__res
     }
 }
 
+// hessian_pyramid.h:141-145: Dxx = (double)wide_box - (double)narrow_box * 3.0 -- both sums are exact integers far below 2^31 / 3 (a box
+// of the largest filter covers 291 x 193 pixels of at most 255), so the int32 difference is exact and its one conversion
+// equals the reference's three double operations bit for bit
+__device__ __forceinline__ double surf_dxx(int wide, int narrow) { return (double)(wide - 3 * narrow); }
+
 // (get_sum_of_area, integral_image.h:64-96, in uint32 arithmetic = the reference's wrapping int32, appears below in
 // its interior form: br - bl - tr + tl.)
 
@@ -431,8 +436,10 @@ __device__ __forceinline__ double surf_lds_interval(const unsigned *__restrict__
         const int l = cx - w / 2, t = cy - h / 2, r = l + w - 1, b = t + h - 1;
         return (int)(at(b, r) - at(b, l - 1) - at(t - 1, r) + at(t - 1, l - 1));
     };
-    double Dxx = box(0, 0, lobe * 3, 2 * lobe - 1) - box(0, 0, lobe, 2 * lobe - 1) * 3.0;
-    double Dyy = box(0, 0, 2 * lobe - 1, lobe * 3) - box(0, 0, 2 * lobe - 1, lobe) * 3.0;
+    // :141-145 form (double)box - (double)box * 3.0: integers below 2^26 (a box of at most 291 x 193 pixels of at most 255), so the
+    // difference is exact in int32 and ONE conversion gives the reference's double (surf_dxx)
+    double Dxx = surf_dxx(box(0, 0, lobe * 3, 2 * lobe - 1), box(0, 0, lobe, 2 * lobe - 1));
+    double Dyy = surf_dxx(box(0, 0, 2 * lobe - 1, lobe * 3), box(0, 0, 2 * lobe - 1, lobe));
     double Dxy = (int)((unsigned)box(-off, off, lobe, lobe) + (unsigned)box(off, -off, lobe, lobe) - (unsigned)box(-off, -off, lobe, lobe) -
                        (unsigned)box(off, off, lobe, lobe));
     Dxx *= area_inv; Dyy *= area_inv; Dxy *= area_inv;
@@ -605,8 +612,8 @@ __global__ void __launch_bounds__(256) surf_pyramid(const unsigned *__restrict__
                 const int l = cx - w / 2, t = cy - h / 2, rr = l + w - 1, b = t + h - 1;
                 return (int)(at(b, rr) - at(b, l - 1) - at(t - 1, rr) + at(t - 1, l - 1));
             };
-            double Dxx = box(0, 0, lobe * 3, 2 * lobe - 1) - box(0, 0, lobe, 2 * lobe - 1) * 3.0;       // :141-142
-            double Dyy = box(0, 0, 2 * lobe - 1, lobe * 3) - box(0, 0, 2 * lobe - 1, lobe) * 3.0;       // :144-145
+            double Dxx = surf_dxx(box(0, 0, lobe * 3, 2 * lobe - 1), box(0, 0, lobe, 2 * lobe - 1));       // :141-142
+            double Dyy = surf_dxx(box(0, 0, 2 * lobe - 1, lobe * 3), box(0, 0, 2 * lobe - 1, lobe));       // :144-145
             double Dxy = (int)((unsigned)box(-off, off, lobe, lobe) + (unsigned)box(off, -off, lobe, lobe) -
                                (unsigned)box(-off, -off, lobe, lobe) - (unsigned)box(off, off, lobe, lobe));  // :147-150
             Dxx *= L.area_inv; Dyy *= L.area_inv; Dxy *= L.area_inv;
@@ -693,8 +700,8 @@ __global__ void __launch_bounds__(256) surf_pyramid_taps(const unsigned *__restr
 #pragma unroll
             for (int k = 0; k < 32; k++) v[k] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, taps.w[e][k] * 4, 0);
             auto box = [&](int j) __attribute__((always_inline)) -> int { return (int)(v[4 * j] - v[4 * j + 1] - v[4 * j + 2] + v[4 * j + 3]); };
-            double Dxx = box(0) - box(1) * 3.0;                                                           // :141-142
-            double Dyy = box(2) - box(3) * 3.0;                                                           // :144-145
+            double Dxx = surf_dxx(box(0), box(1));                                                        // :141-142
+            double Dyy = surf_dxx(box(2), box(3));                                                        // :144-145
             double Dxy = (int)((unsigned)box(4) + (unsigned)box(5) - (unsigned)box(6) - (unsigned)box(7));  // :147-150
             Dxx *= L.area_inv; Dyy *= L.area_inv; Dxy *= L.area_inv;
             double sign = +1;

@@ -270,3 +270,25 @@ def test_batch_dev(be):
         ref, rn = oracle.canny(frames[f])
         assert mismatch(edges[f], ref) <= 3
         assert counts[f] == np.count_nonzero(edges[f])
+
+
+def test_many_unconverged_frames_in_one_batch(be):
+    """canny_finish completes frames the queued sweeps did not finish with two barriers across the workgroups of THAT frame inside one
+    launch.  48 frames, ONE sweep queued, every frame left to it: 48 x 128 workgroups -- three times what the chip holds at once --
+    must neither hang (workgroups are dispatched in order; a frame's workgroups wait for nobody else) nor differ from the oracle."""
+    nx, ny = 384, 200
+    base = _serpentine(nx, ny)
+    frames = np.stack([np.roll(base, 7 * f, axis=1) if f % 3 else base[::-1].copy() for f in range(48 if be.name != "emu" else 3)])
+    try:
+        be.set_tuning("hyst_sweeps", 1)
+        e, c = be.canny_dev(frames, **SERP_KW)
+        if be.name != "emu":
+            assert be.get_counter("canny_frames_unconverged") == len(frames)      # all of them took the union-find path
+        seen = {}
+        for f in range(len(frames)):
+            key = frames[f].tobytes()
+            if key not in seen: seen[key] = oracle.canny(frames[f], **SERP_KW)
+            r, k = seen[key]
+            assert c[f] == k and mismatch(e[f], r) == 0, f
+    finally:
+        be.set_tuning("hyst_sweeps", 0)
