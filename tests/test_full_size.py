@@ -110,6 +110,20 @@ def test_surf_tile_4096(gpu):
             assert s[k].shape == r[k].shape and np.array_equal(s[k], r[k]), (k, max_points)
 
 
+def test_surf_bright_tile_whose_integral_image_wraps(gpu):
+    """a 4096x4096 tile with a mean gray level of ~240: the int32 integral image wraps (sum 4.0e9 > 2^31) long before the last
+    row, as dlib's does (integral_image.h:33-62 with promote<uchar> = int32).  Box sums are differences of four table entries,
+    so the wrap cancels and every determinant -- formed from ONE int32 difference per Dxx / Dyy since round 5 -- equals dlib's."""
+    from test_surf import blobs
+    tile = (255 - np.tile(blobs(6, 1024, 1024), (4, 4, 1)) // 3).astype(np.uint8)
+    tile[::5, ::9] -= 20
+    gray = tile.astype(np.uint64).sum(2) // 3
+    assert int(gray.sum()) > 2 ** 31 + 2 ** 30                      # it does wrap
+    got = gpu.surf_interest_points(tile, 5.0)
+    ref = oracle.surf_interest_points(tile, 5.0)
+    assert len(ref) > 100 and got.shape == ref.shape and np.array_equal(got, ref)
+
+
 def test_config5_stream_of_4k_frames_sampled_against_the_oracle():
     """config 5 shape: frames G(50000+f) generated on the device, Harris defaults + FAST-9 + Canny defaults through
     imgfd_detect_dev (what bench.py times); per-frame counts, and a sample frame checked in full against the oracle"""
