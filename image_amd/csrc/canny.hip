@@ -514,18 +514,20 @@ __global__ void __launch_bounds__(256) canny_grad_nms(const float *__restrict__ 
     const int in_frame = (int)(xcd_order ? imgfd_xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x), bz = blockIdx.y;
     const int by = in_frame / tiles_x, bx = in_frame - by * tiles_x;
     const int x0 = bx * GN_TX, y0 = by * GN_TY;
-    // the hysteresis sweeps behind this kernel start from cleared "changed" words (a memset of their own was 5 us of a
-    // single frame's critical path)
+    // workgroup-uniform: interior tiles skip every clamp and fetch the blurred tile as float4s
+    const bool inside = vec4 && x0 - GN_XO >= 0 && x0 + GN_TX + GN_XO <= nx && y0 - 2 >= 0 && y0 + GN_TY + 2 <= ny;
+    if (inside) canny_grad_nms_tile<true>(sb, sg, blur, S, Wm, nx, ny, words_per_row, accGrad, low_thr, high_thr, bx, by, bz);
+    else canny_grad_nms_tile<false>(sb, sg, blur, S, Wm, nx, ny, words_per_row, accGrad, low_thr, high_thr, bx, by, bz);
+    // The launches behind this kernel start from cleared words: the sweeps' "changed" flags, per frame the last sweep that changed
+    // it, the arrival counter of canny_finish's frame barriers and pixels_nonzero (a memset of their own was 5 us of a single
+    // frame's critical path).  At the END of the kernel: in front of the tile code the 64-bit store through `counts` cost the
+    // mask-word addresses their scalar registers (68 vector instructions more per workgroup, 882 against 830 us per 32 frames).
     if (in_frame == 0 && bz == 0 && (int)threadIdx.x < n_sweep_flags) sweep_flags[threadIdx.x] = 0;
     if (in_frame == 0 && threadIdx.x == 0) {
         sweep_flags[n_sweep_flags + bz] = 0;              // per frame: the last sweep that changed it
         sweep_flags[n_sweep_flags + gridDim.y + bz] = 0;  // ... and the arrival counter of canny_finish's frame barriers
         counts[bz] = 0;                                   // pixels_nonzero: the expansion adds to it
     }
-    // workgroup-uniform: interior tiles skip every clamp and fetch the blurred tile as float4s
-    const bool inside = vec4 && x0 - GN_XO >= 0 && x0 + GN_TX + GN_XO <= nx && y0 - 2 >= 0 && y0 + GN_TY + 2 <= ny;
-    if (inside) canny_grad_nms_tile<true>(sb, sg, blur, S, Wm, nx, ny, words_per_row, accGrad, low_thr, high_thr, bx, by, bz);
-    else canny_grad_nms_tile<false>(sb, sg, blur, S, Wm, nx, ny, words_per_row, accGrad, low_thr, high_thr, bx, by, bz);
 }
 
 // ------------------------------------------------------------------ K12

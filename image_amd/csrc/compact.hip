@@ -150,7 +150,9 @@ __global__ void __launch_bounds__(256) scatter_rows(const unsigned long long *__
 static imgfd_status compact_emit_impl(imgfd_ctx *ctx, const CompactBuffers &cb, int nx, int ny, int n_frames, int kind,
                                       const float *d_R, const AbcSource &abc, void *d_out, int64_t cap, int64_t *d_counts)
 {
-    const bool self_scan = cap > 0 && ny <= SCATTER_SELF_SCAN_MAX_ROWS;
+    // small batches only: a single frame saves the rows_scan launch of its critical chain; at 32 frames the 540 workgroups per frame that each
+    // add up to 2160 counts take 29 us where rows_scan + scatter_rows took 24.5 (profiles/r05/a_pmc_all_kernels.txt)
+    const bool self_scan = cap > 0 && ny <= SCATTER_SELF_SCAN_MAX_ROWS && n_frames < 8;
     if (!self_scan)
         hipLaunchKernelGGL(rows_scan, dim3(n_frames), dim3(SCAN_NT), 0, ctx->stream, cb.rowcount, cb.rowoff, ny,
                            (long long *)d_counts);
