@@ -384,7 +384,9 @@ __global__ void __launch_bounds__(256) surf_int_apply(const unsigned char *__res
 // hessian_pyramid.h:141-145: Dxx = (double)wide_box - (double)narrow_box * 3.0 -- both sums are exact integers far below 2^31 / 3 (a box
 // of the largest filter covers 291 x 193 pixels of at most 255), so the int32 difference is exact and its one conversion
 // equals the reference's three double operations bit for bit
-__device__ __forceinline__ double surf_dxx(int wide, int narrow) { return (double)(wide - 3 * narrow); }
+// (3 * narrow as a 24-bit multiply: the narrow box holds at most 97 x 193 x 255 < 2^23; the plain product compiles to v_mul_lo_u32, a
+// quarter-rate instruction -- 48 of them per thread of the first octave's kernel)
+__device__ __forceinline__ double surf_dxx(int wide, int narrow) { return (double)(wide - __mul24(narrow, 3)); }
 
 // (get_sum_of_area, integral_image.h:64-96, in uint32 arithmetic = the reference's wrapping int32, appears below in
 // its interior form: br - bl - tr + tl.)
