@@ -393,9 +393,10 @@ imgfd_status fhog_fused_hist(imgfd_ctx *ctx, const uint8_t *d_rgb, size_t frame_
     IMGFD_TRY(fhog_fused_init(ctx));
     const int tiles_x = ceil_div(g.cells_nc, FH_CC), n_bands = ceil_div(g.cells_nr, FH_CR);
     int bpw = ctx->tune.fhog_bands;
-    if (bpw <= 0) {  // march as far as the batch leaves >= 8 workgroups per CU
+    if (bpw <= 0) {  // march as far as the batch leaves >= 8 workgroups per CU, four bands at most (16 tiles of 4096^2: 1 / 2 / 4 / 8 / 16
+                     // bands per workgroup 76.5 / 73.2 / 72.8 / 74.4 / 77.1 us per tile, profiles/r05/a_fhog_variants.txt; round 4 the same order)
         const long band_tiles = (long)tiles_x * n_bands * nf;
-        bpw = (int)std::min<long>(8, std::max<long>(1, band_tiles / (8L * ctx->num_cu)));
+        bpw = (int)std::min<long>(4, std::max<long>(1, band_tiles / (8L * ctx->num_cu)));
     }
     bpw = std::min(bpw, n_bands);
     const dim3 grid((unsigned)tiles_x * (unsigned)ceil_div(n_bands, bpw), nf);
