@@ -26,6 +26,8 @@
 // the Hessian pyramid (12 B of doubles per tile pixel) goes out with streaming stores: imgfd_surf_dev 0.306-0.311 -> 0.287 ms per tile
 #define IMGFD_NT_OUT 1
 #include "common.h"
+
+#include <type_traits>
 #include "surf_describe.h"
 
 #include <math.h>
@@ -454,7 +456,7 @@ __device__ __forceinline__ double surf_lds_interval(const unsigned *__restrict__
 
 template <int O>
 __global__ void __launch_bounds__(256) surf_pyramid_lds(const unsigned *__restrict__ I, double *__restrict__ pyr, SurfGeom g,
-                                                        unsigned long long *__restrict__ mask, double thr, int blocks_x, int xcd_order)
+                                                        unsigned long long *__restrict__ mask, double thr, int blocks_x, int xcd_order, int skip_ends)
 {
     using G = SurfPyrLds<O>;
     HIP_DYNAMIC_SHARED(unsigned, win)  // [G::H][G::P]
@@ -506,21 +508,23 @@ __global__ void __launch_bounds__(256) surf_pyramid_lds(const unsigned *__restri
                 if ((tid & 63) == 0 && lr < g.nr[O] && lc < g.nc[O]) mask[L.mask + (size_t)lr * ((g.nc[O] + 63) / 64) + (lc >> 6)] = word; \
             }                                                                                              \
         }
-        SPL_DO(0) SPL_DO(1) SPL_DO(2) SPL_DO(3) SPL_DO(4) SPL_DO(5)
+        if (!skip_ends) SPL_DO(0)  // kernel-uniform: intervals 0 and 5 only lend neighbourhoods to the maxima of 1 and 4 ("surf_ends")
+        SPL_DO(1) SPL_DO(2) SPL_DO(3) SPL_DO(4)
+        if (!skip_ends) SPL_DO(5)
 #undef SPL_DO
     }
 }
 
 template <int O>
 static imgfd_status launch_surf_pyramid_lds(imgfd_ctx *ctx, const unsigned *d_I, double *d_pyr, const SurfGeom &g,
-                                            unsigned long long *d_mask, double thr)
+                                            unsigned long long *d_mask, double thr, int skip_ends)
 {
     static_assert(SurfPyrLds<O>::LX == 64, "a wave's ballot is one mask word");
     using G = SurfPyrLds<O>;
     const size_t lds = sizeof(unsigned) * (size_t)G::H * G::P;
     IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)surf_pyramid_lds<O>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int bx = ceil_div(g.nc[O], G::LX), by = ceil_div(g.nr[O], G::LY);
-    hipLaunchKernelGGL(surf_pyramid_lds<O>, dim3((unsigned)bx * (unsigned)by), dim3(256), lds, ctx->stream, d_I, d_pyr, g, d_mask, thr, bx, ctx->tune.xcd_remap);
+    hipLaunchKernelGGL(surf_pyramid_lds<O>, dim3((unsigned)bx * (unsigned)by), dim3(256), lds, ctx->stream, d_I, d_pyr, g, d_mask, thr, bx, ctx->tune.xcd_remap, skip_ends);
     return IMGFD_OK;
 }
 
@@ -575,7 +579,7 @@ __device__ __forceinline__ int surf_octave_of_block(const SurfBlocks &b, unsigne
 
 template <int LM>  // 0: the plain table; else the residue layout with M = 1 << LM
 __global__ void __launch_bounds__(256) surf_pyramid(const unsigned *__restrict__ I, double *__restrict__ pyr, SurfGeom g, SurfBlocks blocks,
-                                                    unsigned long long *__restrict__ mask, double thr)
+                                                    unsigned long long *__restrict__ mask, double thr, int skip_ends)
 {
     // the octaves of one launch follow each other in the grid, each padded to a multiple of 8 workgroups so that
     // id % 8 (the XCD) is the same thing inside an octave's range as in the whole grid
@@ -596,7 +600,7 @@ __global__ void __launch_bounds__(256) surf_pyramid(const unsigned *__restrict__
     const bool in_level = lr < g.nr[o] && lc < g.nc[o];
     const unsigned *ctr = I + (size_t)r * cols + c;
 #pragma unroll 1
-    for (int it = 0; it < SURF_INT; it++) {
+    for (int it = skip_ends ? 1 : 0; it < SURF_INT - (skip_ends ? 1 : 0); it++) {
         const SurfLevel &L = g.lev[o * SURF_INT + it];
         const bool inside = in_level && !(r < L.border_px || r >= g.rows - L.border_px || c < L.border_px || c >= cols - L.border_px);
         bool hot = false;
@@ -671,7 +675,7 @@ static void surf_make_taps(const SurfGeom &g, SurfTaps *t)
 }
 
 __global__ void __launch_bounds__(256) surf_pyramid_taps(const unsigned *__restrict__ J, double *__restrict__ pyr, SurfGeom g, SurfBlocks blocks,
-                                                         SurfTaps taps, unsigned long long *__restrict__ mask, double thr)
+                                                         SurfTaps taps, unsigned long long *__restrict__ mask, double thr, int skip_ends)
 {
     const int o = surf_octave_of_block(blocks, blockIdx.x);  // >= 1
     const int gx = (g.nc[o] + 63) / 64, gy = (g.nr[o] + 3) / 4;
@@ -691,7 +695,7 @@ __global__ void __launch_bounds__(256) surf_pyramid_taps(const unsigned *__restr
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(J), 0, (int)((unsigned)g.rows * (unsigned)cols * 4u), 0x00027000);
     const int base = r * cols + (c >> 2);  // word of (r, c) in J: c is a multiple of 4
 #pragma unroll 1
-    for (int it = 0; it < SURF_INT; it++) {
+    for (int it = skip_ends ? 1 : 0; it < SURF_INT - (skip_ends ? 1 : 0); it++) {
         const SurfLevel &L = g.lev[o * SURF_INT + it];
         const int e = (o - 1) * SURF_INT + it;
         const bool inside = in_level && !(r < L.border_px || r >= g.rows - L.border_px || c < L.border_px || c >= cols - L.border_px);
@@ -732,7 +736,34 @@ struct SurfNmsParams {
     double step[SURF_OCT];      // get_step_size(o)
     unsigned long long cap;
     SurfBlocks blocks;          // masked form: all octaves in one launch
+    // "surf_ends" (round 5): intervals 0 and 5 of an octave are never maxima themselves (get_interest_points runs i = 1 .. 4,
+    // hessian_pyramid.h:461) -- they only lend their 3x3 neighbourhoods to the survivors of intervals 1 and 4.  The pyramid
+    // kernels then skip them (a third of all level-pixel values and of the pyramid's HBM writes) and the maximum test computes the
+    // nine values it needs from the integral image on the spot: a few thousand survivors per tile.
+    const unsigned *integral;   // non-null: intervals 0 and 5 are not in the pyramid buffer
 };
+
+// one level-pixel value of the Hessian pyramid straight from the integral image (build_pyramid, hessian_pyramid.h:119-171; the
+// arithmetic of surf_pyramid<0>): the determinant with the sign of the trace at the level pixel whose centre is image (r, c)
+__device__ __forceinline__ double surf_level_value(const unsigned *__restrict__ I, int cols, const SurfLevel &L, int r, int c)
+{
+    const unsigned *ctr = I + (size_t)r * cols + c;
+    const int lobe = L.lobe, off = L.off;
+    auto box = [&](int cx, int cy, int w, int h) __attribute__((always_inline)) -> int {  // centered_rect relative to the centre
+        const int l = cx - w / 2, t = cy - h / 2, rr = l + w - 1, b = t + h - 1;
+        return (int)(ctr[(long)b * cols + rr] - ctr[(long)b * cols + l - 1] - ctr[(long)(t - 1) * cols + rr] + ctr[(long)(t - 1) * cols + l - 1]);
+    };
+    double Dxx = surf_dxx(box(0, 0, lobe * 3, 2 * lobe - 1), box(0, 0, lobe, 2 * lobe - 1));
+    double Dyy = surf_dxx(box(0, 0, 2 * lobe - 1, lobe * 3), box(0, 0, 2 * lobe - 1, lobe));
+    double Dxy = (int)((unsigned)box(-off, off, lobe, lobe) + (unsigned)box(off, -off, lobe, lobe) - (unsigned)box(-off, -off, lobe, lobe) -
+                       (unsigned)box(off, off, lobe, lobe));
+    Dxx *= L.area_inv; Dyy *= L.area_inv; Dxy *= L.area_inv;
+    double sign = +1;
+    if (Dxx + Dyy < 0) sign = -1;
+    double det = Dxx * Dyy - 0.81 * Dxy * Dxy;
+    if (det < 0) det = 0;
+    return sign * det;
+}
 
 // ---- K18: 3x3x3 maximum test + interpolation of one level pixel (octave o, interval i, row r, column c)
 // true: `rec` is an interest point
@@ -767,24 +798,44 @@ __device__ __forceinline__ bool surf_nms_pixel(const double *__restrict__ pyr, c
             larger |= v[1][y][x] > val;
         }
     if (larger) return false;
+    // The two neighbouring intervals, the one that is in the pyramid buffer first: with "surf_ends" interval 0 (below i = 1) and
+    // interval 5 (above i = 4) are computed from the integral image here -- 9 values of 32 look-ups each -- and most survivors of
+    // the pixel's own 3x3 fall to the other, stored neighbour before that is needed.
+    const bool low_sparse = q.integral && i == 1, high_sparse = q.integral && i == SURF_INT - 2;
+    // (s is a compile-time constant in every call: v[][][] stays in registers)
+    auto neighbour = [&](auto s_tag, bool sparse) __attribute__((always_inline)) -> bool {  // false: a strictly larger value in interval i - 1 + s
+        constexpr int s = decltype(s_tag)::value;
+        const SurfLevel &Ln = g.lev[o * SURF_INT + i - 1 + s];
+        if (sparse) {  // positions inside border_next: valid in every interval
+            const int step = Ln.step;
 #pragma unroll
-    for (int s = 0; s < 3; s += 2) {
-        const double *P = pyr + g.lev[o * SURF_INT + i - 1 + s].plane + at;
+            for (int y = 0; y < 3; y++)
 #pragma unroll
-        for (int y = 0; y < 3; y++)
+                for (int x = 0; x < 3; x++) v[s][y][x] = surf_level_value(q.integral, g.cols, Ln, (r - 1 + y) * step, (c - 1 + x) * step);
+        } else {
+            const double *P = pyr + Ln.plane + at;
 #pragma unroll
-            for (int x = 0; x < 3; x++) v[s][y][x] = P[(size_t)y * nc + x];
-    }
+            for (int y = 0; y < 3; y++)
 #pragma unroll
-    for (int s = 0; s < 3; s += 2)
+                for (int x = 0; x < 3; x++) v[s][y][x] = P[(size_t)y * nc + x];
+        }
+        bool big = false;
 #pragma unroll
         for (int y = 0; y < 3; y++)
 #pragma unroll
             for (int x = 0; x < 3; x++) {
                 v[s][y][x] = fabs(v[s][y][x]);
-                larger |= v[s][y][x] > val;
+                big |= v[s][y][x] > val;
             }
-    if (larger) return false;
+        return !big;
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S2 = std::integral_constant<int, 2>;
+    if (high_sparse) {
+        if (!neighbour(S0(), false) || !neighbour(S2(), true)) return false;
+    } else {
+        if (!neighbour(S2(), false) || !neighbour(S0(), low_sparse)) return false;
+    }
     // interpolate_point :411-446
 #define V(s, dy, dx) v[s][1 + (dy)][1 + (dx)]
     const double g0 = (V(1, 0, 1) - V(1, 0, -1)) / 2.0;
@@ -1227,13 +1278,14 @@ imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const Surf
     // the pyramid buffer is idle until the integral image is complete: it lends the column scan its scratch
     launch_surf_integral(ctx, d_rgb, d.integral, g.rows, g.cols, d.pyr, d.pyr_bytes);
     IMGFD_HIP(ctx, hipMemsetAsync(d.count, 0, sizeof(unsigned long long), ctx->stream));
+    const int ends = ctx->tune.surf_ends ? 1 : 0;  // 1: intervals 0 and 5 are not built; the maximum test computes what it needs of them (SurfNmsParams::integral)
     for (int o = 0; o < SURF_OCT; o++) {
         if (g.nr[o] < 1 || g.nc[o] < 1) continue;
         static_assert(SURF_INT == 6, "surf_pyramid_lds unrolls six intervals");
         // the LDS kernels assume dlib's level geometry (lobe = step*(i+1) + 1); anything else takes the gather kernel
         const bool std_geom = g.lev[o * SURF_INT].step == (2 << o) && g.lev[o * SURF_INT].lobe == (2 << o) + 1 &&
                               g.lev[o * SURF_INT + SURF_INT - 1].lobe == (2 << o) * SURF_INT + 1 && (size_t)d.integral % 16 == 0;
-        if (o == 0 && std_geom) { IMGFD_TRY(launch_surf_pyramid_lds<0>(ctx, d.integral, d.pyr, g, d.mask, thr)); continue; }
+        if (o == 0 && std_geom) { IMGFD_TRY(launch_surf_pyramid_lds<0>(ctx, d.integral, d.pyr, g, d.mask, thr, ends)); continue; }
         // (octave 1 through the same kernel -- an 86 KB window, one workgroup per CU -- measured 219 us against 164 us for
         // the gather kernel on a 4096^2 tile: not used)
         // the gather kernel: this octave and everything above it in one launch
@@ -1252,20 +1304,21 @@ imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const Surf
             if (ctx->tune.surf_taps && (size_t)g.rows * g.cols * 4 < ((size_t)1 << 31)) {
                 SurfTaps taps;
                 surf_make_taps(g, &taps);
-                hipLaunchKernelGGL(surf_pyramid_taps, dim3(nb), dim3(256), 0, ctx->stream, d.residue, d.pyr, g, blocks, taps, d.mask, thr);
+                hipLaunchKernelGGL(surf_pyramid_taps, dim3(nb), dim3(256), 0, ctx->stream, d.residue, d.pyr, g, blocks, taps, d.mask, thr, ends);
             } else {
-                hipLaunchKernelGGL(surf_pyramid<2>, dim3(nb), dim3(256), 0, ctx->stream, d.residue, d.pyr, g, blocks, d.mask, thr);
+                hipLaunchKernelGGL(surf_pyramid<2>, dim3(nb), dim3(256), 0, ctx->stream, d.residue, d.pyr, g, blocks, d.mask, thr, ends);
             }
         } else if (o >= 1 && d.residue && g.cols % 16 == 0 && modulus == 16) {
             hipLaunchKernelGGL(surf_residue_layout<4>, lgrid, dim3(256), 0, ctx->stream, d.integral, d.residue, g.cols);
-            hipLaunchKernelGGL(surf_pyramid<4>, dim3(nb), dim3(256), 0, ctx->stream, d.residue, d.pyr, g, blocks, d.mask, thr);
+            hipLaunchKernelGGL(surf_pyramid<4>, dim3(nb), dim3(256), 0, ctx->stream, d.residue, d.pyr, g, blocks, d.mask, thr, ends);
         } else {
-            hipLaunchKernelGGL(surf_pyramid<0>, dim3(nb), dim3(256), 0, ctx->stream, d.integral, d.pyr, g, blocks, d.mask, thr);
+            hipLaunchKernelGGL(surf_pyramid<0>, dim3(nb), dim3(256), 0, ctx->stream, d.integral, d.pyr, g, blocks, d.mask, thr, ends);
         }
         break;
     }
     SurfNmsParams q;
     q.thr = thr; q.cap = d.cap;
+    q.integral = ends ? d.integral : nullptr;
     for (int i = 0; i < SURF_INT; i++) q.border_next[i] = (int)surf_border_of(std::min(i + 1, SURF_INT - 1));
     unsigned nb = 0;
     for (int o = 0; o < SURF_OCT; o++) {

@@ -122,6 +122,8 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  *   "surf_lanes" [IMGFD_SURF_LANES]  4 (default): imgfd_surf_dev deals the tiles round-robin to this many HIP streams (1..4)
  *   "surf_async" [IMGFD_SURF_ASYNC]  0 (default): imgfd_surf_dev reads the tile counts back once per call and redoes tiles
  *                                    whose candidates overflowed the record buffer; 1: no wait, such a tile reports -candidates
+ *   "surf_ends" [IMGFD_SURF_ENDS]  1 (default): intervals 0 and 5 of every octave of the Hessian pyramid are not built -- they are never
+ *                                  maxima themselves, the 3x3x3 test computes the neighbourhoods it needs of them; 0: all six intervals
  *   "surf_sort_cap" [IMGFD_SURF_SORT_CAP]  selected records imgfd_surf_dev ranks with its LDS sort (2048); more: all-pairs ranking
  *   "surf_rec_cap" [IMGFD_SURF_REC_CAP]  candidate records per tile imgfd_surf_dev buffers before it redoes the tile (262144)
  * Unknown names give IMGFD_ERR_INVALID. */
