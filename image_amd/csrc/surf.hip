@@ -765,77 +765,78 @@ __device__ __forceinline__ double surf_level_value(const unsigned *__restrict__ 
     return sign * det;
 }
 
-// ---- K18: 3x3x3 maximum test + interpolation of one level pixel (octave o, interval i, row r, column c)
-// true: `rec` is an interest point
-__device__ __forceinline__ bool surf_nms_pixel(const double *__restrict__ pyr, const SurfGeom &g, const SurfNmsParams &q, int o, int i, int r, int c,
-                                               SurfRecord &rec)
+// ---- K18: 3x3x3 maximum test + interpolation of one level pixel (octave o, interval i, row r, column c), in three steps so
+// that the masked kernel can compute the neighbourhoods of the intervals that are not built ("surf_ends") wave-cooperatively
+struct SurfNmsState {
+    double v[3][3][3];  // [interval][row][column] around the pixel (signed as stored until a step takes their absolute values)
+    double raw, val;    // the pixel's own value, its absolute value
+    int r, c;
+};
+// the 3x3 of one neighbouring interval (s = 0: below, 2: above) against the pixel: false = a strictly larger value there
+template <int S>
+__device__ __forceinline__ bool surf_nms_neighbour_ok(SurfNmsState &st)
+{
+    bool big = false;
+#pragma unroll
+    for (int y = 0; y < 3; y++)
+#pragma unroll
+        for (int x = 0; x < 3; x++) {
+            st.v[S][y][x] = fabs(st.v[S][y][x]);
+            big |= st.v[S][y][x] > st.val;
+        }
+    return !big;
+}
+// front: the pixel's own 3x3 and every neighbouring interval that is in the pyramid buffer.
+// 0: not an interest point; 1: all three intervals compared; 2: interval 0 (below i = 1) / 5 (above i = 4) is not built: its nine
+// values have to be put into st.v[0] / st.v[2] (signed) before surf_nms_back
+__device__ __forceinline__ int surf_nms_front(const double *__restrict__ pyr, const SurfGeom &g, const SurfNmsParams &q, int o, int i, int r, int c,
+                                              SurfNmsState &st)
 {
     const int nr = g.nr[o], nc = g.nc[o], b = q.border_next[i];
-    if (r < b + 1 || r >= nr - b - 1 || c < b + 1 || c >= nc - b - 1) return false;  // :474-476
-    // the 3x3x3 block around the pixel in two memory round trips, loads issued back to back with no branch in between:
-    // the pixel's own interval first (most pixels above the threshold are not the largest of their own 3x3), then the
-    // two neighbouring intervals.  (Neighbour-by-neighbour early exits cost a round trip per comparison; all 27 values
-    // at once fetched three times the cache lines for pixels the first nine reject.)
-    double v[3][3][3];  // [interval][row][column], absolute values
+    if (r < b + 1 || r >= nr - b - 1 || c < b + 1 || c >= nc - b - 1) return 0;  // :474-476
+    // the pixel's own interval first (most pixels above the threshold are not the largest of their own 3x3), loads issued back
+    // to back with no branch in between; then the neighbouring intervals.  (Neighbour-by-neighbour early exits cost a round
+    // trip per comparison; all 27 values at once fetched three times the cache lines for pixels the first nine reject.)
+    st.r = r; st.c = c;
     const size_t at = (size_t)(r - 1) * nc + (c - 1);
     {
         const double *P = pyr + g.lev[o * SURF_INT + i].plane + at;
 #pragma unroll
         for (int y = 0; y < 3; y++)
 #pragma unroll
-            for (int x = 0; x < 3; x++) v[1][y][x] = P[(size_t)y * nc + x];
+            for (int x = 0; x < 3; x++) st.v[1][y][x] = P[(size_t)y * nc + x];
     }
-    const double raw = v[1][1][1];
-    const double val = fabs(raw);
-    if (!(val >= q.thr)) return false;
+    st.raw = st.v[1][1][1];
+    st.val = fabs(st.raw);
+    if (!(st.val >= q.thr)) return 0;
     // is_maximum_in_region :324-356: rejected by any strictly larger value in the 3x3x3 block
-    bool larger = false;
-#pragma unroll
-    for (int y = 0; y < 3; y++)
-#pragma unroll
-        for (int x = 0; x < 3; x++) {
-            v[1][y][x] = fabs(v[1][y][x]);
-            larger |= v[1][y][x] > val;
-        }
-    if (larger) return false;
-    // The two neighbouring intervals, the one that is in the pyramid buffer first: with "surf_ends" interval 0 (below i = 1) and
-    // interval 5 (above i = 4) are computed from the integral image here -- 9 values of 32 look-ups each -- and most survivors of
-    // the pixel's own 3x3 fall to the other, stored neighbour before that is needed.
+    if (!surf_nms_neighbour_ok<1>(st)) return 0;
+    // With "surf_ends" interval 0 (below i = 1) and interval 5 (above i = 4) are not in the buffer -- and most survivors of the
+    // pixel's own 3x3 fall to the other, stored neighbour before those are needed: the stored interval first.
     const bool low_sparse = q.integral && i == 1, high_sparse = q.integral && i == SURF_INT - 2;
-    // (s is a compile-time constant in every call: v[][][] stays in registers)
-    auto neighbour = [&](auto s_tag, bool sparse) __attribute__((always_inline)) -> bool {  // false: a strictly larger value in interval i - 1 + s
+    auto load = [&](auto s_tag) __attribute__((always_inline)) {
         constexpr int s = decltype(s_tag)::value;
-        const SurfLevel &Ln = g.lev[o * SURF_INT + i - 1 + s];
-        if (sparse) {  // positions inside border_next: valid in every interval
-            const int step = Ln.step;
-#pragma unroll
-            for (int y = 0; y < 3; y++)
-#pragma unroll
-                for (int x = 0; x < 3; x++) v[s][y][x] = surf_level_value(q.integral, g.cols, Ln, (r - 1 + y) * step, (c - 1 + x) * step);
-        } else {
-            const double *P = pyr + Ln.plane + at;
-#pragma unroll
-            for (int y = 0; y < 3; y++)
-#pragma unroll
-                for (int x = 0; x < 3; x++) v[s][y][x] = P[(size_t)y * nc + x];
-        }
-        bool big = false;
+        const double *P = pyr + g.lev[o * SURF_INT + i - 1 + s].plane + at;
 #pragma unroll
         for (int y = 0; y < 3; y++)
 #pragma unroll
-            for (int x = 0; x < 3; x++) {
-                v[s][y][x] = fabs(v[s][y][x]);
-                big |= v[s][y][x] > val;
-            }
-        return !big;
+            for (int x = 0; x < 3; x++) st.v[s][y][x] = P[(size_t)y * nc + x];
     };
     using S0 = std::integral_constant<int, 0>;
     using S2 = std::integral_constant<int, 2>;
-    if (high_sparse) {
-        if (!neighbour(S0(), false) || !neighbour(S2(), true)) return false;
-    } else {
-        if (!neighbour(S2(), false) || !neighbour(S0(), low_sparse)) return false;
+    if (!high_sparse) { load(S2()); if (!surf_nms_neighbour_ok<2>(st)) return 0; }
+    if (!low_sparse) { load(S0()); if (!surf_nms_neighbour_ok<0>(st)) return 0; }
+    return low_sparse || high_sparse ? 2 : 1;
+}
+// back: the interval that was filled in (state 2) against the pixel, then interpolate_point
+__device__ __forceinline__ bool surf_nms_back(const SurfGeom &g, const SurfNmsParams &q, int o, int i, int state, SurfNmsState &st, SurfRecord &rec)
+{
+    if (state == 2) {
+        if (i == 1 ? !surf_nms_neighbour_ok<0>(st) : !surf_nms_neighbour_ok<2>(st)) return false;
     }
+    const double(&v)[3][3][3] = st.v;
+    const double val = st.val, raw = st.raw;
+    const int r = st.r, c = st.c;
     // interpolate_point :411-446
 #define V(s, dy, dx) v[s][1 + (dy)][1 + (dx)]
     const double g0 = (V(1, 0, 1) - V(1, 0, -1)) / 2.0;
@@ -870,6 +871,25 @@ __device__ __forceinline__ bool surf_nms_pixel(const double *__restrict__ pyr, c
     rec.score = val;
     rec.laplacian = raw > 0 ? +1.0 : -1.0;  // get_laplacian :294-297
     return true;
+}
+// the whole test for one thread (the dense kernel; the masked kernel fills the unbuilt interval wave-cooperatively instead)
+__device__ __forceinline__ bool surf_nms_pixel(const double *__restrict__ pyr, const SurfGeom &g, const SurfNmsParams &q, int o, int i, int r, int c,
+                                               SurfRecord &rec)
+{
+    SurfNmsState st;
+    const int state = surf_nms_front(pyr, g, q, o, i, r, c, st);
+    if (!state) return false;
+    if (state == 2) {  // positions inside border_next: valid in every interval
+        const SurfLevel &Ln = g.lev[o * SURF_INT + (i == 1 ? 0 : SURF_INT - 1)];
+#pragma unroll
+        for (int y = 0; y < 3; y++)
+#pragma unroll
+            for (int x = 0; x < 3; x++) {
+                const double w = surf_level_value(q.integral, g.cols, Ln, (r - 1 + y) * Ln.step, (c - 1 + x) * Ln.step);
+                if (i == 1) st.v[0][y][x] = w; else st.v[2][y][x] = w;
+            }
+    }
+    return surf_nms_back(g, q, o, i, state, st, rec);
 }
 
 // dense form (no threshold masks): one launch per octave, a thread per level pixel, blockIdx.z + 1 = interval (1..4)
@@ -937,23 +957,106 @@ __global__ void __launch_bounds__(NMS_WORDS) surf_nms_masked(const double *__res
     // the records of a trip are counted in LDS and get their places in the record buffer with one atomic on the global
     // counter per workgroup (ten thousand returning atomics on one address, one per record, were most of this kernel's time)
     __shared__ unsigned found;
-    __shared__ unsigned long long base;
+    __shared__ unsigned long long base_rec;
+    // "surf_ends": the workgroup handles ONE interval of ONE octave, so the interval that is not built (0 below i = 1, 5 above
+    // i = 4) is the same for all its pixels: every lane keeps the table offset and the coefficient of ONE of the 32 look-ups of a
+    // level-pixel value (box = t / 4, corner = t % 4; Dxx = wide - 3 narrow in lanes 0-7, Dyy in 8-15, Dxy in 16-31), and a group
+    // of 32 lanes computes the nine values a survivor needs -- nine loads per lane in ONE round trip, three segmented sums per
+    // value -- instead of 288 dependent look-ups in whatever lanes the survivors happen to sit (69 -> ... us per tile).
+    const bool coop = q.integral && (i == 1 || i == SURF_INT - 2);  // workgroup-uniform
+    const SurfLevel &Ls = g.lev[o * SURF_INT + (i == 1 ? 0 : SURF_INT - 1)];
+    const int t32 = tid & 31;
+    long tap_off = 0;
+    int tap_coef = 0;
+    if (coop) {
+        const int lobe = Ls.lobe, off = Ls.off, bb = t32 >> 2, k = t32 & 3;
+        int cx = 0, cy = 0, w = lobe, h = lobe, coef = 1;
+        if (bb == 0) { w = 3 * lobe; h = 2 * lobe - 1; }
+        else if (bb == 1) { w = lobe; h = 2 * lobe - 1; coef = -3; }
+        else if (bb == 2) { w = 2 * lobe - 1; h = 3 * lobe; }
+        else if (bb == 3) { w = 2 * lobe - 1; h = lobe; coef = -3; }
+        else if (bb == 4) { cx = -off; cy = off; }
+        else if (bb == 5) { cx = off; cy = -off; }
+        else if (bb == 6) { cx = -off; cy = -off; coef = -1; }
+        else { cx = off; cy = off; coef = -1; }
+        const int l = cx - w / 2, tp = cy - h / 2, rr = l + w - 1, bt = tp + h - 1;  // centered_rect relative to the centre
+        const int dy = k < 2 ? bt : tp - 1, dx = (k & 1) ? l - 1 : rr;
+        tap_off = (long)dy * g.cols + dx;
+        tap_coef = (k == 0 || k == 3) ? coef : -coef;   // br - bl - tr + tl
+    }
+    constexpr int PEND = 64;  // survivors whose unbuilt interval is computed per round
+    __shared__ int pend_r[NMS_WORDS], pend_c[NMS_WORDS];
+    __shared__ unsigned npend;
+    __shared__ double sv[PEND][9];
     for (unsigned k0 = 0; k0 < total; k0 += NMS_WORDS) {  // uniform trip count: barriers inside
-        if (tid == 0) found = 0;
+        if (tid == 0) { found = 0; npend = 0; }
         __syncthreads();
         SurfRecord rec;
-        bool hit = false;
-        unsigned slot = 0;
+        SurfNmsState st;
+        int state = 0;
+        unsigned slot = 0, my_pend = 0;
         if (k0 + tid < total) {
             const unsigned e = list[k0 + tid];
             const size_t w = w0 + (e >> 6);
-            hit = surf_nms_pixel(pyr, g, q, o, i, (int)(w / wpr), (int)(w % wpr) * 64 + (int)(e & 63), rec);
-            if (hit) slot = atomicAdd(&found, 1u);
+            state = surf_nms_front(pyr, g, q, o, i, (int)(w / wpr), (int)(w % wpr) * 64 + (int)(e & 63), st);
+            if (state == 2) {
+                my_pend = atomicAdd(&npend, 1u);
+                pend_r[my_pend] = st.r;
+                pend_c[my_pend] = st.c;
+            }
         }
+        if (coop) {  // workgroup-uniform
+            __syncthreads();
+            const unsigned np = npend;
+            for (unsigned base = 0; base < np; base += PEND) {
+                const unsigned lim = min(np, base + PEND);
+                // a wave takes two survivors at a time (one per half): entries base + 2 * wave + half, stepping by 2 * waves
+                for (unsigned e0 = base + 2 * (tid >> 6); e0 < lim; e0 += 2 * (NMS_WORDS / 64)) {
+                    const unsigned e = e0 + ((tid >> 5) & 1);
+                    const bool active = e < lim;
+                    const int pr = active ? pend_r[e] : pend_r[base], pc = active ? pend_c[e] : pend_c[base];
+                    const int step = Ls.step;
+                    const unsigned *ctr = q.integral + (size_t)((pr - 1) * step) * g.cols + (pc - 1) * step + tap_off;
+                    int term[9];
+#pragma unroll
+                    for (int n = 0; n < 9; n++) term[n] = (int)ctr[(size_t)((n / 3) * step) * g.cols + (n % 3) * step];  // nine loads in flight
+                    int mine_xx = 0, mine_yy = 0, mine_xy = 0;
+#pragma unroll
+                    for (int n = 0; n < 9; n++) {
+                        int a = term[n] * tap_coef;  // int32 wrap-around arithmetic: the box sums come out exact (surf_dxx)
+                        a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4);   // the 8 look-ups of a lane group
+                        const int a16 = a + __shfl_xor(a, 8);                                     // Dxy: 16 look-ups
+                        const int half = (int)(tid & 32);
+                        const int xx = __shfl(a, half + 0), yy = __shfl(a, half + 8), xy = __shfl(a16, half + 16);
+                        if (t32 == n) { mine_xx = xx; mine_yy = yy; mine_xy = xy; }
+                    }
+                    if (active && t32 < 9) {  // lanes 0..8 of the half finish one value each (hessian_pyramid.h:153-171)
+                        double Dxx = (double)mine_xx, Dyy = (double)mine_yy, Dxy = (double)mine_xy;
+                        Dxx *= Ls.area_inv; Dyy *= Ls.area_inv; Dxy *= Ls.area_inv;
+                        double sign = +1;
+                        if (Dxx + Dyy < 0) sign = -1;
+                        double det = Dxx * Dyy - 0.81 * Dxy * Dxy;
+                        if (det < 0) det = 0;
+                        sv[e - base][t32] = sign * det;
+                    }
+                }
+                __syncthreads();
+                if (state == 2 && my_pend >= base && my_pend < lim) {
+#pragma unroll
+                    for (int n = 0; n < 9; n++) {
+                        const double w = sv[my_pend - base][n];
+                        if (i == 1) st.v[0][n / 3][n % 3] = w; else st.v[2][n / 3][n % 3] = w;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        bool hit = state != 0 && surf_nms_back(g, q, o, i, state, st, rec);
+        if (hit) slot = atomicAdd(&found, 1u);
         __syncthreads();
-        if (tid == 0 && found) base = atomicAdd(count, (unsigned long long)found);
+        if (tid == 0 && found) base_rec = atomicAdd(count, (unsigned long long)found);
         __syncthreads();
-        if (hit && base + slot < q.cap) out[base + slot] = rec;
+        if (hit && base_rec + slot < q.cap) out[base_rec + slot] = rec;
     }
 }
 
