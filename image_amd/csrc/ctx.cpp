@@ -176,6 +176,9 @@ imgfd_status imgfd_get_counter(imgfd_ctx *ctx, const char *name, int64_t *value)
         const imgfd_ctx *c = ctx->canny_flags ? ctx : (ctx->side && ctx->side->canny_flags ? ctx->side : nullptr);
         *value = 0;
         if (!c) return IMGFD_OK;
+        // the flags live in the workspace arena of the call that wrote them: an arena that has been regrown since is gone
+        const char *lo = c->ws, *hi = c->ws + c->ws_size, *p = reinterpret_cast<const char *>(c->canny_flags);
+        if (!c->ws || p < lo || p + 4 * (32 + (size_t)c->canny_frames) > hi) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_get_counter: no Canny call since the workspace was last resized");
         IMGFD_HIP(ctx, hipStreamSynchronize(c->stream));
         std::vector<unsigned> f(32 + (size_t)c->canny_frames);  // HY_SWEEPS_MAX sweep flags, then one word per frame
         IMGFD_HIP(ctx, hipMemcpy(f.data(), c->canny_flags, 4 * f.size(), hipMemcpyDeviceToHost));
@@ -251,6 +254,7 @@ int tile_run_length(const imgfd_ctx *ctx, int tiles_x, int bands, int frames)
 imgfd_status ws_reserve(imgfd_ctx *ctx, size_t bytes)
 {
     ctx->ws_used = 0;
+    ctx->canny_flags = nullptr;  // a new call carves the arena: what the last Canny call left in it (diagnostic counters) is no longer there
     if (bytes <= ctx->ws_size) return IMGFD_OK;
     // Kernels of earlier calls may still be using the old arena: wait for the stream, then free it here.  (Growth is rare --
     // the arena only ever grows -- and parking the old arena until the next imgfd_ctx_sync kept it alive for as long as a
