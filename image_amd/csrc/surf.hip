@@ -202,11 +202,11 @@ __global__ void __launch_bounds__(256) surf_colscan_apply(unsigned *__restrict__
 //   surf_int_sums   per tile: the column sums over its rows (colsum[band][c]) and the row sums over its columns
 //                   (rowsum[row][strip])
 //                   and the tile total (bandstrip[band][strip])
-//   surf_int_carry  a thread per column turns colsum into the sum of the bands ABOVE (exclusive scan down the bands); one
-//                   more workgroup turns bandstrip into its 2-D exclusive prefix: the table's value above the band, left of
-//                   the strip
+//   surf_int_carry  colsum becomes the sum of the bands ABOVE (exclusive scan down the bands), rowsum the sum of the strips to
+//                   the LEFT; one more workgroup turns bandstrip into its 2-D exclusive prefix: the table's value above the
+//                   band, left of the strip
 //   surf_int_apply  per tile: I[r][c] = (bands above or rows of the band <= r, strips to the left: bandstrip + one wave scan
-//                   of the tile's row sums) + (rows above the band, columns of the strip <= c: one wave scan of colsum) +
+//                   of the band's rowsum) + (rows above the band, columns of the strip <= c: one wave scan of colsum) +
 //                   (rows of the band <= r, columns of the strip <= c: running column sums and one wave scan per row).
 //                   No barrier in the two big kernels; all sums wrap like the reference's int32.
 constexpr int SI_RB = 32;       // rows per band
@@ -234,16 +234,40 @@ __device__ __forceinline__ unsigned si_wave_incl(unsigned v, int lane)
     }
     return v;
 }
-// rows r .. r+3 of a lane's 12-byte group (rows past `r1` read as the last row and count as zero)
-struct SiRows { unsigned w[4][3]; };
-__device__ __forceinline__ void si_fetch(const unsigned *src, size_t rd, int r, int r1, bool active, SiRows &o)
+// A lane's 12-byte group in EVERY row of its tile: the 32 loads are all in flight before the first value is used.  (Round 3
+// fetched four rows at a time, one step ahead: 24 KB in flight per CU, and 8 TB/s x ~2 us of latency wants ~64 KB -- the sums
+// kernel ran at 3 TB/s, 16.6 us for 50 MB.)  Rows past the band's end re-read its last row and count as zero.
+struct SiTile { unsigned w[SI_RB][3]; };
+__device__ __forceinline__ void si_fetch_tile(const unsigned *src, size_t rd, int r0, int r1, SiTile &o)
 {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const bool in = active && r + k < r1;
-        const unsigned *p = src + (size_t)min(r + k, r1 - 1) * rd;
-        o.w[k][0] = in ? p[0] : 0u; o.w[k][1] = in ? p[1] : 0u; o.w[k][2] = in ? p[2] : 0u;
+    for (int k = 0; k < SI_RB; k++) {
+        const unsigned *p = src + (size_t)min(r0 + k, r1 - 1) * rd;
+        o.w[k][0] = p[0]; o.w[k][1] = p[1]; o.w[k][2] = p[2];
     }
+}
+__device__ __forceinline__ void si_gray_row(const SiTile &t, int k, bool in, unsigned (&g)[4])
+{
+    si_gray4(in ? t.w[k][0] : 0u, in ? t.w[k][1] : 0u, in ? t.w[k][2] : 0u, g);
+}
+// 32 values per lane -> lane L holds the sum over the wave of value L >> 1.  A butterfly that halves the values a lane
+// carries at every step (16 + 8 + 4 + 2 + 1 + 1 = 32 exchanges; a butterfly per value takes 6 x 32 = 192 trips through the LDS
+// crossbar)
+template <int D, int N>
+__device__ __forceinline__ void si_halve(unsigned (&t)[SI_RB], int lane)
+{
+    const bool upper = (lane & D) != 0;  // this half of the pair keeps the upper half of the values
+#pragma unroll
+    for (int j = 0; j < N / 2; j++) {
+        const unsigned send = upper ? t[j] : t[j + N / 2], keep = upper ? t[j + N / 2] : t[j];
+        t[j] = keep + (unsigned)__shfl_xor(send, D);
+    }
+}
+__device__ __forceinline__ unsigned si_wave_sums32(unsigned (&t)[SI_RB], int lane)
+{
+    static_assert(SI_RB == 32, "five halving steps");
+    si_halve<32, 32>(t, lane); si_halve<16, 16>(t, lane); si_halve<8, 8>(t, lane); si_halve<4, 4>(t, lane); si_halve<2, 2>(t, lane);
+    return t[0] + (unsigned)__shfl_xor(t[0], 1);
 }
 
 __global__ void __launch_bounds__(256) surf_int_sums(const unsigned char *__restrict__ rgb, unsigned *__restrict__ colsum,
@@ -256,49 +280,74 @@ __global__ void __launch_bounds__(256) surf_int_sums(const unsigned char *__rest
     const int r0 = b * SI_RB, r1 = min(rows, r0 + SI_RB);
     const unsigned *src = reinterpret_cast<const unsigned *>(rgb) + 3 * (size_t)(active ? c >> 2 : 0);
     const size_t rd = 3 * (size_t)(cols >> 2);  // dwords per row
-    unsigned acc[4] = {0u, 0u, 0u, 0u};
-    SiRows cur, nxt;
-    si_fetch(src, rd, r0, r1, active, cur);
-    for (int r = r0; r < r1; r += 4) {
-        si_fetch(src, rd, min(r + 4, r1 - 1), r1, active && r + 4 < r1, nxt);  // the next four rows are in flight during the sums
-        unsigned t[4];
+    SiTile tile;
+    si_fetch_tile(src, rd, r0, r1, tile);
+    unsigned acc[4] = {0u, 0u, 0u, 0u}, t[SI_RB];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            unsigned g[4];
-            si_gray4(cur.w[k][0], cur.w[k][1], cur.w[k][2], g);
+    for (int k = 0; k < SI_RB; k++) {
+        unsigned g[4];
+        si_gray_row(tile, k, active && r0 + k < r1, g);
 #pragma unroll
-            for (int e = 0; e < 4; e++) acc[e] += g[e];
-            t[k] = g[0] + g[1] + g[2] + g[3];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) t[k] = si_wave_sum(t[k]);  // four independent butterflies
-        if (lane < 4 && s < nstrips && r + lane < r1) rowsum[(size_t)(r + lane) * nstrips + s] = lane == 0 ? t[0] : lane == 1 ? t[1] : lane == 2 ? t[2] : t[3];
-        cur = nxt;
+        for (int e = 0; e < 4; e++) acc[e] += g[e];
+        t[k] = g[0] + g[1] + g[2] + g[3];
     }
+    const unsigned row_total = si_wave_sums32(t, lane);  // of row r0 + (lane >> 1)
+    if (!(lane & 1) && s < nstrips && r0 + (lane >> 1) < r1) rowsum[(size_t)(r0 + (lane >> 1)) * nstrips + s] = row_total;
     if (active) *reinterpret_cast<uint4 *>(colsum + (size_t)b * cols + c) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
     const unsigned tile_total = si_wave_sum(acc[0] + acc[1] + acc[2] + acc[3]);
     if (lane == 0 && s < nstrips) bandstrip[(size_t)b * nstrips + s] = tile_total;
 }
 
-// blocks 0 .. ceil(cols / 256) - 1: the columns; the last block: the band x strip totals
-__global__ void __launch_bounds__(256) surf_int_carry(unsigned *__restrict__ colsum, unsigned *__restrict__ bandstrip, int nbands, int cols,
-                                                      int nstrips)
+// blocks 0 .. ceil(cols / 64) - 1: 64 columns each, the bands dealt to the workgroup's four waves in runs (a wave's run -- up
+// to 32 bands -- sits in registers: one round trip to memory, where a thread walking all bands of its column made sixteen);
+// the next block: the band x strip totals; the blocks behind it: a thread per image row turns its strip sums into the sums of
+// the strips to the LEFT (the apply kernel summed them itself, lane by lane: up to 15 dependent round trips in front of its tile)
+constexpr int SC_RUN = 32;  // bands of a run held in registers
+__global__ void __launch_bounds__(256) surf_int_carry(unsigned *__restrict__ colsum, unsigned *__restrict__ bandstrip, unsigned *__restrict__ rowsum,
+                                                      int nbands, int rows, int cols, int nstrips)
 {
     __shared__ unsigned tot[SI_MAX_STRIPS][256 + 1];
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x < (int)gridDim.x - 1) {
-        const int c = 256 * blockIdx.x + tid;
-        if (c >= cols) return;
+    const int col_blocks = (cols + 63) / 64;
+    if ((int)blockIdx.x > col_blocks) {
+        const int r = 256 * ((int)blockIdx.x - col_blocks - 1) + tid;
+        if (r >= rows) return;
+        unsigned *p = rowsum + (size_t)r * nstrips, v[SI_MAX_STRIPS];
+#pragma unroll
+        for (int j = 0; j < SI_MAX_STRIPS; j++) v[j] = p[min(j, nstrips - 1)];
         unsigned acc = 0;
-        int b = 0;
-        for (; b + 8 <= nbands; b += 8) {
-            unsigned v[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = colsum[(size_t)(b + k) * cols + c];
+        for (int j = 0; j < SI_MAX_STRIPS; j++)
+            if (j < nstrips) { p[j] = acc; acc += v[j]; }
+        return;
+    }
+    if ((int)blockIdx.x < col_blocks) {
+        __shared__ unsigned run_total[4][64];
+        const int c = 64 * blockIdx.x + (tid & 63), w = tid >> 6;
+        const int per = (nbands + 3) / 4, b0 = min(nbands, w * per), b1 = min(nbands, b0 + per);
+        const bool live = c < cols;
+        unsigned *col = colsum + (live ? c : 0);
+        unsigned v[SC_RUN], sum = 0;
+        if (per <= SC_RUN) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) { colsum[(size_t)(b + k) * cols + c] = acc; acc += v[k]; }
+            for (int k = 0; k < SC_RUN; k++) v[k] = colsum[(size_t)min(b0 + k, nbands - 1) * cols + (live ? c : 0)];
+#pragma unroll
+            for (int k = 0; k < SC_RUN; k++) sum += b0 + k < b1 ? v[k] : 0u;
+        } else {
+            for (int bb = b0; bb < b1; bb++) sum += col[(size_t)bb * cols];
         }
-        for (; b < nbands; b++) { const unsigned v = colsum[(size_t)b * cols + c]; colsum[(size_t)b * cols + c] = acc; acc += v; }
+        run_total[w][tid & 63] = sum;
+        __syncthreads();
+        unsigned acc = 0;
+        for (int j = 0; j < w; j++) acc += run_total[j][tid & 63];
+        if (!live) return;
+        if (per <= SC_RUN) {
+#pragma unroll
+            for (int k = 0; k < SC_RUN; k++)
+                if (b0 + k < b1) { col[(size_t)(b0 + k) * cols] = acc; acc += v[k]; }
+        } else {
+            for (int bb = b0; bb < b1; bb++) { const unsigned x = col[(size_t)bb * cols]; col[(size_t)bb * cols] = acc; acc += x; }
+        }
         return;
     }
     // bandstrip[b][s] := sum over bands < b and strips < s (the table's value above the band, left of the strip), in place.
@@ -332,40 +381,45 @@ __global__ void __launch_bounds__(256) surf_int_carry(unsigned *__restrict__ col
     }
 }
 
+// RES: the table is written a second time in the residue layout the gather kernels of octaves 1-3 read (J[row][x % 4][x / 4],
+// see surf_residue_layout below): a lane's four columns are the four residues at word 64 s + lane of each, so a wave
+// stores four runs of 256 bytes -- 4 B/px written here instead of 4 read + 4 written by a kernel of its own (20.8 us per tile).
+template <bool RES>
 __global__ void __launch_bounds__(256) surf_int_apply(const unsigned char *__restrict__ rgb, const unsigned *__restrict__ colcarry,
                                                       const unsigned *__restrict__ above_left, const unsigned *__restrict__ rowsum,
-                                                      unsigned *__restrict__ out, int rows, int cols, int nstrips)
+                                                      unsigned *__restrict__ out, unsigned *__restrict__ res, int rows, int cols, int nstrips)
 {
     const int lane = threadIdx.x & 63, s = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
     const int c = 256 * s + 4 * lane;
     const bool active = s < nstrips && c < cols;
     const int r0 = b * SI_RB, r1 = min(rows, r0 + SI_RB);
+    const unsigned *src = reinterpret_cast<const unsigned *>(rgb) + 3 * (size_t)(active ? c >> 2 : 0);
+    const size_t rd = 3 * (size_t)(cols >> 2);
+    // the carries first (few, short), then the whole tile: everything is in flight while the carries are scanned
+    const uint4 cc = active ? *reinterpret_cast<const uint4 *>(colcarry + (size_t)b * cols + c) : make_uint4(0u, 0u, 0u, 0u);
+    unsigned left_of = lane < SI_RB && r0 + lane < r1 && s < nstrips ? rowsum[(size_t)(r0 + lane) * nstrips + s] : 0u;  // strips to the left, this row
+    const unsigned corner = s < nstrips ? above_left[(size_t)b * nstrips + s] : 0u;
+    SiTile tile;
+    si_fetch_tile(src, rd, r0, r1, tile);
     // rows above the band, columns of the strip up to c + k
     unsigned base[4];
     {
-        const uint4 cc = active ? *reinterpret_cast<const uint4 *>(colcarry + (size_t)b * cols + c) : make_uint4(0u, 0u, 0u, 0u);
         base[0] = cc.x; base[1] = base[0] + cc.y; base[2] = base[1] + cc.z; base[3] = base[2] + cc.w;
         const unsigned carry = si_wave_incl(base[3], lane) - base[3];
 #pragma unroll
         for (int e = 0; e < 4; e++) base[e] += carry;
     }
     // rows <= the lane's row, strips to the left: above the band from surf_int_carry, inside it a wave scan over the row sums
-    unsigned left_of = 0;
-    if (lane < SI_RB && r0 + lane < r1 && s < nstrips)
-        for (int j = 0; j < s; j++) left_of += rowsum[(size_t)(r0 + lane) * nstrips + j];
-    left_of = si_wave_incl(left_of, lane) + (s < nstrips ? above_left[(size_t)b * nstrips + s] : 0u);
-    const unsigned *src = reinterpret_cast<const unsigned *>(rgb) + 3 * (size_t)(active ? c >> 2 : 0);
-    const size_t rd = 3 * (size_t)(cols >> 2);
+    left_of = si_wave_incl(left_of, lane) + corner;
+    const size_t per = (size_t)(cols >> 2);
     unsigned v[4] = {0u, 0u, 0u, 0u};
-    SiRows cur, nxt;
-    si_fetch(src, rd, r0, r1, active, cur);
-    for (int r = r0; r < r1; r += 4) {
-        si_fetch(src, rd, min(r + 4, r1 - 1), r1, active && r + 4 < r1, nxt);
+#pragma unroll
+    for (int r = 0; r < SI_RB; r += 4) {
         unsigned q[4][4], e[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             unsigned g[4];
-            si_gray4(cur.w[k][0], cur.w[k][1], cur.w[k][2], g);
+            si_gray_row(tile, r + k, active && r0 + r + k < r1, g);
             v[0] += g[0]; v[1] += g[1]; v[2] += g[2]; v[3] += g[3];  // running column sums inside the band
             q[k][0] = v[0]; q[k][1] = q[k][0] + v[1]; q[k][2] = q[k][1] + v[2]; q[k][3] = q[k][2] + v[3];
             e[k] = q[k][3];
@@ -374,12 +428,17 @@ __global__ void __launch_bounds__(256) surf_int_apply(const unsigned char *__res
         for (int k = 0; k < 4; k++) e[k] = si_wave_incl(e[k], lane) - q[k][3];  // four independent scans
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const unsigned add = e[k] + __shfl(left_of, min(r + k, r1 - 1) - r0);
-            if (active && r + k < r1)
-                *reinterpret_cast<uint4 *>(out + (size_t)(r + k) * cols + c) =
-                    make_uint4(base[0] + add + q[k][0], base[1] + add + q[k][1], base[2] + add + q[k][2], base[3] + add + q[k][3]);
+            const unsigned add = e[k] + (unsigned)__builtin_amdgcn_readlane((int)left_of, min(r + k, r1 - 1 - r0));
+            if (active && r0 + r + k < r1) {
+                const uint4 o = make_uint4(base[0] + add + q[k][0], base[1] + add + q[k][1], base[2] + add + q[k][2], base[3] + add + q[k][3]);
+                const size_t row = (size_t)(r0 + r + k) * cols;
+                *reinterpret_cast<uint4 *>(out + row + c) = o;
+                if (RES) {
+                    unsigned *j = res + row + (c >> 2);
+                    j[0] = o.x; j[per] = o.y; j[2 * per] = o.z; j[3 * per] = o.w;
+                }
+            }
         }
-        cur = nxt;
     }
 }
 
@@ -1345,7 +1404,9 @@ size_t surf_integral_scratch(int rows, int cols)
     return sizeof(unsigned) * (nb * (size_t)cols + (size_t)rows * ns + nb * ns) + 512;
 }
 
-void launch_surf_integral(imgfd_ctx *ctx, const uint8_t *d_rgb, unsigned *d_I, int rows, int cols, void *scratch, size_t scratch_bytes)
+// residue (optional): the table a second time in the layout of surf_residue_layout<2>; the return value says whether it was written
+bool launch_surf_integral(imgfd_ctx *ctx, const uint8_t *d_rgb, unsigned *d_I, int rows, int cols, void *scratch, size_t scratch_bytes,
+                          unsigned *residue = nullptr)
 {
     const bool vec = cols % 4 == 0 && (size_t)d_rgb % 4 == 0 && (size_t)d_I % 16 == 0;
     if (vec && scratch && (size_t)scratch % 16 == 0 && scratch_bytes >= surf_integral_scratch(rows, cols) && (size_t)rows * cols >= 65536 &&
@@ -1356,10 +1417,16 @@ void launch_surf_integral(imgfd_ctx *ctx, const uint8_t *d_rgb, unsigned *d_I, i
         unsigned *bandstrip = rowsum + (size_t)rows * ns;  // nb x ns
         const dim3 grid(ceil_div(ns, 4), nb);
         hipLaunchKernelGGL(surf_int_sums, grid, dim3(256), 0, ctx->stream, d_rgb, colsum, rowsum, bandstrip, rows, cols, ns);
-        hipLaunchKernelGGL(surf_int_carry, dim3(ceil_div(cols, 256) + 1), dim3(256), 0, ctx->stream, colsum, bandstrip, nb, cols, ns);
-        hipLaunchKernelGGL(surf_int_apply, grid, dim3(256), 0, ctx->stream, d_rgb, (const unsigned *)colsum, (const unsigned *)bandstrip,
-                           (const unsigned *)rowsum, d_I, rows, cols, ns);
-        return;
+        hipLaunchKernelGGL(surf_int_carry, dim3(ceil_div(cols, 64) + 1 + ceil_div(rows, 256)), dim3(256), 0, ctx->stream, colsum, bandstrip, rowsum, nb, rows,
+                           cols, ns);
+        const bool res = residue && cols % 16 == 0;
+        if (res)
+            hipLaunchKernelGGL(surf_int_apply<true>, grid, dim3(256), 0, ctx->stream, d_rgb, (const unsigned *)colsum, (const unsigned *)bandstrip,
+                               (const unsigned *)rowsum, d_I, residue, rows, cols, ns);
+        else
+            hipLaunchKernelGGL(surf_int_apply<false>, grid, dim3(256), 0, ctx->stream, d_rgb, (const unsigned *)colsum, (const unsigned *)bandstrip,
+                               (const unsigned *)rowsum, d_I, (unsigned *)nullptr, rows, cols, ns);
+        return res;
     }
     if (vec)
         hipLaunchKernelGGL(surf_gray_rowscan4, dim3(rows), dim3(256), 0, ctx->stream, d_rgb, d_I, cols);
@@ -1374,12 +1441,15 @@ void launch_surf_integral(imgfd_ctx *ctx, const uint8_t *d_rgb, unsigned *d_I, i
     } else {
         hipLaunchKernelGGL(surf_colscan, dim3(ceil_div(cols, 64)), dim3(64), 0, ctx->stream, d_I, rows, cols);
     }
+    return false;
 }
 
 imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const SurfGeom &g, double thr, const SurfDevice &d)
 {
     // the pyramid buffer is idle until the integral image is complete: it lends the column scan its scratch
-    launch_surf_integral(ctx, d_rgb, d.integral, g.rows, g.cols, d.pyr, d.pyr_bytes);
+    // (octaves 1-3 read the table in the residue layout: the integral image's last kernel writes it along, "surf_residue_fused")
+    const bool want_residue = d.residue && g.cols % 16 == 0 && ctx->tune.surf_residue == 4 && ctx->tune.surf_residue_fused && g.nr[1] >= 1 && g.nc[1] >= 1;
+    const bool have_residue = launch_surf_integral(ctx, d_rgb, d.integral, g.rows, g.cols, d.pyr, d.pyr_bytes, want_residue ? d.residue : nullptr);
     IMGFD_HIP(ctx, hipMemsetAsync(d.count, 0, sizeof(unsigned long long), ctx->stream));
     const int ends = ctx->tune.surf_ends ? 1 : 0;  // 1: intervals 0 and 5 are not built; the maximum test computes what it needs of them (SurfNmsParams::integral)
     for (int o = 0; o < SURF_OCT; o++) {
@@ -1403,7 +1473,7 @@ imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const Surf
         const int modulus = ctx->tune.surf_residue;  // experiment switch: 0 = the plain table, 4 | 16 = modulus
         const dim3 lgrid(ceil_div(g.cols, RL_COLS), g.rows);
         if (o >= 1 && d.residue && g.cols % 16 == 0 && modulus == 4) {
-            hipLaunchKernelGGL(surf_residue_layout<2>, lgrid, dim3(256), 0, ctx->stream, d.integral, d.residue, g.cols);
+            if (!have_residue) hipLaunchKernelGGL(surf_residue_layout<2>, lgrid, dim3(256), 0, ctx->stream, d.integral, d.residue, g.cols);
             if (ctx->tune.surf_taps && (size_t)g.rows * g.cols * 4 < ((size_t)1 << 31)) {
                 SurfTaps taps;
                 surf_make_taps(g, &taps);

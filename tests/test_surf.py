@@ -21,10 +21,12 @@ def blobs(seed, w, h, n=60):
     return np.clip(img, 0, 255).astype(np.uint8)
 
 
-@pytest.mark.parametrize("w,h", [(64, 48), (257, 129), (400, 300), (1031, 517), (1028, 70), (260, 300), (256, 256), (1284, 97), (2052, 33)])
+@pytest.mark.parametrize("w,h", [(64, 48), (257, 129), (400, 300), (1031, 517), (1028, 70), (260, 300), (256, 256), (1284, 97), (2052, 33),
+                                 (16, 4200), (20, 4127)])
 def test_integral_image_exact(be, w, h):
     """widths that are multiples of 4 take the band / strip form (surf_int_sums / _carry / _apply: partial strips, partial
-    bands, a single band, several workgroups per band); the others the row scan + column scan"""
+    bands, a single band, several workgroups per band; more than 128 bands: a wave of the carry kernel walks its run of bands in
+    memory instead of holding it in registers); the others the row scan + column scan"""
     rgb = synth.frame_rgb(81, w, h)
     assert np.array_equal(be.surf_integral(rgb), oracle.surf_integral(rgb))
 
@@ -124,6 +126,22 @@ def test_upper_octaves_both_gather_forms(be, w, h):
             assert got.shape == ref.shape and np.array_equal(got.view(np.uint64), ref.view(np.uint64)), taps
     finally:
         be.set_tuning("surf_taps", 1)
+
+
+@pytest.mark.parametrize("w,h", [(384, 256), (400, 304), (528, 162)])
+def test_residue_layout_written_by_either_kernel(be, w, h):
+    """the table octaves 1-3 read (columns by residue mod 4) comes from the integral image's last kernel ("surf_residue_fused" 1,
+    the default) or from surf_residue_layout (0): the same interest points, bit for bit"""
+    img = blobs(190 + w, w, h)
+    ref = oracle.surf_interest_points(img, 2.0)
+    assert len(ref) > 20 and len({int(round(np.log2(p[2]))) for p in ref}) >= 2
+    try:
+        for fused in (1, 0):
+            be.set_tuning("surf_residue_fused", fused)
+            got = be.surf_interest_points(img, 2.0)
+            assert got.shape == ref.shape and np.array_equal(got.view(np.uint64), ref.view(np.uint64)), fused
+    finally:
+        be.set_tuning("surf_residue_fused", 1)
 
 
 @pytest.mark.parametrize("max_points", [1, 9, 25])
