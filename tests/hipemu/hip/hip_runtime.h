@@ -338,11 +338,12 @@ static inline unsigned __builtin_amdgcn_perm(unsigned a, unsigned b, unsigned se
 }
 // v_mov_b32_dpp with bound_ctrl: wave_shr:1 (0x138: lane i reads lane i-1) and wave_shl:1 (0x130: lane i reads lane i+1);
 // a lane without a source reads 0
-static inline unsigned __builtin_amdgcn_mov_dpp(unsigned v, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+// (returns int like the device builtin: a result OR-ed into a wider word without a cast sign-extends here as it does there)
+static inline int __builtin_amdgcn_mov_dpp(unsigned v, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     if (ctrl >= 0 && ctrl <= 0xff && row_mask == 0xf && bank_mask == 0xf) {  // quad_perm: lane i reads lane (i & ~3) + perm[i & 3] of its quad
         const int l = (int)__lane_id();
         const unsigned long long *s = hipemu::wave_exchange(v);
-        return (unsigned)s[(l & ~3) + ((ctrl >> (2 * (l & 3))) & 3)];
+        return (int)(unsigned)s[(l & ~3) + ((ctrl >> (2 * (l & 3))) & 3)];
     }
     if ((ctrl != 0x138 && ctrl != 0x130) || row_mask != 0xf || bank_mask != 0xf || !bound_ctrl) {
         fprintf(stderr, "hipemu: DPP control 0x%x not emulated\n", ctrl);
@@ -350,7 +351,7 @@ static inline unsigned __builtin_amdgcn_mov_dpp(unsigned v, int ctrl, int row_ma
     }
     const int lane = (int)__lane_id();
     const unsigned r = ctrl == 0x138 ? __shfl_up(v, 1) : __shfl_down(v, 1);
-    return (ctrl == 0x138 ? lane == 0 : lane == 63) ? 0u : r;
+    return (int)((ctrl == 0x138 ? lane == 0 : lane == 63) ? 0u : r);
 }
 // streaming store hint
 #define __builtin_nontemporal_store(value, ptr) (*(ptr) = (value))
