@@ -248,7 +248,8 @@ __device__ __forceinline__ void si_fetch_tile(const unsigned *src, size_t rd, in
 }
 __device__ __forceinline__ void si_gray_row(const SiTile &t, int k, bool in, unsigned (&g)[4])
 {
-    si_gray4(in ? t.w[k][0] : 0u, in ? t.w[k][1] : 0u, in ? t.w[k][2] : 0u, g);
+    const unsigned keep = in ? 0xffffffffu : 0u;  // (an AND, not a select: the compiler sinks a selected load into a branch of its own, behind every other load)
+    si_gray4(t.w[k][0] & keep, t.w[k][1] & keep, t.w[k][2] & keep, g);
 }
 // 32 values per lane -> lane L holds the sum over the wave of value L >> 1.  A butterfly that halves the values a lane
 // carries at every step (16 + 8 + 4 + 2 + 1 + 1 = 32 exchanges; a butterfly per value takes 6 x 32 = 192 trips through the LDS
