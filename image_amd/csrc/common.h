@@ -93,6 +93,7 @@ struct imgfd_ctx {
         int surf_rec_cap = 1 << 18;  // imgfd_surf_dev: candidate records a tile's buffer holds before the tile is redone (tests lower it)
         int surf_sort_cap = 2048;    // imgfd_surf_dev: selected records ranked by the LDS sort; more are ranked all-pairs (tests lower it)
         int surf_residue_fused = 1;  // SURF: 1 = the integral image's last kernel also writes the residue layout of octaves 1-3; 0: a kernel of its own re-lays the table
+        int surf_split = 1;      // SURF: 1 = a tile that has the device to itself (one lane) runs octaves 1-3 on the companion's stream beside octave 0
         int surf_ends = 1;       // SURF: 1 = intervals 0 and 5 of every octave are not built (the maximum test computes the 3x3 neighbourhoods it needs of them from the integral image); 0: all six
         int surf_async = 0;      // imgfd_surf_dev: 1 = never wait for the host (a tile whose candidates overflow reports -candidates)
     } tune;

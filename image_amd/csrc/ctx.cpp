@@ -41,6 +41,7 @@ const std::vector<TuneKey> &tune_keys()
         {"surf_taps", "IMGFD_SURF_TAPS", &imgfd_ctx::Tune::surf_taps},
         {"surf_async", "IMGFD_SURF_ASYNC", &imgfd_ctx::Tune::surf_async},
         {"surf_ends", "IMGFD_SURF_ENDS", &imgfd_ctx::Tune::surf_ends},
+        {"surf_split", "IMGFD_SURF_SPLIT", &imgfd_ctx::Tune::surf_split},
         {"surf_residue_fused", "IMGFD_SURF_RESIDUE_FUSED", &imgfd_ctx::Tune::surf_residue_fused},
         {"surf_sort_cap", "IMGFD_SURF_SORT_CAP", &imgfd_ctx::Tune::surf_sort_cap},
         {"surf_rec_cap", "IMGFD_SURF_REC_CAP", &imgfd_ctx::Tune::surf_rec_cap},

@@ -1445,13 +1445,23 @@ bool launch_surf_integral(imgfd_ctx *ctx, const uint8_t *d_rgb, unsigned *d_I, i
     return false;
 }
 
-imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const SurfGeom &g, double thr, const SurfDevice &d)
+// fork (optional): the context's companion.  Octave 0 and octaves 1-3 are two kernels that both read the finished table and
+// write different planes: with a companion at hand (a call with ONE tile has no other tile to fill the chip with) the second
+// runs on its stream beside the first -- a VALU / LDS bound kernel next to one that waits for its gathers -- and the maximum
+// test waits for both ("surf_split").
+imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const SurfGeom &g, double thr, const SurfDevice &d, imgfd_ctx *fork = nullptr)
 {
     // the pyramid buffer is idle until the integral image is complete: it lends the column scan its scratch
     // (octaves 1-3 read the table in the residue layout: the integral image's last kernel writes it along, "surf_residue_fused")
     const bool want_residue = d.residue && g.cols % 16 == 0 && ctx->tune.surf_residue == 4 && ctx->tune.surf_residue_fused && g.nr[1] >= 1 && g.nc[1] >= 1;
     const bool have_residue = launch_surf_integral(ctx, d_rgb, d.integral, g.rows, g.cols, d.pyr, d.pyr_bytes, want_residue ? d.residue : nullptr);
     IMGFD_HIP(ctx, hipMemsetAsync(d.count, 0, sizeof(unsigned long long), ctx->stream));
+    hipStream_t upper = ctx->stream;  // the stream of the gather kernel (octaves 1-3)
+    if (fork && g.nr[1] >= 1 && g.nc[1] >= 1) {
+        IMGFD_HIP(ctx, hipEventRecord(ctx->ev_gate, ctx->stream));
+        IMGFD_HIP(ctx, hipStreamWaitEvent(fork->stream, ctx->ev_gate, 0));
+        upper = fork->stream;
+    }
     const int ends = ctx->tune.surf_ends ? 1 : 0;  // 1: intervals 0 and 5 are not built; the maximum test computes what it needs of them (SurfNmsParams::integral)
     for (int o = 0; o < SURF_OCT; o++) {
         if (g.nr[o] < 1 || g.nc[o] < 1) continue;
@@ -1474,21 +1484,25 @@ imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const Surf
         const int modulus = ctx->tune.surf_residue;  // experiment switch: 0 = the plain table, 4 | 16 = modulus
         const dim3 lgrid(ceil_div(g.cols, RL_COLS), g.rows);
         if (o >= 1 && d.residue && g.cols % 16 == 0 && modulus == 4) {
-            if (!have_residue) hipLaunchKernelGGL(surf_residue_layout<2>, lgrid, dim3(256), 0, ctx->stream, d.integral, d.residue, g.cols);
+            if (!have_residue) hipLaunchKernelGGL(surf_residue_layout<2>, lgrid, dim3(256), 0, o >= 1 ? upper : ctx->stream, d.integral, d.residue, g.cols);
             if (ctx->tune.surf_taps && (size_t)g.rows * g.cols * 4 < ((size_t)1 << 31)) {
                 SurfTaps taps;
                 surf_make_taps(g, &taps);
-                hipLaunchKernelGGL(surf_pyramid_taps, dim3(nb), dim3(256), 0, ctx->stream, d.residue, d.pyr, g, blocks, taps, d.mask, thr, ends);
+                hipLaunchKernelGGL(surf_pyramid_taps, dim3(nb), dim3(256), 0, o >= 1 ? upper : ctx->stream, d.residue, d.pyr, g, blocks, taps, d.mask, thr, ends);
             } else {
-                hipLaunchKernelGGL(surf_pyramid<2>, dim3(nb), dim3(256), 0, ctx->stream, d.residue, d.pyr, g, blocks, d.mask, thr, ends);
+                hipLaunchKernelGGL(surf_pyramid<2>, dim3(nb), dim3(256), 0, o >= 1 ? upper : ctx->stream, d.residue, d.pyr, g, blocks, d.mask, thr, ends);
             }
         } else if (o >= 1 && d.residue && g.cols % 16 == 0 && modulus == 16) {
-            hipLaunchKernelGGL(surf_residue_layout<4>, lgrid, dim3(256), 0, ctx->stream, d.integral, d.residue, g.cols);
-            hipLaunchKernelGGL(surf_pyramid<4>, dim3(nb), dim3(256), 0, ctx->stream, d.residue, d.pyr, g, blocks, d.mask, thr, ends);
+            hipLaunchKernelGGL(surf_residue_layout<4>, lgrid, dim3(256), 0, o >= 1 ? upper : ctx->stream, d.integral, d.residue, g.cols);
+            hipLaunchKernelGGL(surf_pyramid<4>, dim3(nb), dim3(256), 0, o >= 1 ? upper : ctx->stream, d.residue, d.pyr, g, blocks, d.mask, thr, ends);
         } else {
-            hipLaunchKernelGGL(surf_pyramid<0>, dim3(nb), dim3(256), 0, ctx->stream, d.integral, d.pyr, g, blocks, d.mask, thr, ends);
+            hipLaunchKernelGGL(surf_pyramid<0>, dim3(nb), dim3(256), 0, o >= 1 ? upper : ctx->stream, d.integral, d.pyr, g, blocks, d.mask, thr, ends);
         }
         break;
+    }
+    if (upper != ctx->stream) {
+        IMGFD_HIP(ctx, hipEventRecord(ctx->ev_gate2, upper));
+        IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gate2, 0));
     }
     SurfNmsParams q;
     q.thr = thr; q.cap = d.cap;
@@ -1541,7 +1555,9 @@ imgfd_status surf_points_host(imgfd_ctx *ctx, const void *rgb, int kind, int row
         d.count = (unsigned long long *)ws_alloc(ctx, 256);
         if (!d_rgb || !d.integral || !d.pyr || !d.rec || !d.count) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
         IMGFD_TRY(upload_image(ctx, rgb, kind, 3 * n, d_rgb));
-        IMGFD_TRY(surf_device_stages(ctx, d_rgb, g, thr, d));
+        imgfd_ctx *fork = nullptr;
+        if (ctx->tune.surf_split) IMGFD_TRY(ctx_side(ctx, &fork));
+        IMGFD_TRY(surf_device_stages(ctx, d_rgb, g, thr, d, fork));
         unsigned long long cnt = 0;
         IMGFD_HIP(ctx, hipMemcpyAsync(&cnt, d.count, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
         IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1707,10 +1723,12 @@ imgfd_status imgfd_surf_points_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_f
     d.pyr_bytes = 8 * std::max<size_t>(total, 1);
     if (!d.integral || !d.pyr) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
     d.cap = (unsigned long long)cap;
+    imgfd_ctx *fork = nullptr;
+    if (ctx->tune.surf_split) IMGFD_TRY(ctx_side(ctx, &fork));
     for (int f = 0; f < n_frames; f++) {  // tiles are processed back to back on the context's stream, no host sync
         d.rec = reinterpret_cast<SurfRecord *>(d_points) + (size_t)f * cap;
         d.count = reinterpret_cast<unsigned long long *>(d_counts) + f;
-        IMGFD_TRY(surf_device_stages(ctx, d_rgb + (size_t)f * frame_stride_bytes, g, detection_threshold, d));
+        IMGFD_TRY(surf_device_stages(ctx, d_rgb + (size_t)f * frame_stride_bytes, g, detection_threshold, d, fork));
     }
     return IMGFD_OK;
 }
@@ -1748,6 +1766,8 @@ try {
         IMGFD_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));          // the tiles (and whatever produced them) come first
         for (int l = 1; l < nlanes; l++) IMGFD_HIP(ctx, hipStreamWaitEvent(lanes[l].c->stream, ctx->ev_fork, 0));
     }
+    imgfd_ctx *fork = nullptr;  // one tile, one lane: its two pyramid kernels side by side (surf_device_stages)
+    if (nlanes == 1 && ctx->tune.surf_split) IMGFD_TRY(ctx_side(ctx, &fork));
     auto carve = [&](Lane &L, unsigned long long rcap) -> imgfd_status {
         imgfd_ctx *c = L.c;
         // no more records than the buffer holds can be asked for (and the all-pairs ranking is quadratic in that number)
@@ -1775,7 +1795,7 @@ try {
         imgfd_ctx *c = L.c;
         const unsigned lim = L.lim;
         double *d_pts = L.k19, *d_trig = L.k19 + 3 * (size_t)lim;
-        imgfd_status st = surf_device_stages(c, d_rgb + (size_t)f * frame_stride_bytes, g, detection_threshold, L.d);
+        imgfd_status st = surf_device_stages(c, d_rgb + (size_t)f * frame_stride_bytes, g, detection_threshold, L.d, fork);
         double *feat = d_features + (size_t)f * (size_t)cap * 70;
         SurfRankParams q;
         q.rec = L.d.rec; q.count = L.d.count; q.cap = L.d.cap; q.lim = lim; q.rows = rows; q.cols = cols; q.sel = L.sel; q.order = L.sel + lim;

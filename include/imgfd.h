@@ -124,6 +124,8 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  *                                    whose candidates overflowed the record buffer; 1: no wait, such a tile reports -candidates
  *   "surf_ends" [IMGFD_SURF_ENDS]  1 (default): intervals 0 and 5 of every octave of the Hessian pyramid are not built -- they are never
  *                                  maxima themselves, the 3x3x3 test computes the neighbourhoods it needs of them; 0: all six intervals
+ *   "surf_split" [IMGFD_SURF_SPLIT]  1 (default): a tile that has the device to itself (imgfd_surf, imgfd_surf_dev with one tile, the interest-point
+ *                                  doorways) runs the Hessian pyramid of octaves 1-3 on the companion context's stream beside octave 0; 0: one stream
  *   "surf_residue_fused" [IMGFD_SURF_RESIDUE_FUSED]  1 (default): the integral image's last kernel writes the table a second time in the
  *                                  residue layout octaves 1-3 read; 0: a kernel of its own re-lays it (round 3-4)
  *   "surf_sort_cap" [IMGFD_SURF_SORT_CAP]  selected records imgfd_surf_dev ranks with its LDS sort (2048); more: all-pairs ranking
