@@ -234,7 +234,8 @@ __device__ __forceinline__ unsigned si_wave_incl(unsigned v, int lane)
     }
     return v;
 }
-// A lane's 12-byte group in EVERY row of its tile: the 32 loads are all in flight before the first value is used.  (Round 3
+// A lane's 12-byte group in EVERY row of its tile: 32 loads that depend on nothing, issued ahead of the arithmetic a dozen and
+// more at a time (the compiler's schedule: the rows are consumed in the order they were asked for).  (Round 3
 // fetched four rows at a time, one step ahead: 24 KB in flight per CU, and 8 TB/s x ~2 us of latency wants ~64 KB -- the sums
 // kernel ran at 3 TB/s, 16.6 us for 50 MB.)  Rows past the band's end re-read its last row and count as zero.
 struct SiTile { unsigned w[SI_RB][3]; };
