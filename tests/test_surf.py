@@ -22,11 +22,12 @@ def blobs(seed, w, h, n=60):
 
 
 @pytest.mark.parametrize("w,h", [(64, 48), (257, 129), (400, 300), (1031, 517), (1028, 70), (260, 300), (256, 256), (1284, 97), (2052, 33),
-                                 (16, 4200), (20, 4127)])
+                                 (16, 4200), (20, 4127), (8192, 9), (8196, 8), (320, 205), (772, 96), (512, 129), (4100, 31), (64, 1025)])
 def test_integral_image_exact(be, w, h):
     """widths that are multiples of 4 take the band / strip form (surf_int_sums / _carry / _apply: partial strips, partial
     bands, a single band, several workgroups per band; more than 128 bands: a wave of the carry kernel walks its run of bands in
-    memory instead of holding it in registers); the others the row scan + column scan"""
+    memory instead of holding it in registers; 8192 columns = the 32 strips the carry kernel's scan holds, 8196: one more, back to
+    the row scan + column scan; a last band of one row, of 31; a last strip of four columns); the others the row scan + column scan"""
     rgb = synth.frame_rgb(81, w, h)
     assert np.array_equal(be.surf_integral(rgb), oracle.surf_integral(rgb))
 
