@@ -458,6 +458,9 @@ __device__ __forceinline__ double surf_dxx(int wide, int narrow) { return (doubl
 // it loses to the gather kernel): the integral-image window of a block of level
 // pixels, with the widest filter's reach around it, is staged in LDS once and serves all six intervals (6 x 32 look-ups
 // per level pixel from LDS instead of scattered global loads).  Same arithmetic as surf_pyramid below.
+#ifndef SURF_LDS_NT
+#define SURF_LDS_NT 512  // threads of a first-octave workgroup: the 47 KB window allows three workgroups per CU whatever their size (256: 12 waves per CU; four lanes 0.256 -> 0.244 ms per tile)
+#endif
 #ifndef SURF_LDS_LY
 #define SURF_LDS_LY 16  // level rows per workgroup of the first octave's LDS kernel (imgfd_surf_dev per tile: 8 -> 0.453, 16 -> 0.441-0.455, 32 -> 0.472 ms)
 #endif
@@ -471,9 +474,10 @@ struct SurfPyrLds {
     static constexpr int HR = REACH;
     static constexpr int W = STEP * (LX - 1) + 1 + HL + HR, H = STEP * (LY - 1) + 1 + HL + HR;
     static constexpr int P = (W + 3) / 4 * 4;                          // row pitch in words, a multiple of 4 and of STEP
-    static constexpr int PX_PER_THREAD = LX * LY / 256;
+    static constexpr int NT = SURF_LDS_NT;                            // threads per workgroup
+    static constexpr int PX_PER_THREAD = LX * LY / NT;
     static constexpr int BIAS = HL * P + HL / STEP;                    // window words from (row - HL, column - HL) to the centre
-    static_assert(HL % STEP == 0 && P % STEP == 0 && (LX * LY) % 256 == 0 && LX <= 64 && 64 % LX == 0, "tile geometry");
+    static_assert(HL % STEP == 0 && P % STEP == 0 && (LX * LY) % NT == 0 && LX <= 64 && 64 % LX == 0, "tile geometry");
     static_assert(sizeof(unsigned) * (size_t)H * P <= 120 * 1024, "window fits the LDS");
     // window word of image column x0 + dx: columns are stored by residue mod STEP, so that the lanes of a look-up
     // (columns STEP*lane + const) sit on consecutive words
@@ -516,7 +520,7 @@ __device__ __forceinline__ double surf_lds_interval(const unsigned *__restrict__
 }
 
 template <int O>
-__global__ void __launch_bounds__(256) surf_pyramid_lds(const unsigned *__restrict__ I, double *__restrict__ pyr, SurfGeom g,
+__global__ void __launch_bounds__(SURF_LDS_NT) surf_pyramid_lds(const unsigned *__restrict__ I, double *__restrict__ pyr, SurfGeom g,
                                                         unsigned long long *__restrict__ mask, double thr, int blocks_x, int xcd_order, int skip_ends)
 {
     using G = SurfPyrLds<O>;
@@ -529,14 +533,14 @@ __global__ void __launch_bounds__(256) surf_pyramid_lds(const unsigned *__restri
     const int x0 = G::STEP * lc0 - G::HL, y0 = G::STEP * lr0 - G::HL;
     const int cols = g.cols, rows = g.rows;
     if (x0 >= 0 && y0 >= 0 && x0 + G::P <= cols && y0 + G::H <= rows && (cols & 3) == 0) {  // workgroup-uniform; x0 % 4 == 0
-        for (int i = tid; i < G::H * (G::P / 4); i += 256) {
+        for (int i = tid; i < G::H * (G::P / 4); i += G::NT) {
             const int ry = i / (G::P / 4), q = i - ry * (G::P / 4);
             const uint4 v = *reinterpret_cast<const uint4 *>(I + (size_t)(y0 + ry) * cols + x0 + 4 * q);
             unsigned *row = win + ry * G::P;
             row[G::col(4 * q)] = v.x; row[G::col(4 * q + 1)] = v.y; row[G::col(4 * q + 2)] = v.z; row[G::col(4 * q + 3)] = v.w;
         }
     } else {  // at the image border: clamped coordinates (entries outside the image are never used by a valid centre)
-        for (int i = tid; i < G::H * G::P; i += 256) {
+        for (int i = tid; i < G::H * G::P; i += G::NT) {
             const int ry = i / G::P, rx = i - ry * G::P;
             const int gy = min(max(y0 + ry, 0), rows - 1), gx = min(max(x0 + rx, 0), cols - 1);
             win[ry * G::P + G::col(rx)] = I[(size_t)gy * cols + gx];
@@ -545,7 +549,7 @@ __global__ void __launch_bounds__(256) surf_pyramid_lds(const unsigned *__restri
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < G::PX_PER_THREAD; k++) {
-        const int e = tid + 256 * k;  // level pixel of the block: row-major, LX per row
+        const int e = tid + G::NT * k;  // level pixel of the block: row-major, LX per row
         const int lr = lr0 + e / G::LX, lc = lc0 + e % G::LX;
         const int r = lr * G::STEP, c = lc * G::STEP;
         // a wave = 64 consecutive level pixels of one row (LX = 64, lc0 a multiple of 64): its ballot is one word of the
@@ -585,7 +589,7 @@ static imgfd_status launch_surf_pyramid_lds(imgfd_ctx *ctx, const unsigned *d_I,
     const size_t lds = sizeof(unsigned) * (size_t)G::H * G::P;
     IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)surf_pyramid_lds<O>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int bx = ceil_div(g.nc[O], G::LX), by = ceil_div(g.nr[O], G::LY);
-    hipLaunchKernelGGL(surf_pyramid_lds<O>, dim3((unsigned)bx * (unsigned)by), dim3(256), lds, ctx->stream, d_I, d_pyr, g, d_mask, thr, bx, ctx->tune.xcd_remap, skip_ends);
+    hipLaunchKernelGGL(surf_pyramid_lds<O>, dim3((unsigned)bx * (unsigned)by), dim3(G::NT), lds, ctx->stream, d_I, d_pyr, g, d_mask, thr, bx, ctx->tune.xcd_remap, skip_ends);
     return IMGFD_OK;
 }
 
