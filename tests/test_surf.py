@@ -145,6 +145,16 @@ def test_residue_layout_written_by_either_kernel(be, w, h):
         be.set_tuning("surf_residue_fused", 1)
 
 
+@pytest.mark.parametrize("w,h", [(256, 200), (330, 170)])
+def test_threshold_zero_lists_every_level_pixel(be, w, h):
+    """detection threshold 0: every level pixel is marked, a workgroup of the maximum test hands its 16384 listed pixels out in 64
+    trips of 256 (the list in LDS holds one trip); the reference's points, bit for bit"""
+    img = blobs(250 + w, w, h)
+    ref = oracle.surf_interest_points(img, 0.0)
+    got = be.surf_interest_points(img, 0.0)
+    assert len(ref) > 50 and got.shape == ref.shape and np.array_equal(got.view(np.uint64), ref.view(np.uint64))
+
+
 def test_single_tile_pyramid_on_one_stream_or_two(be):
     """"surf_split" 1 (default): a call with one tile runs octaves 1-3 on the companion context's stream beside octave 0 and the
     maximum test waits for both; 0: everything on the context's stream.  Same points, same features; repeated calls reuse
