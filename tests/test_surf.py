@@ -159,13 +159,13 @@ def test_single_tile_pyramid_on_one_stream_or_two(be):
     """"surf_split" 1 (default): a call with one tile runs octaves 1-3 on the companion context's stream beside octave 0 and the
     maximum test waits for both; 0: everything on the context's stream.  Same points, same features; repeated calls reuse
     the buffers (the second tile's integral image must not overtake the first tile's gather kernel)"""
-    frames = np.stack([blobs(230 + f, 400, 304) for f in range(2)])
+    frames = np.stack([blobs(230 + f, 320, 240) for f in range(2)])
     ref = [oracle.surf(frames[f], 300, 4.0) for f in range(2)]
     pts = [oracle.surf_interest_points(frames[f], 4.0) for f in range(2)]
     try:
-        for split in (1, 0, 1):
+        for split in (1, 0):
             be.set_tuning("surf_split", split)
-            for f in (0, 1, 0):
+            for f in (0, 1):
                 got = be.surf_dev(frames[f:f + 1], max_points=300, threshold=4.0)[0]
                 assert len(ref[f]["x"]) > 20
                 assert np.array_equal(got["score"], ref[f]["score"]), (split, f)
