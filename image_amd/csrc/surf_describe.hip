@@ -54,6 +54,27 @@ struct Haar {
         const long left = x - width / 2, top = y - width / 2, right = left + width - 1;
         return (int)(box(left, y, right, top + width - 1) - box(left, top, right, y - 1));
     }
+    // haar_x and haar_y of one sample together.  Their four boxes tile one w x w square cut in two along x and along y: the
+    // sixteen corners of :124-183 are eight distinct table entries -- rows top-1, y-1, bottom x columns left-1, x-1, right,
+    // without the centre.  With the square inside the image (every sample of a valid point: surf.h:271-285 keeps a point only
+    // if its 32*scale box is) no corner is clamped or zeroed, so eight independent loads in ONE round trip give both
+    // responses -- integer sums, the reference's values exactly; the general case-by-case form above was two dependent round
+    // trips per box and twice the table traffic.  A square that touches the border takes that form.
+    __device__ __forceinline__ void haar_xy(long x, long y, long width, int *hx, int *hy) const
+    {
+        const long left = x - width / 2, top = y - width / 2, right = left + width - 1, bottom = top + width - 1;
+        if (left >= 1 && top >= 1 && right < cols && bottom < rows) {
+            const unsigned *rt = I + (size_t)(top - 1) * cols, *rm = I + (size_t)(y - 1) * cols, *rb = I + (size_t)bottom * cols;
+            const unsigned tl = rt[left - 1], tm = rt[x - 1], tr = rt[right];
+            const unsigned ml = rm[left - 1], mr = rm[right];
+            const unsigned bl = rb[left - 1], bm = rb[x - 1], br = rb[right];
+            *hx = (int)((br - bm - tr + tm) - (bm - bl - tm + tl));  // box(x, top, right, bottom) - box(left, top, x - 1, bottom)
+            *hy = (int)((br - bl - mr + ml) - (mr - ml - tr + tl));  // box(left, y, right, bottom) - box(left, top, right, y - 1)
+        } else {
+            *hx = haar_x(x, y, width);
+            *hy = haar_y(x, y, width);
+        }
+    }
 };
 
 __device__ __forceinline__ long surf_to_long(double v) { return (long)floor(v + 0.5); }
@@ -78,8 +99,10 @@ __global__ void __launch_bounds__(128) surf_orient(const unsigned *__restrict__ 
     if (i < SURF_NSAMP) {
         const long r = T.r[i], c = T.c[i];
         const long px = surf_to_long((double)(sc * c) + x), py = surf_to_long((double)(sc * r) + y);
-        const double vx = T.w[i] * H.haar_x(px, py, 4 * sc);
-        const double vy = T.w[i] * H.haar_y(px, py, 4 * sc);
+        int hx, hy;
+        H.haar_xy(px, py, 4 * sc, &hx, &hy);
+        const double vx = T.w[i] * hx;
+        const double vy = T.w[i] * hy;
         if (samples) {
             samples[p * (2 * SURF_NSAMP) + i] = vx;
             samples[p * (2 * SURF_NSAMP) + SURF_NSAMP + i] = vy;
@@ -142,8 +165,7 @@ __global__ void __launch_bounds__(64) surf_desc(const unsigned *__restrict__ I, 
         const long yy = s / 20 - 10, xx = s % 20 - 10;
         const double qx = xx * scale, qy = yy * scale;
         const long px = surf_to_long((cs * qx - sn * qy) + x), py = surf_to_long((sn * qx + cs * qy) + y);
-        hx[s] = H.haar_x(px, py, 2 * sc);
-        hy[s] = H.haar_y(px, py, 2 * sc);
+        H.haar_xy(px, py, 2 * sc, &hx[s], &hy[s]);
     }
     __syncthreads();
     // weighted, rotated back (:188-199), per bucket slot j = (yy - (r-1))*7 + (xx - (c-1))
