@@ -89,8 +89,9 @@ __global__ void __launch_bounds__(128) surf_orient(const unsigned *__restrict__ 
                                                    const unsigned *__restrict__ m_dev)
 {
     if (m_dev && blockIdx.x >= *m_dev) return;  // the grid covers the upper bound; the number of points lives on the device
-    __shared__ double sx[SURF_NSAMP], sy[SURF_NSAMP], sa[SURF_NSAMP];
+    __shared__ double sx[SURF_NSAMP], sy[SURF_NSAMP];
     __shared__ double wx[45], wy[45];
+    __shared__ unsigned long long in_windows[SURF_NSAMP];  // bit k: the sample's angle lies in window k
     const size_t p = blockIdx.x;
     const int i = threadIdx.x;
     const double x = pts[3 * p], y = pts[3 * p + 1], scale = pts[3 * p + 2];
@@ -109,30 +110,39 @@ __global__ void __launch_bounds__(128) surf_orient(const unsigned *__restrict__ 
         }
         sx[i] = vx;
         sy[i] = vy;
-        if (trig) sa[i] = atan2(vy, vx);
+        if (trig) {
+            // which of the 45 windows hold this sample's angle (:113-127): the tests of all windows here, one sample per lane, so
+            // that a window's lane -- which has to add its samples in the reference's order -- only looks a bit up per sample
+            const double pi = 3.1415926535897932384626433832795;
+            const double ang_step = (2 * pi) / 45;
+            const double a = atan2(vy, vx);
+            unsigned long long bits = 0;
+            for (int k = 0; k < 45; k++) {
+                const double a1 = ang_step * k - pi, a2 = a1 + pi / 3;
+                const bool in = (a1 <= a && a <= a2) || (a2 > pi && (a >= a1 || a <= (-2 * pi + a2)));
+                bits |= (unsigned long long)in << k;
+            }
+            in_windows[i] = bits;
+        }
     }
     if (!trig) return;
     __syncthreads();
-    const double pi = 3.1415926535897932384626433832795;
     if (i < 45) {  // :111-131
-        const double ang_step = (2 * pi) / 45;
-        const double a1 = ang_step * i - pi, a2 = a1 + pi / 3;
         double vx = 0, vy = 0;
-        for (int s = 0; s < SURF_NSAMP; s++) {
-            const double a = sa[s];
-            const bool in = (a1 <= a && a <= a2) || (a2 > pi && (a >= a1 || a <= (-2 * pi + a2)));
-            if (in) { vx += sx[s]; vy += sy[s]; }
-        }
+        for (int s = 0; s < SURF_NSAMP; s++)
+            if ((in_windows[s] >> i) & 1ull) { vx += sx[s]; vy += sy[s]; }
         wx[i] = vx;
         wy[i] = vy;
     }
     __syncthreads();
-    if (i == 0) {  // :132-137: first strictly longest window
-        double best_len = 0, best_ang = 0;
+    if (i == 0) {  // :132-137: first strictly longest window (its angle is formed once, behind the search: the reference's value)
+        double best_len = 0;
+        int best = -1;
         for (int k = 0; k < 45; k++) {
             const double len = wx[k] * wx[k] + wy[k] * wy[k];
-            if (len > best_len) { best_len = len; best_ang = atan2(wy[k], wx[k]); }
+            if (len > best_len) { best_len = len; best = k; }
         }
+        const double best_ang = best >= 0 ? atan2(wy[best], wx[best]) : 0.0;
         double *t = trig + 5 * p;
         t[0] = best_ang;
         t[1] = sin(best_ang);
