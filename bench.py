@@ -109,19 +109,7 @@ def cpu_harris_fast9_canny(img, want_fast9=True, gpu_frame0=None):
     parts["canny_fft_blur_ms"] = round(1e3 * t_c, 2)
     parts["canny_restatement_direct_convolution_ms"] = round(1e3 * t_c_direct, 2)
     if gpu_frame0 is not None:
-        rh = oracle.ref_harris(f32, threads=cores) if have_ref else oracle.harris(f32)
-        gh, gf, ge = gpu_frame0
-        same_h = gh.shape == rh.shape and bool(np.array_equal(gh[:, :2], rh[:, :2]))
-        par = {"harris_corners": int(len(rh)), "harris_coordinates_match": same_h,
-               # the timed mode (fir_mode 1: fused f64 accumulate) promises coordinates + 1e-4; how many strengths of this sample differ in a bit at all
-               "harris_strengths_differing_in_any_bit": int(np.count_nonzero(gh[:, 2].astype(np.float32).view(np.uint32) != rh[:, 2].astype(np.float32).view(np.uint32))) if same_h else None,
-               "harris_strength_max_rel_err": float(np.max(np.abs(gh[:, 2] - rh[:, 2]) / np.maximum(1.0, np.abs(rh[:, 2])))) if same_h and len(rh) else None}
-        if gf is not None:
-            rf = oracle.ref_fast9(img, 20, True) if have_ref else oracle.fast9(img, 20, True)
-            par.update({"fast9_corners": int(len(rf)), "fast9_coordinates_match": bool(gf.shape == rf.shape and np.array_equal(gf, rf))})
-        re_, rn = oracle.canny(img)
-        par.update({"canny_edge_pixels": int(rn), "canny_mismatching_pixels": int(np.count_nonzero(ge != re_))})
-        out["parity_frame0"] = par
+        out["parity_frame0"] = parity_of_frame(img, gpu_frame0, threads=cores)
     total = t_h + t_f + t_c
     out.update({"value": round(px / total / 1e6, 3), "kind": kind, "cores": cores,
                 "reference_only_value": round(px / (t_h + t_f) / 1e6, 3),   # top level: the driver's parsed line keeps it
@@ -133,6 +121,29 @@ def cpu_harris_fast9_canny(img, want_fast9=True, gpu_frame0=None):
                           "restated gradient / maxima / hysteresis stages (pinned against the reference sources), 1 thread",
                 "parts": parts})
     return out
+
+
+def parity_of_frame(img, gpu, threads=1):
+    """the metric's "feature-coordinate match vs CPU" for one gray frame: gpu = (corner list, FAST-9 point list or None, edge map)
+    as the device left them; the CPU side is the reference's own code (Harris, FAST-9) and the pinned restatement (Canny)"""
+    import numpy as np
+
+    import oracle
+    have_ref = oracle.have_ref("harris") and oracle.have_ref("f9")
+    f32 = img.astype(np.float32)
+    rh = oracle.ref_harris(f32, threads=threads) if have_ref else oracle.harris(f32)
+    gh, gf, ge = gpu
+    same_h = gh.shape == rh.shape and bool(np.array_equal(gh[:, :2], rh[:, :2]))
+    par = {"harris_corners": int(len(rh)), "harris_coordinates_match": same_h,
+           # the timed mode (fir_mode 1: fused f64 accumulate) promises coordinates + 1e-4; how many strengths of this sample differ in a bit at all
+           "harris_strengths_differing_in_any_bit": int(np.count_nonzero(gh[:, 2].astype(np.float32).view(np.uint32) != rh[:, 2].astype(np.float32).view(np.uint32))) if same_h else None,
+           "harris_strength_max_rel_err": float(np.max(np.abs(gh[:, 2] - rh[:, 2]) / np.maximum(1.0, np.abs(rh[:, 2])))) if same_h and len(rh) else None}
+    if gf is not None:
+        rf = oracle.ref_fast9(img, 20, True) if have_ref else oracle.fast9(img, 20, True)
+        par.update({"fast9_corners": int(len(rf)), "fast9_coordinates_match": bool(gf.shape == rf.shape and np.array_equal(gf, rf))})
+    re_, rn = oracle.canny(img)
+    par.update({"canny_edge_pixels": int(rn), "canny_mismatching_pixels": int(np.count_nonzero(ge != re_))})
+    return par
 
 
 # ------------------------------------------------------------------------------------------------ workloads
@@ -337,7 +348,9 @@ class Detect4K(Workload):
         iy = torch.empty_like(ix)
         for f in range(B):
             det.gradients_of(self.frames[f], ix[f], iy[f])
+        det.clock_probe(20000)   # 20 ms of the doorway's ~100 ms of back-to-back launches: the clock this kernel alone runs at
         us = det.time_structure_tensor_batch(ix, iy, warmup=12, iters=max(20, min(60, steps)))   # warm-up covers the first touch of the freshly allocated A, B, C
+        k3_clock = det.clock_probe_read()
         del ix, iy
         k3_bytes = TENSOR_BYTES_PER_PX * NX * NY * B
         achieved = k3_bytes / (us * 1e-6) / 1e9
@@ -357,6 +370,7 @@ class Detect4K(Workload):
                                    "part, measured (scripts/ubench/ubench7.hip); the phase split and the barrier-free experiment behind this number: profiles/r04/k3_phase_split.txt, "
                                    "k3_wave_experiment.txt; DESIGN.md, K3"},
              "avg_launch_us": round(us, 2), "frames_per_launch": B, "algorithmic_bytes_per_launch": k3_bytes,
+             "shader_clock_GHz": k3_clock["mean_GHz"],   # while these launches ran (imgfd_clock_probe, 20 ms): tells a slow box from a slow kernel
              "timed": "HIP events on the context's stream around back-to-back launches of the stage doorway on this batch's gradients, after the timed region"}
         tr = traffic_for("fir_tensor", B)
         r["traffic"], r["traffic_unit"] = tr, "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/k3_traffic.json; refreshed by scripts/gpu_pmc_k3.sh)"
@@ -378,12 +392,19 @@ class Detect4K(Workload):
 
         from image_amd import stream, synth
         if not self.stream_mode:
+            def dev(f):   # what the last pass of the timed region left for frame f of the batch
+                n_h, n_f = int(self.counts[0, f]), int(self.counts[1, f])
+                return (self.corners[f, :min(n_h, self.cap_h)].cpu().numpy(), self.points[f, :min(n_f, self.cap_f)].cpu().numpy(), self.edges[f].cpu().numpy())
             host = synth.frame(stream.frame_seed(50000, self.first), self.NX, self.NY)   # host twin of device frame 0
             assert np.array_equal(self.frames[0].cpu().numpy(), host), "device and host frame generators diverged"
-            n_h, n_f = int(self.counts[0, 0]), int(self.counts[1, 0])
-            gpu0 = (self.corners[0, :min(n_h, self.cap_h)].cpu().numpy(), self.points[0, :min(n_f, self.cap_f)].cpu().numpy(),
-                    self.edges[0].cpu().numpy())
-            return cpu_harris_fast9_canny(host, True, gpu0) if want_cpu else None
+            out = cpu_harris_fast9_canny(host, True, dev(0)) if want_cpu else {"parity_frame0": parity_of_frame(host, dev(0))}
+            # frame 0 is not the batch: the middle and the last frame too ("check >= 2 frames of the default batch")
+            more = sorted({self.B // 2, self.B - 1} - {0})[: max(0, self.args.max_parity_frames - 1)]
+            out["parity_frames"] = {}
+            for f in more:
+                img = synth.frame(stream.frame_seed(50000, self.first + f), self.NX, self.NY)
+                out["parity_frames"][str(f)] = parity_of_frame(img, dev(f), threads=min(16, _avail_cores()))
+            return out
         return stream_sample_check(self, want_cpu)
 
 
@@ -497,7 +518,8 @@ class Canny1080p(Workload):
         ach = alg / (ms_per_step * 1e-3) / 1e9
         return {"kernel": "imgfd_canny_dev (whole function: blur, gradient+NMS, hysteresis, expansion)", "bound": "f64-valu",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "algorithmic_bytes_per_step": alg, "traffic": None,
+                "algorithmic_bytes_per_step": alg, "traffic": function_traffic("canny", self.F * self.NX * self.NY / (3840 * 2160)),
+                "traffic_unit": "bytes/step (PMC FETCH_SIZE x2 + WRITE_SIZE over every kernel of imgfd_canny_dev on 4K frames, scaled by the pixels; profiles/function_traffic.json)",
                 "note": "2 B/px compulsory traffic over the whole function's time; the f64 blur and gradient arithmetic of the reference bound it, not HBM"}
 
     def parity_and_cpu(self, want_cpu):
@@ -596,12 +618,22 @@ class DlibTiles(Workload):
         tf, ts = self.t_fhog / n, self.t_surf / n
         hog_bytes = 3 * px + self.hog.numel() * 4
         surf_bytes = 43 * px   # RGB in, int32 integral write+read, f64 pyramid write + one read
+        # what the code is DESIGNED to move since round 6 (SURF): RGB read twice by the band / strip scans (6), the table
+        # written once (4) and read once per pyramid kernel (8), four of six intervals of the f64 pyramid written and read once
+        # (2 x 4 x 8 x (1/4 + 1/16 + 1/64 + 1/256) = 21.25): 39.25 B/px -- beside SURVEY's staged 43 with all six intervals
+        surf_design = 39.25 * px
         af, asf = hog_bytes / (tf * 1e-3) / 1e9, surf_bytes / (ts * 1e-3) / 1e9
+        scale = self.S * self.S / (4096 * 4096)
+        unit = "bytes/step (PMC FETCH_SIZE x2 + WRITE_SIZE over every kernel of the function on 4096^2 tiles, profiles/function_traffic.json)"
         return {"kernel": "imgfd_fhog_dev (K13-K15, whole function)", "bound": "hbm", "achieved": round(af, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(af / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_step": hog_bytes, "ms_per_step": round(tf, 3), "traffic": None,
+                "frac": round(af / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_step": hog_bytes, "ms_per_step": round(tf, 3),
+                "traffic": function_traffic("fhog", self.T * scale), "traffic_unit": unit,
                 "surf": {"kernel": "imgfd_surf_dev (K16-K19, whole function)", "bound": "hbm", "achieved": round(asf, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(asf / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_step": surf_bytes, "ms_per_step": round(ts, 3),
-                         "ms_per_tile": round(ts / self.T, 4)},
+                         "ms_per_tile": round(ts / self.T, 4), "traffic": function_traffic("surf", self.T * scale), "traffic_unit": unit,
+                         "designed_bytes_per_step": int(surf_design), "frac_of_designed_bytes": round(surf_design / (ts * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "designed_bytes": "39.25 B/px: RGB read twice (band / strip scans), the int32 table written once and read by both pyramid kernels, "
+                                           "four of the six intervals per octave of the f64 pyramid written and read once (intervals 0 and 5 are never built)"},
                 "fhog_ms_per_tile": round(tf / self.T, 4)}
 
     def parity_and_cpu(self, want_cpu):
@@ -661,13 +693,31 @@ def traffic_for(kernel, batch):
         return None
 
 
-def kernel_source_hash():
+def kernel_source_hash(files=("fir_tensor.hip", "fir_tensor_device.h", "fir_device.h")):
     import hashlib
     h = hashlib.sha1()
-    for f in ("fir_tensor.hip", "fir_tensor_device.h", "fir_device.h"):
+    for f in files:
         with open(os.path.join(ROOT, "image_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
+
+
+# whole functions whose HBM traffic (PMC, all their kernels) is kept beside their roofline entries: name -> sources the number is tied to
+FUNCTION_SOURCES = {"canny": ("canny.hip",), "fhog": ("fhog.hip", "fhog_fused.hip", "fhog_device.h"),
+                    "surf": ("surf.hip", "surf_describe.hip", "surf_describe.h")}
+
+
+def function_traffic(name, units):
+    """HBM bytes of `units` frames / tiles through one whole function (every kernel it launches): PMC FETCH_SIZE x 2 + WRITE_SIZE
+    per unit from profiles/function_traffic.json (scripts/gpu_pmc_functions.sh; separate passes, never beside a timing run), or
+    None when the function's kernel sources have changed since it was measured."""
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "function_traffic.json")))[name]
+        if tr.get("kernel_source_sha1") != kernel_source_hash(FUNCTION_SOURCES[name]):
+            return None
+        return int(tr["traffic_bytes_per_unit"] * units)
+    except Exception:
+        return None
 
 
 # ------------------------------------------------------------------------------------------------ launch
@@ -793,11 +843,13 @@ def measure(args, det, rank, world, dist, want_cpu, light=False):
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
     for k in range(steps):
+        det.clock_probe(200)   # one wavefront on a stream of its own, 200 us: the shader clock WHILE this step's kernels run
         ev[k][0].record()
         wl.step()
         ev[k][1].record()
     barrier()
     dt = time.perf_counter() - t0
+    clock = det.clock_probe_read()
     k3_us, k3_n = det.profile_k3_read()
     det.lib.imgfd_profile_k3(det.ctx.handle, 0)
     step_ms = sorted(a.elapsed_time(b) for a, b in ev)
@@ -840,6 +892,8 @@ def measure(args, det, rank, world, dist, want_cpu, light=False):
                        **wl.describe(counts)},
         }
         res["config"]["per_rank"] = per_rank
+        res["config"]["shader_clock"] = {**clock, "how": "imgfd_clock_probe: one wavefront per step on a stream of its own reads s_memtime (shader cycles) and "
+                                                         "s_memrealtime (constant rate) 200 us apart while the step's kernels run; rank 0"}
         if pass_ms:
             res["ms_per_pass_median_hip_events"] = round(pass_ms[len(pass_ms) // 2], 4)
             res["passes_event_timed"] = len(pass_ms)
@@ -1005,7 +1059,7 @@ def extra_configs(args, det, dist):
     plan = [("2_batch1", dict(config=2, batch=1, inner=50, steps=20, warmup=3), False),
             ("3", dict(config=3, batch=0, steps=3, warmup=1), True),
             ("4", dict(config=4, batch=0, steps=2, warmup=1), True),
-            ("5", dict(config=5, batch=0, frames=10000, steps=None, warmup=1, max_parity_frames=16), False)]
+            ("5", dict(config=5, batch=0, frames=10000, steps=None, warmup=1, max_parity_frames=100), False)]
     for name, over, cpu in plan:
         a = copy.copy(args)
         for k, v in over.items():
@@ -1033,6 +1087,60 @@ def extra_configs(args, det, dist):
             out[name]["wall_s"] = round(time.perf_counter() - t0, 1)
         except Exception as e:
             out[name] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def line_summary(res):
+    """the numbers a reader of the driver's record needs, in one short object: every configuration's rate and time, the
+    structure-tensor kernel's roofline fraction and clock, the parity verdicts"""
+    def g(d, *path, default=None):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return default
+            d = d[k]
+        return d
+    rf = res.get("roofline", {})
+    out = {"default": {"Mpx_s": res.get("value"), "ms_step": res.get("ms_per_step"), "clock_GHz": g(res, "config", "shader_clock", "mean_GHz")}}
+    if "frac" in rf and "avg_launch_us" in rf:
+        out["k3"] = {"frac": rf.get("frac"), "us": rf.get("avg_launch_us"), "clock_GHz": rf.get("shader_clock_GHz"), "traffic": rf.get("traffic"),
+                     "pipe_us": g(rf, "in_pipeline", "avg_launch_us")}
+    cb = res.get("cpu_baseline") or res.get("parity") or {}
+    par = {}
+    p0 = [cb.get("parity_frame0")] + list((cb.get("parity_frames") or {}).values())
+    p0 = [p for p in p0 if p]
+    if p0:
+        par["default"] = {"frames": len(p0), "harris_xy": all(p.get("harris_coordinates_match") for p in p0),
+                          "harris_R_bits_differing": sum(p.get("harris_strengths_differing_in_any_bit") or 0 for p in p0),
+                          "fast9_xy": all(p.get("fast9_coordinates_match", True) for p in p0), "canny_px_differing": sum(p.get("canny_mismatching_pixels") or 0 for p in p0)}
+    if cb.get("value") is not None:
+        out["cpu"] = {"Mpx_s": cb.get("value"), "cores": cb.get("cores"), "ref_only_Mpx_s": cb.get("reference_only_value")}
+    cfgs = res.get("configs") or {}
+    for name in ("2_batch1", "3", "4", "5"):
+        c = cfgs.get(name)
+        if not c:
+            continue
+        if "error" in c:
+            out[name] = {"error": c["error"][:80]}
+            continue
+        e = {"Mpx_s": c.get("value"), "ms_step": c.get("ms_per_step")}
+        if name == "2_batch1":
+            e["ms_frame"] = round(c["ms_per_step"] / max(1, g(c, "config", "passes_per_step", default=1)), 4) if c.get("ms_per_step") else None
+        if name == "4":
+            e.update({"surf_ms_tile": g(c, "roofline", "surf", "ms_per_tile"), "fhog_ms_tile": g(c, "roofline", "fhog_ms_per_tile")})
+        out[name] = e
+        ps = g(c, "cpu_baseline", "parity_sample") or g(c, "parity", "parity_sample")
+        if ps:
+            keep = ("frames_checked", "tiles_checked", "canny_mismatching_pixels_total", "frames_with_different_corner_coordinates", "frames_with_strength_rel_err_above_1e-4",
+                    "frames_whose_streamed_counts_differ", "fhog_bit_equal", "surf_points_equal", "surf_descriptor_max_abs_err", "pixels_nonzero_equal")
+            par[name] = {k: ps[k] for k in keep if k in ps}
+    h = cfgs.get("5_h2d")
+    if h and "value" in h:
+        out["5_h2d"] = {"Mpx_s": h.get("value"), "of_pcie_floor": h.get("frac_of_pcie_floor")}
+    ha = g(cfgs, "host_api", "calls")
+    if ha:
+        out["host_api_ms"] = {k.replace("imgfd_", ""): [v.get("ms_best"), v.get("floor_over_best")] for k, v in ha.items()}
+    if par:
+        out["parity"] = par
     return out
 
 
@@ -1122,6 +1230,8 @@ def main(argv=None):
         except Exception as e:
             dist_note = f"RCCL all_gather failed: {type(e).__name__}: {e}"
     if rank == 0:
+        res["summary"] = line_summary(res)   # LAST key of the line: the tail of stdout the driver keeps always holds it
+        res["config"]["summary"] = res["summary"]   # and inside a key the driver's parser keeps
         if rccl is not None:
             same = [int(v) for v in rccl.sum(0).tolist()] == main_reduced
             res["config"]["collectives"] += (f"; then ONE RCCL all_gather of the per-rank count vectors (nccl backend, device tensors), after every clock has stopped: "

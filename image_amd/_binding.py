@@ -123,6 +123,8 @@ SIGNATURES = {
     "imgfd_tensor_kernel_name": (C.c_char_p, [C.c_void_p]),
     "imgfd_k_tensor_response": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]),
     "imgfd_profile_k3": (C.c_int, [C.c_void_p, C.c_int]),
+    "imgfd_clock_probe": (C.c_int, [C.c_void_p, C.c_int]),
+    "imgfd_clock_probe_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "imgfd_profile_k3_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "imgfd_synth_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_uint32,
                                      C.c_void_p, C.c_int]),

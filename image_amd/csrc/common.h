@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <functional>
 #include <new>
 #include <string>
@@ -75,7 +76,6 @@ struct imgfd_ctx {
         int hyst_prio = 1;          // block sweeps run at wave priority 3 (0: default priority)
         int hyst_shift = 1;         // block sweeps: odd launches group the tiles half a block up and left (0: the same grouping in every launch)
         int detect_defer = -1;      // imgfd_detect_dev: 1 = FAST-9 and the Harris chain are QUEUED only after the whole Canny chain (their release point on the device stays where canny_gate / harris_gate put it); 0 = queued where they are released; -1: 1 below 8 frames
-        int surf_taps = 1;          // SURF octaves 1-3: look-ups as buffer loads with host-made offsets (0: address arithmetic per look-up)
         int gauss_march = 1;        // u8 frames whose width is a multiple of 16: the marching Gaussian + gradient kernel (0: the tile kernel)
         int gauss_march_seg = 0;    // rows per segment of that kernel (0: from the batch)
         int harris_gate = -1;       // imgfd_detect_dev: the Harris chain is released behind Canny's gradient/NMS kernel (1), behind its blur (2), or together with FAST-9 (0); -1: 2 below 8 frames, else 1
@@ -84,7 +84,6 @@ struct imgfd_ctx {
         int fused_response = 1;     // Harris: corner response in the structure-tensor kernel's epilogue
         int nms_tiled = 0;          // Harris batch path: 1 = the tiled NMS kernel instead of the sparse one
         int tensor_per_cu = 0, tensor_workers = 0, tensor_tw = 0;  // fir_tensor launch geometry (0: chosen)
-        int surf_residue = 4;       // SURF octaves 1-3: modulus of the residue layout (0: plain table, 4, 16)
         int max_chunk_frames = 0;   // frames per sub-batch of the *_dev entry points (0: from the 12 GiB / 1 GiB budgets)
         int tile_run = 0;           // tiles per workgroup of the u8 tile kernels (0: from the batch size)
         int detect_graph = 0;       // imgfd_detect_dev: batches of fewer frames than this replay a recorded hipGraph when the call repeats
@@ -92,11 +91,13 @@ struct imgfd_ctx {
         int surf_lanes = 4;      // imgfd_surf_dev: tiles go round-robin over this many HIP streams (1..4), each with its own buffers
         int surf_rec_cap = 1 << 18;  // imgfd_surf_dev: candidate records a tile's buffer holds before the tile is redone (tests lower it)
         int surf_sort_cap = 2048;    // imgfd_surf_dev: selected records ranked by the LDS sort; more are ranked all-pairs (tests lower it)
-        int surf_residue_fused = 1;  // SURF: 1 = the integral image's last kernel also writes the residue layout of octaves 1-3; 0: a kernel of its own re-lays the table
         int surf_split = 1;      // SURF: 1 = a tile that has the device to itself (one lane) runs octaves 1-3 on the companion's stream beside octave 0
-        int surf_ends = 1;       // SURF: 1 = intervals 0 and 5 of every octave are not built (the maximum test computes the 3x3 neighbourhoods it needs of them from the integral image); 0: all six
         int surf_async = 0;      // imgfd_surf_dev: 1 = never wait for the host (a tile whose candidates overflow reports -candidates)
     } tune;
+    // imgfd_clock_probe (clock.hip): a stream of its own, a ring of (shader cycles, wall ticks) samples
+    hipStream_t clk_stream = nullptr;
+    unsigned long long *clk_ring = nullptr;
+    int clk_n = 0, clk_rate_khz = 0;
     // in-pipeline K3 timing (imgfd_profile_k3)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;  // pairs

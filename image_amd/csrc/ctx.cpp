@@ -32,17 +32,13 @@ const std::vector<TuneKey> &tune_keys()
         {"tensor_per_cu", "IMGFD_TENSOR_PER_CU", &imgfd_ctx::Tune::tensor_per_cu},
         {"tensor_workers", "IMGFD_TENSOR_WORKERS", &imgfd_ctx::Tune::tensor_workers},
         {"tensor_tw", "IMGFD_TENSOR_TW", &imgfd_ctx::Tune::tensor_tw},
-        {"surf_residue", "IMGFD_SURF_RESIDUE", &imgfd_ctx::Tune::surf_residue},
         {"max_chunk_frames", "IMGFD_MAX_CHUNK_FRAMES", &imgfd_ctx::Tune::max_chunk_frames},
         {"tile_run", "IMGFD_TILE_RUN", &imgfd_ctx::Tune::tile_run},
         {"fir_mode", "IMGFD_FIR_MODE", nullptr},
         {"detect_graph", "IMGFD_DETECT_GRAPH", &imgfd_ctx::Tune::detect_graph},
         {"surf_lanes", "IMGFD_SURF_LANES", &imgfd_ctx::Tune::surf_lanes},
-        {"surf_taps", "IMGFD_SURF_TAPS", &imgfd_ctx::Tune::surf_taps},
         {"surf_async", "IMGFD_SURF_ASYNC", &imgfd_ctx::Tune::surf_async},
-        {"surf_ends", "IMGFD_SURF_ENDS", &imgfd_ctx::Tune::surf_ends},
         {"surf_split", "IMGFD_SURF_SPLIT", &imgfd_ctx::Tune::surf_split},
-        {"surf_residue_fused", "IMGFD_SURF_RESIDUE_FUSED", &imgfd_ctx::Tune::surf_residue_fused},
         {"surf_sort_cap", "IMGFD_SURF_SORT_CAP", &imgfd_ctx::Tune::surf_sort_cap},
         {"surf_rec_cap", "IMGFD_SURF_REC_CAP", &imgfd_ctx::Tune::surf_rec_cap},
     };
@@ -123,6 +119,8 @@ void imgfd_ctx_destroy(imgfd_ctx *ctx)
     if (ctx->aux) (void)hipFree(ctx->aux);
     if (ctx->fhog_lut) (void)hipFree(ctx->fhog_lut);
     if (ctx->taps_dev) (void)hipFree(ctx->taps_dev);
+    if (ctx->clk_stream) { (void)hipStreamSynchronize(ctx->clk_stream); (void)hipStreamDestroy(ctx->clk_stream); }
+    if (ctx->clk_ring) (void)hipFree(ctx->clk_ring);
     if (ctx->canny_taps && ctx->canny_taps_free) ctx->canny_taps_free(ctx->canny_taps);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

@@ -70,10 +70,15 @@ static size_t surf_geometry(int rows, int cols, SurfGeom *g)
             L.lobe = (int)((long)(pow(2.0, o + 1.0) + 0.5) * (i + 1) + 1);
             L.off = L.lobe / 2 + 1;
             L.area_inv = 1.0 / pow(3.0 * L.lobe, 2.0);
+            // Intervals 0 and 5 of an octave are never maxima themselves (get_interest_points runs i = 1 .. 4,
+            // hessian_pyramid.h:461): they only lend their 3x3 neighbourhoods to the survivors of intervals 1 and 4, which the
+            // maximum test computes from the integral image on the spot.  They have no plane and no mask in the buffers.
             L.plane = total;
-            total += (size_t)g->nr[o] * g->nc[o];
             L.mask = mask_words;
-            mask_words += (size_t)g->nr[o] * ((g->nc[o] + 63) / 64);
+            if (i >= 1 && i <= SURF_INT - 2) {
+                total += (size_t)g->nr[o] * g->nc[o];
+                mask_words += (size_t)g->nr[o] * ((g->nc[o] + 63) / 64);
+            }
         }
     }
     g->mask_words = mask_words;
@@ -383,13 +388,14 @@ __global__ void __launch_bounds__(256) surf_int_carry(unsigned *__restrict__ col
     }
 }
 
-// RES: the table is written a second time in the residue layout the gather kernels of octaves 1-3 read (J[row][x % 4][x / 4],
-// see surf_residue_layout below): a lane's four columns are the four residues at word 64 s + lane of each, so a wave
-// stores four runs of 256 bytes -- 4 B/px written here instead of 4 read + 4 written by a kernel of its own (20.8 us per tile).
+// RES: the table is written in the residue layout (SurfTable: J[row][x % 4][x / 4]) INSTEAD of the plain one: a lane's four
+// columns are the four residues at word 64 s + lane of each, so a wave stores four runs of 256 bytes per row.  (Rounds 3-4 re-laid
+// the plain table with a kernel of its own, 4 B/px read + 4 written; round 5 wrote both layouts here, 8 B/px; since round 6 every
+// reader of the table addresses the residue layout and the plain copy is gone: 4 B/px.)
 template <bool RES>
 __global__ void __launch_bounds__(256) surf_int_apply(const unsigned char *__restrict__ rgb, const unsigned *__restrict__ colcarry,
                                                       const unsigned *__restrict__ above_left, const unsigned *__restrict__ rowsum,
-                                                      unsigned *__restrict__ out, unsigned *__restrict__ res, int rows, int cols, int nstrips)
+                                                      unsigned *__restrict__ out, int rows, int cols, int nstrips)
 {
     const int lane = threadIdx.x & 63, s = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
     const int c = 256 * s + 4 * lane;
@@ -434,10 +440,11 @@ __global__ void __launch_bounds__(256) surf_int_apply(const unsigned char *__res
             if (active && r0 + r + k < r1) {
                 const uint4 o = make_uint4(base[0] + add + q[k][0], base[1] + add + q[k][1], base[2] + add + q[k][2], base[3] + add + q[k][3]);
                 const size_t row = (size_t)(r0 + r + k) * cols;
-                *reinterpret_cast<uint4 *>(out + row + c) = o;
                 if (RES) {
-                    unsigned *j = res + row + (c >> 2);
+                    unsigned *j = out + row + (c >> 2);
                     j[0] = o.x; j[per] = o.y; j[2 * per] = o.z; j[3 * per] = o.w;
+                } else {
+                    *reinterpret_cast<uint4 *>(out + row + c) = o;
                 }
             }
         }
@@ -520,8 +527,8 @@ __device__ __forceinline__ double surf_lds_interval(const unsigned *__restrict__
 }
 
 template <int O>
-__global__ void __launch_bounds__(SURF_LDS_NT) surf_pyramid_lds(const unsigned *__restrict__ I, double *__restrict__ pyr, SurfGeom g,
-                                                        unsigned long long *__restrict__ mask, double thr, int blocks_x, int xcd_order, int skip_ends)
+__global__ void __launch_bounds__(SURF_LDS_NT) surf_pyramid_lds(SurfTable T, double *__restrict__ pyr, SurfGeom g,
+                                                                unsigned long long *__restrict__ mask, double thr, int blocks_x, int xcd_order)
 {
     using G = SurfPyrLds<O>;
     HIP_DYNAMIC_SHARED(unsigned, win)  // [G::H][G::P]
@@ -532,7 +539,22 @@ __global__ void __launch_bounds__(SURF_LDS_NT) surf_pyramid_lds(const unsigned *
     const int lc0 = blk_x * G::LX, lr0 = blk_y * G::LY;
     const int x0 = G::STEP * lc0 - G::HL, y0 = G::STEP * lr0 - G::HL;
     const int cols = g.cols, rows = g.rows;
-    if (x0 >= 0 && y0 >= 0 && x0 + G::P <= cols && y0 + G::H <= rows && (cols & 3) == 0) {  // workgroup-uniform; x0 % 4 == 0
+    const unsigned *__restrict__ I = T.p;
+    const bool interior = x0 >= 0 && y0 >= 0 && x0 + G::P <= cols && y0 + G::H <= rows && (cols & 3) == 0;  // workgroup-uniform; x0 % 4 == 0
+    if (interior && T.per) {
+        // residue layout: window column dx = 4 k + m of a row is word k of plane m, from (x0 / 4) on: a thread keeps one
+        // (m, k) and walks down the rows, NT / P rows per trip -- runs of P / 4 consecutive words, no division in the loop
+        static_assert(G::P % 4 == 0, "whole quads per window row");
+        constexpr int RPT = G::NT / G::P;                     // rows per trip
+        const int slot = tid % G::P, rr = tid / G::P;         // (tid < RPT * P take part)
+        const int m = slot / (G::P / 4), k = slot - m * (G::P / 4);
+        const unsigned *src = I + (size_t)y0 * cols + (size_t)m * T.per + (x0 >> 2) + k;
+        unsigned *dst = win + G::col(4 * k + m);
+        if (rr < RPT) {
+#pragma unroll 4
+            for (int ry = rr; ry < G::H; ry += RPT) dst[ry * G::P] = src[(size_t)ry * cols];
+        }
+    } else if (interior) {
         for (int i = tid; i < G::H * (G::P / 4); i += G::NT) {
             const int ry = i / (G::P / 4), q = i - ry * (G::P / 4);
             const uint4 v = *reinterpret_cast<const uint4 *>(I + (size_t)(y0 + ry) * cols + x0 + 4 * q);
@@ -543,7 +565,7 @@ __global__ void __launch_bounds__(SURF_LDS_NT) surf_pyramid_lds(const unsigned *
         for (int i = tid; i < G::H * G::P; i += G::NT) {
             const int ry = i / G::P, rx = i - ry * G::P;
             const int gy = min(max(y0 + ry, 0), rows - 1), gx = min(max(x0 + rx, 0), cols - 1);
-            win[ry * G::P + G::col(rx)] = I[(size_t)gy * cols + gx];
+            win[ry * G::P + G::col(rx)] = T.at(gy, gx);
         }
     }
     __syncthreads();
@@ -553,7 +575,7 @@ __global__ void __launch_bounds__(SURF_LDS_NT) surf_pyramid_lds(const unsigned *
         const int lr = lr0 + e / G::LX, lc = lc0 + e % G::LX;
         const int r = lr * G::STEP, c = lc * G::STEP;
         // a wave = 64 consecutive level pixels of one row (LX = 64, lc0 a multiple of 64): its ballot is one word of the
-        // level's threshold mask (|det| >= thr: the only pixels surf_nms_interp has to look at); every lane votes
+        // level's threshold mask (|det| >= thr: the only pixels surf_nms_masked has to look at); every lane votes
         const bool inside = lr < g.nr[O] && lc < g.nc[O];
         unsigned top = (unsigned)((r - y0) * G::P + (c - x0) / G::STEP - G::BIAS);  // (c - x0) is a multiple of STEP: residue plane 0
         IMGFD_OPAQUE(top);
@@ -568,104 +590,83 @@ __global__ void __launch_bounds__(SURF_LDS_NT) surf_pyramid_lds(const unsigned *
                 IMGFD_OUT_STORE(v, &dst[L.plane]);                                                         \
                 hot = fabs(v) >= thr;                                                                      \
             }                                                                                              \
-            if (mask) {                                                                                    \
-                const unsigned long long word = __ballot(hot);                                             \
-                if ((tid & 63) == 0 && lr < g.nr[O] && lc < g.nc[O]) mask[L.mask + (size_t)lr * ((g.nc[O] + 63) / 64) + (lc >> 6)] = word; \
-            }                                                                                              \
+            const unsigned long long word = __ballot(hot);                                                 \
+            if ((tid & 63) == 0 && lr < g.nr[O] && lc < g.nc[O]) mask[L.mask + (size_t)lr * ((g.nc[O] + 63) / 64) + (lc >> 6)] = word; \
         }
-        if (!skip_ends) SPL_DO(0)  // kernel-uniform: intervals 0 and 5 only lend neighbourhoods to the maxima of 1 and 4 ("surf_ends")
-        SPL_DO(1) SPL_DO(2) SPL_DO(3) SPL_DO(4)
-        if (!skip_ends) SPL_DO(5)
+        SPL_DO(1) SPL_DO(2) SPL_DO(3) SPL_DO(4)  // intervals 0 and 5 are not built (surf_geometry)
 #undef SPL_DO
     }
 }
 
 template <int O>
-static imgfd_status launch_surf_pyramid_lds(imgfd_ctx *ctx, const unsigned *d_I, double *d_pyr, const SurfGeom &g,
-                                            unsigned long long *d_mask, double thr, int skip_ends)
+static imgfd_status launch_surf_pyramid_lds(imgfd_ctx *ctx, const SurfTable &T, double *d_pyr, const SurfGeom &g,
+                                            unsigned long long *d_mask, double thr)
 {
     static_assert(SurfPyrLds<O>::LX == 64, "a wave's ballot is one mask word");
     using G = SurfPyrLds<O>;
     const size_t lds = sizeof(unsigned) * (size_t)G::H * G::P;
     IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)surf_pyramid_lds<O>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int bx = ceil_div(g.nc[O], G::LX), by = ceil_div(g.nr[O], G::LY);
-    hipLaunchKernelGGL(surf_pyramid_lds<O>, dim3((unsigned)bx * (unsigned)by), dim3(G::NT), lds, ctx->stream, d_I, d_pyr, g, d_mask, thr, bx, ctx->tune.xcd_remap, skip_ends);
+    hipLaunchKernelGGL(surf_pyramid_lds<O>, dim3((unsigned)bx * (unsigned)by), dim3(G::NT), lds, ctx->stream, T, d_pyr, g, d_mask, thr, bx, ctx->tune.xcd_remap);
     return IMGFD_OK;
 }
 
-// ---- the integral image re-laid by column residue: J[row][x % M][x / M] = I[row][x] (M = 1 << LM, cols a multiple of 16).
-// A wave of surf_pyramid evaluates 64 consecutive level pixels, i.e. image columns step*lane + const: in I that is one
-// word out of every `step` (4, 8, 16: 25 / 12 / 6 % of each cache line used, 32 look-ups per pixel).  In J with M = 4 the
-// lanes of an octave-1 look-up read 64 consecutive words (octave 2: every second word, octave 3: every fourth); M = 16 gives
-// runs of 16 / 8 / 4 words to octaves 1 / 2 / 3.  One pass over the table (67 MB at 4096^2) serves octaves 1-3.
-// A workgroup moves 4096 columns of one row through LDS (word x at (M + 1) * (x / M) + x % M: the transposed reads of 64
-// lanes fall into 64 different banks), so that both the loads and the stores are runs of consecutive words.
-#define RL_COLS 4096
-template <int LM>
-__global__ void __launch_bounds__(256) surf_residue_layout(const unsigned *__restrict__ I, unsigned *__restrict__ J, int cols)
-{
-    constexpr int M = 1 << LM, RUN = RL_COLS / M;
-    __shared__ unsigned t[RUN * (M + 1)];
-    const size_t row = blockIdx.y;
-    const int x0 = blockIdx.x * RL_COLS, per = cols >> LM, tid = threadIdx.x;
-    const unsigned *src = I + row * cols + x0;
-#pragma unroll
-    for (int j = 0; j < RL_COLS / 1024; j++) {
-        const int x = (j * 256 + tid) * 4;  // cols % 16 == 0: a quad is inside the row or outside it
-        if (x0 + x < cols) {
-            const uint4 q = *reinterpret_cast<const uint4 *>(src + x);
-            unsigned *d = t + (M + 1) * (x >> LM) + (x & (M - 1));
-            d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
-        }
-    }
-    __syncthreads();
-    unsigned *dst = J + row * cols + (x0 >> LM);
-#pragma unroll
-    for (int j = 0; j < RL_COLS / 256; j++) {
-        const int idx = j * 256 + tid, m = idx / RUN, k = idx % RUN;
-        if ((x0 >> LM) + k < per) dst[(size_t)m * per + k] = t[(M + 1) * k + m];
-    }
-}
-
-// ---- K17, gather form: one launch for the octaves it serves, a thread evaluates all six intervals of one level pixel (the six filters
-// look at the same neighbourhood of the table: one pass over it instead of six).  Workgroup ids are dealt round-robin to the
-// 8 XCDs, each with its own L2: the ids are remapped so that an XCD owns a contiguous band of level rows and streams one
-// eighth of the table instead of all of it.  RES: look-ups go to the residue layout J.
-struct SurfBlocks {
-    unsigned first[SURF_OCT + 1];  // first workgroup id of each octave in a launch that covers several (empty ranges allowed)
+// ---- K17, octaves 1-3.  A level pixel of octave o sits on image columns that are multiples of 4, 8, 16: a wave of 64
+// consecutive level pixels reads one word out of every `step` of the plain table (25 / 12 / 6 % of each cache line used, 32
+// look-ups per pixel and interval).  In the residue layout (SurfTable) the lanes of an octave-1 look-up read 64 consecutive
+// words (octave 2: every second, octave 3: every fourth).
+//
+// One launch for the three octaves; a workgroup = 4 level rows x 64 level columns of one octave, a thread evaluates the four
+// built intervals of one level pixel (the filters look at the same neighbourhood of the table).  Order of the workgroups
+// (SurfBands): the image is cut into bands of 4 * step(octave 3) = 64 rows; band j holds the block rows 4j .. 4j+3 of octave 1,
+// 2j, 2j+1 of octave 2 and j of octave 3 -- everything that is centred on those image rows -- and workgroup ids are remapped so
+// that each XCD (ids are dealt round-robin to the 8 XCDs, each with an L2 of its own) owns a contiguous run of bands.  (Rounds 3-5
+// ran octave after octave, each XCD a band of LEVEL rows per octave: the table was streamed from HBM once per octave, 9.1 B per
+// tile pixel fetched for a 4 B table.)
+struct SurfBands {
+    int gx[SURF_OCT], gy[SURF_OCT];  // workgroups across / down per octave (0: the octave is not in this launch)
+    int per_band;                    // 4 gx[1] + 2 gx[2] + gx[3]
+    int nbands;
+    unsigned total;                  // nbands * per_band, rounded up to a multiple of 8
 };
-__device__ __forceinline__ int surf_octave_of_block(const SurfBlocks &b, unsigned bid)
+static SurfBands surf_bands(const SurfGeom &g)
 {
-    int o = 0;
-#pragma unroll
-    for (int k = 1; k < SURF_OCT; k++) o += bid >= b.first[k] ? 1 : 0;
-    return o;
+    SurfBands b;
+    memset(&b, 0, sizeof b);
+    for (int o = 1; o < SURF_OCT; o++)
+        if (g.nr[o] >= 1 && g.nc[o] >= 1) { b.gx[o] = (g.nc[o] + 63) / 64; b.gy[o] = (g.nr[o] + 3) / 4; }
+    b.per_band = 4 * b.gx[1] + 2 * b.gx[2] + b.gx[3];
+    b.nbands = std::max(std::max((b.gy[1] + 3) / 4, (b.gy[2] + 1) / 2), b.gy[3]);
+    b.total = (unsigned)align_up((size_t)b.nbands * b.per_band, (size_t)8);
+    return b;
+}
+// workgroup id -> (octave, block column, block row); false: nothing to do
+__device__ __forceinline__ bool surf_band_block(const SurfBands &b, unsigned id, int &o, int &bx, int &by)
+{
+    const unsigned nid = (id & 7u) * (b.total >> 3) + (id >> 3);  // XCD id % 8 owns a contiguous run of the band order
+    const int band = (int)(nid / (unsigned)b.per_band);
+    int r = (int)(nid - (unsigned)band * (unsigned)b.per_band);
+    if (band >= b.nbands) return false;
+    if (r < 4 * b.gx[1]) { o = 1; by = 4 * band + r / b.gx[1]; bx = r % b.gx[1]; }
+    else if ((r -= 4 * b.gx[1]) < 2 * b.gx[2]) { o = 2; by = 2 * band + r / b.gx[2]; bx = r % b.gx[2]; }
+    else { r -= 2 * b.gx[2]; o = 3; by = band; bx = r; }
+    return by < b.gy[o];
 }
 
-template <int LM>  // 0: the plain table; else the residue layout with M = 1 << LM
-__global__ void __launch_bounds__(256) surf_pyramid(const unsigned *__restrict__ I, double *__restrict__ pyr, SurfGeom g, SurfBlocks blocks,
-                                                    unsigned long long *__restrict__ mask, double thr, int skip_ends)
+// plain table (images whose width is no multiple of 16, or too small for the band / strip scans): address arithmetic per look-up
+__global__ void __launch_bounds__(256) surf_pyramid_plain(const unsigned *__restrict__ I, double *__restrict__ pyr, SurfGeom g, SurfBands bands,
+                                                          unsigned long long *__restrict__ mask, double thr)
 {
-    // the octaves of one launch follow each other in the grid, each padded to a multiple of 8 workgroups so that
-    // id % 8 (the XCD) is the same thing inside an octave's range as in the whole grid
-    const int o = surf_octave_of_block(blocks, blockIdx.x);
-    const int gx = (g.nc[o] + 63) / 64, gy = (g.nr[o] + 3) / 4;
-    int bx, by;
-    {
-        const int id = blockIdx.x - blocks.first[o], padded = blocks.first[o + 1] - blocks.first[o];
-        const int nid = (id & 7) * (padded >> 3) + (id >> 3);
-        if (nid >= gx * gy) return;
-        bx = nid % gx;
-        by = nid / gx;
-    }
+    int o, bx, by;
+    if (!surf_band_block(bands, blockIdx.x, o, bx, by)) return;
     const int lc = bx * 64 + (threadIdx.x & 63);
     const int lr = by * 4 + (threadIdx.x >> 6);
-    const int step = g.lev[o * SURF_INT].step, cols = g.cols, per = cols >> LM;
+    const int step = g.lev[o * SURF_INT].step, cols = g.cols;
     const int r = lr * step, c = lc * step;
     const bool in_level = lr < g.nr[o] && lc < g.nc[o];
     const unsigned *ctr = I + (size_t)r * cols + c;
 #pragma unroll 1
-    for (int it = skip_ends ? 1 : 0; it < SURF_INT - (skip_ends ? 1 : 0); it++) {
+    for (int it = 1; it < SURF_INT - 1; it++) {
         const SurfLevel &L = g.lev[o * SURF_INT + it];
         const bool inside = in_level && !(r < L.border_px || r >= g.rows - L.border_px || c < L.border_px || c >= cols - L.border_px);
         bool hot = false;
@@ -674,11 +675,7 @@ __global__ void __launch_bounds__(256) surf_pyramid(const unsigned *__restrict__
             // A centre at least border_px = ceil(3(2i+3)/2) * step inside the image keeps every box corner inside it in
             // every octave (3*lobe/2 + 1 < border_px), so the border cases of integral_image.h:64-96 cannot occur: the 32
             // look-ups are issued without branches in between (one memory round trip instead of sixteen).
-            auto at = [&](int dy, int dx) __attribute__((always_inline)) -> unsigned {
-                if (LM == 0) return ctr[(long)dy * cols + dx];
-                const int x = c + dx;
-                return I[(size_t)(r + dy) * cols + (x & ((1 << LM) - 1)) * per + (x >> LM)];
-            };
+            auto at = [&](int dy, int dx) __attribute__((always_inline)) -> unsigned { return ctr[(long)dy * cols + dx]; };
             auto box = [&](int cx, int cy, int w, int h) __attribute__((always_inline)) -> int {  // centered_rect relative to the centre
                 const int l = cx - w / 2, t = cy - h / 2, rr = l + w - 1, b = t + h - 1;
                 return (int)(at(b, rr) - at(b, l - 1) - at(t - 1, rr) + at(t - 1, l - 1));
@@ -695,36 +692,35 @@ __global__ void __launch_bounds__(256) surf_pyramid(const unsigned *__restrict__
             IMGFD_OUT_STORE(sign * det, &pyr[L.plane + (size_t)lr * g.nc[o] + lc]);
             hot = det >= thr;
         }
-        if (mask) {  // one wave = 64 consecutive level pixels of a row = one word of the level's threshold mask
-            const unsigned long long word = __ballot(hot);
-            if ((threadIdx.x & 63) == 0 && in_level) mask[L.mask + (size_t)lr * ((g.nc[o] + 63) / 64) + (lc >> 6)] = word;
-        }
+        // one wave = 64 consecutive level pixels of a row = one word of the level's threshold mask
+        const unsigned long long word = __ballot(hot);
+        if ((threadIdx.x & 63) == 0 && in_level) mask[L.mask + (size_t)lr * ((g.nc[o] + 63) / 64) + (lc >> 6)] = word;
     }
 }
 
-// ---- K17, gather form with the look-ups as buffer loads (octaves 1-3 from the residue layout with M = 4, the default).
-// In surf_pyramid<2> every look-up costs ~7 vector instructions of address arithmetic (column residue, quotient, row x pitch
-// in 64 bits): 224 of them per level pixel value against ~60 for the determinant itself.  But a level pixel of these octaves
-// sits on a column that is a multiple of 4, so the word of look-up (dy, dx) is
+// ---- K17, octaves 1-3 from the residue layout with the look-ups as buffer loads.  A level pixel of these octaves sits on a
+// column that is a multiple of 4, so the word of look-up (dy, dx) is
 //     (r + dy) * cols + ((c + dx) & 3) * per + ((c + dx) >> 2)  =  [r * cols + c / 4]  +  [dy * cols + (dx & 3) * per + (dx >> 2)]:
-// a per-lane base plus a constant of the (octave, interval, look-up).  The 18 x 32 constants come from the host
+// a per-lane base plus a constant of the (octave, interval, look-up).  The 12 x 32 constants come from the host
 // (SurfTaps, made non-negative by moving the interval's smallest one into the base), land in scalar registers, and each
-// look-up is ONE buffer load with the lane's byte offset in a VGPR and the constant in an SGPR.
+// look-up is ONE buffer load with the lane's byte offset in a VGPR and the constant in an SGPR (address arithmetic per look-up --
+// column residue, quotient, row x pitch in 64 bits -- cost ~7 vector instructions each, 224 per level-pixel value against ~60 for
+// the determinant itself: round 3).
 struct SurfTaps {
-    int w[(SURF_OCT - 1) * SURF_INT][32];  // word offsets >= 0 of the 32 look-ups from (lane base + adj), box by box, corner by corner
-    int adj[(SURF_OCT - 1) * SURF_INT];    // the interval's smallest offset (<= 0)
+    int w[(SURF_OCT - 1) * (SURF_INT - 2)][32];  // word offsets >= 0 of the 32 look-ups from (lane base + adj), box by box, corner by corner
+    int adj[(SURF_OCT - 1) * (SURF_INT - 2)];    // the interval's smallest offset (<= 0)
 };
 static void surf_make_taps(const SurfGeom &g, SurfTaps *t)
 {
     const int cols = g.cols, per = cols >> 2;
     for (int o = 1; o < SURF_OCT; o++)
-        for (int it = 0; it < SURF_INT; it++) {
+        for (int it = 1; it < SURF_INT - 1; it++) {
             const SurfLevel &L = g.lev[o * SURF_INT + it];
             const int lobe = L.lobe, off = L.off;
             long w[32];
             int n = 0;
             auto at = [&](int dy, int dx) { w[n++] = (long)dy * cols + (long)(dx & 3) * per + (dx >> 2); };
-            auto box = [&](int cx, int cy, int bw, int bh) {  // the corners in the order surf_pyramid's box() reads them
+            auto box = [&](int cx, int cy, int bw, int bh) {  // the corners in the order the kernel's box() reads them
                 const int l = cx - bw / 2, tp = cy - bh / 2, rr = l + bw - 1, b = tp + bh - 1;
                 at(b, rr); at(b, l - 1); at(tp - 1, rr); at(tp - 1, l - 1);
             };
@@ -733,25 +729,17 @@ static void surf_make_taps(const SurfGeom &g, SurfTaps *t)
             box(-off, off, lobe, lobe); box(off, -off, lobe, lobe); box(-off, -off, lobe, lobe); box(off, off, lobe, lobe);
             long lo = 0;
             for (int k = 0; k < 32; k++) lo = std::min(lo, w[k]);
-            const int e = (o - 1) * SURF_INT + it;
+            const int e = (o - 1) * (SURF_INT - 2) + it - 1;
             t->adj[e] = (int)lo;
             for (int k = 0; k < 32; k++) t->w[e][k] = (int)(w[k] - lo);
         }
 }
 
-__global__ void __launch_bounds__(256) surf_pyramid_taps(const unsigned *__restrict__ J, double *__restrict__ pyr, SurfGeom g, SurfBlocks blocks,
-                                                         SurfTaps taps, unsigned long long *__restrict__ mask, double thr, int skip_ends)
+__global__ void __launch_bounds__(256) surf_pyramid_taps(const unsigned *__restrict__ J, double *__restrict__ pyr, SurfGeom g, SurfBands bands,
+                                                         SurfTaps taps, unsigned long long *__restrict__ mask, double thr)
 {
-    const int o = surf_octave_of_block(blocks, blockIdx.x);  // >= 1
-    const int gx = (g.nc[o] + 63) / 64, gy = (g.nr[o] + 3) / 4;
-    int bx, by;
-    {
-        const int id = blockIdx.x - blocks.first[o], padded = blocks.first[o + 1] - blocks.first[o];
-        const int nid = (id & 7) * (padded >> 3) + (id >> 3);
-        if (nid >= gx * gy) return;
-        bx = nid % gx;
-        by = nid / gx;
-    }
+    int o, bx, by;
+    if (!surf_band_block(bands, blockIdx.x, o, bx, by)) return;
     const int lc = bx * 64 + (threadIdx.x & 63);
     const int lr = by * 4 + (threadIdx.x >> 6);
     const int step = g.lev[o * SURF_INT].step, cols = g.cols;
@@ -760,9 +748,9 @@ __global__ void __launch_bounds__(256) surf_pyramid_taps(const unsigned *__restr
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(J), 0, (int)((unsigned)g.rows * (unsigned)cols * 4u), 0x00027000);
     const int base = r * cols + (c >> 2);  // word of (r, c) in J: c is a multiple of 4
 #pragma unroll 1
-    for (int it = skip_ends ? 1 : 0; it < SURF_INT - (skip_ends ? 1 : 0); it++) {
+    for (int it = 1; it < SURF_INT - 1; it++) {
         const SurfLevel &L = g.lev[o * SURF_INT + it];
-        const int e = (o - 1) * SURF_INT + it;
+        const int e = (o - 1) * (SURF_INT - 2) + it - 1;
         const bool inside = in_level && !(r < L.border_px || r >= g.rows - L.border_px || c < L.border_px || c >= cols - L.border_px);
         bool hot = false;
         if (inside) {
@@ -782,10 +770,8 @@ __global__ void __launch_bounds__(256) surf_pyramid_taps(const unsigned *__restr
             IMGFD_OUT_STORE(sign * det, &pyr[L.plane + (size_t)lr * g.nc[o] + lc]);
             hot = det >= thr;
         }
-        if (mask) {
-            const unsigned long long word = __ballot(hot);
-            if ((threadIdx.x & 63) == 0 && in_level) mask[L.mask + (size_t)lr * ((g.nc[o] + 63) / 64) + (lc >> 6)] = word;
-        }
+        const unsigned long long word = __ballot(hot);
+        if ((threadIdx.x & 63) == 0 && in_level) mask[L.mask + (size_t)lr * ((g.nc[o] + 63) / 64) + (lc >> 6)] = word;
     }
 }
 
@@ -794,44 +780,32 @@ struct SurfRecord {
     double x, y, scale, score, laplacian;
 };
 
+struct SurfBlocks {
+    unsigned first[SURF_OCT + 1];  // first workgroup id of each octave in a launch that covers several (empty ranges allowed)
+};
+__device__ __forceinline__ int surf_octave_of_block(const SurfBlocks &b, unsigned bid)
+{
+    int o = 0;
+#pragma unroll
+    for (int k = 1; k < SURF_OCT; k++) o += bid >= b.first[k] ? 1 : 0;
+    return o;
+}
+
 struct SurfNmsParams {
     int border_next[SURF_INT];  // get_border_size(i+1) for the interval handled (level coordinates)
     double thr;
     double pow2_o1[SURF_OCT];   // std::pow(2.0, o+1.0)
     double step[SURF_OCT];      // get_step_size(o)
     unsigned long long cap;
-    SurfBlocks blocks;          // masked form: all octaves in one launch
-    // "surf_ends" (round 5): intervals 0 and 5 of an octave are never maxima themselves (get_interest_points runs i = 1 .. 4,
-    // hessian_pyramid.h:461) -- they only lend their 3x3 neighbourhoods to the survivors of intervals 1 and 4.  The pyramid
-    // kernels then skip them (a third of all level-pixel values and of the pyramid's HBM writes) and the maximum test computes the
-    // nine values it needs from the integral image on the spot: a few thousand survivors per tile.
-    const unsigned *integral;   // non-null: intervals 0 and 5 are not in the pyramid buffer
+    SurfBlocks blocks;          // all octaves in one launch
+    // Intervals 0 and 5 of an octave are not in the pyramid buffer (surf_geometry): the maximum test computes the nine values it
+    // needs of them from the integral image on the spot -- a few thousand survivors per tile (round 5: a third of all level-pixel
+    // values and of the pyramid's HBM writes less).
+    SurfTable integral;
 };
 
-// one level-pixel value of the Hessian pyramid straight from the integral image (build_pyramid, hessian_pyramid.h:119-171; the
-// arithmetic of surf_pyramid<0>): the determinant with the sign of the trace at the level pixel whose centre is image (r, c)
-__device__ __forceinline__ double surf_level_value(const unsigned *__restrict__ I, int cols, const SurfLevel &L, int r, int c)
-{
-    const unsigned *ctr = I + (size_t)r * cols + c;
-    const int lobe = L.lobe, off = L.off;
-    auto box = [&](int cx, int cy, int w, int h) __attribute__((always_inline)) -> int {  // centered_rect relative to the centre
-        const int l = cx - w / 2, t = cy - h / 2, rr = l + w - 1, b = t + h - 1;
-        return (int)(ctr[(long)b * cols + rr] - ctr[(long)b * cols + l - 1] - ctr[(long)(t - 1) * cols + rr] + ctr[(long)(t - 1) * cols + l - 1]);
-    };
-    double Dxx = surf_dxx(box(0, 0, lobe * 3, 2 * lobe - 1), box(0, 0, lobe, 2 * lobe - 1));
-    double Dyy = surf_dxx(box(0, 0, 2 * lobe - 1, lobe * 3), box(0, 0, 2 * lobe - 1, lobe));
-    double Dxy = (int)((unsigned)box(-off, off, lobe, lobe) + (unsigned)box(off, -off, lobe, lobe) - (unsigned)box(-off, -off, lobe, lobe) -
-                       (unsigned)box(off, off, lobe, lobe));
-    Dxx *= L.area_inv; Dyy *= L.area_inv; Dxy *= L.area_inv;
-    double sign = +1;
-    if (Dxx + Dyy < 0) sign = -1;
-    double det = Dxx * Dyy - 0.81 * Dxy * Dxy;
-    if (det < 0) det = 0;
-    return sign * det;
-}
-
-// ---- K18: 3x3x3 maximum test + interpolation of one level pixel (octave o, interval i, row r, column c), in three steps so
-// that the masked kernel can compute the neighbourhoods of the intervals that are not built ("surf_ends") wave-cooperatively
+// ---- K18: 3x3x3 maximum test + interpolation of one level pixel (octave o, interval i, row r, column c), in two steps; between
+// them the masked kernel computes the neighbourhood in an interval that is not built, wave-cooperatively
 struct SurfNmsState {
     double v[3][3][3];  // [interval][row][column] around the pixel (signed as stored until a step takes their absolute values)
     double raw, val;    // the pixel's own value, its absolute value
@@ -876,9 +850,9 @@ __device__ __forceinline__ int surf_nms_front(const double *__restrict__ pyr, co
     if (!(st.val >= q.thr)) return 0;
     // is_maximum_in_region :324-356: rejected by any strictly larger value in the 3x3x3 block
     if (!surf_nms_neighbour_ok<1>(st)) return 0;
-    // With "surf_ends" interval 0 (below i = 1) and interval 5 (above i = 4) are not in the buffer -- and most survivors of the
-    // pixel's own 3x3 fall to the other, stored neighbour before those are needed: the stored interval first.
-    const bool low_sparse = q.integral && i == 1, high_sparse = q.integral && i == SURF_INT - 2;
+    // Interval 0 (below i = 1) and interval 5 (above i = 4) are not in the buffer -- and most survivors of the pixel's own 3x3
+    // fall to the other, stored neighbour before those are needed: the stored interval first.
+    const bool low_sparse = i == 1, high_sparse = i == SURF_INT - 2;
     auto load = [&](auto s_tag) __attribute__((always_inline)) {
         constexpr int s = decltype(s_tag)::value;
         const double *P = pyr + g.lev[o * SURF_INT + i - 1 + s].plane + at;
@@ -937,39 +911,6 @@ __device__ __forceinline__ bool surf_nms_back(const SurfGeom &g, const SurfNmsPa
     rec.laplacian = raw > 0 ? +1.0 : -1.0;  // get_laplacian :294-297
     return true;
 }
-// the whole test for one thread (the dense kernel; the masked kernel fills the unbuilt interval wave-cooperatively instead)
-__device__ __forceinline__ bool surf_nms_pixel(const double *__restrict__ pyr, const SurfGeom &g, const SurfNmsParams &q, int o, int i, int r, int c,
-                                               SurfRecord &rec)
-{
-    SurfNmsState st;
-    const int state = surf_nms_front(pyr, g, q, o, i, r, c, st);
-    if (!state) return false;
-    if (state == 2) {  // positions inside border_next: valid in every interval
-        const SurfLevel &Ln = g.lev[o * SURF_INT + (i == 1 ? 0 : SURF_INT - 1)];
-#pragma unroll
-        for (int y = 0; y < 3; y++)
-#pragma unroll
-            for (int x = 0; x < 3; x++) {
-                const double w = surf_level_value(q.integral, g.cols, Ln, (r - 1 + y) * Ln.step, (c - 1 + x) * Ln.step);
-                if (i == 1) st.v[0][y][x] = w; else st.v[2][y][x] = w;
-            }
-    }
-    return surf_nms_back(g, q, o, i, state, st, rec);
-}
-
-// dense form (no threshold masks): one launch per octave, a thread per level pixel, blockIdx.z + 1 = interval (1..4)
-__global__ void __launch_bounds__(256) surf_nms_interp(const double *__restrict__ pyr, SurfGeom g, SurfNmsParams q, int o,
-                                                       SurfRecord *__restrict__ out, unsigned long long *__restrict__ count)
-{
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int r = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (r >= g.nr[o] || c >= g.nc[o]) return;
-    SurfRecord rec;
-    if (surf_nms_pixel(pyr, g, q, o, blockIdx.z + 1, r, c, rec)) {
-        const unsigned long long k = atomicAdd(count, 1ull);
-        if (k < q.cap) out[k] = rec;
-    }
-}
 
 // masked form: the pyramid kernels published which level pixels reach the threshold, one bit each -- a fraction of a
 // percent in octave 0, a few percent above (measured on the bench tiles).  One launch for all octaves (q.blocks).  A
@@ -1019,16 +960,16 @@ __global__ void __launch_bounds__(NMS_WORDS) surf_nms_masked(const double *__res
     // counter per workgroup (ten thousand returning atomics on one address, one per record, were most of this kernel's time)
     __shared__ unsigned found;
     __shared__ unsigned long long base_rec;
-    // "surf_ends": the workgroup handles ONE interval of ONE octave, so the interval that is not built (0 below i = 1, 5 above
-    // i = 4) is the same for all its pixels: every lane keeps the table offset and the coefficient of ONE of the 32 look-ups of a
+    // The workgroup handles ONE interval of ONE octave, so the interval that is not built (0 below i = 1, 5 above i = 4) is the
+    // same for all its pixels: every lane keeps the offset (dy, dx) and the coefficient of ONE of the 32 look-ups of a
     // level-pixel value (box = t / 4, corner = t % 4; Dxx = wide - 3 narrow in lanes 0-7, Dyy in 8-15, Dxy in 16-31), and a group
     // of 32 lanes computes the nine values a survivor needs -- nine loads per lane in ONE round trip, three segmented sums per
-    // value -- instead of 288 dependent look-ups in whatever lanes the survivors happen to sit (69 -> ... us per tile).
-    const bool coop = q.integral && (i == 1 || i == SURF_INT - 2);  // workgroup-uniform
+    // value -- instead of 288 dependent look-ups in whatever lanes the survivors happen to sit (69 -> 51 us per tile, round 5).
+    const bool coop = i == 1 || i == SURF_INT - 2;  // workgroup-uniform
     const SurfLevel &Ls = g.lev[o * SURF_INT + (i == 1 ? 0 : SURF_INT - 1)];
     const int t32 = tid & 31;
-    long tap_off = 0;
-    int tap_coef = 0;
+    int tap_dy = 0, tap_dx = 0;
+    unsigned tap_coef = 0;
     if (coop) {
         const int lobe = Ls.lobe, off = Ls.off, bb = t32 >> 2, k = t32 & 3;
         int cx = 0, cy = 0, w = lobe, h = lobe, coef = 1;
@@ -1041,9 +982,9 @@ __global__ void __launch_bounds__(NMS_WORDS) surf_nms_masked(const double *__res
         else if (bb == 6) { cx = -off; cy = -off; coef = -1; }
         else { cx = off; cy = off; coef = -1; }
         const int l = cx - w / 2, tp = cy - h / 2, rr = l + w - 1, bt = tp + h - 1;  // centered_rect relative to the centre
-        const int dy = k < 2 ? bt : tp - 1, dx = (k & 1) ? l - 1 : rr;
-        tap_off = (long)dy * g.cols + dx;
-        tap_coef = (k == 0 || k == 3) ? coef : -coef;   // br - bl - tr + tl
+        tap_dy = k < 2 ? bt : tp - 1;
+        tap_dx = (k & 1) ? l - 1 : rr;
+        tap_coef = (unsigned)((k == 0 || k == 3) ? coef : -coef);   // br - bl - tr + tl
     }
     constexpr int PEND = 64;  // survivors whose unbuilt interval is computed per round
     __shared__ int pend_r[NMS_WORDS], pend_c[NMS_WORDS];
@@ -1084,22 +1025,22 @@ __global__ void __launch_bounds__(NMS_WORDS) surf_nms_masked(const double *__res
                     const bool active = e < lim;
                     const int pr = active ? pend_r[e] : pend_r[base], pc = active ? pend_c[e] : pend_c[base];
                     const int step = Ls.step;
-                    const unsigned *ctr = q.integral + (size_t)((pr - 1) * step) * g.cols + (pc - 1) * step + tap_off;
-                    int term[9];
+                    const int ty = (pr - 1) * step + tap_dy, tx = (pc - 1) * step + tap_dx;  // this lane's look-up for the value at (pr - 1, pc - 1)
+                    unsigned term[9];
 #pragma unroll
-                    for (int n = 0; n < 9; n++) term[n] = (int)ctr[(size_t)((n / 3) * step) * g.cols + (n % 3) * step];  // nine loads in flight
-                    int mine_xx = 0, mine_yy = 0, mine_xy = 0;
+                    for (int n = 0; n < 9; n++) term[n] = q.integral.at(ty + (n / 3) * step, tx + (n % 3) * step);  // nine loads in flight
+                    unsigned mine_xx = 0, mine_yy = 0, mine_xy = 0;
 #pragma unroll
                     for (int n = 0; n < 9; n++) {
-                        int a = term[n] * tap_coef;  // int32 wrap-around arithmetic: the box sums come out exact (surf_dxx)
-                        a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4);   // the 8 look-ups of a lane group
-                        const int a16 = a + __shfl_xor(a, 8);                                     // Dxy: 16 look-ups
+                        unsigned a = term[n] * tap_coef;  // wrap-around (unsigned) arithmetic: the box sums come out exact (surf_dxx)
+                        a += (unsigned)__shfl_xor((int)a, 1); a += (unsigned)__shfl_xor((int)a, 2); a += (unsigned)__shfl_xor((int)a, 4);   // the 8 look-ups of a lane group
+                        const unsigned a16 = a + (unsigned)__shfl_xor((int)a, 8);                  // Dxy: 16 look-ups
                         const int half = (int)(tid & 32);
-                        const int xx = __shfl(a, half + 0), yy = __shfl(a, half + 8), xy = __shfl(a16, half + 16);
+                        const unsigned xx = (unsigned)__shfl((int)a, half + 0), yy = (unsigned)__shfl((int)a, half + 8), xy = (unsigned)__shfl((int)a16, half + 16);
                         if (t32 == n) { mine_xx = xx; mine_yy = yy; mine_xy = xy; }
                     }
                     if (active && t32 < 9) {  // lanes 0..8 of the half finish one value each (hessian_pyramid.h:153-171)
-                        double Dxx = (double)mine_xx, Dyy = (double)mine_yy, Dxy = (double)mine_xy;
+                        double Dxx = (double)(int)mine_xx, Dyy = (double)(int)mine_yy, Dxy = (double)(int)mine_xy;
                         Dxx *= Ls.area_inv; Dyy *= Ls.area_inv; Dxy *= Ls.area_inv;
                         double sign = +1;
                         if (Dxx + Dyy < 0) sign = -1;
@@ -1375,21 +1316,19 @@ __global__ void __launch_bounds__(SR_NT) surf_rank_select(SurfRankParams q)
     if (tid == 0) { *q.count_out = (long long)carry; *q.m_out = carry; }
 }
 
-// surf_host.cpp
 // surf_describe.hip
 // m_dev != nullptr: m is an upper bound (the grid); the number of points is read from *m_dev on the device
-imgfd_status launch_surf_orient(imgfd_ctx *ctx, const unsigned *d_I, int rows, int cols, const double *d_pts, int m,
+imgfd_status launch_surf_orient(imgfd_ctx *ctx, const SurfTable &T, const double *d_pts, int m,
                                 double *d_samples, double *d_trig, const unsigned *m_dev = nullptr);
-imgfd_status launch_surf_desc(imgfd_ctx *ctx, const unsigned *d_I, int rows, int cols, const double *d_pts,
+imgfd_status launch_surf_desc(imgfd_ctx *ctx, const SurfTable &T, const double *d_pts,
                               const double *d_trig, int m, double *d_des, int des_stride, double *d_angle,
                               const unsigned *m_dev = nullptr);
 
 namespace {
 
 struct SurfDevice {
-    unsigned *integral = nullptr;
-    unsigned *residue = nullptr;          // optional: the integral image re-laid by column residue (surf_residue_layout)
-    unsigned long long *mask = nullptr;   // optional: threshold masks of all pyramid levels (SurfGeom::mask_words words)
+    unsigned *integral = nullptr;         // the table, in the layout launch_surf_integral chooses (SurfTable)
+    unsigned long long *mask = nullptr;   // threshold masks of the built pyramid levels (SurfGeom::mask_words words)
     double *pyr = nullptr;
     size_t pyr_bytes = 0;
     SurfRecord *rec = nullptr;
@@ -1397,26 +1336,32 @@ struct SurfDevice {
     unsigned long long cap = 0;
 };
 
-size_t surf_ws_bytes(const SurfGeom &g, size_t pyr_total, unsigned long long cap)
-{
-    const size_t n = (size_t)g.rows * g.cols;
-    return align_up(3 * n, 256) + 2 * align_up(4 * n, 256) + align_up(8 * pyr_total, 256) + align_up(8 * g.mask_words, 256) +
-           align_up(sizeof(SurfRecord) * cap, 256) + 4096;
-}
-
-// K16-K18 for one image already in device memory; leaves the records (unordered) + count on the device
-// K16 on the stream; scratch (optional): room for the column scan's segment sums
-// scratch the band / strip form needs (bytes)
+// scratch the band / strip form of the integral image needs (bytes)
 size_t surf_integral_scratch(int rows, int cols)
 {
     const size_t nb = ceil_div(rows, SI_RB), ns = ceil_div(cols, 256);
     return sizeof(unsigned) * (nb * (size_t)cols + (size_t)rows * ns + nb * ns) + 512;
 }
-
-// residue (optional): the table a second time in the layout of surf_residue_layout<2>; the return value says whether it was written
-bool launch_surf_integral(imgfd_ctx *ctx, const uint8_t *d_rgb, unsigned *d_I, int rows, int cols, void *scratch, size_t scratch_bytes,
-                          unsigned *residue = nullptr)
+// the pyramid buffer is idle until the integral image is complete: it lends the scans their scratch
+size_t surf_pyr_bytes(const SurfGeom &g, size_t pyr_total)
 {
+    return std::max(std::max<size_t>(8 * pyr_total, 8), std::max(surf_integral_scratch(g.rows, g.cols), sizeof(unsigned) * 32 * (size_t)g.cols));
+}
+
+size_t surf_ws_bytes(const SurfGeom &g, size_t pyr_total, unsigned long long cap)
+{
+    const size_t n = (size_t)g.rows * g.cols;
+    return align_up(3 * n, 256) + align_up(4 * n, 256) + align_up(surf_pyr_bytes(g, pyr_total), 256) + align_up(8 * std::max<size_t>(g.mask_words, 1), 256) +
+           align_up(sizeof(SurfRecord) * cap, 256) + 4096;
+}
+
+// K16 on the context's stream.  allow_residue: the band / strip form may write the table in the residue layout (SurfTable; the
+// return value's `per` says whether it did): images whose width is a multiple of 16 and whose table stays below 2 GiB (the gather
+// kernel of octaves 1-3 addresses it with 32-bit byte offsets).
+SurfTable launch_surf_integral(imgfd_ctx *ctx, const uint8_t *d_rgb, unsigned *d_I, int rows, int cols, void *scratch, size_t scratch_bytes,
+                               bool allow_residue)
+{
+    SurfTable T{d_I, rows, cols, 0};
     const bool vec = cols % 4 == 0 && (size_t)d_rgb % 4 == 0 && (size_t)d_I % 16 == 0;
     if (vec && scratch && (size_t)scratch % 16 == 0 && scratch_bytes >= surf_integral_scratch(rows, cols) && (size_t)rows * cols >= 65536 &&
         ceil_div(cols, 256) <= SI_MAX_STRIPS) {
@@ -1428,14 +1373,15 @@ bool launch_surf_integral(imgfd_ctx *ctx, const uint8_t *d_rgb, unsigned *d_I, i
         hipLaunchKernelGGL(surf_int_sums, grid, dim3(256), 0, ctx->stream, d_rgb, colsum, rowsum, bandstrip, rows, cols, ns);
         hipLaunchKernelGGL(surf_int_carry, dim3(ceil_div(cols, 64) + 1 + ceil_div(rows, 256)), dim3(256), 0, ctx->stream, colsum, bandstrip, rowsum, nb, rows,
                            cols, ns);
-        const bool res = residue && cols % 16 == 0;
+        const bool res = allow_residue && cols % 16 == 0 && (size_t)rows * cols * 4 < ((size_t)1 << 31);
         if (res)
             hipLaunchKernelGGL(surf_int_apply<true>, grid, dim3(256), 0, ctx->stream, d_rgb, (const unsigned *)colsum, (const unsigned *)bandstrip,
-                               (const unsigned *)rowsum, d_I, residue, rows, cols, ns);
+                               (const unsigned *)rowsum, d_I, rows, cols, ns);
         else
             hipLaunchKernelGGL(surf_int_apply<false>, grid, dim3(256), 0, ctx->stream, d_rgb, (const unsigned *)colsum, (const unsigned *)bandstrip,
-                               (const unsigned *)rowsum, d_I, (unsigned *)nullptr, rows, cols, ns);
-        return res;
+                               (const unsigned *)rowsum, d_I, rows, cols, ns);
+        T.per = res ? cols >> 2 : 0;
+        return T;
     }
     if (vec)
         hipLaunchKernelGGL(surf_gray_rowscan4, dim3(rows), dim3(256), 0, ctx->stream, d_rgb, d_I, cols);
@@ -1450,63 +1396,41 @@ bool launch_surf_integral(imgfd_ctx *ctx, const uint8_t *d_rgb, unsigned *d_I, i
     } else {
         hipLaunchKernelGGL(surf_colscan, dim3(ceil_div(cols, 64)), dim3(64), 0, ctx->stream, d_I, rows, cols);
     }
-    return false;
+    return T;
 }
 
+// K16-K18 for one image already in device memory; leaves the records (unordered) + count on the device and says in *table where
+// and how the integral image lies.
 // fork (optional): the context's companion.  Octave 0 and octaves 1-3 are two kernels that both read the finished table and
 // write different planes: with a companion at hand (a call with ONE tile has no other tile to fill the chip with) the second
 // runs on its stream beside the first -- a VALU / LDS bound kernel next to one that waits for its gathers -- and the maximum
 // test waits for both ("surf_split").
-imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const SurfGeom &g, double thr, const SurfDevice &d, imgfd_ctx *fork = nullptr)
+imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const SurfGeom &g, double thr, const SurfDevice &d, SurfTable *table,
+                                imgfd_ctx *fork = nullptr)
 {
-    // the pyramid buffer is idle until the integral image is complete: it lends the column scan its scratch
-    // (octaves 1-3 read the table in the residue layout: the integral image's last kernel writes it along, "surf_residue_fused")
-    const bool want_residue = d.residue && g.cols % 16 == 0 && ctx->tune.surf_residue == 4 && ctx->tune.surf_residue_fused && g.nr[1] >= 1 && g.nc[1] >= 1;
-    const bool have_residue = launch_surf_integral(ctx, d_rgb, d.integral, g.rows, g.cols, d.pyr, d.pyr_bytes, want_residue ? d.residue : nullptr);
+    const SurfTable T = launch_surf_integral(ctx, d_rgb, d.integral, g.rows, g.cols, d.pyr, d.pyr_bytes, true);
+    if (table) *table = T;
     IMGFD_HIP(ctx, hipMemsetAsync(d.count, 0, sizeof(unsigned long long), ctx->stream));
+    static_assert(SURF_INT == 6 && SURF_OCT == 4, "dlib's build_pyramid(img, 4, 6, 2): the kernels unroll its geometry");
+    const SurfBands bands = surf_bands(g);
     hipStream_t upper = ctx->stream;  // the stream of the gather kernel (octaves 1-3)
-    if (fork && g.nr[1] >= 1 && g.nc[1] >= 1) {
+    if (fork && bands.total) {
         IMGFD_HIP(ctx, hipEventRecord(ctx->ev_gate, ctx->stream));
         IMGFD_HIP(ctx, hipStreamWaitEvent(fork->stream, ctx->ev_gate, 0));
         upper = fork->stream;
     }
-    const int ends = ctx->tune.surf_ends ? 1 : 0;  // 1: intervals 0 and 5 are not built; the maximum test computes what it needs of them (SurfNmsParams::integral)
-    for (int o = 0; o < SURF_OCT; o++) {
-        if (g.nr[o] < 1 || g.nc[o] < 1) continue;
-        static_assert(SURF_INT == 6, "surf_pyramid_lds unrolls six intervals");
-        // the LDS kernels assume dlib's level geometry (lobe = step*(i+1) + 1); anything else takes the gather kernel
-        const bool std_geom = g.lev[o * SURF_INT].step == (2 << o) && g.lev[o * SURF_INT].lobe == (2 << o) + 1 &&
-                              g.lev[o * SURF_INT + SURF_INT - 1].lobe == (2 << o) * SURF_INT + 1 && (size_t)d.integral % 16 == 0;
-        if (o == 0 && std_geom) { IMGFD_TRY(launch_surf_pyramid_lds<0>(ctx, d.integral, d.pyr, g, d.mask, thr, ends)); continue; }
-        // (octave 1 through the same kernel -- an 86 KB window, one workgroup per CU -- measured 219 us against 164 us for
-        // the gather kernel on a 4096^2 tile: not used)
-        // the gather kernel: this octave and everything above it in one launch
-        SurfBlocks blocks;
-        unsigned nb = 0;
-        for (int k = 0; k < SURF_OCT; k++) {
-            blocks.first[k] = nb;
-            if (k >= o && g.nr[k] >= 1 && g.nc[k] >= 1) nb += (unsigned)align_up((size_t)ceil_div(g.nc[k], 64) * ceil_div(g.nr[k], 4), (size_t)8);
-        }
-        blocks.first[SURF_OCT] = nb;
-        if (!nb) break;
-        const int modulus = ctx->tune.surf_residue;  // experiment switch: 0 = the plain table, 4 | 16 = modulus
-        const dim3 lgrid(ceil_div(g.cols, RL_COLS), g.rows);
-        if (o >= 1 && d.residue && g.cols % 16 == 0 && modulus == 4) {
-            if (!have_residue) hipLaunchKernelGGL(surf_residue_layout<2>, lgrid, dim3(256), 0, o >= 1 ? upper : ctx->stream, d.integral, d.residue, g.cols);
-            if (ctx->tune.surf_taps && (size_t)g.rows * g.cols * 4 < ((size_t)1 << 31)) {
-                SurfTaps taps;
-                surf_make_taps(g, &taps);
-                hipLaunchKernelGGL(surf_pyramid_taps, dim3(nb), dim3(256), 0, o >= 1 ? upper : ctx->stream, d.residue, d.pyr, g, blocks, taps, d.mask, thr, ends);
-            } else {
-                hipLaunchKernelGGL(surf_pyramid<2>, dim3(nb), dim3(256), 0, o >= 1 ? upper : ctx->stream, d.residue, d.pyr, g, blocks, d.mask, thr, ends);
-            }
-        } else if (o >= 1 && d.residue && g.cols % 16 == 0 && modulus == 16) {
-            hipLaunchKernelGGL(surf_residue_layout<4>, lgrid, dim3(256), 0, o >= 1 ? upper : ctx->stream, d.integral, d.residue, g.cols);
-            hipLaunchKernelGGL(surf_pyramid<4>, dim3(nb), dim3(256), 0, o >= 1 ? upper : ctx->stream, d.residue, d.pyr, g, blocks, d.mask, thr, ends);
+    // octave 0 (three quarters of all level pixels): the table window of a block of level pixels in LDS
+    if (g.nr[0] >= 1 && g.nc[0] >= 1) IMGFD_TRY(launch_surf_pyramid_lds<0>(ctx, T, d.pyr, g, d.mask, thr));
+    // (octave 1 through the same kernel -- an 86 KB window, one workgroup per CU -- measured 219 us against 164 us for
+    // the gather kernel on a 4096^2 tile: not used)
+    if (bands.total) {
+        if (T.per) {
+            SurfTaps taps;
+            surf_make_taps(g, &taps);
+            hipLaunchKernelGGL(surf_pyramid_taps, dim3(bands.total), dim3(256), 0, upper, (const unsigned *)d.integral, d.pyr, g, bands, taps, d.mask, thr);
         } else {
-            hipLaunchKernelGGL(surf_pyramid<0>, dim3(nb), dim3(256), 0, o >= 1 ? upper : ctx->stream, d.integral, d.pyr, g, blocks, d.mask, thr, ends);
+            hipLaunchKernelGGL(surf_pyramid_plain, dim3(bands.total), dim3(256), 0, upper, (const unsigned *)d.integral, d.pyr, g, bands, d.mask, thr);
         }
-        break;
     }
     if (upper != ctx->stream) {
         IMGFD_HIP(ctx, hipEventRecord(ctx->ev_gate2, upper));
@@ -1514,7 +1438,7 @@ imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const Surf
     }
     SurfNmsParams q;
     q.thr = thr; q.cap = d.cap;
-    q.integral = ends ? d.integral : nullptr;
+    q.integral = T;
     for (int i = 0; i < SURF_INT; i++) q.border_next[i] = (int)surf_border_of(std::min(i + 1, SURF_INT - 1));
     unsigned nb = 0;
     for (int o = 0; o < SURF_OCT; o++) {
@@ -1524,15 +1448,7 @@ imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const Surf
         if (g.nr[o] >= 1 && g.nc[o] >= 1) nb += surf_nms_blocks(g.nr[o], g.nc[o], o) * (SURF_INT - 2);
     }
     q.blocks.first[SURF_OCT] = nb;
-    if (d.mask) {
-        if (nb) hipLaunchKernelGGL(surf_nms_masked, dim3(nb), dim3(NMS_WORDS), 0, ctx->stream, d.pyr, g, q, d.rec, d.count, (const unsigned long long *)d.mask);
-    } else {
-        for (int o = 0; o < SURF_OCT; o++) {
-            if (g.nr[o] < 1 || g.nc[o] < 1) continue;
-            dim3 grid(ceil_div(g.nc[o], 64), ceil_div(g.nr[o], 4), SURF_INT - 2);
-            hipLaunchKernelGGL(surf_nms_interp, grid, dim3(256), 0, ctx->stream, d.pyr, g, q, o, d.rec, d.count);
-        }
-    }
+    if (nb) hipLaunchKernelGGL(surf_nms_masked, dim3(nb), dim3(NMS_WORDS), 0, ctx->stream, d.pyr, g, q, d.rec, d.count, (const unsigned long long *)d.mask);
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }
@@ -1540,7 +1456,7 @@ imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const Surf
 // uploads the image, runs the device stages, returns the interest points in the reference's emission order
 // (and, if asked, where the integral image sits in the workspace: valid until the next call carves the arena)
 imgfd_status surf_points_host(imgfd_ctx *ctx, const void *rgb, int kind, int rows, int cols, double thr,
-                              std::vector<SurfRecord> &pts, const unsigned **d_integral)
+                              std::vector<SurfRecord> &pts, SurfTable *d_integral)
 {
     pts.clear();
     if (rows < 1 || cols < 1) return IMGFD_OK;
@@ -1555,24 +1471,24 @@ imgfd_status surf_points_host(imgfd_ctx *ctx, const void *rgb, int kind, int row
         ctx->ws_used = 0;
         uint8_t *d_rgb = (uint8_t *)ws_alloc(ctx, 3 * n);
         d.integral = (unsigned *)ws_alloc(ctx, 4 * n);
-        d.residue = (unsigned *)ws_alloc(ctx, 4 * n);
         d.mask = (unsigned long long *)ws_alloc(ctx, 8 * std::max<size_t>(g.mask_words, 1));
-        d.pyr = (double *)ws_alloc(ctx, 8 * std::max<size_t>(total, 1));
-        d.pyr_bytes = 8 * std::max<size_t>(total, 1);
+        d.pyr_bytes = surf_pyr_bytes(g, total);
+        d.pyr = (double *)ws_alloc(ctx, d.pyr_bytes);
         d.rec = (SurfRecord *)ws_alloc(ctx, sizeof(SurfRecord) * d.cap);
         d.count = (unsigned long long *)ws_alloc(ctx, 256);
-        if (!d_rgb || !d.integral || !d.pyr || !d.rec || !d.count) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+        if (!d_rgb || !d.integral || !d.mask || !d.pyr || !d.rec || !d.count) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
         IMGFD_TRY(upload_image(ctx, rgb, kind, 3 * n, d_rgb));
         imgfd_ctx *fork = nullptr;
         if (ctx->tune.surf_split) IMGFD_TRY(ctx_side(ctx, &fork));
-        IMGFD_TRY(surf_device_stages(ctx, d_rgb, g, thr, d, fork));
+        SurfTable T;
+        IMGFD_TRY(surf_device_stages(ctx, d_rgb, g, thr, d, &T, fork));
         unsigned long long cnt = 0;
         IMGFD_HIP(ctx, hipMemcpyAsync(&cnt, d.count, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
         IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (cnt > d.cap) { d.cap = cnt + 1024; continue; }  // rare: more candidates than the record buffer holds
         pts.resize((size_t)cnt);
         if (cnt) IMGFD_HIP(ctx, hipMemcpyAsync(pts.data(), d.rec, sizeof(SurfRecord) * cnt, hipMemcpyDeviceToHost, ctx->stream));
-        if (d_integral) *d_integral = d.integral;
+        if (d_integral) *d_integral = T;
         IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
         break;
     }
@@ -1618,7 +1534,7 @@ imgfd_status surf_k19_carve(imgfd_ctx *ctx, size_t m, SurfK19 *k)
 }
 
 // imgfd_surf's K19: Haar sampling and the descriptor on the device, atan2 / sin / cos on the host's glibc
-imgfd_status surf_describe_assisted(imgfd_ctx *ctx, const unsigned *d_I, int rows, int cols, const std::vector<SurfRecord> &pts,
+imgfd_status surf_describe_assisted(imgfd_ctx *ctx, const SurfTable &T, const std::vector<SurfRecord> &pts,
                                     const std::vector<size_t> &keep, imgfd_surf_out *out)
 {
     const size_t m = keep.size();
@@ -1629,7 +1545,7 @@ imgfd_status surf_describe_assisted(imgfd_ctx *ctx, const unsigned *d_I, int row
         k.h_pts[3 * j] = p.x; k.h_pts[3 * j + 1] = p.y; k.h_pts[3 * j + 2] = p.scale;
     }
     IMGFD_HIP(ctx, hipMemcpyAsync(k.d_pts, k.h_pts, sizeof(double) * 3 * m, hipMemcpyHostToDevice, ctx->stream));
-    IMGFD_TRY(launch_surf_orient(ctx, d_I, rows, cols, k.d_pts, (int)m, k.d_samples, nullptr));
+    IMGFD_TRY(launch_surf_orient(ctx, T, k.d_pts, (int)m, k.d_samples, nullptr));
     IMGFD_HIP(ctx, hipMemcpyAsync(k.h_samples, k.d_samples, sizeof(double) * 2 * SURF_NSAMP * m, hipMemcpyDeviceToHost, ctx->stream));
     IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     // points are independent: share them out over a few threads; every point runs the code one thread would run
@@ -1656,7 +1572,7 @@ imgfd_status surf_describe_assisted(imgfd_ctx *ctx, const unsigned *d_I, int row
         for (auto &th : pool) th.join();
     }
     IMGFD_HIP(ctx, hipMemcpyAsync(k.d_trig, k.h_trig, sizeof(double) * 5 * m, hipMemcpyHostToDevice, ctx->stream));
-    IMGFD_TRY(launch_surf_desc(ctx, d_I, rows, cols, k.d_pts, k.d_trig, (int)m, k.d_des, 64, nullptr));
+    IMGFD_TRY(launch_surf_desc(ctx, T, k.d_pts, k.d_trig, (int)m, k.d_des, 64, nullptr));
     IMGFD_HIP(ctx, hipMemcpyAsync(k.h_des, k.d_des, sizeof(double) * 64 * m, hipMemcpyDeviceToHost, ctx->stream));
     IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (size_t j = 0; j < m; j++) out->angle[j] = k.h_trig[5 * j];
@@ -1669,7 +1585,7 @@ imgfd_status surf_describe_assisted(imgfd_ctx *ctx, const unsigned *d_I, int row
 extern "C" {
 
 imgfd_status imgfd_k_surf_integral(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, int32_t *out)
-{
+try {
     if (!ctx) return IMGFD_ERR_INVALID;
     if (!rgb || !out || rows < 1 || cols < 1) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_k_surf_integral: bad argument");
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
@@ -1681,11 +1597,25 @@ imgfd_status imgfd_k_surf_integral(imgfd_ctx *ctx, const uint8_t *rgb, int rows,
     void *d_part = ws_alloc(ctx, part_bytes);
     if (!d_rgb || !d_I || !d_part) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
     IMGFD_HIP(ctx, hipMemcpyAsync(d_rgb, rgb, 3 * n, hipMemcpyHostToDevice, ctx->stream));
-    launch_surf_integral(ctx, d_rgb, d_I, rows, cols, d_part, part_bytes);
+    // the kernels and the layout the product path runs for this shape; a table in the residue layout (SurfTable) is put back
+    // into row-major order on the host: the doorway returns integral_image.h:33-62's table either way
+    const SurfTable T = launch_surf_integral(ctx, d_rgb, d_I, rows, cols, d_part, part_bytes, true);
     IMGFD_HIP(ctx, hipGetLastError());
-    IMGFD_HIP(ctx, hipMemcpyAsync(out, d_I, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
+    if (!T.per) {
+        IMGFD_HIP(ctx, hipMemcpyAsync(out, d_I, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
+        IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return IMGFD_OK;
+    }
+    std::vector<int32_t> j(n);
+    IMGFD_HIP(ctx, hipMemcpyAsync(j.data(), d_I, 4 * n, hipMemcpyDeviceToHost, ctx->stream));
     IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int r = 0; r < rows; r++)
+        for (int x = 0; x < cols; x++) out[(size_t)r * cols + x] = j[(size_t)r * cols + (size_t)(x & 3) * T.per + (x >> 2)];
     return IMGFD_OK;
+} catch (const std::bad_alloc &) {
+    return imgfd_fail(ctx, IMGFD_ERR_OOM, "imgfd_k_surf_integral: out of host memory");
+} catch (...) {
+    return imgfd_fail(ctx, IMGFD_ERR_HIP, "imgfd_k_surf_integral: unexpected C++ exception");
 }
 
 imgfd_status imgfd_surf_interest_points(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, double detection_threshold,
@@ -1722,21 +1652,20 @@ imgfd_status imgfd_surf_points_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_f
     SurfGeom g;
     const size_t total = surf_geometry(rows, cols, &g);
     const size_t n = (size_t)rows * cols;
-    IMGFD_TRY(ws_reserve(ctx, 2 * align_up(4 * n, 256) + align_up(8 * std::max<size_t>(g.mask_words, 1), 256) + align_up(8 * std::max<size_t>(total, 1), 256) + 4096));
+    IMGFD_TRY(ws_reserve(ctx, align_up(4 * n, 256) + align_up(8 * std::max<size_t>(g.mask_words, 1), 256) + align_up(surf_pyr_bytes(g, total), 256) + 4096));
     SurfDevice d;
     d.integral = (unsigned *)ws_alloc(ctx, 4 * n);
-    d.residue = (unsigned *)ws_alloc(ctx, 4 * n);
     d.mask = (unsigned long long *)ws_alloc(ctx, 8 * std::max<size_t>(g.mask_words, 1));
-    d.pyr = (double *)ws_alloc(ctx, 8 * std::max<size_t>(total, 1));
-    d.pyr_bytes = 8 * std::max<size_t>(total, 1);
-    if (!d.integral || !d.pyr) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    d.pyr_bytes = surf_pyr_bytes(g, total);
+    d.pyr = (double *)ws_alloc(ctx, d.pyr_bytes);
+    if (!d.integral || !d.mask || !d.pyr) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
     d.cap = (unsigned long long)cap;
     imgfd_ctx *fork = nullptr;
     if (ctx->tune.surf_split) IMGFD_TRY(ctx_side(ctx, &fork));
     for (int f = 0; f < n_frames; f++) {  // tiles are processed back to back on the context's stream, no host sync
         d.rec = reinterpret_cast<SurfRecord *>(d_points) + (size_t)f * cap;
         d.count = reinterpret_cast<unsigned long long *>(d_counts) + f;
-        IMGFD_TRY(surf_device_stages(ctx, d_rgb + (size_t)f * frame_stride_bytes, g, detection_threshold, d, fork));
+        IMGFD_TRY(surf_device_stages(ctx, d_rgb + (size_t)f * frame_stride_bytes, g, detection_threshold, d, nullptr, fork));
     }
     return IMGFD_OK;
 }
@@ -1786,16 +1715,15 @@ try {
         (void)ws_alloc(c, 3 * n);  // the slot imgfd_surf uses for the uploaded image (same carving, same size function)
         L.d.cap = rcap;
         L.d.integral = (unsigned *)ws_alloc(c, 4 * n);
-        L.d.residue = (unsigned *)ws_alloc(c, 4 * n);
         L.d.mask = (unsigned long long *)ws_alloc(c, 8 * std::max<size_t>(g.mask_words, 1));
-        L.d.pyr = (double *)ws_alloc(c, 8 * std::max<size_t>(total, 1));
-        L.d.pyr_bytes = 8 * std::max<size_t>(total, 1);
+        L.d.pyr_bytes = surf_pyr_bytes(g, total);
+        L.d.pyr = (double *)ws_alloc(c, L.d.pyr_bytes);
         L.d.rec = (SurfRecord *)ws_alloc(c, sizeof(SurfRecord) * rcap);
         L.d.count = (unsigned long long *)ws_alloc(c, 256);
         L.sel = (unsigned *)ws_alloc(c, sizeof(unsigned) * 2 * (size_t)L.lim);
         L.cand = (unsigned *)ws_alloc(c, sizeof(unsigned) * 2 * (size_t)rcap);
         L.k19 = (double *)ws_alloc(c, sizeof(double) * 8 * (size_t)L.lim);  // x, y, scale | angle, sin, cos, sin(-), cos(-)
-        if (!L.d.integral || !L.d.pyr || !L.d.rec || !L.d.count || !L.sel || !L.cand || !L.k19) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+        if (!L.d.integral || !L.d.mask || !L.d.pyr || !L.d.rec || !L.d.count || !L.sel || !L.cand || !L.k19) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
         L.m_dev = reinterpret_cast<unsigned *>(L.d.count) + 8;  // inside the 256-byte counter slot
         return IMGFD_OK;
     };
@@ -1803,7 +1731,8 @@ try {
         imgfd_ctx *c = L.c;
         const unsigned lim = L.lim;
         double *d_pts = L.k19, *d_trig = L.k19 + 3 * (size_t)lim;
-        imgfd_status st = surf_device_stages(c, d_rgb + (size_t)f * frame_stride_bytes, g, detection_threshold, L.d, fork);
+        SurfTable T;
+        imgfd_status st = surf_device_stages(c, d_rgb + (size_t)f * frame_stride_bytes, g, detection_threshold, L.d, &T, fork);
         double *feat = d_features + (size_t)f * (size_t)cap * 70;
         SurfRankParams q;
         q.rec = L.d.rec; q.count = L.d.count; q.cap = L.d.cap; q.lim = lim; q.rows = rows; q.cols = cols; q.sel = L.sel; q.order = L.sel + lim;
@@ -1811,9 +1740,9 @@ try {
         q.pts = d_pts; q.feat = feat; q.count_out = reinterpret_cast<long long *>(d_counts) + f; q.m_out = L.m_dev;
         if (st == IMGFD_OK) {
             hipLaunchKernelGGL(surf_rank_select, dim3(1), dim3(SR_NT), 0, c->stream, q);
-            st = launch_surf_orient(c, L.d.integral, rows, cols, d_pts, (int)lim, nullptr, d_trig, L.m_dev);
+            st = launch_surf_orient(c, T, d_pts, (int)lim, nullptr, d_trig, L.m_dev);
         }
-        if (st == IMGFD_OK) st = launch_surf_desc(c, L.d.integral, rows, cols, d_pts, d_trig, (int)lim, feat + 6, 70, feat + 2, L.m_dev);
+        if (st == IMGFD_OK) st = launch_surf_desc(c, T, d_pts, d_trig, (int)lim, feat + 6, 70, feat + 2, L.m_dev);
         if (st != IMGFD_OK && c != ctx) ctx->err = c->err;
         return st;
     };
@@ -1860,8 +1789,8 @@ static imgfd_status surf_host(imgfd_ctx *ctx, const void *rgb, int kind, int row
     if (!rgb || rows < 0 || cols < 0 || !(max_points > 0) || !(detection_threshold >= 0) || !frame_fits(rows, cols, 3))
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_surf: bad argument (DLIB_ASSERT of surf.h:243-248)");
     std::vector<SurfRecord> pts;
-    const unsigned *d_I = nullptr;
-    IMGFD_TRY(surf_points_host(ctx, rgb, kind, rows, cols, detection_threshold, pts, &d_I));
+    SurfTable T{nullptr, rows, cols, 0};
+    IMGFD_TRY(surf_points_host(ctx, rgb, kind, rows, cols, detection_threshold, pts, &T));
     if (pts.empty()) return IMGFD_OK;
     std::vector<size_t> keep;
     surf_select(pts, max_points, rows, cols, keep);
@@ -1876,7 +1805,7 @@ static imgfd_status surf_host(imgfd_ctx *ctx, const void *rgb, int kind, int row
         const SurfRecord &p = pts[keep[j]];
         out->x[j] = p.x; out->y[j] = p.y; out->pyramid_scale[j] = p.scale; out->score[j] = p.score; out->laplacian[j] = p.laplacian;
     }
-    const imgfd_status st = surf_describe_assisted(ctx, d_I, rows, cols, pts, keep, out);
+    const imgfd_status st = surf_describe_assisted(ctx, T, pts, keep, out);
     if (st != IMGFD_OK) {
         free(data);
         memset(out, 0, sizeof *out);

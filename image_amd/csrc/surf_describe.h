@@ -17,4 +17,19 @@ void surf_orient_host(const double *sx, const double *sy, double *out5);
 #ifdef IMGFD_BUILD
 struct imgfd_ctx;
 void surf_orient_table(SurfOrientTable *T);
+
+// The int32 integral image (integral_image.h:33-62) as the device kernels hold it, in ONE of two layouts:
+//   per == 0         plain:      word of (row, x) = row * cols + x
+//   per == cols / 4  by residue: word of (row, x) = row * cols + (x & 3) * per + (x >> 2)
+// The residue layout is what the gather kernels of octaves 1-3 want (their level pixels sit on columns that are multiples of
+// 4, 8, 16: consecutive lanes read consecutive words of one residue plane); since round 6 it is the ONLY copy of the table
+// whenever the image allows it (cols a multiple of 16, band / strip scans), and every reader addresses it through this.
+struct SurfTable {
+    const unsigned *p;
+    int rows, cols, per;
+#ifdef __device__  /* (surf_host.cpp includes this header without the HIP runtime) */
+    __device__ __forceinline__ size_t word(int r, int x) const { return (size_t)r * cols + (per ? (x & 3) * per + (x >> 2) : x); }
+    __device__ __forceinline__ unsigned at(int r, int x) const { return p[word(r, x)]; }
+#endif
+};
 #endif

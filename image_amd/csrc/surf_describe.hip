@@ -24,7 +24,7 @@
 namespace {
 
 struct Haar {
-    const unsigned *I;
+    SurfTable T;  // the integral image, plain or by column residue
     int rows, cols;
     __device__ __forceinline__ unsigned at(long r, long c) const
     {
@@ -32,7 +32,7 @@ struct Haar {
         // a corrupt record from reading outside the table
         r = r < 0 ? 0 : (r >= rows ? rows - 1 : r);
         c = c < 0 ? 0 : (c >= cols ? cols - 1 : c);
-        return I[(size_t)r * cols + c];
+        return T.at((int)r, (int)c);
     }
     // get_sum_of_area(rectangle(l,t,r,b)), integral_image.h:64-96; unsigned arithmetic = the reference's wrapping int32
     __device__ __forceinline__ unsigned box(long l, long t, long r, long b) const
@@ -64,10 +64,10 @@ struct Haar {
     {
         const long left = x - width / 2, top = y - width / 2, right = left + width - 1, bottom = top + width - 1;
         if (left >= 1 && top >= 1 && right < cols && bottom < rows) {
-            const unsigned *rt = I + (size_t)(top - 1) * cols, *rm = I + (size_t)(y - 1) * cols, *rb = I + (size_t)bottom * cols;
-            const unsigned tl = rt[left - 1], tm = rt[x - 1], tr = rt[right];
-            const unsigned ml = rm[left - 1], mr = rm[right];
-            const unsigned bl = rb[left - 1], bm = rb[x - 1], br = rb[right];
+            const int rt = (int)top - 1, rm = (int)y - 1, rb = (int)bottom, cl = (int)left - 1, cm = (int)x - 1, cr = (int)right;
+            const unsigned tl = T.at(rt, cl), tm = T.at(rt, cm), tr = T.at(rt, cr);
+            const unsigned ml = T.at(rm, cl), mr = T.at(rm, cr);
+            const unsigned bl = T.at(rb, cl), bm = T.at(rb, cm), br = T.at(rb, cr);
             *hx = (int)((br - bm - tr + tm) - (bm - bl - tm + tl));  // box(x, top, right, bottom) - box(left, top, x - 1, bottom)
             *hy = (int)((br - bl - mr + ml) - (mr - ml - tr + tl));  // box(left, y, right, bottom) - box(left, top, right, y - 1)
         } else {
@@ -83,7 +83,7 @@ __device__ __forceinline__ long surf_to_long(double v) { return (long)floor(v + 
 
 // pts: m x 3 (x, y, scale).  samples != nullptr: write sx[109], sy[109] per point (assisted mode).
 // trig != nullptr: write angle, sin, cos, sin(-), cos(-) per point (device mode).
-__global__ void __launch_bounds__(128) surf_orient(const unsigned *__restrict__ I, int rows, int cols,
+__global__ void __launch_bounds__(128) surf_orient(SurfTable I,
                                                    const double *__restrict__ pts, SurfOrientTable T,
                                                    double *__restrict__ samples, double *__restrict__ trig,
                                                    const unsigned *__restrict__ m_dev)
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(128) surf_orient(const unsigned *__restrict__ 
     const int i = threadIdx.x;
     const double x = pts[3 * p], y = pts[3 * p + 1], scale = pts[3 * p + 2];
     const long sc = (long)(scale + 0.5);
-    const Haar H{I, rows, cols};
+    const Haar H{I, I.rows, I.cols};
     if (i < SURF_NSAMP) {
         const long r = T.r[i], c = T.c[i];
         const long px = surf_to_long((double)(sc * c) + x), py = surf_to_long((double)(sc * r) + y);
@@ -128,9 +128,17 @@ __global__ void __launch_bounds__(128) surf_orient(const unsigned *__restrict__ 
     if (!trig) return;
     __syncthreads();
     if (i < 45) {  // :111-131
+        // A sample outside the window adds +0.0 instead of being skipped: a sum that starts at +0.0 never becomes -0.0 (x + y is
+        // -0.0 only for two negative zeros), and x + 0.0 = x for every other x, so the bits are those of the reference's skipping
+        // loop -- and the 109 steps are one chain of dependent f64 adds with every LDS read issued ahead of it (a branch per sample
+        // put two dependent LDS round trips into every step: ~10 of the kernel's 24-31 us, round 5)
         double vx = 0, vy = 0;
-        for (int s = 0; s < SURF_NSAMP; s++)
-            if ((in_windows[s] >> i) & 1ull) { vx += sx[s]; vy += sy[s]; }
+#pragma unroll 8
+        for (int s = 0; s < SURF_NSAMP; s++) {
+            const bool in = (in_windows[s] >> i) & 1ull;
+            vx += in ? sx[s] : 0.0;
+            vy += in ? sy[s] : 0.0;
+        }
         wx[i] = vx;
         wy[i] = vy;
     }
@@ -154,7 +162,7 @@ __global__ void __launch_bounds__(128) surf_orient(const unsigned *__restrict__ 
 
 // trig: m x 5 (angle, sin, cos, sin(-angle), cos(-angle)); point p's descriptor goes to des[p*des_stride .. +64) and, if
 // angle_out, its angle to angle_out[p*des_stride]
-__global__ void __launch_bounds__(64) surf_desc(const unsigned *__restrict__ I, int rows, int cols,
+__global__ void __launch_bounds__(64) surf_desc(SurfTable I,
                                                 const double *__restrict__ pts, const double *__restrict__ trig,
                                                 double *__restrict__ des, int des_stride, double *__restrict__ angle_out,
                                                 const unsigned *__restrict__ m_dev)
@@ -169,7 +177,7 @@ __global__ void __launch_bounds__(64) surf_desc(const unsigned *__restrict__ I, 
     const double x = pts[3 * p], y = pts[3 * p + 1], scale = pts[3 * p + 2];
     const double sn = trig[5 * p + 1], cs = trig[5 * p + 2], isn = trig[5 * p + 3], ics = trig[5 * p + 4];
     const long sc = (long)(scale + 0.5);
-    const Haar H{I, rows, cols};
+    const Haar H{I, I.rows, I.cols};
     // the 20 x 20 sample grid (:176-186)
     for (int s = lane; s < 400; s += 64) {
         const long yy = s / 20 - 10, xx = s % 20 - 10;
@@ -199,10 +207,12 @@ __global__ void __launch_bounds__(64) surf_desc(const unsigned *__restrict__ I, 
         const int bucket = lane >> 2, comp = lane & 3;
         const long r = -10 + 5 * (bucket >> 2), c = -10 + 5 * (bucket & 3);
         const double *src = (comp & 1) ? ry + bucket * 49 : rx + bucket * 49;
+        // slots outside the 20 x 20 grid hold +0.0 (written above): adding them leaves the sum's bits alone (a sum that starts at
+        // +0.0 never becomes -0.0), so the 49 steps need no test and the LDS reads run ahead of the chain of adds
+        (void)r; (void)c;
         double acc = 0;
+#pragma unroll 7
         for (int j = 0; j < 49; j++) {
-            const long yy = r - 1 + j / 7, xx = c - 1 + j % 7;
-            if (yy < -10 || yy >= 10 || xx < -10 || xx >= 10) continue;
             const double v = src[j];
             acc += (comp & 2) ? fabs(v) : v;
         }
@@ -233,22 +243,22 @@ void surf_orient_table(SurfOrientTable *T)
         }
 }
 
-imgfd_status launch_surf_orient(imgfd_ctx *ctx, const unsigned *d_I, int rows, int cols, const double *d_pts, int m,
+imgfd_status launch_surf_orient(imgfd_ctx *ctx, const SurfTable &I, const double *d_pts, int m,
                                 double *d_samples, double *d_trig, const unsigned *m_dev)
 {
     if (m < 1) return IMGFD_OK;
     SurfOrientTable T;
     surf_orient_table(&T);
-    hipLaunchKernelGGL(surf_orient, dim3(m), dim3(128), 0, ctx->stream, d_I, rows, cols, d_pts, T, d_samples, d_trig, m_dev);
+    hipLaunchKernelGGL(surf_orient, dim3(m), dim3(128), 0, ctx->stream, I, d_pts, T, d_samples, d_trig, m_dev);
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }
 
-imgfd_status launch_surf_desc(imgfd_ctx *ctx, const unsigned *d_I, int rows, int cols, const double *d_pts,
+imgfd_status launch_surf_desc(imgfd_ctx *ctx, const SurfTable &I, const double *d_pts,
                               const double *d_trig, int m, double *d_des, int des_stride, double *d_angle, const unsigned *m_dev)
 {
     if (m < 1) return IMGFD_OK;
-    hipLaunchKernelGGL(surf_desc, dim3(m), dim3(64), 0, ctx->stream, d_I, rows, cols, d_pts, d_trig, d_des, des_stride, d_angle, m_dev);
+    hipLaunchKernelGGL(surf_desc, dim3(m), dim3(64), 0, ctx->stream, I, d_pts, d_trig, d_des, des_stride, d_angle, m_dev);
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }

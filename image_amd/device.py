@@ -149,6 +149,16 @@ class DeviceDetector:
         self.ctx.check(self.lib.imgfd_profile_k3_read(self.ctx.handle, C.byref(us), C.byref(n)), "imgfd_profile_k3_read")
         return us.value, n.value
 
+    def clock_probe(self, span_us=200):
+        """queue one shader-clock sample beside whatever runs (imgfd_clock_probe: one wavefront on a stream of its own)"""
+        self.ctx.check(self.lib.imgfd_clock_probe(self.ctx.handle, int(span_us)), "imgfd_clock_probe")
+
+    def clock_probe_read(self):
+        """{"mean_GHz", "min_GHz", "max_GHz", "samples"} over the probes queued since the last read (waits for them)"""
+        a, b, c, n = C.c_double(0), C.c_double(0), C.c_double(0), C.c_int(0)
+        self.ctx.check(self.lib.imgfd_clock_probe_read(self.ctx.handle, C.byref(a), C.byref(b), C.byref(c), C.byref(n)), "imgfd_clock_probe_read")
+        return {"mean_GHz": round(a.value, 4), "min_GHz": round(b.value, 4), "max_GHz": round(c.value, 4), "samples": n.value}
+
     def tensor_kernel_name(self) -> str:
         """which kernel imgfd_harris_dev / imgfd_detect_dev launch for the structure-tensor pass on the default path"""
         name = self.lib.imgfd_tensor_kernel_name(self.ctx.handle)

@@ -113,21 +113,15 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  *   "nms_tiled" [IMGFD_NMS_TILED]  1: the tiled Harris NMS kernel instead of the sparse one
  *   "tensor_per_cu", "tensor_workers", "tensor_tw" [IMGFD_TENSOR_*]  launch geometry of fir_tensor: workgroups per CU, workers
  *                  (each takes an equal share of the batch's line of 16-row chunk units), strip width 128 | 256 (0: chosen)
- *   "surf_residue" [IMGFD_SURF_RESIDUE]  SURF octaves 1-3: modulus of the residue layout (4; 0 = plain table, 16)
  *   "max_chunk_frames" [IMGFD_MAX_CHUNK_FRAMES]  frames per sub-batch of the *_dev entry points (0: from the memory budgets)
  *   "tile_run" [IMGFD_TILE_RUN]  tiles per workgroup of the u8 tile kernels (0: from the batch size)
  *   "detect_graph" [IMGFD_DETECT_GRAPH]  imgfd_detect_dev replays a recorded hipGraph for repeating calls on fewer frames than this
  *                                        (0 = never, the default: a single 4K frame takes the same time either way, 0.20 ms in round 5)
- *   "surf_taps" [IMGFD_SURF_TAPS]  1 (default): SURF octaves 1-3 look their 32 table words up with buffer loads and host-made offsets
  *   "surf_lanes" [IMGFD_SURF_LANES]  4 (default): imgfd_surf_dev deals the tiles round-robin to this many HIP streams (1..4)
  *   "surf_async" [IMGFD_SURF_ASYNC]  0 (default): imgfd_surf_dev reads the tile counts back once per call and redoes tiles
  *                                    whose candidates overflowed the record buffer; 1: no wait, such a tile reports -candidates
- *   "surf_ends" [IMGFD_SURF_ENDS]  1 (default): intervals 0 and 5 of every octave of the Hessian pyramid are not built -- they are never
- *                                  maxima themselves, the 3x3x3 test computes the neighbourhoods it needs of them; 0: all six intervals
  *   "surf_split" [IMGFD_SURF_SPLIT]  1 (default): a tile that has the device to itself (imgfd_surf, imgfd_surf_dev with one tile, the interest-point
  *                                  doorways) runs the Hessian pyramid of octaves 1-3 on the companion context's stream beside octave 0; 0: one stream
- *   "surf_residue_fused" [IMGFD_SURF_RESIDUE_FUSED]  1 (default): the integral image's last kernel writes the table a second time in the
- *                                  residue layout octaves 1-3 read; 0: a kernel of its own re-lays it (round 3-4)
  *   "surf_sort_cap" [IMGFD_SURF_SORT_CAP]  selected records imgfd_surf_dev ranks with its LDS sort (2048); more: all-pairs ranking
  *   "surf_rec_cap" [IMGFD_SURF_REC_CAP]  candidate records per tile imgfd_surf_dev buffers before it redoes the tile (262144)
  * Unknown names give IMGFD_ERR_INVALID. */
@@ -388,6 +382,15 @@ IMGFD_API const char *imgfd_tensor_kernel_name(imgfd_ctx *ctx);
  * the last read, and resets the counters. */
 IMGFD_API imgfd_status imgfd_profile_k3(imgfd_ctx *ctx, int enable);
 IMGFD_API imgfd_status imgfd_profile_k3_read(imgfd_ctx *ctx, double *total_us, int *launches);
+
+/* The shader clock the device runs at while the library's kernels run (the chip clocks to its power budget: the same kernel
+ * is 3-7 % slower on one box than on another, and slower beside an f64-heavy load than alone).  imgfd_clock_probe queues ONE
+ * wavefront on a stream of the context's own -- beside whatever its other streams run, it does not wait for them and they do
+ * not wait for it -- that reads the shader-cycle counter and the constant-rate wall counter span_us (1 .. 100000) microseconds
+ * apart; imgfd_clock_probe_read waits for the probes queued since the last read and returns mean / min / max GHz over them
+ * (samples = 0 and zeros when none was queued; at most 4096 probes are kept between two reads). */
+IMGFD_API imgfd_status imgfd_clock_probe(imgfd_ctx *ctx, int span_us);
+IMGFD_API imgfd_status imgfd_clock_probe_read(imgfd_ctx *ctx, double *mean_ghz, double *min_ghz, double *max_ghz, int *samples);
 
 /* Fill n_frames synthetic u8 frames G(seed0+f) directly in HBM (image_amd/synth.py is the host twin). */
 IMGFD_API imgfd_status imgfd_synth_frames(imgfd_ctx *ctx, uint8_t *d_frames, int n_frames, int nx, int ny,

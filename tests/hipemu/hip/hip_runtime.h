@@ -319,6 +319,10 @@ static inline int __builtin_amdgcn_readlane(int v, int src) { return __shfl(v, s
 // ---- gfx950 builtins the product sources use unconditionally (emulated here, so that the kernels carry no test branches)
 static inline double __builtin_amdgcn_rsq(double x) { return 1.0 / sqrt(x); }  // v_rsq_f64: a seed, refined by the caller
 static inline void __builtin_amdgcn_s_sleep(int) {}
+// s_memtime / s_memrealtime (clock.hip): one wall counter that advances per read, 21 shader cycles per tick ("2.1 GHz" at 100 MHz)
+inline unsigned long long &hipemu_wall_ticks() { static unsigned long long t = 0; return t; }
+static inline unsigned long long __builtin_amdgcn_s_memrealtime() { return hipemu_wall_ticks() += 100; }
+static inline unsigned long long __builtin_amdgcn_s_memtime() { return 21 * hipemu_wall_ticks(); }
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
@@ -430,6 +434,8 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
     p->sharedMemPerBlock = 160 * 1024; p->maxThreadsPerBlock = 1024; p->clockRate = 2400000;
     return hipSuccess;
 }
+enum hipDeviceAttribute_t { hipDeviceAttributeWallClockRate = 1 };
+static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 100000; return hipSuccess; }  // kHz
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <typename T> static inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }

@@ -113,36 +113,20 @@ def test_batch_surf_dev_descriptors_on_the_device(be):
     assert len(few["x"]) <= 7 and np.array_equal(few["score"], np.sort(few["score"])[::-1])
 
 
-@pytest.mark.parametrize("w,h", [(384, 256), (400, 304), (640, 272), (528, 162)])
-def test_upper_octaves_both_gather_forms(be, w, h):
-    """octaves 1-3: the look-ups as buffer loads with host-made offsets (surf_pyramid_taps, the default) and with per-look-up
-    address arithmetic (surf_pyramid<2>, "surf_taps" 0) give the reference's interest points, bit for bit"""
+@pytest.mark.parametrize("w,h", [(384, 256), (400, 304), (640, 272), (528, 162), (396, 260), (330, 200)])
+def test_upper_octaves_in_both_table_layouts(be, w, h):
+    """octaves 1-3 (points from more than one octave): widths that are a multiple of 16 keep the integral image in the residue
+    layout only -- the first octave's LDS window, the buffer-load gathers of surf_pyramid_taps, the maximum test's look-ups for
+    the intervals that are not built and K19 all address it --, the other widths (396, 330) the plain table with
+    surf_pyramid_plain: the reference's interest points and descriptors, bit for bit"""
     img = blobs(170 + w, w, h)
     ref = oracle.surf_interest_points(img, 2.0)
     assert len(ref) > 20 and len({int(round(np.log2(p[2]))) for p in ref}) >= 2   # points from more than one octave
-    try:
-        for taps in (1, 0):
-            be.set_tuning("surf_taps", taps)
-            got = be.surf_interest_points(img, 2.0)
-            assert got.shape == ref.shape and np.array_equal(got.view(np.uint64), ref.view(np.uint64)), taps
-    finally:
-        be.set_tuning("surf_taps", 1)
-
-
-@pytest.mark.parametrize("w,h", [(384, 256), (400, 304), (528, 162)])
-def test_residue_layout_written_by_either_kernel(be, w, h):
-    """the table octaves 1-3 read (columns by residue mod 4) comes from the integral image's last kernel ("surf_residue_fused" 1,
-    the default) or from surf_residue_layout (0): the same interest points, bit for bit"""
-    img = blobs(190 + w, w, h)
-    ref = oracle.surf_interest_points(img, 2.0)
-    assert len(ref) > 20 and len({int(round(np.log2(p[2]))) for p in ref}) >= 2
-    try:
-        for fused in (1, 0):
-            be.set_tuning("surf_residue_fused", fused)
-            got = be.surf_interest_points(img, 2.0)
-            assert got.shape == ref.shape and np.array_equal(got.view(np.uint64), ref.view(np.uint64)), fused
-    finally:
-        be.set_tuning("surf_residue_fused", 1)
+    got = be.surf_interest_points(img, 2.0)
+    assert got.shape == ref.shape and np.array_equal(got.view(np.uint64), ref.view(np.uint64))
+    full, rfull = be.surf(img, 300, 2.0), oracle.surf(img, 300, 2.0)
+    for k in ("x", "y", "pyramid_scale", "score", "laplacian", "angle", "surf"):
+        assert full[k].shape == rfull[k].shape and np.array_equal(full[k], rfull[k], equal_nan=True), k
 
 
 @pytest.mark.parametrize("w,h", [(256, 200), (330, 170)])
