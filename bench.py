@@ -835,6 +835,7 @@ def measure(args, det, rank, world, dist, want_cpu, light=False):
             dist.all_reduce(torch.zeros(1))   # a host tensor: gloo; no RCCL communicator exists before the timed region ends
         torch.cuda.synchronize()
 
+    det.clock_probe(50); det.clock_probe_read()   # the probe's stream and ring exist before the clock starts
     for _ in range(args.warmup):
         wl.step()
     barrier()

@@ -70,6 +70,7 @@ SIGNATURES = {
     "imgfd_surf_interest_points": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "imgfd_surf_points_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_double, C.c_void_p, C.c_int64, C.c_void_p]),
     "imgfd_surf_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_long, C.c_double, C.c_void_p, C.c_int64, C.c_void_p]),
+    "imgfd_surf_dev_redo": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_long, C.c_double, C.c_void_p, C.c_int64, C.c_void_p, c_int_p]),
     "imgfd_knn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "imgfd_knn_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                 C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

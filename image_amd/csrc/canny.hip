@@ -526,6 +526,7 @@ __global__ void __launch_bounds__(256) canny_grad_nms(const float *__restrict__ 
     if (in_frame == 0 && threadIdx.x == 0) {
         sweep_flags[n_sweep_flags + bz] = 0;              // per frame: the last sweep that changed it
         sweep_flags[n_sweep_flags + gridDim.y + bz] = 0;  // ... and the arrival counter of canny_finish's frame barriers
+        if (bz == 0) sweep_flags[n_sweep_flags + 2 * gridDim.y] = 0;  // ... and its ticket counter
         counts[bz] = 0;                                   // pixels_nonzero: the expansion adds to it
     }
 }
@@ -1018,9 +1019,16 @@ __global__ void __launch_bounds__(256) canny_expand_count(const unsigned long lo
 // The three kernels above as ONE launch (round 5; a single 4K frame spent 10 us of its critical chain in the two union-find
 // launches that find nothing to do).  A frame the last sweep left alone -- the case in practice -- is expanded at once.  A frame
 // it did not finish takes the same three steps with two barriers between them, each across the workgroups of THAT FRAME only
-// (a counter in the flags block, cleared by the gradient/NMS kernel): workgroups are dispatched in order, a frame's
-// EXP_BLOCKS workgroups are consecutive and wait for nobody else, so they become resident together whatever else runs.
-// Needs workgroups that can wait for each other (not the one-block-at-a-time emulator of the tests: the host asks the device).
+// (a counter in the flags block, cleared by the gradient/NMS kernel).
+// Forward progress, by construction (round 6; round 5 relied on workgroups being dispatched in grid order): a workgroup does not
+// work on the (frame, slice) its grid position names but on the one its TICKET names -- tickets are handed out by an atomic counter
+// as workgroups START RUNNING, frame by frame (ticket / blocks per frame).  The workgroups that are resident at any time therefore
+// hold a gap-free prefix of the tickets: every frame but the last one they have reached is complete in tickets, so its barriers open
+// with no further dispatch, its workgroups leave and make room; and the last frame completes as soon as the blocks of ONE frame are
+// resident together -- which the host guarantees by launching no more blocks per frame than the stream's compute units hold at
+// once (hipOccupancyMaxActiveBlocksPerMultiprocessor x the compute units of the stream's CU mask; canny_finish_blocks).  Whatever
+// else runs on the device only delays that.  Needs workgroups that can wait for each other (not the one-block-at-a-time emulator
+// of the tests: the host asks the device).
 __device__ __forceinline__ void frame_barrier(unsigned *counter, unsigned target)
 {
     __syncthreads();
@@ -1035,18 +1043,21 @@ __global__ void __launch_bounds__(256) canny_finish(const unsigned long long *__
                                                     unsigned long long *__restrict__ counts, const unsigned long long *__restrict__ Wm,
                                                     unsigned *__restrict__ parents, unsigned *__restrict__ flags, unsigned last_sweep, int n_frames)
 {
-    const int frame = blockIdx.y;
+    __shared__ unsigned ticket_s;
+    if (threadIdx.x == 0) ticket_s = __hip_atomic_fetch_add(flags + HY_SWEEPS_MAX + 2 * n_frames, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int frame = (int)(ticket_s / gridDim.x), bid = (int)(ticket_s - (unsigned)frame * gridDim.x);  // grid: (blocks per frame, frames)
     const bool united = flags[HY_SWEEPS_MAX + frame] == last_sweep;  // workgroup-uniform
     if (united) {
         unsigned *bar = flags + HY_SWEEPS_MAX + n_frames + frame;
-        uf_init_frame(S, Wm, wpr, nx, ny, parents, frame, blockIdx.x, gridDim.x);
+        uf_init_frame(S, Wm, wpr, nx, ny, parents, frame, bid, gridDim.x);
         __threadfence();
         frame_barrier(bar, gridDim.x);
-        uf_merge_frame(S, Wm, wpr, nx, ny, parents, frame, blockIdx.x, gridDim.x);
+        uf_merge_frame(S, Wm, wpr, nx, ny, parents, frame, bid, gridDim.x);
         __threadfence();
         frame_barrier(bar, 2u * gridDim.x);
     }
-    expand_count_frame(S, wpr, edges, nx, ny, counts, Wm, parents, united, frame, blockIdx.x, gridDim.x);
+    expand_count_frame(S, wpr, edges, nx, ny, counts, Wm, parents, united, frame, bid, gridDim.x);
 }
 namespace {
 
@@ -1162,8 +1173,27 @@ size_t canny_ws_bytes(int nx, int ny, int nf)
     const size_t words = (size_t)ceil_div(nx, 64) * ny * nf;
     return align_up(n * sizeof(double), 256) + align_up(n * sizeof(float), 256) + 2 * align_up(words * 8, 256) +
            align_up(12 * ((size_t)nx + ny), 256) + 512 +  // taps in memory (kernels of more than CANNY_MAX_TAPS taps)
-           align_up(4 * ((size_t)HY_SWEEPS_MAX + 2 * (size_t)nf), 256) +  // sweep flags, per-frame flags and counters
+           align_up(4 * ((size_t)HY_SWEEPS_MAX + 2 * (size_t)nf + 1), 256) +  // sweep flags, per-frame flags and counters, the finishing kernel's tickets
            align_up(2 * (size_t)nf * ceil_div(nx, 64) * ceil_div(ny, 64), 256) + 4096;
+}
+
+// Workgroups of canny_finish that can be resident together on the compute units this context's stream may use: the occupancy API's
+// answer per compute unit x the units of the stream's CU mask (a stream made by hipExtStreamCreateWithCUMask, a partitioned device).
+// Computed once per context; 0 when the runtime does not say.
+int canny_finish_blocks(imgfd_ctx *ctx)
+{
+    if (ctx->canny_finish_fit >= 0) return ctx->canny_finish_fit;
+    int per_cu = 0, cus = ctx->num_cu;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)canny_finish, 256, 0) != hipSuccess || per_cu < 1) return ctx->canny_finish_fit = 0;
+    uint32_t mask[32] = {0};
+    const uint32_t words = (uint32_t)std::min(32, (ctx->num_cu + 31) / 32);
+    if (ctx->stream && hipExtStreamGetCUMask(ctx->stream, words, mask) == hipSuccess) {
+        int n = 0;
+        for (int i = 0; i < ctx->num_cu; i++) n += (mask[i >> 5] >> (i & 31)) & 1u;
+        if (n >= 1) cus = std::min(cus, n);
+    }
+    (void)hipGetLastError();
+    return ctx->canny_finish_fit = per_cu * cus;
 }
 
 // all device work for nf frames; d_edges / d_counts are device buffers
@@ -1206,7 +1236,7 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
     float *blur = (float *)ws_alloc(ctx, n * sizeof(float));
     unsigned long long *S = (unsigned long long *)ws_alloc(ctx, words * 8);
     unsigned long long *Wm = (unsigned long long *)ws_alloc(ctx, words * 8);
-    unsigned *flags = (unsigned *)ws_alloc(ctx, 4 * ((size_t)HY_SWEEPS_MAX + 2 * (size_t)nf));
+    unsigned *flags = (unsigned *)ws_alloc(ctx, 4 * ((size_t)HY_SWEEPS_MAX + 2 * (size_t)nf + 1));
     const size_t act_bytes = 2 * (size_t)nf * wpr * ceil_div(ny, 64);  // tile activity of the sweeps, two parities (tiles of one word at the least)
     unsigned char *act = (unsigned char *)ws_alloc(ctx, act_bytes);
     const size_t tap_bytes = big ? align_up(12 * (offx.size() + offy.size()), 256) + 256 : 0;
@@ -1285,8 +1315,10 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
         IMGFD_HIP(ctx, hipGetLastError());
     }
     // the blur plane is dead behind the gradient/NMS kernel: 4 bytes per pixel for the union-find forest
-    const int exp_blocks = std::min(EXP_BLOCKS, ny);
-    if (ctx->coop && ctx->tune.canny_finish) {
+    int exp_blocks = std::min(EXP_BLOCKS, ny);
+    const int fit = canny_finish_blocks(ctx);  // blocks of canny_finish the stream's compute units hold at once (0: unknown)
+    if (ctx->coop && fit >= 16) {  // (fewer: a stream confined to one or two compute units -- the three launches below)
+        exp_blocks = std::min(exp_blocks, fit);  // a frame's blocks wait for each other: no more of them than can be resident together
         // union-find (frames the sweeps did not finish only), 0/255 bytes and pixels_nonzero in ONE launch
         hipLaunchKernelGGL(canny_finish, dim3(exp_blocks, nf), dim3(256), 0, ctx->stream, (const unsigned long long *)S, wpr, d_edges, nx, ny,
                            (unsigned long long *)d_counts, (const unsigned long long *)Wm, reinterpret_cast<unsigned *>(blur), flags, uf_last_sweep, nf);

@@ -55,6 +55,7 @@ struct imgfd_ctx {
     void *canny_taps = nullptr;
     void (*canny_taps_free)(void *) = nullptr;
     const unsigned *canny_flags = nullptr;
+    int canny_finish_fit = -1;  // blocks of canny_finish the stream's compute units hold at once (-1: not asked yet; canny.hip)
     int canny_sweeps = 0, canny_frames = 0;
     std::string detect_key, detect_seen;  // the call it was recorded for / the call seen last (raw bytes of a DetectKey)
     std::string detect_unrecordable;  // the key of a launch sequence that refused to be captured: run eagerly, do not try again
@@ -71,7 +72,6 @@ struct imgfd_ctx {
         int hyst_sweeps = 0;        // Canny hysteresis: sweeps queued before the union-find step (0: 8 up to 12 frames, 9 for batches)
         int hyst_words = 0;         // words per sweep tile: 1, 2 or 4 (0: 1 up to 12 frames, else 4)
         int hyst_block = 0;         // tiles per workgroup of a sweep, 10 * across + down: 22, 42, 24, 44 (0: 24 up to 12 frames, else 22)
-        int canny_finish = 1;       // 1: union-find + expansion + count as one launch (canny_finish) where workgroups can wait for each other; 0: three launches
         int detect_swap = -1;       // imgfd_detect_dev: 1 = Canny's chain on the context's own stream, FAST-9 and the Harris chain on the companion's; 0: the other way round; -1: 1 below 8 frames
         int hyst_prio = 1;          // block sweeps run at wave priority 3 (0: default priority)
         int hyst_shift = 1;         // block sweeps: odd launches group the tiles half a block up and left (0: the same grouping in every launch)
@@ -88,12 +88,14 @@ struct imgfd_ctx {
         int tile_run = 0;           // tiles per workgroup of the u8 tile kernels (0: from the batch size)
         int detect_graph = 0;       // imgfd_detect_dev: batches of fewer frames than this replay a recorded hipGraph when the call repeats
                                     // (0 = never, the default: replay measured no faster than eager launches, profiles/r03)
-        int surf_lanes = 4;      // imgfd_surf_dev: tiles go round-robin over this many HIP streams (1..4), each with its own buffers
+        int surf_lanes = 2;      // imgfd_surf_dev: the fronts (integral image + pyramid) of a group's tiles go round-robin over this many HIP streams (1..4)
+        int surf_group = 8;      // imgfd_surf_dev: tiles per group (1..16): a buffer set per tile, the latency-bound back stages (maximum test, ranking, K19) as ONE launch each per group
         int surf_rec_cap = 1 << 18;  // imgfd_surf_dev: candidate records a tile's buffer holds before the tile is redone (tests lower it)
         int surf_sort_cap = 2048;    // imgfd_surf_dev: selected records ranked by the LDS sort; more are ranked all-pairs (tests lower it)
         int surf_split = 1;      // SURF: 1 = a tile that has the device to itself (one lane) runs octaves 1-3 on the companion's stream beside octave 0
-        int surf_async = 0;      // imgfd_surf_dev: 1 = never wait for the host (a tile whose candidates overflow reports -candidates)
     } tune;
+    // imgfd_surf_dev: events between the front streams and the back stream of a batch (created on first use)
+    std::vector<hipEvent_t> surf_ev;
     // imgfd_clock_probe (clock.hip): a stream of its own, a ring of (shader cycles, wall ticks) samples
     hipStream_t clk_stream = nullptr;
     unsigned long long *clk_ring = nullptr;

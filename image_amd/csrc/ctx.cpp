@@ -19,7 +19,6 @@ const std::vector<TuneKey> &tune_keys()
         {"hyst_block", "IMGFD_HYST_BLOCK", &imgfd_ctx::Tune::hyst_block},
         {"hyst_shift", "IMGFD_HYST_SHIFT", &imgfd_ctx::Tune::hyst_shift},
         {"hyst_prio", "IMGFD_HYST_PRIO", &imgfd_ctx::Tune::hyst_prio},
-        {"canny_finish", "IMGFD_CANNY_FINISH", &imgfd_ctx::Tune::canny_finish},
         {"detect_defer", "IMGFD_DETECT_DEFER", &imgfd_ctx::Tune::detect_defer},
         {"detect_swap", "IMGFD_DETECT_SWAP", &imgfd_ctx::Tune::detect_swap},
         {"canny_gate", "IMGFD_CANNY_GATE", &imgfd_ctx::Tune::canny_gate},
@@ -37,7 +36,7 @@ const std::vector<TuneKey> &tune_keys()
         {"fir_mode", "IMGFD_FIR_MODE", nullptr},
         {"detect_graph", "IMGFD_DETECT_GRAPH", &imgfd_ctx::Tune::detect_graph},
         {"surf_lanes", "IMGFD_SURF_LANES", &imgfd_ctx::Tune::surf_lanes},
-        {"surf_async", "IMGFD_SURF_ASYNC", &imgfd_ctx::Tune::surf_async},
+        {"surf_group", "IMGFD_SURF_GROUP", &imgfd_ctx::Tune::surf_group},
         {"surf_split", "IMGFD_SURF_SPLIT", &imgfd_ctx::Tune::surf_split},
         {"surf_sort_cap", "IMGFD_SURF_SORT_CAP", &imgfd_ctx::Tune::surf_sort_cap},
         {"surf_rec_cap", "IMGFD_SURF_REC_CAP", &imgfd_ctx::Tune::surf_rec_cap},
@@ -119,6 +118,7 @@ void imgfd_ctx_destroy(imgfd_ctx *ctx)
     if (ctx->aux) (void)hipFree(ctx->aux);
     if (ctx->fhog_lut) (void)hipFree(ctx->fhog_lut);
     if (ctx->taps_dev) (void)hipFree(ctx->taps_dev);
+    for (hipEvent_t e : ctx->surf_ev) (void)hipEventDestroy(e);
     if (ctx->clk_stream) { (void)hipStreamSynchronize(ctx->clk_stream); (void)hipStreamDestroy(ctx->clk_stream); }
     if (ctx->clk_ring) (void)hipFree(ctx->clk_ring);
     if (ctx->canny_taps && ctx->canny_taps_free) ctx->canny_taps_free(ctx->canny_taps);

@@ -794,153 +794,95 @@ __device__ __forceinline__ int surf_octave_of_block(const SurfBlocks &b, unsigne
 struct SurfNmsParams {
     int border_next[SURF_INT];  // get_border_size(i+1) for the interval handled (level coordinates)
     double thr;
-    double pow2_o1[SURF_OCT];   // std::pow(2.0, o+1.0)
-    double step[SURF_OCT];      // get_step_size(o)
-    unsigned long long cap;
+    unsigned long long cap;     // records / survivors the buffers hold
     SurfBlocks blocks;          // all octaves in one launch
+    // blockIdx.y = tile of a group (imgfd_surf_dev): distances between consecutive tiles' buffers, in elements
+    size_t tile_pyr, tile_mask, tile_rec, tile_count, tile_table, tile_surv, tile_cand;
+    unsigned long long cand_cap;  // entries of the candidate list (one per built level pixel: a threshold of 0 marks them all)
     // Intervals 0 and 5 of an octave are not in the pyramid buffer (surf_geometry): the maximum test computes the nine values it
     // needs of them from the integral image on the spot -- a few thousand survivors per tile (round 5: a third of all level-pixel
     // values and of the pyramid's HBM writes less).
     SurfTable integral;
 };
 
-// ---- K18: 3x3x3 maximum test + interpolation of one level pixel (octave o, interval i, row r, column c), in two steps; between
-// them the masked kernel computes the neighbourhood in an interval that is not built, wave-cooperatively
-struct SurfNmsState {
-    double v[3][3][3];  // [interval][row][column] around the pixel (signed as stored until a step takes their absolute values)
-    double raw, val;    // the pixel's own value, its absolute value
-    int r, c;
+// ---- K18: get_interest_points (hessian_pyramid.h:453-506) in two kernels.
+//
+// The pyramid kernels published which level pixels reach the threshold, one bit each -- a fraction of a percent in octave 0,
+// a few percent above (measured on the bench tiles): some 4 x 10^5 marked pixels per 4096^2 tile, of which ~10^4 are interest
+// points.
+//   surf_nms_screen  a workgroup takes up to 256 consecutive mask words of one interval, a thread each, and turns their set bits
+//                    into a dense list in LDS (popcount, block scan, one entry per bit: thread << 6 | bit); the threads then share
+//                    the listed pixels evenly.  A pixel's own 3x3 first (most marked pixels are not the largest of their own
+//                    3x3), then the 3x3 of every neighbouring interval that is in the pyramid buffer, nine loads back to back per
+//                    step and nothing kept between the steps: a pixel that no STORED value beats is appended to the survivor list
+//                    (its key: octave, interval, row, column).  17 registers of values at a time: eight waves per SIMD.
+//   surf_nms_finish  nine threads per survivor, one per position of the 3x3: each fetches its position's value in the three
+//                    intervals -- a load where the interval is stored, the 32 table look-ups of build_pyramid (:119-171) where it
+//                    is not (interval 0 below i = 1, interval 5 above i = 4: surf_geometry) -- and leaves the absolute values in
+//                    LDS; the survivor's first thread finishes is_maximum_in_region (:324-356) against the computed interval and
+//                    runs interpolate_point (:411-446) with the closed-form 3x3 inverse (matrix_la.h:922-962), f64, the
+//                    reference's operation order (no contraction).
+// (Rounds 3-5 did all of this in one kernel that kept a pixel's 27 values and its record in registers across workgroup barriers
+// and wave-cooperative rounds: 158 registers + scratch, three waves per SIMD, ~50 us of dependent round trips per workgroup --
+// 54 us per tile whatever the number of tiles in flight: profiles/r06/surf_timeline_group8.txt.)
+// geometry of dlib's build_pyramid(img, 4, 6, 2) for a per-LANE (octave, interval): arithmetic instead of the SurfGeom tables (a
+// kernel argument indexed by a lane-varying value is copied to scratch memory first: surf_nms_finish took 169 us that way)
+__device__ __forceinline__ int surf_pick4(const int (&a)[SURF_OCT], int o) { return o == 0 ? a[0] : o == 1 ? a[1] : o == 2 ? a[2] : a[3]; }
+struct SurfLaneLevel {
+    int nr, nc;
+    size_t plane0;  // first built plane (interval 1) of the octave; interval it is (it - 1) * nr * nc further
 };
-// the 3x3 of one neighbouring interval (s = 0: below, 2: above) against the pixel: false = a strictly larger value there
-template <int S>
-__device__ __forceinline__ bool surf_nms_neighbour_ok(SurfNmsState &st)
+__device__ __forceinline__ SurfLaneLevel surf_lane_level(const SurfGeom &g, int o)
 {
-    bool big = false;
+    SurfLaneLevel L;
+    L.nr = surf_pick4(g.nr, o); L.nc = surf_pick4(g.nc, o);
+    size_t p = 0;
 #pragma unroll
-    for (int y = 0; y < 3; y++)
-#pragma unroll
-        for (int x = 0; x < 3; x++) {
-            st.v[S][y][x] = fabs(st.v[S][y][x]);
-            big |= st.v[S][y][x] > st.val;
-        }
-    return !big;
-}
-// front: the pixel's own 3x3 and every neighbouring interval that is in the pyramid buffer.
-// 0: not an interest point; 1: all three intervals compared; 2: interval 0 (below i = 1) / 5 (above i = 4) is not built: its nine
-// values have to be put into st.v[0] / st.v[2] (signed) before surf_nms_back
-__device__ __forceinline__ int surf_nms_front(const double *__restrict__ pyr, const SurfGeom &g, const SurfNmsParams &q, int o, int i, int r, int c,
-                                              SurfNmsState &st)
-{
-    const int nr = g.nr[o], nc = g.nc[o], b = q.border_next[i];
-    if (r < b + 1 || r >= nr - b - 1 || c < b + 1 || c >= nc - b - 1) return 0;  // :474-476
-    // the pixel's own interval first (most pixels above the threshold are not the largest of their own 3x3), loads issued back
-    // to back with no branch in between; then the neighbouring intervals.  (Neighbour-by-neighbour early exits cost a round
-    // trip per comparison; all 27 values at once fetched three times the cache lines for pixels the first nine reject.)
-    st.r = r; st.c = c;
-    const size_t at = (size_t)(r - 1) * nc + (c - 1);
-    {
-        const double *P = pyr + g.lev[o * SURF_INT + i].plane + at;
-#pragma unroll
-        for (int y = 0; y < 3; y++)
-#pragma unroll
-            for (int x = 0; x < 3; x++) st.v[1][y][x] = P[(size_t)y * nc + x];
-    }
-    st.raw = st.v[1][1][1];
-    st.val = fabs(st.raw);
-    if (!(st.val >= q.thr)) return 0;
-    // is_maximum_in_region :324-356: rejected by any strictly larger value in the 3x3x3 block
-    if (!surf_nms_neighbour_ok<1>(st)) return 0;
-    // Interval 0 (below i = 1) and interval 5 (above i = 4) are not in the buffer -- and most survivors of the pixel's own 3x3
-    // fall to the other, stored neighbour before those are needed: the stored interval first.
-    const bool low_sparse = i == 1, high_sparse = i == SURF_INT - 2;
-    auto load = [&](auto s_tag) __attribute__((always_inline)) {
-        constexpr int s = decltype(s_tag)::value;
-        const double *P = pyr + g.lev[o * SURF_INT + i - 1 + s].plane + at;
-#pragma unroll
-        for (int y = 0; y < 3; y++)
-#pragma unroll
-            for (int x = 0; x < 3; x++) st.v[s][y][x] = P[(size_t)y * nc + x];
-    };
-    using S0 = std::integral_constant<int, 0>;
-    using S2 = std::integral_constant<int, 2>;
-    if (!high_sparse) { load(S2()); if (!surf_nms_neighbour_ok<2>(st)) return 0; }
-    if (!low_sparse) { load(S0()); if (!surf_nms_neighbour_ok<0>(st)) return 0; }
-    return low_sparse || high_sparse ? 2 : 1;
-}
-// back: the interval that was filled in (state 2) against the pixel, then interpolate_point
-__device__ __forceinline__ bool surf_nms_back(const SurfGeom &g, const SurfNmsParams &q, int o, int i, int state, SurfNmsState &st, SurfRecord &rec)
-{
-    if (state == 2) {
-        if (i == 1 ? !surf_nms_neighbour_ok<0>(st) : !surf_nms_neighbour_ok<2>(st)) return false;
-    }
-    const double(&v)[3][3][3] = st.v;
-    const double val = st.val, raw = st.raw;
-    const int r = st.r, c = st.c;
-    // interpolate_point :411-446
-#define V(s, dy, dx) v[s][1 + (dy)][1 + (dx)]
-    const double g0 = (V(1, 0, 1) - V(1, 0, -1)) / 2.0;
-    const double g1 = (V(1, 1, 0) - V(1, -1, 0)) / 2.0;
-    const double g2 = (V(2, 0, 0) - V(0, 0, 0)) / 2.0;
-    const double Dxx = (V(1, 0, 1) + V(1, 0, -1)) - 2 * val;
-    const double Dyy = (V(1, 1, 0) + V(1, -1, 0)) - 2 * val;
-    const double Dss = (V(2, 0, 0) + V(0, 0, 0)) - 2 * val;
-    const double Dxy = (V(1, 1, 1) + V(1, -1, -1) - V(1, -1, 1) - V(1, 1, -1)) / 4.0;
-    const double Dxs = (V(2, 0, 1) + V(0, 0, -1) - V(0, 0, 1) - V(2, 0, -1)) / 4.0;
-    const double Dys = (V(2, 1, 0) + V(0, -1, 0) - V(0, 1, 0) - V(2, -1, 0)) / 4.0;
-#undef V
-    // inv() of the symmetric 3x3 [a b c; d e f; g h i], matrix_la.h:922-962 with det :1576-1590
-    const double ma = Dxx, mb = Dxy, mc = Dxs, md = Dxy, me = Dyy, mf = Dys, mg = Dxs, mh = Dys, mi = Dss;
-    double de = ma * (me * mi - mf * mh) - mb * (md * mi - mf * mg) + mc * (md * mh - me * mg);
-    double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
-    if (de != 0) {
-        de = 1.0 / de;
-        v00 = (me * mi - mf * mh) * de; v10 = (mf * mg - md * mi) * de; v20 = (md * mh - me * mg) * de;
-        v01 = (mc * mh - mb * mi) * de; v11 = (ma * mi - mc * mg) * de; v21 = (mb * mg - ma * mh) * de;
-        v02 = (mb * mf - mc * me) * de; v12 = (mc * md - ma * mf) * de; v22 = (ma * me - mb * md) * de;
-    }
-    const double ix = -(v00 * g0 + v01 * g1 + v02 * g2);
-    const double iy = -(v10 * g0 + v11 * g1 + v12 * g2);
-    const double iz = -(v20 * g0 + v21 * g1 + v22 * g2);
-    if (!(fmax(fabs(ix), fmax(fabs(iy), fabs(iz))) < 0.5)) return false;
-    rec.key = ((unsigned long long)(o * 8 + i) << 40) | ((unsigned long long)r << 20) | (unsigned long long)c;
-    rec.x = (c + ix) * q.step[o];
-    rec.y = (r + iy) * q.step[o];
-    const double lobe = q.pow2_o1[o] * (i + iz + 1) + 1;
-    rec.scale = 1.2 / 9.0 * (3 * lobe);
-    rec.score = val;
-    rec.laplacian = raw > 0 ? +1.0 : -1.0;  // get_laplacian :294-297
-    return true;
+    for (int k = 0; k < SURF_OCT - 1; k++) p += k < o ? (size_t)(SURF_INT - 2) * g.nr[k] * g.nc[k] : 0;
+    L.plane0 = p;
+    return L;
 }
 
-// masked form: the pyramid kernels published which level pixels reach the threshold, one bit each -- a fraction of a
-// percent in octave 0, a few percent above (measured on the bench tiles).  One launch for all octaves (q.blocks).  A
-// workgroup takes up to 256 consecutive mask words of one interval, a thread each, and turns their set bits into a dense list
-// in LDS (popcount, block scan, one entry per bit: thread << 6 | bit); the threads then share the listed pixels evenly,
-// so that the 27-value neighbourhood test runs on full waves in one memory round trip.  (A thread per level pixel spent
-// its time dispatching workgroups that read one word and left; a wave per word waited on four dependent rows.)
-#define NMS_WORDS 256
-// words per workgroup: the masks get denser with the octave (and the levels smaller): 256, 128, 64, 32 keeps the listed
-// pixels per workgroup near one per thread and the number of workgroups per octave within a factor of two of each other
-__host__ __device__ inline int surf_nms_words(int o) { return NMS_WORDS >> (o < 3 ? o : 3); }
-__host__ __device__ inline unsigned surf_nms_blocks(int nr, int nc, int o)
+// All three kernels append to lists in global memory, and a returning atomic on ONE address costs ~9 ns whoever issues it (7 680
+// waves of a first cut of surf_nms_list, one atomic each: 69 us for a kernel that moves 6 MB; the round-5 kernel's one atomic per
+// workgroup trip was a third of its time): every kernel here gathers what a whole 1024-thread workgroup appends in LDS first and
+// takes its places in the list with one atomic.
+//
+// K18a: mask bits -> keys.  A thread takes one mask word of one interval.
+#define NMS_WORDS 1024  /* mask words per workgroup of surf_nms_list */
+__host__ __device__ inline unsigned surf_nms_blocks(int nr, int nc)
 {
-    return (unsigned)(((size_t)nr * ((nc + 63) / 64) + surf_nms_words(o) - 1) / surf_nms_words(o));
+    return (unsigned)(((size_t)nr * ((nc + 63) / 64) + NMS_WORDS - 1) / NMS_WORDS);
 }
-__global__ void __launch_bounds__(NMS_WORDS) surf_nms_masked(const double *__restrict__ pyr, SurfGeom g, SurfNmsParams q,
-                                                             SurfRecord *__restrict__ out, unsigned long long *__restrict__ count,
-                                                             const unsigned long long *__restrict__ mask)
+__global__ void __launch_bounds__(NMS_WORDS) surf_nms_list(SurfGeom g, SurfNmsParams q, unsigned long long *__restrict__ cand,
+                                                           unsigned long long *__restrict__ ncand, const unsigned long long *__restrict__ mask)
 {
-    // the listed pixels of ONE trip (thread << 6 | bit): 7 KB of LDS per workgroup instead of the 42 KB the whole list (64 entries per
-    // word) took while the kernel waits for its gathers.  (Measured neutral with four lanes, 0.248-0.249 against 0.247-0.250 ms per tile.)
-    __shared__ unsigned short list[NMS_WORDS];
     __shared__ unsigned wave_sum[NMS_WORDS / 64];
-    const int o = surf_octave_of_block(q.blocks, blockIdx.x), tid = threadIdx.x, lane = tid & 63;
-    const int wpr = (g.nc[o] + 63) / 64;
-    const size_t words = (size_t)g.nr[o] * wpr;
-    const unsigned per = surf_nms_blocks(g.nr[o], g.nc[o], o), id = blockIdx.x - q.blocks.first[o];
+    __shared__ unsigned long long base_s;
+    {
+        const size_t t = blockIdx.y;
+        mask += t * q.tile_mask; cand += t * q.tile_cand; ncand += t * q.tile_count;
+    }
+    const int o = surf_octave_of_block(q.blocks, blockIdx.x), tid = threadIdx.x, lane = tid & 63;  // workgroup-uniform octave and interval
+    const int nr = g.nr[o], nc = g.nc[o];
+    const int wpr = (nc + 63) / 64;
+    const size_t words = (size_t)nr * wpr;
+    const unsigned per = surf_nms_blocks(nr, nc), id = blockIdx.x - q.blocks.first[o];
     const int i = (int)(id / per) + 1;
-    const size_t w0 = (size_t)(id % per) * surf_nms_words(o);
-    unsigned long long word = tid < surf_nms_words(o) && w0 + tid < words ? mask[g.lev[o * SURF_INT + i].mask + w0 + tid] : 0ull;
+    const size_t w = (size_t)(id % per) * NMS_WORDS + tid;
+    unsigned long long word = w < words ? mask[g.lev[o * SURF_INT + i].mask + w] : 0ull;
+    const int r = (int)(w / wpr), c0 = (int)(w % wpr) * 64;
+    // :474-476 -- a marked pixel closer than border_next + 1 to the level's edge is no candidate
+    const int b = q.border_next[i];
+    if (r < b + 1 || r >= nr - b - 1) word = 0;
+    else {
+        const int lo = b + 1 - c0, hi = nc - b - 1 - c0;  // columns [lo, hi) of this word are inside
+        if (hi <= 0 || lo >= 64) word = 0;
+        else {
+            if (lo > 0) word &= ~0ull << lo;
+            if (hi < 64) word &= (1ull << hi) - 1ull;
+        }
+    }
     const unsigned cnt = (unsigned)__popcll(word);
     unsigned incl = cnt;
 #pragma unroll
@@ -956,116 +898,208 @@ __global__ void __launch_bounds__(NMS_WORDS) surf_nms_masked(const double *__res
         if (k < (tid >> 6)) pos += wave_sum[k];
         total += wave_sum[k];
     }
-    // the records of a trip are counted in LDS and get their places in the record buffer with one atomic on the global
-    // counter per workgroup (ten thousand returning atomics on one address, one per record, were most of this kernel's time)
-    __shared__ unsigned found;
-    __shared__ unsigned long long base_rec;
-    // The workgroup handles ONE interval of ONE octave, so the interval that is not built (0 below i = 1, 5 above i = 4) is the
-    // same for all its pixels: every lane keeps the offset (dy, dx) and the coefficient of ONE of the 32 look-ups of a
-    // level-pixel value (box = t / 4, corner = t % 4; Dxx = wide - 3 narrow in lanes 0-7, Dyy in 8-15, Dxy in 16-31), and a group
-    // of 32 lanes computes the nine values a survivor needs -- nine loads per lane in ONE round trip, three segmented sums per
-    // value -- instead of 288 dependent look-ups in whatever lanes the survivors happen to sit (69 -> 51 us per tile, round 5).
-    const bool coop = i == 1 || i == SURF_INT - 2;  // workgroup-uniform
-    const SurfLevel &Ls = g.lev[o * SURF_INT + (i == 1 ? 0 : SURF_INT - 1)];
-    const int t32 = tid & 31;
-    int tap_dy = 0, tap_dx = 0;
-    unsigned tap_coef = 0;
-    if (coop) {
-        const int lobe = Ls.lobe, off = Ls.off, bb = t32 >> 2, k = t32 & 3;
-        int cx = 0, cy = 0, w = lobe, h = lobe, coef = 1;
-        if (bb == 0) { w = 3 * lobe; h = 2 * lobe - 1; }
-        else if (bb == 1) { w = lobe; h = 2 * lobe - 1; coef = -3; }
-        else if (bb == 2) { w = 2 * lobe - 1; h = 3 * lobe; }
-        else if (bb == 3) { w = 2 * lobe - 1; h = lobe; coef = -3; }
-        else if (bb == 4) { cx = -off; cy = off; }
-        else if (bb == 5) { cx = off; cy = -off; }
-        else if (bb == 6) { cx = -off; cy = -off; coef = -1; }
-        else { cx = off; cy = off; coef = -1; }
-        const int l = cx - w / 2, tp = cy - h / 2, rr = l + w - 1, bt = tp + h - 1;  // centered_rect relative to the centre
-        tap_dy = k < 2 ? bt : tp - 1;
-        tap_dx = (k & 1) ? l - 1 : rr;
-        tap_coef = (unsigned)((k == 0 || k == 3) ? coef : -coef);   // br - bl - tr + tl
+    if (!total) return;  // workgroup-uniform
+    if (tid == 0) base_s = atomicAdd(ncand, (unsigned long long)total);
+    __syncthreads();
+    unsigned long long at = base_s + pos;
+    const unsigned long long key0 = ((unsigned long long)(o * 8 + i) << 40) | ((unsigned long long)r << 20) | (unsigned long long)c0;
+    while (word) {
+        const int bit = __ffsll((long long)word) - 1;
+        word &= word - 1;
+        if (at < q.cand_cap) cand[at] = key0 + (unsigned long long)bit;
+        at++;
     }
-    constexpr int PEND = 64;  // survivors whose unbuilt interval is computed per round
-    __shared__ int pend_r[NMS_WORDS], pend_c[NMS_WORDS];
-    __shared__ unsigned npend;
-    __shared__ double sv[PEND][9];
-    for (unsigned k0 = 0; k0 < total; k0 += NMS_WORDS) {  // uniform trip count: barriers inside
-        if (tid == 0) { found = 0; npend = 0; }
-        // this trip's entries: the set bits whose place in the workgroup's order is k0 .. k0 + NMS_WORDS - 1 (a thread's bits are
-        // consecutive places from `pos` on: it hands them out trip by trip)
-        while (word && pos < k0 + NMS_WORDS) {
-            const int bit = __ffsll((long long)word) - 1;
-            word &= word - 1;
-            list[pos++ - k0] = (unsigned short)(tid << 6 | bit);
-        }
-        __syncthreads();
-        SurfRecord rec;
-        SurfNmsState st;
-        int state = 0;
-        unsigned slot = 0, my_pend = 0;
-        if (k0 + tid < total) {
-            const unsigned e = list[tid];
-            const size_t w = w0 + (e >> 6);
-            state = surf_nms_front(pyr, g, q, o, i, (int)(w / wpr), (int)(w % wpr) * 64 + (int)(e & 63), st);
-            if (state == 2) {
-                my_pend = atomicAdd(&npend, 1u);
-                pend_r[my_pend] = st.r;
-                pend_c[my_pend] = st.c;
-            }
-        }
-        if (coop) {  // workgroup-uniform
+}
+
+// K18b: a thread per candidate.  The pixel's own 3x3 first (most marked pixels are not the largest of their own 3x3), then the 3x3
+// of every neighbouring interval that is in the pyramid buffer, nine loads back to back per step and nothing kept between the
+// steps: a pixel that no STORED value beats is appended to the survivor list.
+// the 3x3 around (r, c) of one stored level: true = no value there is strictly larger in magnitude than val
+__device__ __forceinline__ bool surf_nms_3x3_ok(const double *__restrict__ P, int nc, double val)
+{
+    double v[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) v[k] = P[(size_t)(k / 3) * nc + (k % 3)];
+    bool big = false;
+#pragma unroll
+    for (int k = 0; k < 9; k++) big |= fabs(v[k]) > val;
+    return !big;
+}
+#define NS_NT 512    /* threads of surf_nms_screen */
+#define NS_KEEP 1024 /* survivors a workgroup gathers in LDS before it takes places in the list */
+__global__ void __launch_bounds__(NS_NT) surf_nms_screen(const double *__restrict__ pyr, SurfGeom g, SurfNmsParams q,
+                                                         const unsigned long long *__restrict__ cand, const unsigned long long *__restrict__ ncand,
+                                                         unsigned long long *__restrict__ surv, unsigned long long *__restrict__ nsurv)
+{
+    __shared__ unsigned long long kept[NS_KEEP];
+    __shared__ unsigned nkept;
+    __shared__ unsigned long long base_s;
+    {
+        const size_t t = blockIdx.y;
+        pyr += t * q.tile_pyr; cand += t * q.tile_cand; ncand += t * q.tile_count; surv += t * q.tile_surv; nsurv += t * q.tile_count;
+    }
+    const unsigned long long n_all = *ncand;
+    const unsigned long long n = n_all < q.cand_cap ? n_all : q.cand_cap;
+    const int tid = threadIdx.x;
+    if (tid == 0) nkept = 0;
+    __syncthreads();
+    auto flush = [&]() {  // every thread of the workgroup
+        const unsigned m = nkept;
+        if (m) {
+            if (tid == 0) base_s = atomicAdd(nsurv, (unsigned long long)m);
             __syncthreads();
-            const unsigned np = npend;
-            for (unsigned base = 0; base < np; base += PEND) {
-                const unsigned lim = min(np, base + PEND);
-                // a wave takes two survivors at a time (one per half): entries base + 2 * wave + half, stepping by 2 * waves
-                for (unsigned e0 = base + 2 * (tid >> 6); e0 < lim; e0 += 2 * (NMS_WORDS / 64)) {
-                    const unsigned e = e0 + ((tid >> 5) & 1);
-                    const bool active = e < lim;
-                    const int pr = active ? pend_r[e] : pend_r[base], pc = active ? pend_c[e] : pend_c[base];
-                    const int step = Ls.step;
-                    const int ty = (pr - 1) * step + tap_dy, tx = (pc - 1) * step + tap_dx;  // this lane's look-up for the value at (pr - 1, pc - 1)
-                    unsigned term[9];
+            for (unsigned e = tid; e < m; e += NS_NT)
+                if (base_s + e < q.cap) surv[base_s + e] = kept[e];
+            __syncthreads();
+            if (tid == 0) nkept = 0;
+        }
+        __syncthreads();
+    };
+    for (unsigned long long k0 = (unsigned long long)blockIdx.x * NS_NT; k0 < n; k0 += (unsigned long long)gridDim.x * NS_NT) {  // workgroup-uniform trips
+        const unsigned long long k = k0 + tid;
+        if (k < n) {
+            const unsigned long long key = cand[k];
+            const int o = (int)(key >> 43) & 7, i = (int)(key >> 40) & 7, r = (int)(key >> 20) & 0xfffff, c = (int)(key & 0xfffff);
+            const SurfLaneLevel L = surf_lane_level(g, o);
+            const size_t lvl = (size_t)L.nr * L.nc;
+            const double *own = pyr + L.plane0 + (size_t)(i - 1) * lvl + (size_t)(r - 1) * L.nc + (c - 1);
+            const double val = fabs(own[L.nc + 1]);
+            // is_maximum_in_region :324-356: rejected by any strictly larger value in the 3x3x3 block; the stored part of it here
+            bool keep = val >= q.thr && surf_nms_3x3_ok(own, L.nc, val);
+            if (keep && i < SURF_INT - 2) keep = surf_nms_3x3_ok(own + lvl, L.nc, val);  // interval 5 is not built
+            if (keep && i > 1) keep = surf_nms_3x3_ok(own - lvl, L.nc, val);             // nor is interval 0
+            if (keep) kept[atomicAdd(&nkept, 1u)] = key;  // (at most NS_NT per trip, and a trip starts with at most NS_KEEP - NS_NT)
+        }
+        __syncthreads();
+        if (nkept > NS_KEEP - NS_NT) flush();  // workgroup-uniform
+    }
+    flush();
+}
+
+// one level-pixel value of the Hessian pyramid straight from the integral image (build_pyramid, hessian_pyramid.h:119-171): the
+// determinant with the sign of the trace at the level pixel whose centre is image (r, c)
+__device__ __forceinline__ double surf_level_value(const SurfTable &T, int lobe, double area_inv, int r, int c)
+{
+    const int off = lobe / 2 + 1;
+    auto box = [&](int cx, int cy, int w, int h) __attribute__((always_inline)) -> unsigned {  // centered_rect relative to the centre
+        const int l = c + cx - w / 2, t = r + cy - h / 2, rr = l + w - 1, b = t + h - 1;
+        return T.at(b, rr) - T.at(b, l - 1) - T.at(t - 1, rr) + T.at(t - 1, l - 1);
+    };
+    // wide - 3 narrow in wrap-around arithmetic = the exact integer (surf_dxx)
+    double Dxx = (double)(int)(box(0, 0, lobe * 3, 2 * lobe - 1) - 3u * box(0, 0, lobe, 2 * lobe - 1));
+    double Dyy = (double)(int)(box(0, 0, 2 * lobe - 1, lobe * 3) - 3u * box(0, 0, 2 * lobe - 1, lobe));
+    double Dxy = (double)(int)(box(-off, off, lobe, lobe) + box(off, -off, lobe, lobe) - box(-off, -off, lobe, lobe) - box(off, off, lobe, lobe));
+    Dxx *= area_inv; Dyy *= area_inv; Dxy *= area_inv;
+    double sign = +1;
+    if (Dxx + Dyy < 0) sign = -1;
+    double det = Dxx * Dyy - 0.81 * Dxy * Dxy;
+    if (det < 0) det = 0;
+    return sign * det;
+}
+
+#define NF_NT 256
+#define NF_SURV (NF_NT / 9)  /* survivors per workgroup trip of surf_nms_finish: 9 threads each */
+__global__ void __launch_bounds__(NF_NT) surf_nms_finish(const double *__restrict__ pyr, SurfGeom g, SurfNmsParams q,
+                                                         const unsigned long long *__restrict__ surv, const unsigned long long *__restrict__ nsurv,
+                                                         SurfRecord *__restrict__ out, unsigned long long *__restrict__ count)
+{
+    __shared__ double v[NF_SURV][3][9];  // |value| [interval below, own, above][position]
+    __shared__ double raw_s[NF_SURV];
+    __shared__ unsigned nhit;
+    __shared__ unsigned long long base_s;
+    {
+        const size_t t = blockIdx.y;
+        pyr += t * q.tile_pyr; surv += t * q.tile_surv; nsurv += t * q.tile_count; out += t * q.tile_rec; count += t * q.tile_count;
+        q.integral.p += t * q.tile_table;
+    }
+    const int tid = threadIdx.x, s = tid / 9, j = tid - 9 * s;
+    const unsigned long long ns_all = *nsurv;
+    if (ns_all > q.cap) {  // more survivors than their list holds: report it the way too many records are reported (the caller redoes the tile)
+        if (blockIdx.x == 0 && tid == 0) *count = ns_all;
+        return;
+    }
+    const unsigned ns = (unsigned)ns_all;
+    for (unsigned base = blockIdx.x * NF_SURV; base < ns; base += gridDim.x * NF_SURV) {  // workgroup-uniform trips
+        const bool live = s < NF_SURV && base + s < ns;
+        int o = 0, i = 0, r = 0, c = 0;
+        if (tid == 0) nhit = 0;
+        if (live) {
+            const unsigned long long key = surv[base + s];
+            o = (int)(key >> 43) & 7; i = (int)(key >> 40) & 7; r = (int)(key >> 20) & 0xfffff; c = (int)(key & 0xfffff);
+            const SurfLaneLevel L = surf_lane_level(g, o);
+            const int pr = r - 1 + j / 3, pc = c - 1 + j % 3;  // this thread's position of the 3x3
+            const size_t at = (size_t)pr * L.nc + pc, lvl = (size_t)L.nr * L.nc;
 #pragma unroll
-                    for (int n = 0; n < 9; n++) term[n] = q.integral.at(ty + (n / 3) * step, tx + (n % 3) * step);  // nine loads in flight
-                    unsigned mine_xx = 0, mine_yy = 0, mine_xy = 0;
-#pragma unroll
-                    for (int n = 0; n < 9; n++) {
-                        unsigned a = term[n] * tap_coef;  // wrap-around (unsigned) arithmetic: the box sums come out exact (surf_dxx)
-                        a += (unsigned)__shfl_xor((int)a, 1); a += (unsigned)__shfl_xor((int)a, 2); a += (unsigned)__shfl_xor((int)a, 4);   // the 8 look-ups of a lane group
-                        const unsigned a16 = a + (unsigned)__shfl_xor((int)a, 8);                  // Dxy: 16 look-ups
-                        const int half = (int)(tid & 32);
-                        const unsigned xx = (unsigned)__shfl((int)a, half + 0), yy = (unsigned)__shfl((int)a, half + 8), xy = (unsigned)__shfl((int)a16, half + 16);
-                        if (t32 == n) { mine_xx = xx; mine_yy = yy; mine_xy = xy; }
-                    }
-                    if (active && t32 < 9) {  // lanes 0..8 of the half finish one value each (hessian_pyramid.h:153-171)
-                        double Dxx = (double)(int)mine_xx, Dyy = (double)(int)mine_yy, Dxy = (double)(int)mine_xy;
-                        Dxx *= Ls.area_inv; Dyy *= Ls.area_inv; Dxy *= Ls.area_inv;
-                        double sign = +1;
-                        if (Dxx + Dyy < 0) sign = -1;
-                        double det = Dxx * Dyy - 0.81 * Dxy * Dxy;
-                        if (det < 0) det = 0;
-                        sv[e - base][t32] = sign * det;
-                    }
+            for (int d = 0; d < 3; d++) {
+                const int it = i - 1 + d;
+                double w;
+                if (it >= 1 && it <= SURF_INT - 2) w = pyr[L.plane0 + (size_t)(it - 1) * lvl + at];
+                else {  // hessian_pyramid.h:119-128 for this lane's (octave, interval); positions inside border_next are valid in every interval
+                    const int step = 2 << o, lobe = step * (it + 1) + 1;
+                    const double tl = 3.0 * lobe;
+                    w = surf_level_value(q.integral, lobe, 1.0 / (tl * tl), pr * step, pc * step);
                 }
-                __syncthreads();
-                if (state == 2 && my_pend >= base && my_pend < lim) {
-#pragma unroll
-                    for (int n = 0; n < 9; n++) {
-                        const double w = sv[my_pend - base][n];
-                        if (i == 1) st.v[0][n / 3][n % 3] = w; else st.v[2][n / 3][n % 3] = w;
-                    }
-                }
-                __syncthreads();
+                if (d == 1 && j == 4) raw_s[s] = w;
+                v[s][d][j] = fabs(w);
             }
         }
-        bool hit = state != 0 && surf_nms_back(g, q, o, i, state, st, rec);
-        if (hit) slot = atomicAdd(&found, 1u);
         __syncthreads();
-        if (tid == 0 && found) base_rec = atomicAdd(count, (unsigned long long)found);
+        bool hit = false;
+        unsigned slot = 0;
+        SurfRecord rec;
+        if (live && j == 0) {
+            const double val = v[s][1][4], raw = raw_s[s];
+            bool ok = true;
+            if (i == 1 || i == SURF_INT - 2) {  // the interval that was computed here has not been compared yet
+                const int d = i == 1 ? 0 : 2;
+#pragma unroll
+                for (int k = 0; k < 9; k++) ok &= !(v[s][d][k] > val);
+            }
+            if (ok) {
+                // interpolate_point :411-446 (on the absolute values, as is_maximum_in_region left them)
+#define V(d, dy, dx) v[s][d][3 * (1 + (dy)) + 1 + (dx)]
+                const double g0 = (V(1, 0, 1) - V(1, 0, -1)) / 2.0;
+                const double g1 = (V(1, 1, 0) - V(1, -1, 0)) / 2.0;
+                const double g2 = (V(2, 0, 0) - V(0, 0, 0)) / 2.0;
+                const double Dxx = (V(1, 0, 1) + V(1, 0, -1)) - 2 * val;
+                const double Dyy = (V(1, 1, 0) + V(1, -1, 0)) - 2 * val;
+                const double Dss = (V(2, 0, 0) + V(0, 0, 0)) - 2 * val;
+                const double Dxy = (V(1, 1, 1) + V(1, -1, -1) - V(1, -1, 1) - V(1, 1, -1)) / 4.0;
+                const double Dxs = (V(2, 0, 1) + V(0, 0, -1) - V(0, 0, 1) - V(2, 0, -1)) / 4.0;
+                const double Dys = (V(2, 1, 0) + V(0, -1, 0) - V(0, 1, 0) - V(2, -1, 0)) / 4.0;
+#undef V
+                // inv() of the symmetric 3x3 [a b c; d e f; g h i], matrix_la.h:922-962 with det :1576-1590
+                const double ma = Dxx, mb = Dxy, mc = Dxs, md = Dxy, me = Dyy, mf = Dys, mg = Dxs, mh = Dys, mi = Dss;
+                double de = ma * (me * mi - mf * mh) - mb * (md * mi - mf * mg) + mc * (md * mh - me * mg);
+                double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
+                if (de != 0) {
+                    de = 1.0 / de;
+                    v00 = (me * mi - mf * mh) * de; v10 = (mf * mg - md * mi) * de; v20 = (md * mh - me * mg) * de;
+                    v01 = (mc * mh - mb * mi) * de; v11 = (ma * mi - mc * mg) * de; v21 = (mb * mg - ma * mh) * de;
+                    v02 = (mb * mf - mc * me) * de; v12 = (mc * md - ma * mf) * de; v22 = (ma * me - mb * md) * de;
+                }
+                const double ix = -(v00 * g0 + v01 * g1 + v02 * g2);
+                const double iy = -(v10 * g0 + v11 * g1 + v12 * g2);
+                const double iz = -(v20 * g0 + v21 * g1 + v22 * g2);
+                if (fmax(fabs(ix), fmax(fabs(iy), fabs(iz))) < 0.5) {
+                    rec.key = ((unsigned long long)(o * 8 + i) << 40) | ((unsigned long long)r << 20) | (unsigned long long)c;
+                    const double step = (double)(2 << o);  // get_step_size(o) = 2 * 2^o = std::pow(2.0, o + 1.0)
+                    rec.x = (c + ix) * step;
+                    rec.y = (r + iy) * step;
+                    const double lobe = step * (i + iz + 1) + 1;
+                    rec.scale = 1.2 / 9.0 * (3 * lobe);
+                    rec.score = val;
+                    rec.laplacian = raw > 0 ? +1.0 : -1.0;  // get_laplacian :294-297
+                    hit = true;
+                    slot = atomicAdd(&nhit, 1u);
+                }
+            }
+        }
         __syncthreads();
-        if (hit && base_rec + slot < q.cap) out[base_rec + slot] = rec;
+        if (tid == 0 && nhit) base_s = atomicAdd(count, (unsigned long long)nhit);  // the records of a trip take their places with one atomic
+        __syncthreads();
+        if (hit && base_s + slot < q.cap) out[base_s + slot] = rec;
+        __syncthreads();
     }
 }
 
@@ -1095,6 +1129,8 @@ struct SurfRankParams {
     double *feat;            // lim x 70 feature records of this tile
     long long *count_out;    // d_counts[f]
     unsigned *m_out;         // the same number for the K19 kernels
+    // blockIdx.x = tile of a group: distances between consecutive tiles' buffers, in elements (count_out, m_out: 1)
+    size_t tile_rec, tile_count, tile_sel, tile_cand, tile_pts, tile_feat;
 };
 
 __device__ __forceinline__ unsigned long long surf_score_bits(double v)
@@ -1129,6 +1165,11 @@ __global__ void __launch_bounds__(SR_NT) surf_rank_select(SurfRankParams q)
     __shared__ unsigned long long st_s[SR_SORT], st_k[SR_SORT];
     __shared__ unsigned sidx[SR_SORT];
     const int tid = threadIdx.x;
+    {
+        const size_t t = blockIdx.x;
+        q.rec += t * q.tile_rec; q.count += t * q.tile_count; q.sel += t * q.tile_sel; q.order += t * q.tile_sel; q.cand += t * q.tile_cand;
+        q.pts += t * q.tile_pts; q.feat += t * q.tile_feat; q.count_out += t; q.m_out += t;
+    }
     const unsigned long long cnt = *q.count;
     if (cnt > q.cap) {  // more candidates than the record buffer holds: report, leave the feature rows alone
         if (tid == 0) { *q.count_out = -(long long)cnt; *q.m_out = 0; }
@@ -1318,11 +1359,12 @@ __global__ void __launch_bounds__(SR_NT) surf_rank_select(SurfRankParams q)
 
 // surf_describe.hip
 // m_dev != nullptr: m is an upper bound (the grid); the number of points is read from *m_dev on the device
+// grp != nullptr: one launch for a group of tiles (blockIdx.y), their buffers SurfGroup's strides apart
 imgfd_status launch_surf_orient(imgfd_ctx *ctx, const SurfTable &T, const double *d_pts, int m,
-                                double *d_samples, double *d_trig, const unsigned *m_dev = nullptr);
+                                double *d_samples, double *d_trig, const unsigned *m_dev = nullptr, const SurfGroup *grp = nullptr);
 imgfd_status launch_surf_desc(imgfd_ctx *ctx, const SurfTable &T, const double *d_pts,
                               const double *d_trig, int m, double *d_des, int des_stride, double *d_angle,
-                              const unsigned *m_dev = nullptr);
+                              const unsigned *m_dev = nullptr, const SurfGroup *grp = nullptr);
 
 namespace {
 
@@ -1332,7 +1374,11 @@ struct SurfDevice {
     double *pyr = nullptr;
     size_t pyr_bytes = 0;
     SurfRecord *rec = nullptr;
-    unsigned long long *count = nullptr;
+    unsigned long long *count = nullptr;  // records found
+    unsigned long long *cands = nullptr;  // keys of the marked level pixels (surf_nms_list -> surf_nms_screen), cand_cap entries
+    unsigned long long cand_cap = 0;      //   = the built level pixels of the pyramid: a threshold of 0 marks them all
+    unsigned long long *surv = nullptr;   // keys of the level pixels no stored value beats (surf_nms_screen -> surf_nms_finish), cap entries
+    // counters: count[0] records found, count[1] survivors, count[2] candidates (one 256-byte slot)
     unsigned long long cap = 0;
 };
 
@@ -1352,7 +1398,7 @@ size_t surf_ws_bytes(const SurfGeom &g, size_t pyr_total, unsigned long long cap
 {
     const size_t n = (size_t)g.rows * g.cols;
     return align_up(3 * n, 256) + align_up(4 * n, 256) + align_up(surf_pyr_bytes(g, pyr_total), 256) + align_up(8 * std::max<size_t>(g.mask_words, 1), 256) +
-           align_up(sizeof(SurfRecord) * cap, 256) + 4096;
+           align_up(sizeof(SurfRecord) * cap, 256) + align_up(sizeof(unsigned long long) * cap, 256) + align_up(8 * std::max<size_t>(pyr_total, 1), 256) + 4096;
 }
 
 // K16 on the context's stream.  allow_residue: the band / strip form may write the table in the residue layout (SurfTable; the
@@ -1399,18 +1445,26 @@ SurfTable launch_surf_integral(imgfd_ctx *ctx, const uint8_t *d_rgb, unsigned *d
     return T;
 }
 
-// K16-K18 for one image already in device memory; leaves the records (unordered) + count on the device and says in *table where
-// and how the integral image lies.
+// Launches of a scope go to stream `s` instead of the context's own (the launch helpers of this library take the stream from the
+// context; a context is used by one host thread at a time)
+struct SurfStreamScope {
+    imgfd_ctx *c;
+    hipStream_t old;
+    SurfStreamScope(imgfd_ctx *ctx, hipStream_t s) : c(ctx), old(ctx->stream) { ctx->stream = s; }
+    ~SurfStreamScope() { c->stream = old; }
+};
+
+// FRONT of a tile: K16 + K17, the kernels that fill the chip (integral image, Hessian pyramid + threshold masks), on the context's
+// stream; says in *table where and how the integral image lies.
 // fork (optional): the context's companion.  Octave 0 and octaves 1-3 are two kernels that both read the finished table and
 // write different planes: with a companion at hand (a call with ONE tile has no other tile to fill the chip with) the second
-// runs on its stream beside the first -- a VALU / LDS bound kernel next to one that waits for its gathers -- and the maximum
-// test waits for both ("surf_split").
-imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const SurfGeom &g, double thr, const SurfDevice &d, SurfTable *table,
-                                imgfd_ctx *fork = nullptr)
+// runs on its stream beside the first -- a VALU / LDS bound kernel next to one that waits for its gathers -- and whatever is
+// queued on the context's stream next waits for both ("surf_split").
+imgfd_status surf_front(imgfd_ctx *ctx, const uint8_t *d_rgb, const SurfGeom &g, double thr, const SurfDevice &d, SurfTable *table,
+                        imgfd_ctx *fork = nullptr)
 {
     const SurfTable T = launch_surf_integral(ctx, d_rgb, d.integral, g.rows, g.cols, d.pyr, d.pyr_bytes, true);
     if (table) *table = T;
-    IMGFD_HIP(ctx, hipMemsetAsync(d.count, 0, sizeof(unsigned long long), ctx->stream));
     static_assert(SURF_INT == 6 && SURF_OCT == 4, "dlib's build_pyramid(img, 4, 6, 2): the kernels unroll its geometry");
     const SurfBands bands = surf_bands(g);
     hipStream_t upper = ctx->stream;  // the stream of the gather kernel (octaves 1-3)
@@ -1436,21 +1490,59 @@ imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const Surf
         IMGFD_HIP(ctx, hipEventRecord(ctx->ev_gate2, upper));
         IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_gate2, 0));
     }
+    IMGFD_HIP(ctx, hipGetLastError());
+    return IMGFD_OK;
+}
+
+// BACK, first part: K18 (maximum test + interpolation from the masks) on the context's stream, ONE launch for the `tiles` tiles of a
+// group (d = the first tile's buffers, d_next = the second's: the distances between consecutive sets); leaves the records
+// (unordered) + counts on the device.  Latency-bound (a chain of dependent round trips per workgroup, issue 0.09), like the
+// ranking and K19 behind it.
+imgfd_status surf_back_nms(imgfd_ctx *ctx, const SurfGeom &g, double thr, const SurfDevice &d, const SurfTable &T, int tiles = 1,
+                           const SurfDevice *d_next = nullptr)
+{
     SurfNmsParams q;
-    q.thr = thr; q.cap = d.cap;
+    q.thr = thr; q.cap = d.cap; q.cand_cap = d.cand_cap;
     q.integral = T;
+    q.tile_pyr = q.tile_mask = q.tile_rec = q.tile_count = q.tile_table = q.tile_surv = q.tile_cand = 0;
+    if (tiles > 1 && d_next) {
+        q.tile_pyr = (size_t)(d_next->pyr - d.pyr); q.tile_mask = (size_t)(d_next->mask - d.mask); q.tile_rec = (size_t)(d_next->rec - d.rec);
+        q.tile_count = (size_t)(d_next->count - d.count); q.tile_table = (size_t)(d_next->integral - d.integral);
+        q.tile_surv = (size_t)(d_next->surv - d.surv); q.tile_cand = (size_t)(d_next->cands - d.cands);
+        // the counter slots of a group lie side by side (256 bytes per tile, imgfd_surf_dev): one memset
+        if (q.tile_count * sizeof(unsigned long long) != 256) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "surf_back_nms: the counters of a group must be 256 bytes apart");
+    }
+    IMGFD_HIP(ctx, hipMemsetAsync(d.count, 0, 256 * (size_t)tiles, ctx->stream));
     for (int i = 0; i < SURF_INT; i++) q.border_next[i] = (int)surf_border_of(std::min(i + 1, SURF_INT - 1));
     unsigned nb = 0;
     for (int o = 0; o < SURF_OCT; o++) {
-        q.pow2_o1[o] = pow(2.0, o + 1.0);
-        q.step[o] = (double)surf_step_of(o);
         q.blocks.first[o] = nb;
-        if (g.nr[o] >= 1 && g.nc[o] >= 1) nb += surf_nms_blocks(g.nr[o], g.nc[o], o) * (SURF_INT - 2);
+        if (g.nr[o] >= 1 && g.nc[o] >= 1) nb += surf_nms_blocks(g.nr[o], g.nc[o]) * (SURF_INT - 2);
     }
     q.blocks.first[SURF_OCT] = nb;
-    if (nb) hipLaunchKernelGGL(surf_nms_masked, dim3(nb), dim3(NMS_WORDS), 0, ctx->stream, d.pyr, g, q, d.rec, d.count, (const unsigned long long *)d.mask);
+    if (nb) {
+        unsigned long long *ncount = d.count;  // [0] records, [1] survivors, [2] candidates
+        hipLaunchKernelGGL(surf_nms_list, dim3(nb, (unsigned)tiles), dim3(NMS_WORDS), 0, ctx->stream, g, q, d.cands, ncount + 2, (const unsigned long long *)d.mask);
+        // grids that cover full lists in a few trips per workgroup; the numbers of candidates and survivors are read on the device
+        const unsigned scr = (unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>(512, (d.cand_cap + NS_NT - 1) / NS_NT));
+        hipLaunchKernelGGL(surf_nms_screen, dim3(scr, (unsigned)tiles), dim3(NS_NT), 0, ctx->stream, (const double *)d.pyr, g, q, (const unsigned long long *)d.cands,
+                           (const unsigned long long *)(ncount + 2), d.surv, ncount + 1);
+        const unsigned fin = (unsigned)std::max<unsigned long long>(1, std::min<unsigned long long>(1024, (d.cap + NF_SURV - 1) / NF_SURV));
+        hipLaunchKernelGGL(surf_nms_finish, dim3(fin, (unsigned)tiles), dim3(NF_NT), 0, ctx->stream, (const double *)d.pyr, g, q, (const unsigned long long *)d.surv,
+                           (const unsigned long long *)(ncount + 1), d.rec, ncount);
+    }
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
+}
+
+// K16-K18 for one image already in device memory, one after the other on the context's stream
+imgfd_status surf_device_stages(imgfd_ctx *ctx, const uint8_t *d_rgb, const SurfGeom &g, double thr, const SurfDevice &d, SurfTable *table,
+                                imgfd_ctx *fork = nullptr)
+{
+    SurfTable T;
+    IMGFD_TRY(surf_front(ctx, d_rgb, g, thr, d, &T, fork));
+    if (table) *table = T;
+    return surf_back_nms(ctx, g, thr, d, T);
 }
 
 // uploads the image, runs the device stages, returns the interest points in the reference's emission order
@@ -1475,8 +1567,11 @@ imgfd_status surf_points_host(imgfd_ctx *ctx, const void *rgb, int kind, int row
         d.pyr_bytes = surf_pyr_bytes(g, total);
         d.pyr = (double *)ws_alloc(ctx, d.pyr_bytes);
         d.rec = (SurfRecord *)ws_alloc(ctx, sizeof(SurfRecord) * d.cap);
+        d.surv = (unsigned long long *)ws_alloc(ctx, sizeof(unsigned long long) * d.cap);
+        d.cand_cap = std::max<size_t>(total, 1);
+        d.cands = (unsigned long long *)ws_alloc(ctx, 8 * (size_t)d.cand_cap);
         d.count = (unsigned long long *)ws_alloc(ctx, 256);
-        if (!d_rgb || !d.integral || !d.mask || !d.pyr || !d.rec || !d.count) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+        if (!d_rgb || !d.integral || !d.mask || !d.pyr || !d.rec || !d.surv || !d.cands || !d.count) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
         IMGFD_TRY(upload_image(ctx, rgb, kind, 3 * n, d_rgb));
         imgfd_ctx *fork = nullptr;
         if (ctx->tune.surf_split) IMGFD_TRY(ctx_side(ctx, &fork));
@@ -1652,21 +1747,189 @@ imgfd_status imgfd_surf_points_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_f
     SurfGeom g;
     const size_t total = surf_geometry(rows, cols, &g);
     const size_t n = (size_t)rows * cols;
-    IMGFD_TRY(ws_reserve(ctx, align_up(4 * n, 256) + align_up(8 * std::max<size_t>(g.mask_words, 1), 256) + align_up(surf_pyr_bytes(g, total), 256) + 4096));
+    IMGFD_TRY(ws_reserve(ctx, align_up(4 * n, 256) + align_up(8 * std::max<size_t>(g.mask_words, 1), 256) + align_up(surf_pyr_bytes(g, total), 256) +
+                              align_up(sizeof(unsigned long long) * (size_t)cap, 256) + align_up(8 * std::max<size_t>(total, 1), 256) + 4096));
     SurfDevice d;
     d.integral = (unsigned *)ws_alloc(ctx, 4 * n);
     d.mask = (unsigned long long *)ws_alloc(ctx, 8 * std::max<size_t>(g.mask_words, 1));
     d.pyr_bytes = surf_pyr_bytes(g, total);
     d.pyr = (double *)ws_alloc(ctx, d.pyr_bytes);
-    if (!d.integral || !d.mask || !d.pyr) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+    d.surv = (unsigned long long *)ws_alloc(ctx, sizeof(unsigned long long) * (size_t)cap);
+    d.cand_cap = std::max<size_t>(total, 1);
+    d.cands = (unsigned long long *)ws_alloc(ctx, 8 * (size_t)d.cand_cap);
+    d.count = (unsigned long long *)ws_alloc(ctx, 256);
+    if (!d.integral || !d.mask || !d.pyr || !d.surv || !d.cands || !d.count) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
     d.cap = (unsigned long long)cap;
     imgfd_ctx *fork = nullptr;
     if (ctx->tune.surf_split) IMGFD_TRY(ctx_side(ctx, &fork));
     for (int f = 0; f < n_frames; f++) {  // tiles are processed back to back on the context's stream, no host sync
         d.rec = reinterpret_cast<SurfRecord *>(d_points) + (size_t)f * cap;
-        d.count = reinterpret_cast<unsigned long long *>(d_counts) + f;
         IMGFD_TRY(surf_device_stages(ctx, d_rgb + (size_t)f * frame_stride_bytes, g, detection_threshold, d, nullptr, fork));
+        IMGFD_HIP(ctx, hipMemcpyAsync(d_counts + f, d.count, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));  // (the counter slot also holds the lists' lengths)
     }
+    return IMGFD_OK;
+}
+
+// imgfd_surf_dev / imgfd_surf_dev_redo.  `only` (redo): the tiles to run, with the record capacity each asked for; else all tiles.
+//
+// Schedule.  A tile is a chain of ten kernels: a FRONT that fills the chip (integral image 3 kernels, first octave, octaves 1-3:
+// ~210 us one after the other on a 4096^2 tile, streaming the tile and its table) and a BACK of latency-bound kernels that do not
+// (maximum test 54 us at issue 0.09, ranking 50 us in ONE workgroup, orientation 22, descriptor 33: chains of dependent scattered
+// reads).  Rounds 3-5 ran whole chains on up to four streams ("lanes"): the small kernels of one tile were to fill the gaps of the
+// other tiles' big ones -- but lanes that start together stay in step, beside another tile's gathers every streaming kernel ran
+// at a quarter of its own rate (surf_int_sums 48-94 us instead of 13), and 0.222 ms per tile came out where the fronts alone take
+// 0.144 (profiles/r06/surf_leave_one_out.txt, surf_timeline_two_lanes.txt).  Round 6: tiles go in GROUPS ("surf_group", 8).  The
+// fronts of a group run one after the other on two streams ("surf_lanes", 2: the first octave's kernel beside the next tile's
+// scans), every tile into a buffer set of its own; then the back of the WHOLE group is four launches -- maximum test, ranking
+// (a workgroup per tile: eight in flight instead of one), orientation, descriptor, blockIdx.y = tile -- so that the
+// latency-bound kernels fill the chip with eight tiles' worth of independent chains and never sit beside a streaming kernel.
+static imgfd_status surf_dev_run(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, int rows, int cols, size_t frame_stride_bytes,
+                                 long max_points, double detection_threshold, double *d_features, int64_t cap, int64_t *d_counts,
+                                 const std::vector<std::pair<int, unsigned long long>> *only)
+{
+    IMGFD_HIP(ctx, hipSetDevice(ctx->device));
+    SurfGeom g;
+    const size_t total = surf_geometry(rows, cols, &g);
+    const size_t n = (size_t)rows * cols;
+    const int n_run = only ? (int)only->size() : n_frames;
+    if (!n_run) return IMGFD_OK;
+    constexpr int MAX_LANES = 4, MAX_GROUP = 16;
+    const int G = only ? 1 : std::max(1, std::min(std::min(ctx->tune.surf_group, MAX_GROUP), n_run));  // tiles per group
+    const int nlanes = std::max(1, std::min(std::min(ctx->tune.surf_lanes, MAX_LANES), G));             // front streams
+    imgfd_ctx *lane[MAX_LANES];
+    lane[0] = ctx;
+    for (int l = 1; l < nlanes; l++) {  // lane l's stream: the companion of lane l-1's context
+        const imgfd_status st = ctx_side(lane[l - 1], &lane[l]);
+        if (st != IMGFD_OK) { ctx->err = lane[l - 1]->err; return st; }
+    }
+    imgfd_ctx *fork = nullptr;  // one tile: its two pyramid kernels side by side (surf_front, "surf_split")
+    if (G == 1 && ctx->tune.surf_split) IMGFD_TRY(ctx_side(ctx, &fork));
+    // More than one group: two BANKS of buffer sets, and the back of group k on a stream of its own beside the fronts of group k + 1
+    const int banks = !only && n_run > G ? 2 : 1;
+    imgfd_ctx *back = ctx;
+    if (banks == 2) {
+        IMGFD_TRY(ctx_side(lane[nlanes - 1], &back));
+        while (ctx->surf_ev.size() < MAX_LANES + 2) {  // front done per lane, back done per bank
+            hipEvent_t e;
+            IMGFD_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->surf_ev.push_back(e);
+        }
+    }
+    SurfDevice sets[2][MAX_GROUP];
+    unsigned *sel = nullptr, *cand = nullptr, *m_dev = nullptr;
+    double *k19 = nullptr;
+    unsigned lim = 0;
+    auto carve = [&](unsigned long long rcap) -> imgfd_status {
+        // no more records than the buffer holds can be asked for (and the all-pairs ranking is quadratic in that number)
+        lim = (unsigned)std::min<unsigned long long>((unsigned long long)std::min<int64_t>((int64_t)max_points, cap), rcap);
+        const imgfd_status st = ws_reserve(ctx, align_up(3 * n, 256) + (size_t)banks * G * (surf_ws_bytes(g, total, rcap) - align_up(3 * n, 256)) +
+                                                    (size_t)G * (align_up(sizeof(unsigned) * 2 * (size_t)lim, 256) + align_up(sizeof(unsigned) * 2 * (size_t)rcap, 256) +
+                                                                 align_up(sizeof(double) * 8 * (size_t)lim, 256)) + 4096);
+        if (st != IMGFD_OK) return imgfd_fail(ctx, st, "imgfd_surf_dev: workspace allocation failed");
+        (void)ws_alloc(ctx, 3 * n);  // the slot imgfd_surf uses for the uploaded image (same carving, same size function)
+        for (int t = 0; t < banks * G; t++) {  // buffer sets, carved alike: consecutive sets are the same distance apart
+            SurfDevice &d = sets[t / G][t % G];
+            d.cap = rcap;
+            d.integral = (unsigned *)ws_alloc(ctx, 4 * n);
+            d.mask = (unsigned long long *)ws_alloc(ctx, 8 * std::max<size_t>(g.mask_words, 1));
+            d.pyr_bytes = surf_pyr_bytes(g, total);
+            d.pyr = (double *)ws_alloc(ctx, d.pyr_bytes);
+            d.rec = (SurfRecord *)ws_alloc(ctx, sizeof(SurfRecord) * rcap);
+            d.surv = (unsigned long long *)ws_alloc(ctx, sizeof(unsigned long long) * rcap);
+            d.cand_cap = std::max<size_t>(total, 1);
+            d.cands = (unsigned long long *)ws_alloc(ctx, 8 * (size_t)d.cand_cap);
+            if (!d.integral || !d.mask || !d.pyr || !d.rec || !d.surv || !d.cands) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+        }
+        unsigned long long *counters = (unsigned long long *)ws_alloc(ctx, 256 * (size_t)banks * G);  // one 256-byte slot per tile, side by side: one memset clears a group's
+        if (!counters) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+        for (int t = 0; t < banks * G; t++) sets[t / G][t % G].count = counters + 32 * (size_t)t;
+        sel = (unsigned *)ws_alloc(ctx, align_up(sizeof(unsigned) * 2 * (size_t)lim, 256) * G);
+        cand = (unsigned *)ws_alloc(ctx, align_up(sizeof(unsigned) * 2 * (size_t)rcap, 256) * G);
+        k19 = (double *)ws_alloc(ctx, align_up(sizeof(double) * 8 * (size_t)lim, 256) * G);  // per tile: x, y, scale | angle, sin, cos, sin(-), cos(-)
+        m_dev = (unsigned *)ws_alloc(ctx, sizeof(unsigned) * MAX_GROUP);
+        if (!sel || !cand || !k19 || !m_dev) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
+        return IMGFD_OK;
+    };
+    // tiles f0 .. f0 + ng - 1 (ng <= G), group number k: fronts on the lanes, then the group's back (one bank: on the context's
+    // stream; two: on the back stream, behind events)
+    auto run_group = [&](int f0, int ng, const int *frames, int k) -> imgfd_status {
+        SurfDevice *set = sets[k % banks];
+        hipEvent_t *ev_lane = banks == 2 ? ctx->surf_ev.data() : nullptr, *ev_bank = banks == 2 ? ctx->surf_ev.data() + MAX_LANES : nullptr;
+        if (banks == 2 && k >= 2)  // this bank's sets were last read by the back of the group two before
+            for (int l = 0; l < std::min(nlanes, ng); l++) IMGFD_HIP(ctx, hipStreamWaitEvent(lane[l]->stream, ev_bank[k % 2], 0));
+        SurfTable T{nullptr, rows, cols, 0};
+        for (int t = 0; t < ng; t++) {
+            const int f = frames ? frames[t] : f0 + t;
+            imgfd_ctx *c = lane[t % nlanes];
+            SurfStreamScope scope(ctx, c->stream);  // every buffer lives in the context's arena; the lane lends its stream
+            SurfTable Tt;
+            IMGFD_TRY(surf_front(ctx, d_rgb + (size_t)f * frame_stride_bytes, g, detection_threshold, set[t], &Tt, fork));
+            if (t == 0) T = Tt;  // same geometry, same carving: every tile's table lies alike, set[t].integral apart
+        }
+        if (banks == 2) {
+            for (int l = 0; l < std::min(nlanes, ng); l++) {  // the back waits for every lane's fronts
+                IMGFD_HIP(ctx, hipEventRecord(ev_lane[l], lane[l]->stream));
+                IMGFD_HIP(ctx, hipStreamWaitEvent(back->stream, ev_lane[l], 0));
+            }
+        } else {
+            for (int l = 1; l < std::min(nlanes, ng); l++) {
+                hipEvent_t ev = lane[l - 1]->ev_join;  // the event pair of (lane l-1, its companion)
+                IMGFD_HIP(ctx, hipEventRecord(ev, lane[l]->stream));
+                IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ev, 0));
+            }
+        }
+        SurfStreamScope back_scope(ctx, back->stream);
+        const SurfDevice *next = ng > 1 ? &set[1] : nullptr;
+        IMGFD_TRY(surf_back_nms(ctx, g, detection_threshold, set[0], T, ng, next));
+        const size_t sel_stride = align_up(sizeof(unsigned) * 2 * (size_t)lim, 256) / sizeof(unsigned);
+        const size_t cand_stride = align_up(sizeof(unsigned) * 2 * (size_t)set[0].cap, 256) / sizeof(unsigned);
+        const size_t k19_stride = align_up(sizeof(double) * 8 * (size_t)lim, 256) / sizeof(double);
+        const int fa = frames ? frames[0] : f0;
+        double *feat = d_features + (size_t)fa * (size_t)cap * 70;
+        SurfRankParams q;
+        q.rec = set[0].rec; q.count = set[0].count; q.cap = set[0].cap; q.lim = lim; q.rows = rows; q.cols = cols; q.sel = sel; q.order = sel + lim;
+        q.cand = cand; q.sort_cap = (unsigned)std::max(0, ctx->tune.surf_sort_cap);
+        q.pts = k19; q.feat = feat; q.count_out = reinterpret_cast<long long *>(d_counts) + fa; q.m_out = m_dev;
+        q.tile_rec = next ? (size_t)(next->rec - set[0].rec) : 0; q.tile_count = next ? (size_t)(next->count - set[0].count) : 0;
+        q.tile_sel = sel_stride; q.tile_cand = cand_stride; q.tile_pts = k19_stride; q.tile_feat = (size_t)cap * 70;
+        hipLaunchKernelGGL(surf_rank_select, dim3((unsigned)ng), dim3(SR_NT), 0, ctx->stream, q);
+        const SurfGroup grp{ng, next ? (size_t)(next->integral - set[0].integral) : 0, k19_stride, k19_stride, (size_t)cap * 70};
+        IMGFD_TRY(launch_surf_orient(ctx, T, k19, (int)lim, nullptr, k19 + 3 * (size_t)lim, m_dev, &grp));
+        IMGFD_TRY(launch_surf_desc(ctx, T, k19, k19 + 3 * (size_t)lim, (int)lim, feat + 6, 70, feat + 2, m_dev, &grp));
+        if (banks == 2) IMGFD_HIP(ctx, hipEventRecord(ev_bank[k % 2], back->stream));
+        return IMGFD_OK;
+    };
+    if (!only) {
+        const unsigned long long rec_cap = (unsigned long long)std::max(16, ctx->tune.surf_rec_cap);  // candidate records per tile (262144: 14 MB); a tile with more reports -candidates
+        IMGFD_TRY(carve(rec_cap));
+        int k = 0;
+        for (int f0 = 0; f0 < n_frames; f0 += G, k++) {
+            // the lanes' streams start behind what the context's stream holds: the tiles' producer (first group) and, with one bank,
+            // the back of the group before (whose buffer sets the fronts are about to overwrite)
+            if (nlanes > 1 && (k == 0 || banks == 1)) {
+                IMGFD_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+                for (int l = 1; l < nlanes; l++) IMGFD_HIP(ctx, hipStreamWaitEvent(lane[l]->stream, ctx->ev_fork, 0));
+            }
+            IMGFD_TRY(run_group(f0, std::min(G, n_frames - f0), nullptr, k));
+        }
+        if (banks == 2) {  // whoever waits for the context's stream waits for the lanes and for the last backs
+            for (int l = 1; l < nlanes; l++) {
+                IMGFD_HIP(ctx, hipEventRecord(ctx->surf_ev[l], lane[l]->stream));
+                IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->surf_ev[l], 0));
+            }
+            for (int b = 0; b < std::min(2, k); b++) IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->surf_ev[MAX_LANES + b], 0));
+        }
+    } else {
+        // redo: one tile at a time, each with the buffer it asked for (the arena is carved anew per tile: ws_reserve waits for
+        // everything queued before when it has to grow, and the context's stream orders the rest)
+        for (const auto &job : *only) {
+            IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            IMGFD_TRY(carve(job.second));
+            const int f = job.first;
+            IMGFD_TRY(run_group(f, 1, &f, 0));
+        }
+    }
+    IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }
 
@@ -1678,107 +1941,47 @@ try {
         !(detection_threshold >= 0) || !frame_fits(rows, cols, 3))
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_surf_dev: bad argument");
     if (!n_frames) return IMGFD_OK;
-    IMGFD_HIP(ctx, hipSetDevice(ctx->device));
-    SurfGeom g;
-    const size_t total = surf_geometry(rows, cols, &g);
-    const size_t n = (size_t)rows * cols;
-    const unsigned long long rec_cap = (unsigned long long)std::max(16, ctx->tune.surf_rec_cap);  // candidate records per tile (262144: 14 MB); a tile with more is redone below
-    // Lanes: tile f goes to lane f mod nlanes -- the context's stream and up to three companion streams, each lane with its own
-    // buffers.  A tile is a chain of a dozen kernels, several of them small (the ranking runs in ONE workgroup, the descriptor
-    // grids are a few hundred workgroups): with several tiles in flight those fill the gaps of the other tiles' pyramid kernels
-    // (1 / 2 / 3 / 4 lanes: 0.448 / 0.346 / 0.334 / 0.327 ms per 4096^2 tile, profiles/r03).
-    // Within a lane the tiles go through the same buffers back to back; the host is not waited for until the batch is queued.
-    struct Lane { imgfd_ctx *c; SurfDevice d; unsigned *sel, *cand; double *k19; unsigned *m_dev; unsigned lim; };
-    constexpr int MAX_LANES = 4;
-    Lane lanes[MAX_LANES];
-    const int nlanes = std::max(1, std::min(std::min(ctx->tune.surf_lanes, MAX_LANES), n_frames));
-    lanes[0].c = ctx;
-    for (int l = 1; l < nlanes; l++) {  // lane l runs on the companion of lane l-1's context
-        imgfd_ctx *side = nullptr;
-        const imgfd_status st = ctx_side(lanes[l - 1].c, &side);
-        if (st != IMGFD_OK) { ctx->err = lanes[l - 1].c->err; return st; }
-        lanes[l].c = side;
-    }
-    if (nlanes > 1) {
-        IMGFD_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));          // the tiles (and whatever produced them) come first
-        for (int l = 1; l < nlanes; l++) IMGFD_HIP(ctx, hipStreamWaitEvent(lanes[l].c->stream, ctx->ev_fork, 0));
-    }
-    imgfd_ctx *fork = nullptr;  // one tile, one lane: its two pyramid kernels side by side (surf_device_stages)
-    if (nlanes == 1 && ctx->tune.surf_split) IMGFD_TRY(ctx_side(ctx, &fork));
-    auto carve = [&](Lane &L, unsigned long long rcap) -> imgfd_status {
-        imgfd_ctx *c = L.c;
-        // no more records than the buffer holds can be asked for (and the all-pairs ranking is quadratic in that number)
-        L.lim = (unsigned)std::min<unsigned long long>((unsigned long long)std::min<int64_t>((int64_t)max_points, cap), rcap);
-        const imgfd_status st = ws_reserve(c, surf_ws_bytes(g, total, rcap) + align_up(sizeof(unsigned) * 2 * (size_t)L.lim, 256) +
-                                                  align_up(sizeof(unsigned) * 2 * (size_t)rcap, 256) + align_up(sizeof(double) * 8 * (size_t)L.lim, 256) + 1024);
-        if (st != IMGFD_OK) return imgfd_fail(ctx, st, "imgfd_surf_dev: workspace allocation failed");
-        (void)ws_alloc(c, 3 * n);  // the slot imgfd_surf uses for the uploaded image (same carving, same size function)
-        L.d.cap = rcap;
-        L.d.integral = (unsigned *)ws_alloc(c, 4 * n);
-        L.d.mask = (unsigned long long *)ws_alloc(c, 8 * std::max<size_t>(g.mask_words, 1));
-        L.d.pyr_bytes = surf_pyr_bytes(g, total);
-        L.d.pyr = (double *)ws_alloc(c, L.d.pyr_bytes);
-        L.d.rec = (SurfRecord *)ws_alloc(c, sizeof(SurfRecord) * rcap);
-        L.d.count = (unsigned long long *)ws_alloc(c, 256);
-        L.sel = (unsigned *)ws_alloc(c, sizeof(unsigned) * 2 * (size_t)L.lim);
-        L.cand = (unsigned *)ws_alloc(c, sizeof(unsigned) * 2 * (size_t)rcap);
-        L.k19 = (double *)ws_alloc(c, sizeof(double) * 8 * (size_t)L.lim);  // x, y, scale | angle, sin, cos, sin(-), cos(-)
-        if (!L.d.integral || !L.d.mask || !L.d.pyr || !L.d.rec || !L.d.count || !L.sel || !L.cand || !L.k19) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
-        L.m_dev = reinterpret_cast<unsigned *>(L.d.count) + 8;  // inside the 256-byte counter slot
-        return IMGFD_OK;
-    };
-    auto run_tile = [&](Lane &L, int f) -> imgfd_status {
-        imgfd_ctx *c = L.c;
-        const unsigned lim = L.lim;
-        double *d_pts = L.k19, *d_trig = L.k19 + 3 * (size_t)lim;
-        SurfTable T;
-        imgfd_status st = surf_device_stages(c, d_rgb + (size_t)f * frame_stride_bytes, g, detection_threshold, L.d, &T, fork);
-        double *feat = d_features + (size_t)f * (size_t)cap * 70;
-        SurfRankParams q;
-        q.rec = L.d.rec; q.count = L.d.count; q.cap = L.d.cap; q.lim = lim; q.rows = rows; q.cols = cols; q.sel = L.sel; q.order = L.sel + lim;
-        q.cand = L.cand; q.sort_cap = (unsigned)std::max(0, ctx->tune.surf_sort_cap);
-        q.pts = d_pts; q.feat = feat; q.count_out = reinterpret_cast<long long *>(d_counts) + f; q.m_out = L.m_dev;
-        if (st == IMGFD_OK) {
-            hipLaunchKernelGGL(surf_rank_select, dim3(1), dim3(SR_NT), 0, c->stream, q);
-            st = launch_surf_orient(c, T, d_pts, (int)lim, nullptr, d_trig, L.m_dev);
-        }
-        if (st == IMGFD_OK) st = launch_surf_desc(c, T, d_pts, d_trig, (int)lim, feat + 6, 70, feat + 2, L.m_dev);
-        if (st != IMGFD_OK && c != ctx) ctx->err = c->err;
-        return st;
-    };
-    for (int l = 0; l < nlanes; l++) IMGFD_TRY(carve(lanes[l], rec_cap));
-    for (int f = 0; f < n_frames; f++) IMGFD_TRY(run_tile(lanes[f % nlanes], f));
-    for (int l = 1; l < nlanes; l++) {  // whoever waits for the context's stream waits for the other lanes' tiles too
-        hipEvent_t ev = lanes[l - 1].c->ev_join;  // the event pair of (lane l-1, its companion)
-        IMGFD_HIP(ctx, hipEventRecord(ev, lanes[l].c->stream));
-        IMGFD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ev, 0));
-    }
-    IMGFD_HIP(ctx, hipGetLastError());
-    // A tile with more candidates than the record buffer holds has left -candidates in its count and no features (its
-    // best records may be among those that found no room).  Once the batch is queued its counts are read back -- one wait
-    // per call, not per tile -- and such tiles are redone with a buffer of the size they asked for.  "surf_async" 1 skips the
-    // wait: the caller then finds the negative counts.
-    if (!ctx->tune.surf_async) {
-        std::vector<int64_t> h((size_t)n_frames);
-        IMGFD_HIP(ctx, hipMemcpyAsync(h.data(), d_counts, sizeof(int64_t) * (size_t)n_frames, hipMemcpyDeviceToHost, ctx->stream));
-        IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (int f = 0; f < n_frames; f++) {
-            int64_t cnt = h[(size_t)f];
-            for (int tries = 0; cnt < 0 && tries < 4; tries++) {
-                IMGFD_TRY(carve(lanes[0], (unsigned long long)(-cnt) + 1024));
-                IMGFD_TRY(run_tile(lanes[0], f));
-                IMGFD_HIP(ctx, hipMemcpyAsync(&cnt, d_counts + f, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
-                IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            }
-            if (cnt < 0) return imgfd_fail(ctx, IMGFD_ERR_OOM, "imgfd_surf_dev: a tile's candidates do not fit its record buffer");
-        }
-    }
-    IMGFD_HIP(ctx, hipGetLastError());
-    return IMGFD_OK;
+    return surf_dev_run(ctx, d_rgb, n_frames, rows, cols, frame_stride_bytes, max_points, detection_threshold, d_features, cap, d_counts, nullptr);
 } catch (const std::bad_alloc &) {
     return imgfd_fail(ctx, IMGFD_ERR_OOM, "imgfd_surf_dev: out of host memory");
 } catch (...) {
     return imgfd_fail(ctx, IMGFD_ERR_HIP, "imgfd_surf_dev: unexpected C++ exception");
+}
+
+// A tile with more candidates than its record buffer holds has left -candidates in its count and no features (its best
+// records may be among those that found no room).  This call waits for the context's stream, reads the counts of the batch back
+// and redoes such tiles with a buffer of the size they asked for.
+imgfd_status imgfd_surf_dev_redo(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, int rows, int cols, size_t frame_stride_bytes,
+                                 long max_points, double detection_threshold, double *d_features, int64_t cap, int64_t *d_counts,
+                                 int *n_redone)
+try {
+    if (!ctx) return IMGFD_ERR_INVALID;
+    if (n_redone) *n_redone = 0;
+    if (!d_rgb || !d_features || !d_counts || n_frames < 0 || rows < 1 || cols < 1 || cap < 1 || !(max_points > 0) ||
+        !(detection_threshold >= 0) || !frame_fits(rows, cols, 3))
+        return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_surf_dev_redo: bad argument");
+    if (!n_frames) return IMGFD_OK;
+    IMGFD_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<int64_t> h((size_t)n_frames);
+    for (int tries = 0; tries < 4; tries++) {
+        IMGFD_HIP(ctx, hipMemcpyAsync(h.data(), d_counts, sizeof(int64_t) * (size_t)n_frames, hipMemcpyDeviceToHost, ctx->stream));
+        IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<std::pair<int, unsigned long long>> jobs;
+        for (int f = 0; f < n_frames; f++)
+            if (h[(size_t)f] < 0) jobs.emplace_back(f, (unsigned long long)(-h[(size_t)f]) + 1024);
+        if (jobs.empty()) return IMGFD_OK;
+        if (n_redone && !tries) *n_redone = (int)jobs.size();
+        IMGFD_TRY(surf_dev_run(ctx, d_rgb, n_frames, rows, cols, frame_stride_bytes, max_points, detection_threshold, d_features, cap, d_counts, &jobs));
+    }
+    IMGFD_HIP(ctx, hipMemcpyAsync(h.data(), d_counts, sizeof(int64_t) * (size_t)n_frames, hipMemcpyDeviceToHost, ctx->stream));
+    IMGFD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int f = 0; f < n_frames; f++)
+        if (h[(size_t)f] < 0) return imgfd_fail(ctx, IMGFD_ERR_OOM, "imgfd_surf_dev_redo: a tile's candidates do not fit its record buffer");
+    return IMGFD_OK;
+} catch (const std::bad_alloc &) {
+    return imgfd_fail(ctx, IMGFD_ERR_OOM, "imgfd_surf_dev_redo: out of host memory");
+} catch (...) {
+    return imgfd_fail(ctx, IMGFD_ERR_HIP, "imgfd_surf_dev_redo: unexpected C++ exception");
 }
 
 static imgfd_status surf_host(imgfd_ctx *ctx, const void *rgb, int kind, int rows, int cols, long max_points,

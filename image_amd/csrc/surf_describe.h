@@ -24,6 +24,13 @@ void surf_orient_table(SurfOrientTable *T);
 // The residue layout is what the gather kernels of octaves 1-3 want (their level pixels sit on columns that are multiples of
 // 4, 8, 16: consecutive lanes read consecutive words of one residue plane); since round 6 it is the ONLY copy of the table
 // whenever the image allows it (cols a multiple of 16, band / strip scans), and every reader addresses it through this.
+// a group of tiles handled by ONE launch of a back-stage kernel (blockIdx.y = tile): distances between consecutive tiles'
+// buffers, in elements (all tiles of a call share one geometry, so their buffer sets are carved alike)
+struct SurfGroup {
+    int tiles;
+    size_t table, pts, trig, des;
+};
+
 struct SurfTable {
     const unsigned *p;
     int rows, cols, per;

@@ -86,8 +86,14 @@ __device__ __forceinline__ long surf_to_long(double v) { return (long)floor(v + 
 __global__ void __launch_bounds__(128) surf_orient(SurfTable I,
                                                    const double *__restrict__ pts, SurfOrientTable T,
                                                    double *__restrict__ samples, double *__restrict__ trig,
-                                                   const unsigned *__restrict__ m_dev)
+                                                   const unsigned *__restrict__ m_dev, SurfGroup grp)
 {
+    {   // blockIdx.y = tile of the group (imgfd_surf_dev: the K19 kernels of a group of tiles are one launch)
+        const size_t t = blockIdx.y;
+        I.p += t * grp.table; pts += t * grp.pts;
+        if (trig) trig += t * grp.trig;
+        if (m_dev) m_dev += t;
+    }
     if (m_dev && blockIdx.x >= *m_dev) return;  // the grid covers the upper bound; the number of points lives on the device
     __shared__ double sx[SURF_NSAMP], sy[SURF_NSAMP];
     __shared__ double wx[45], wy[45];
@@ -165,8 +171,14 @@ __global__ void __launch_bounds__(128) surf_orient(SurfTable I,
 __global__ void __launch_bounds__(64) surf_desc(SurfTable I,
                                                 const double *__restrict__ pts, const double *__restrict__ trig,
                                                 double *__restrict__ des, int des_stride, double *__restrict__ angle_out,
-                                                const unsigned *__restrict__ m_dev)
+                                                const unsigned *__restrict__ m_dev, SurfGroup grp)
 {
+    {
+        const size_t t = blockIdx.y;
+        I.p += t * grp.table; pts += t * grp.pts; trig += t * grp.trig; des += t * grp.des;
+        if (angle_out) angle_out += t * grp.des;
+        if (m_dev) m_dev += t;
+    }
     if (m_dev && blockIdx.x >= *m_dev) return;
     __shared__ int hx[400], hy[400];
     __shared__ double rx[16 * 49], ry[16 * 49];
@@ -244,21 +256,26 @@ void surf_orient_table(SurfOrientTable *T)
 }
 
 imgfd_status launch_surf_orient(imgfd_ctx *ctx, const SurfTable &I, const double *d_pts, int m,
-                                double *d_samples, double *d_trig, const unsigned *m_dev)
+                                double *d_samples, double *d_trig, const unsigned *m_dev, const SurfGroup *grp)
 {
     if (m < 1) return IMGFD_OK;
     SurfOrientTable T;
     surf_orient_table(&T);
-    hipLaunchKernelGGL(surf_orient, dim3(m), dim3(128), 0, ctx->stream, I, d_pts, T, d_samples, d_trig, m_dev);
+    const SurfGroup one{1, 0, 0, 0, 0};
+    const SurfGroup &G = grp ? *grp : one;
+    hipLaunchKernelGGL(surf_orient, dim3(m, G.tiles), dim3(128), 0, ctx->stream, I, d_pts, T, d_samples, d_trig, m_dev, G);
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }
 
 imgfd_status launch_surf_desc(imgfd_ctx *ctx, const SurfTable &I, const double *d_pts,
-                              const double *d_trig, int m, double *d_des, int des_stride, double *d_angle, const unsigned *m_dev)
+                              const double *d_trig, int m, double *d_des, int des_stride, double *d_angle, const unsigned *m_dev,
+                              const SurfGroup *grp)
 {
     if (m < 1) return IMGFD_OK;
-    hipLaunchKernelGGL(surf_desc, dim3(m), dim3(64), 0, ctx->stream, I, d_pts, d_trig, d_des, des_stride, d_angle, m_dev);
+    const SurfGroup one{1, 0, 0, 0, 0};
+    const SurfGroup &G = grp ? *grp : one;
+    hipLaunchKernelGGL(surf_desc, dim3(m, G.tiles), dim3(64), 0, ctx->stream, I, d_pts, d_trig, d_des, des_stride, d_angle, m_dev, G);
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }

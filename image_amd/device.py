@@ -111,16 +111,19 @@ class DeviceDetector:
                                                pad_r, pad_c, out.data_ptr()), "imgfd_fhog_dev")
         return out
 
-    def surf(self, tiles: torch.Tensor, feat: torch.Tensor, counts: torch.Tensor, max_points=1000, threshold=30.0):
+    def surf(self, tiles: torch.Tensor, feat: torch.Tensor, counts: torch.Tensor, max_points=1000, threshold=30.0, redo=True):
         """imgfd_surf_dev: tiles [n, rows, cols, 3] u8 -> feat [n, cap, 70] f64 (x, y, angle, scale, score, laplacian,
-        surf[64]), counts [n] i64.  The call returns with the counts final: a tile whose candidates overflowed the record
-        buffer has been redone by then (with the lab switch "surf_async" it is not, and reports a NEGATIVE count: check
-        ``(counts < 0).any()`` before slicing with them)."""
+        surf[64]), counts [n] i64.  imgfd_surf_dev only queues work; a tile whose candidates overflowed its record buffer
+        reports a NEGATIVE count.  redo=True (default) follows it with imgfd_surf_dev_redo -- one wait for the stream, the
+        counts read back once, such tiles redone with a larger buffer -- so that the counts are final when this returns;
+        redo=False leaves the call asynchronous: check ``(counts < 0).any()`` before slicing with them."""
         n, rows, cols, _ = tiles.shape
         assert tiles.is_contiguous() and feat.is_contiguous()
-        self.ctx.check(self.lib.imgfd_surf_dev(self.ctx.handle, tiles.data_ptr(), n, rows, cols, rows * cols * 3, int(max_points),
-                                               float(threshold), feat.data_ptr(), feat.shape[1], counts.data_ptr()),
-                       "imgfd_surf_dev")
+        args = (self.ctx.handle, tiles.data_ptr(), n, rows, cols, rows * cols * 3, int(max_points), float(threshold), feat.data_ptr(),
+                feat.shape[1], counts.data_ptr())
+        self.ctx.check(self.lib.imgfd_surf_dev(*args), "imgfd_surf_dev")
+        if redo:
+            self.ctx.check(self.lib.imgfd_surf_dev_redo(*args, None), "imgfd_surf_dev_redo")
         return feat, counts
 
     def gradients_of(self, frame: torch.Tensor, ix: torch.Tensor, iy: torch.Tensor, sigma_d=1.0):

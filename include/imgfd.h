@@ -97,7 +97,6 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  *   "hyst_block" [IMGFD_HYST_BLOCK]  tiles per workgroup of a sweep, 10 * across + down: 22, 42, 24 or 44 (0: 24 up to 12 frames, else 22)
  *   "hyst_shift" [IMGFD_HYST_SHIFT]  1 (default): odd sweep launches group the tiles half a block up and left; 0: one grouping
  *   "hyst_prio" [IMGFD_HYST_PRIO]  1 (default): the sweeps run at wave priority 3
- *   "canny_finish" [IMGFD_CANNY_FINISH]  1 (default): union-find, 0/255 expansion and count in one launch; 0: three launches
  *   "canny_gate" [IMGFD_CANNY_GATE]  imgfd_detect_dev: where Canny releases FAST-9 on the other stream (0 before the blur,
  *                  1 behind it, 2 behind gradient/NMS; -1, default: 0)
  *   "detect_defer" [IMGFD_DETECT_DEFER]  imgfd_detect_dev: 1: FAST-9 and the Harris chain are QUEUED after Canny's last launch
@@ -117,9 +116,10 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  *   "tile_run" [IMGFD_TILE_RUN]  tiles per workgroup of the u8 tile kernels (0: from the batch size)
  *   "detect_graph" [IMGFD_DETECT_GRAPH]  imgfd_detect_dev replays a recorded hipGraph for repeating calls on fewer frames than this
  *                                        (0 = never, the default: a single 4K frame takes the same time either way, 0.20 ms in round 5)
- *   "surf_lanes" [IMGFD_SURF_LANES]  4 (default): imgfd_surf_dev deals the tiles round-robin to this many HIP streams (1..4)
- *   "surf_async" [IMGFD_SURF_ASYNC]  0 (default): imgfd_surf_dev reads the tile counts back once per call and redoes tiles
- *                                    whose candidates overflowed the record buffer; 1: no wait, such a tile reports -candidates
+ *   "surf_group" [IMGFD_SURF_GROUP]  8 (default): imgfd_surf_dev handles the tiles in groups of this many (1..16): a buffer set per tile,
+ *                                    the latency-bound back stages (maximum test, ranking, orientation, descriptor) as one launch each per group
+ *   "surf_lanes" [IMGFD_SURF_LANES]  2 (default): the front stages (integral image, Hessian pyramid) of a group's tiles go round-robin
+ *                                    over this many HIP streams (1..4)
  *   "surf_split" [IMGFD_SURF_SPLIT]  1 (default): a tile that has the device to itself (imgfd_surf, imgfd_surf_dev with one tile, the interest-point
  *                                  doorways) runs the Hessian pyramid of octaves 1-3 on the companion context's stream beside octave 0; 0: one stream
  *   "surf_sort_cap" [IMGFD_SURF_SORT_CAP]  selected records imgfd_surf_dev ranks with its LDS sort (2048); more: all-pairs ranking
@@ -232,14 +232,19 @@ IMGFD_API imgfd_status imgfd_surf_points_dev(imgfd_ctx *ctx, const uint8_t *d_rg
  * bit for bit (SURVEY.md 8d asks for 1e-6); the interest points themselves are identical.  No tile waits for the host:
  * the candidates of a tile are ranked on the device (the max_points strongest, strongest first; two candidates with
  * exactly equal scores keep the order get_interest_points emitted them in -- the reference leaves that order to std::sort)
- * and the descriptor kernels read the point count on the device.  A tile with more candidates than the record buffer
- * holds (262144: a very low detection_threshold on a large tile) is redone with a larger buffer: for that the counts of
- * the batch are read back ONCE, after the whole batch has been queued (the call returns with the context's stream
- * drained).  With the lab switch "surf_async" 1 that wait is skipped and such a tile reports d_counts[f] = -candidates
- * with its feature rows untouched. */
+ * and the descriptor kernels read the point count on the device.  The call only QUEUES work (on the context's stream and
+ * streams of its own that the context's stream waits for at the end): it never waits for the device, so it is safe on a
+ * caller's stream.  A tile with more candidates than the record buffer holds (262144: a very low detection_threshold on a
+ * large tile) reports d_counts[f] = -(records it needs room for) and leaves its feature rows untouched; imgfd_surf_dev_redo, called with the
+ * same arguments, waits for the context's stream, reads the counts of the batch back once and redoes such tiles with a buffer
+ * of the size they asked for (*n_redone, optional: how many).  A caller that cannot see such tiles (the R default threshold 30
+ * on a 4096^2 tile yields ~10^4 candidates) need not call it. */
 IMGFD_API imgfd_status imgfd_surf_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, int rows, int cols,
                                       size_t frame_stride_bytes, long max_points, double detection_threshold,
                                       double *d_features, int64_t cap, int64_t *d_counts);
+IMGFD_API imgfd_status imgfd_surf_dev_redo(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, int rows, int cols,
+                                           size_t frame_stride_bytes, long max_points, double detection_threshold,
+                                           double *d_features, int64_t cap, int64_t *d_counts, int *n_redone);
 IMGFD_API imgfd_status imgfd_k_surf_integral(imgfd_ctx *ctx, const uint8_t *rgb, int rows, int cols, int32_t *out);
 
 /* ------------------------------------------------------------------ descriptor matching

@@ -6,7 +6,7 @@ if os.environ.get("VARIANT_LIB"):
     _lib.LIB_PATH = os.path.abspath(os.environ["VARIANT_LIB"])
 import torch
 from image_amd.device import DeviceDetector
-T, S = (1 if os.environ.get("TILES1") else 16), 4096
+T, S = (1 if os.environ.get("TILES1") else int(os.environ.get("TILES", "16"))), 4096
 det = DeviceDetector(0)
 tiles = torch.empty((T, S, S, 3), dtype=torch.uint8, device="cuda")
 for t in range(T):

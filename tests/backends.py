@@ -19,14 +19,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 class _Base:
     name = "?"
 
-    def __init__(self, lib):
+    def __init__(self, lib, stream=None):
         self.lib = lib
         self.ctx = C.c_void_p()
-        st = lib.imgfd_ctx_create(0, C.byref(self.ctx))
+        if stream is None:
+            st = lib.imgfd_ctx_create(0, C.byref(self.ctx))
+        else:   # a context on the caller's HIP stream (imgfd_ctx_create_on_stream)
+            st = lib.imgfd_ctx_create_on_stream(0, stream, C.byref(self.ctx))
         assert st == 0, f"imgfd_ctx_create -> {st}"
 
     def check(self, st, what=""):
         _binding.check(self.lib, self.ctx, st, what)
+
+    def close(self):
+        if self.ctx:
+            self.lib.imgfd_ctx_destroy(self.ctx)
+            self.ctx = C.c_void_p()
 
     def set_fir_mode(self, mode):
         self.check(self.lib.imgfd_set_fir_mode(self.ctx, mode))
@@ -243,7 +251,7 @@ class _Base:
         return self.to_host(idx), self.to_host(dist)
 
     def surf_dev_counts(self, frames, max_points=1000, threshold=30.0):
-        """imgfd_surf_dev: the raw per-tile counts (negative: candidates that overflowed the record buffer, surf_async 1)"""
+        """imgfd_surf_dev alone: the raw per-tile counts (negative: candidates that overflowed the record buffer)"""
         frames = np.ascontiguousarray(frames, np.uint8)
         n, rows, cols, _ = frames.shape
         d = self.to_dev(frames)
@@ -262,6 +270,10 @@ class _Base:
         feat = self.empty((n, cap, 70), np.float64); cnt = self.empty((n,), np.int64)
         self.check(self.lib.imgfd_surf_dev(self.ctx, self.ptr(d), n, rows, cols, rows * cols * 3, max_points, threshold,
                                            self.ptr(feat), cap, self.ptr(cnt)), "imgfd_surf_dev")
+        redone = C.c_int(0)
+        self.check(self.lib.imgfd_surf_dev_redo(self.ctx, self.ptr(d), n, rows, cols, rows * cols * 3, max_points, threshold,
+                                                self.ptr(feat), cap, self.ptr(cnt), C.byref(redone)), "imgfd_surf_dev_redo")
+        self.last_surf_redone = redone.value
         self.sync()
         feat = self.to_host(feat); cnt = self.to_host(cnt)
         out = []
@@ -367,12 +379,12 @@ class EmuBackend(_Base):
 class GpuBackend(_Base):
     name = "gpu"
 
-    def __init__(self):
+    def __init__(self, stream=None):
         import torch
         assert torch.cuda.is_available(), "GPU tests need a device"
         from image_amd import _lib
         self.torch = torch
-        super().__init__(_lib.load())
+        super().__init__(_lib.load(), stream)
 
     def to_dev(self, a):
         return self.torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")

@@ -295,3 +295,48 @@ def test_many_unconverged_frames_in_one_batch(be):
             assert c[f] == k and mismatch(e[f], r) == 0, f
     finally:
         be.set_tuning("hyst_sweeps", 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cus", [32, 4, 1])
+def test_unconverged_frames_on_a_cu_masked_stream(cus):
+    """canny_finish's frame barriers on a stream that may use only `cus` of the device's compute units (hipExtStreamCreateWithCUMask:
+    1/8 of an MI355X, 4 units, one), while another context keeps the rest of the device busy with the Harris chain.  48 frames the one
+    queued sweep leaves unfinished: the kernel hands its (frame, slice) pairs out by ticket and launches no more blocks per frame
+    than the stream's units hold at once (canny_finish_blocks), so the barriers open whatever the units are; with a single unit
+    the call takes the three-launch form (no barrier at all).  Must neither hang nor differ from the oracle."""
+    import ctypes as C
+
+    import torch
+    from backends import GpuBackend
+    hip = C.CDLL("libamdhip64.so")
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    words = (n_cu + 31) // 32
+    mask = (C.c_uint32 * words)()
+    for i in range(cus):
+        mask[i >> 5] |= 1 << (i & 31)
+    stream = C.c_void_p()
+    assert hip.hipExtStreamCreateWithCUMask(C.byref(stream), words, mask) == 0
+    masked, other = GpuBackend(stream), GpuBackend()
+    nx, ny = 384, 200
+    base = _serpentine(nx, ny)
+    frames = np.stack([np.roll(base, 7 * f, axis=1) if f % 3 else base[::-1].copy() for f in range(48)])
+    big = np.stack([synth.frame(900 + f, 1920, 1080) for f in range(8)])
+    try:
+        masked.set_tuning("hyst_sweeps", 1)
+        d_big, fr_big = other.upload_frames_u8(big)
+        cnt_big = other.empty((8,), np.int64)
+        for _ in range(6):   # ~10 ms of structure-tensor launches on every compute unit, queued before the masked call and running beside it
+            other.check(other.lib.imgfd_harris_dev(other.ctx, C.byref(fr_big), 0.06, 1.0, 2.5, 130.0, 0, 0, 0, None, 0, other.ptr(cnt_big)), "harris_dev")
+        e, c = masked.canny_dev(frames, **SERP_KW)
+        assert masked.get_counter("canny_frames_unconverged") == len(frames)
+        other.sync()
+        seen = {}
+        for f in range(len(frames)):
+            key = frames[f].tobytes()
+            if key not in seen: seen[key] = oracle.canny(frames[f], **SERP_KW)
+            r, k = seen[key]
+            assert c[f] == k and mismatch(e[f], r) == 0, (cus, f)
+    finally:
+        masked.close(); other.close()
+        hip.hipStreamDestroy(stream)

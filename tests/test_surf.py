@@ -192,9 +192,9 @@ def test_surf_dev_ranks_and_cuts_on_the_device(be, max_points, sort_cap):
 
 
 def test_surf_dev_redoes_tiles_whose_candidates_overflow(be):
-    """a tile with more candidates than the record buffer holds (lab switch surf_rec_cap lowers the buffer to 16 records) is
-    redone with a larger buffer after the batch: same features as with room for everything.  With surf_async 1 the call does
-    not wait for the host and such a tile reports -candidates instead."""
+    """a tile with more candidates than the record buffer holds (lab switch surf_rec_cap lowers the buffer to 16 records)
+    reports -candidates (imgfd_surf_dev never waits for the host); imgfd_surf_dev_redo redoes it with a larger buffer: same
+    features as with room for everything"""
     frames = np.stack([blobs(160 + f, 320, 224) for f in range(3)])
     ref = be.surf_dev(frames, max_points=20, threshold=5.0)
     ncand = [len(oracle.surf_interest_points(frames[f], 5.0)) for f in range(3)]
@@ -206,10 +206,34 @@ def test_surf_dev_redoes_tiles_whose_candidates_overflow(be):
             assert len(got[f]["x"]) == len(ref[f]["x"]) > 0
             for k in ("x", "y", "score", "pyramid_scale", "laplacian", "angle", "surf"):
                 assert np.array_equal(got[f][k], ref[f][k]), (f, k)
-        be.set_tuning("surf_async", 1)
-        assert be.surf_dev_counts(frames, max_points=20, threshold=5.0).tolist() == [-c for c in ncand]
+        assert be.last_surf_redone == 3
+        raw = be.surf_dev_counts(frames, max_points=20, threshold=5.0).tolist()   # -(room to redo the tile with): survivors of the screening >= candidates
+        assert all(-r >= c for r, c in zip(raw, ncand)) and all(-r < 4 * c for r, c in zip(raw, ncand))
     finally:
-        be.set_tuning("surf_rec_cap", 1 << 18); be.set_tuning("surf_async", 0)
+        be.set_tuning("surf_rec_cap", 1 << 18)
+
+
+@pytest.mark.parametrize("group,lanes", [(1, 1), (2, 1), (3, 2), (8, 2), (4, 4), (16, 3)])
+def test_surf_dev_groups_of_tiles(be, group, lanes):
+    """imgfd_surf_dev handles the tiles in groups ("surf_group"): the fronts of a group (integral image, pyramid) go round-robin
+    over "surf_lanes" streams, each tile into a buffer set of its own, and the back stages (maximum test, ranking, orientation,
+    descriptor) are ONE launch each for the whole group (blockIdx.y = tile).  Seven tiles of different content: full groups, a
+    short last group, a group larger than the batch, more lanes than tiles in the last group; a buffer set read too early or
+    a wrong stride between the sets shows as another tile's points.  Twice: the second call reuses the sets while nothing
+    of the first is waited for in between."""
+    frames = np.stack([blobs(300 + f, 320, 240, n=25 + 9 * f) for f in range(7)])
+    ref = [oracle.surf(frames[f], 150, 3.0) for f in range(7)]
+    try:
+        be.set_tuning("surf_group", group); be.set_tuning("surf_lanes", lanes)
+        for _ in range(2):
+            got = be.surf_dev(frames, max_points=150, threshold=3.0)
+            for f in range(7):
+                assert len(ref[f]["x"]) > 5
+                for k in ("x", "y", "pyramid_scale", "score", "laplacian"):
+                    assert np.array_equal(got[f][k], ref[f][k]), (group, lanes, f, k)
+                assert np.abs(got[f]["surf"] - ref[f]["surf"]).max() <= 1e-9
+    finally:
+        be.set_tuning("surf_group", 8); be.set_tuning("surf_lanes", 2)
 
 
 def test_surf_dev_exact_score_ties_keep_emission_order(be):
