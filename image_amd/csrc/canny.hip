@@ -958,6 +958,8 @@ __global__ void __launch_bounds__(UF_NT) canny_uf_merge(const unsigned long long
 }
 
 #define EXP_BLOCKS 128
+#define CANNY_REPORTS 4  /* reports of working sweeps kept per context (pinned: sequence number, value) */
+static_assert(CANNY_REPORTS == sizeof(imgfd_ctx::canny_report_queued) / sizeof(unsigned), "one host slot per report slot");
 // rcpp_canny.cpp:226-243: the edge map as 0/255 bytes and its number of non-zero pixels; a workgroup walks every
 // EXP_BLOCKS-th row and adds its count once
 // A frame that went through the union-find kernels (uf != nullptr and its flag says so): the runs of W & ~S whose root is LIT
@@ -1026,8 +1028,8 @@ __global__ void __launch_bounds__(256) canny_expand_count(const unsigned long lo
 // hold a gap-free prefix of the tickets: every frame but the last one they have reached is complete in tickets, so its barriers open
 // with no further dispatch, its workgroups leave and make room; and the last frame completes as soon as the blocks of ONE frame are
 // resident together -- which the host guarantees by launching no more blocks per frame than the stream's compute units hold at
-// once (hipOccupancyMaxActiveBlocksPerMultiprocessor x the compute units of the stream's CU mask; canny_finish_blocks).  Whatever
-// else runs on the device only delays that.  Needs workgroups that can wait for each other (not the one-block-at-a-time emulator
+// once (hipOccupancyMaxActiveBlocksPerMultiprocessor x the device's compute units; a stream confined to some of them by a CU mask
+// takes the three launches instead: canny_finish_blocks).  Whatever else runs on the device only delays that.  Needs workgroups that can wait for each other (not the one-block-at-a-time emulator
 // of the tests: the host asks the device).
 __device__ __forceinline__ void frame_barrier(unsigned *counter, unsigned target)
 {
@@ -1041,11 +1043,26 @@ __device__ __forceinline__ void frame_barrier(unsigned *counter, unsigned target
 }
 __global__ void __launch_bounds__(256) canny_finish(const unsigned long long *__restrict__ S, int wpr, unsigned char *__restrict__ edges, int nx, int ny,
                                                     unsigned long long *__restrict__ counts, const unsigned long long *__restrict__ Wm,
-                                                    unsigned *__restrict__ parents, unsigned *__restrict__ flags, unsigned last_sweep, int n_frames)
+                                                    unsigned *__restrict__ parents, unsigned *__restrict__ flags, unsigned last_sweep, int n_frames,
+                                                    unsigned *__restrict__ report, unsigned report_seq)
 {
     __shared__ unsigned ticket_s;
     if (threadIdx.x == 0) ticket_s = __hip_atomic_fetch_add(flags + HY_SWEEPS_MAX + 2 * n_frames, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    // small batches: the first workgroup tells the HOST (pinned memory, no copy, nobody waits) how many sweeps this call's frames
+    // needed -- the next calls on this context queue that many and one more (canny_device)
+    if (report && ticket_s == 0) {
+        unsigned most = 0;
+        if ((int)threadIdx.x < n_frames) most = flags[HY_SWEEPS_MAX + threadIdx.x];
+        if (threadIdx.x < 64) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) most = max(most, (unsigned)__shfl_xor((int)most, d));
+            if (threadIdx.x == 0) {
+                __hip_atomic_store(report + 1, most, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(report, report_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
     const int frame = (int)(ticket_s / gridDim.x), bid = (int)(ticket_s - (unsigned)frame * gridDim.x);  // grid: (blocks per frame, frames)
     const bool united = flags[HY_SWEEPS_MAX + frame] == last_sweep;  // workgroup-uniform
     if (united) {
@@ -1177,23 +1194,25 @@ size_t canny_ws_bytes(int nx, int ny, int nf)
            align_up(2 * (size_t)nf * ceil_div(nx, 64) * ceil_div(ny, 64), 256) + 4096;
 }
 
-// Workgroups of canny_finish that can be resident together on the compute units this context's stream may use: the occupancy API's
-// answer per compute unit x the units of the stream's CU mask (a stream made by hipExtStreamCreateWithCUMask, a partitioned device).
-// Computed once per context; 0 when the runtime does not say.
+// Workgroups of canny_finish that can be resident together on this context's stream: the occupancy API's answer per compute unit x
+// the device's units -- or 0 ("use the three launches") when the runtime does not say, or when the stream may NOT use every unit
+// (hipExtStreamCreateWithCUMask): how a CU mask maps onto the XCDs a queue's workgroups are dealt to is not documented, so the
+// units such a stream really has cannot be counted (a first cut multiplied by the mask's bits: 48 unfinished frames on a stream
+// masked to 32 of 256 units never came back).  Computed once per context.
 int canny_finish_blocks(imgfd_ctx *ctx)
 {
     if (ctx->canny_finish_fit >= 0) return ctx->canny_finish_fit;
-    int per_cu = 0, cus = ctx->num_cu;
+    int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)canny_finish, 256, 0) != hipSuccess || per_cu < 1) return ctx->canny_finish_fit = 0;
     uint32_t mask[32] = {0};
     const uint32_t words = (uint32_t)std::min(32, (ctx->num_cu + 31) / 32);
     if (ctx->stream && hipExtStreamGetCUMask(ctx->stream, words, mask) == hipSuccess) {
         int n = 0;
         for (int i = 0; i < ctx->num_cu; i++) n += (mask[i >> 5] >> (i & 31)) & 1u;
-        if (n >= 1) cus = std::min(cus, n);
+        if (n < ctx->num_cu) { (void)hipGetLastError(); return ctx->canny_finish_fit = 0; }
     }
     (void)hipGetLastError();
-    return ctx->canny_finish_fit = per_cu * cus;
+    return ctx->canny_finish_fit = per_cu * ctx->num_cu;
 }
 
 // all device work for nf frames; d_edges / d_counts are device buffers
@@ -1292,6 +1311,8 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
     IMGFD_HIP(ctx, hipGetLastError());
     IMGFD_TRY(at(2));
     unsigned uf_last_sweep = 0;
+    unsigned *report = nullptr;
+    unsigned report_seq = 0;
     // Hysteresis, terminated on the device -- no host read-back anywhere.  A fixed number of sweeps is queued (a sweep whose
     // predecessor changed nothing returns at once: an idle launch costs a few microseconds), then the union-find kernel, which
     // leaves at once for every frame the last sweep left alone and otherwise completes the frame whatever its chains look like.
@@ -1307,7 +1328,45 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
         // once costs ~1.5 us, a frame the queued launches do not finish 0.3-0.9 ms in the union-find part of canny_finish: the
         // margin is three launches.
         int sweeps = few ? 8 : 9;
+        // Small batches (a single frame is ONE chain of dependent launches, and an idle sweep launch is 5-6 us of it: four of the
+        // eight queued for a bench frame, round 5): as many as the recent calls on this context needed, and one more that finds
+        // nothing.  The numbers come back through pinned memory (canny_finish's report), read here without waiting for anything:
+        // a call may see the report of a call a few before it.  A frame that needs more than were queued is finished by
+        // canny_finish's union-find part -- correct, 0.3-0.9 ms slower for that frame.
+        report = nullptr;
+        if (few && ctx->coop && canny_finish_blocks(ctx) >= 16 && nf <= 64) {
+            if (!ctx->canny_report) {
+                void *p = nullptr;
+                if (hipHostMalloc(&p, sizeof(unsigned) * 2 * CANNY_REPORTS, hipHostMallocDefault) == hipSuccess) {
+                    memset(p, 0, sizeof(unsigned) * 2 * CANNY_REPORTS);
+                    ctx->canny_report = (unsigned *)p;
+                }
+                (void)hipGetLastError();
+            }
+            if (ctx->canny_report) {
+                if (ctx->canny_report_nx != nx || ctx->canny_report_ny != ny) {  // another frame size: what its frames need is not known yet
+                    ctx->canny_report_nx = nx; ctx->canny_report_ny = ny;
+                    ctx->canny_report_base = ctx->canny_report_seq;
+                }
+                // the reports that have arrived (the host may be many calls ahead of the device: whatever the slots hold of calls on
+                // this frame size counts): the largest number of working sweeps among them; a call whose LAST queued sweep still changed
+                // something (its frames went to the union-find part) asks for all eight
+                unsigned known = 0;
+                bool any = false;
+                for (int k = 0; k < CANNY_REPORTS; k++) {
+                    const unsigned seq = __atomic_load_n(ctx->canny_report + 2 * k, __ATOMIC_ACQUIRE), val = __atomic_load_n(ctx->canny_report + 2 * k + 1, __ATOMIC_RELAXED);
+                    if (seq > ctx->canny_report_base && seq <= ctx->canny_report_seq) {
+                        any = true;
+                        known = std::max(known, val >= ctx->canny_report_queued[seq % CANNY_REPORTS] && seq + CANNY_REPORTS > ctx->canny_report_seq ? 8u : val);
+                    }
+                }
+                if (any) sweeps = std::max(2, std::min(8, (int)known + 1));
+                report_seq = ++ctx->canny_report_seq;
+                report = ctx->canny_report + 2 * (report_seq % CANNY_REPORTS);
+            }
+        }
         if (ctx->tune.hyst_sweeps >= 1 && ctx->tune.hyst_sweeps <= HY_SWEEPS_MAX) sweeps = ctx->tune.hyst_sweeps;  // tests: leave the work to the union-find part
+        if (report) ctx->canny_report_queued[report_seq % CANNY_REPORTS] = (unsigned)sweeps;
         const int tiles_x = ceil_div(wpr, hw), tiles_y = ceil_div(ny, 64);
         IMGFD_TRY(launch_hyst_blocks(ctx, hw, shape, S, Wm, wpr, ny, tiles_x, tiles_y, nf, flags, act, sweeps));
         uf_last_sweep = (unsigned)sweeps;
@@ -1321,7 +1380,7 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
         exp_blocks = std::min(exp_blocks, fit);  // a frame's blocks wait for each other: no more of them than can be resident together
         // union-find (frames the sweeps did not finish only), 0/255 bytes and pixels_nonzero in ONE launch
         hipLaunchKernelGGL(canny_finish, dim3(exp_blocks, nf), dim3(256), 0, ctx->stream, (const unsigned long long *)S, wpr, d_edges, nx, ny,
-                           (unsigned long long *)d_counts, (const unsigned long long *)Wm, reinterpret_cast<unsigned *>(blur), flags, uf_last_sweep, nf);
+                           (unsigned long long *)d_counts, (const unsigned long long *)Wm, reinterpret_cast<unsigned *>(blur), flags, uf_last_sweep, nf, report, report_seq);
     } else {
         // Workgroups per frame of the union-find kernels: enough to spread a frame that needs them over the chip, few enough
         // that the idle case stays one short launch each

@@ -55,6 +55,10 @@ struct imgfd_ctx {
     void *canny_taps = nullptr;
     void (*canny_taps_free)(void *) = nullptr;
     const unsigned *canny_flags = nullptr;
+    // small batches: how many sweeps the recent calls needed, reported by canny_finish into pinned memory (canny.hip)
+    unsigned *canny_report = nullptr;
+    unsigned canny_report_seq = 0, canny_report_base = 0, canny_report_queued[4] = {0, 0, 0, 0};  // (CANNY_REPORTS slots)
+    int canny_report_nx = 0, canny_report_ny = 0;
     int canny_finish_fit = -1;  // blocks of canny_finish the stream's compute units hold at once (-1: not asked yet; canny.hip)
     int canny_sweeps = 0, canny_frames = 0;
     std::string detect_key, detect_seen;  // the call it was recorded for / the call seen last (raw bytes of a DetectKey)

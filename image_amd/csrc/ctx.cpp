@@ -122,6 +122,7 @@ void imgfd_ctx_destroy(imgfd_ctx *ctx)
     if (ctx->clk_stream) { (void)hipStreamSynchronize(ctx->clk_stream); (void)hipStreamDestroy(ctx->clk_stream); }
     if (ctx->clk_ring) (void)hipFree(ctx->clk_ring);
     if (ctx->canny_taps && ctx->canny_taps_free) ctx->canny_taps_free(ctx->canny_taps);
+    if (ctx->canny_report) (void)hipHostFree(ctx->canny_report);
     for (hipEvent_t e : ctx->prof_ev) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -170,6 +171,10 @@ imgfd_status imgfd_get_counter(imgfd_ctx *ctx, const char *name, int64_t *value)
     if (!strcmp(name, "detect_graph_replays")) { *value = ctx->detect_replays; return IMGFD_OK; }
     if (!strcmp(name, "detect_graph_records")) { *value = ctx->detect_records; return IMGFD_OK; }
     if (!strcmp(name, "gauss_march_launches")) { *value = ctx->gauss_march_launches; return IMGFD_OK; }
+    if (!strcmp(name, "canny_sweeps_queued")) {  // sweep launches the last Canny call on this context (its companion's, for imgfd_detect_dev) queued
+        *value = ctx->canny_sweeps ? ctx->canny_sweeps : (ctx->side ? ctx->side->canny_sweeps : 0);
+        return IMGFD_OK;
+    }
     if (!strcmp(name, "canny_frames_unconverged") || !strcmp(name, "canny_sweeps_working")) {
         // diagnostics of the last Canny call on this context (its companion's, for imgfd_detect_dev): frames the queued sweeps
         // did not finish (the union-find kernels did), and the number of the last sweep that changed anything.  Waits for the stream.

@@ -300,11 +300,11 @@ def test_many_unconverged_frames_in_one_batch(be):
 @pytest.mark.gpu
 @pytest.mark.parametrize("cus", [32, 4, 1])
 def test_unconverged_frames_on_a_cu_masked_stream(cus):
-    """canny_finish's frame barriers on a stream that may use only `cus` of the device's compute units (hipExtStreamCreateWithCUMask:
-    1/8 of an MI355X, 4 units, one), while another context keeps the rest of the device busy with the Harris chain.  48 frames the one
-    queued sweep leaves unfinished: the kernel hands its (frame, slice) pairs out by ticket and launches no more blocks per frame
-    than the stream's units hold at once (canny_finish_blocks), so the barriers open whatever the units are; with a single unit
-    the call takes the three-launch form (no barrier at all).  Must neither hang nor differ from the oracle."""
+    """a stream that may use only `cus` of the device's compute units (hipExtStreamCreateWithCUMask: 1/8 of an MI355X, 4 units, one),
+    with the Harris chain of another context queued in front.  48 frames the one queued sweep leaves unfinished.  canny_finish --
+    the kernel whose workgroups wait for each other at frame barriers -- is launched only on streams that may use the whole
+    device (canny_finish_blocks asks the stream for its CU mask); a masked stream takes the three launches without any barrier.
+    Must neither hang nor differ from the oracle."""
     import ctypes as C
 
     import torch
@@ -340,3 +340,37 @@ def test_unconverged_frames_on_a_cu_masked_stream(cus):
     finally:
         masked.close(); other.close()
         hip.hipStreamDestroy(stream)
+
+
+@pytest.mark.gpu
+def test_small_batches_queue_the_sweeps_recent_calls_needed():
+    """up to 12 frames per call: canny_finish reports through pinned memory how many sweeps the frames needed, and the next calls on
+    the context queue that many and one more instead of eight (an idle launch is 5-6 us of a single frame's chain).  Same edges
+    every time; the number queued falls from 8 to working + 1; a frame that suddenly needs more than were queued (the serpentine:
+    dozens of sweeps) is finished by the union-find part -- still the oracle's edges -- and the calls after it queue more again;
+    another frame size starts from 8."""
+    from backends import GpuBackend
+    be = GpuBackend()
+    try:
+        img = synth.frame(77, 1920, 1080)
+        ref, rn = oracle.canny(img)
+        queued = []
+        for _ in range(6):
+            e, c = be.canny_dev(img[None])
+            assert c[0] == rn and mismatch(e[0], ref) == 0
+            queued.append(be.get_counter("canny_sweeps_queued"))
+        working = be.get_counter("canny_sweeps_working")
+        assert queued[0] == 8 and queued[-1] == min(8, max(2, working + 1)) and queued[-1] <= queued[0], (queued, working)
+        serp = _serpentine(1920, 1080)
+        rs, ks = oracle.canny(serp, **SERP_KW)
+        e, c = be.canny_dev(serp[None], **SERP_KW)      # needs far more sweeps than the few that are queued now
+        assert c[0] == ks and mismatch(e[0], rs) == 0
+        assert be.get_counter("canny_frames_unconverged") == 1
+        e, c = be.canny_dev(serp[None], **SERP_KW)
+        assert c[0] == ks and mismatch(e[0], rs) == 0 and be.get_counter("canny_sweeps_queued") == 8   # the call before said "not finished": all the sweeps there are
+        small = synth.frame(78, 640, 480)
+        e, c = be.canny_dev(small[None])
+        r2, k2 = oracle.canny(small)
+        assert c[0] == k2 and mismatch(e[0], r2) == 0 and be.get_counter("canny_sweeps_queued") == 8        # a new size: nothing known yet
+    finally:
+        be.close()
