@@ -368,7 +368,7 @@ class Detect4K(Workload):
                            "frac": round(TENSOR_F64_RATE_OPS_PER_PX * NX * NY * B / F64_LANE_OPS_3_WAVES * 1e6 / us, 4),
                            "what": "the kernel's f64-rate instructions alone (90 FIR operations + 17.25 conversions per pixel) at the rate three waves per SIMD issue them on this "
                                    "part, measured (scripts/ubench/ubench7.hip); the phase split and the barrier-free experiment behind this number: profiles/r04/k3_phase_split.txt, "
-                                   "k3_wave_experiment.txt; DESIGN.md, K3"},
+                                   "k3_wave_experiment.txt; DESIGN.md section 4, LOG.md"},
              "avg_launch_us": round(us, 2), "frames_per_launch": B, "algorithmic_bytes_per_launch": k3_bytes,
              "shader_clock_GHz": k3_clock["mean_GHz"],   # while these launches ran (imgfd_clock_probe, 20 ms): tells a slow box from a slow kernel
              "timed": "HIP events on the context's stream around back-to-back launches of the stage doorway on this batch's gradients, after the timed region"}

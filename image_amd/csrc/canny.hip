@@ -1145,7 +1145,7 @@ imgfd_status launch_blur_march(imgfd_ctx *ctx, BlurMarchParams &p, int nf)
     }
     p.seg_rows = seg;
     p.strips = strips;
-    p.xcd_order = ctx->tune.xcd_remap;
+    p.xcd_order = 1;
     dim3 grid((unsigned)strips * (unsigned)ceil_div(p.ny, seg), nf);
     IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)canny_blur_march<R>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)G::LDS_BYTES));
@@ -1163,11 +1163,11 @@ imgfd_status launch_hyst_block(imgfd_ctx *ctx, unsigned long long *S, const unsi
     if (lds > 48 * 1024)
         IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)canny_hyst_block<HW, BX, BY>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (int i = 0; i < sweeps; i++) {
-        // odd launches group the tiles half a block up and left ("hyst_shift" 0: every launch the same grouping)
-        const int sx = (i & 1) && ctx->tune.hyst_shift ? BX / 2 : 0, sy = (i & 1) && ctx->tune.hyst_shift ? BY / 2 : 0;
+        // odd launches group the tiles half a block up and left
+        const int sx = (i & 1) ? BX / 2 : 0, sy = (i & 1) ? BY / 2 : 0;
         const int blocks_x = ceil_div(tiles_x + sx, BX), blocks_y = ceil_div(tiles_y + sy, BY);
         hipLaunchKernelGGL((canny_hyst_block<HW, BX, BY>), dim3(blocks_x * blocks_y, nf), dim3(64 * BX * BY), lds, ctx->stream, S, Wm, wpr, ny, tiles_x,
-                           tiles_y, blocks_x, sx, sy, flags, i, act, ctx->tune.hyst_prio);
+                           tiles_y, blocks_x, sx, sy, flags, i, act, 1 /* wave priority 3: the sweeps run beside chip-filling kernels */);
     }
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
@@ -1177,11 +1177,9 @@ imgfd_status launch_hyst_blocks(imgfd_ctx *ctx, int hw, int shape, unsigned long
 {
 #define HY_CASE(W, X, Y) \
     if (hw == W && shape == 10 * X + Y) return launch_hyst_block<W, X, Y>(ctx, S, Wm, wpr, ny, tiles_x, tiles_y, nf, flags, act, sweeps);
-    HY_CASE(1, 2, 2) HY_CASE(1, 4, 2) HY_CASE(1, 2, 4) HY_CASE(1, 4, 4)
-    HY_CASE(2, 2, 2) HY_CASE(2, 4, 2) HY_CASE(2, 2, 4) HY_CASE(2, 4, 4)
-    HY_CASE(4, 2, 2) HY_CASE(4, 4, 2) HY_CASE(4, 2, 4) HY_CASE(4, 4, 4)
+    HY_CASE(1, 2, 4) HY_CASE(4, 2, 2)
 #undef HY_CASE
-    return imgfd_fail(ctx, IMGFD_ERR_INVALID, "hyst_block: 22, 42, 24 or 44 (tiles per workgroup, 10 * across + down)");
+    return imgfd_fail(ctx, IMGFD_ERR_INVALID, "canny: no sweep kernel for this tile width / block shape");
 }
 
 size_t canny_ws_bytes(int nx, int ny, int nf)
@@ -1306,7 +1304,7 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
     IMGFD_TRY(at(1));
     dim3 g2((unsigned)wpr * (unsigned)ceil_div(ny, GN_TY), nf);
     hipLaunchKernelGGL(canny_grad_nms, g2, dim3(256), 0, ctx->stream, blur, S, Wm, nx, ny, wpr, accGrad, (int)low_thr,
-                       (int)high_thr, (int)(nx % 4 == 0 && (size_t)blur % 16 == 0), flags, HY_SWEEPS_MAX, wpr, ctx->tune.xcd_remap,
+                       (int)high_thr, (int)(nx % 4 == 0 && (size_t)blur % 16 == 0), flags, HY_SWEEPS_MAX, wpr, 1,
                        (unsigned long long *)d_counts);
     IMGFD_HIP(ctx, hipGetLastError());
     IMGFD_TRY(at(2));
@@ -1322,8 +1320,7 @@ imgfd_status canny_device(imgfd_ctx *ctx, const uint8_t *d_in, int row_stride, s
         // with two- / four-word tiles: a sweep's length is its slowest wave's fixpoint loop, and a pass over a tile costs its words);
         // batches four-word tiles in blocks of 2 x 2 (56.5 per frame at 32 frames, one-word tiles 59).
         const bool few = nf <= 12;
-        const int hw = ctx->tune.hyst_words == 1 || ctx->tune.hyst_words == 2 || ctx->tune.hyst_words == 4 ? ctx->tune.hyst_words : (few ? 1 : 4);
-        const int shape = ctx->tune.hyst_block > 0 ? ctx->tune.hyst_block : (few ? 24 : 22);
+        const int hw = few ? 1 : 4, shape = few ? 24 : 22;  // (the other widths and block shapes measured: profiles/r05/canny_block_sweeps.txt)
         // The bench frames need 4 (one frame) to 6 launches (a batch) and one more that finds nothing; a launch that returns at
         // once costs ~1.5 us, a frame the queued launches do not finish 0.3-0.9 ms in the union-find part of canny_finish: the
         // margin is three launches.

@@ -44,9 +44,6 @@ struct imgfd_ctx {
     // Gaussian taps beyond the IMGFD_MAX_TAPS a kernel argument holds (sigma > 21): grow-only device copy (fir.hip)
     double *taps_dev = nullptr;
     size_t taps_cap = 0;
-    // imgfd_detect_dev: the recorded launch sequence of a repeating small-batch call (detect.hip)
-    void *detect_exec = nullptr;          // hipGraphExec_t
-    long detect_replays = 0, detect_records = 0;  // statistics (imgfd_get_counter)
     long gauss_march_launches = 0;
     // Canny hysteresis, last call on this context: where its sweep flags live (workspace), sweeps queued, frames (diagnostic
     // counters "canny_frames_unconverged" / "canny_sweeps_working": imgfd_get_counter waits for the stream and reads them back)
@@ -61,42 +58,25 @@ struct imgfd_ctx {
     int canny_report_nx = 0, canny_report_ny = 0;
     int canny_finish_fit = -1;  // blocks of canny_finish the stream's compute units hold at once (-1: not asked yet; canny.hip)
     int canny_sweeps = 0, canny_frames = 0;
-    std::string detect_key, detect_seen;  // the call it was recorded for / the call seen last (raw bytes of a DetectKey)
-    std::string detect_unrecordable;  // the key of a launch sequence that refused to be captured: run eagerly, do not try again
     // fHOG: magnitude + orientation of every integer gradient (fhog_fused.hip), built on first use
     unsigned *fhog_lut = nullptr;
     // lab switches (imgfd_set_tuning / IMGFD_* environment variables read ONCE at context creation; include/imgfd.h
     // lists them).  Defaults are the measured best; none changes a result.
     struct Tune {
-        int fhog_fused = 1;  // 1: cell_size 8 through fhog_hist8; 0: the three stage kernels
-        int fhog_bands = 0;  // bands a workgroup of fhog_hist8 marches through (0: chosen from the batch size)
-        int fhog_threads = 256;  // workgroup size of fhog_hist8 (256 | 512)
-        int fhog_arith = 32;     // fhog_hist8: a wave with >= this many lanes outside the table's LDS centre computes their words (0: always gathers)
-        // round-1/2 experiment switches (formerly getenv() at their point of use)
-        int hyst_sweeps = 0;        // Canny hysteresis: sweeps queued before the union-find step (0: 8 up to 12 frames, 9 for batches)
-        int hyst_words = 0;         // words per sweep tile: 1, 2 or 4 (0: 1 up to 12 frames, else 4)
-        int hyst_block = 0;         // tiles per workgroup of a sweep, 10 * across + down: 22, 42, 24, 44 (0: 24 up to 12 frames, else 22)
-        int detect_swap = -1;       // imgfd_detect_dev: 1 = Canny's chain on the context's own stream, FAST-9 and the Harris chain on the companion's; 0: the other way round; -1: 1 below 8 frames
-        int hyst_prio = 1;          // block sweeps run at wave priority 3 (0: default priority)
-        int hyst_shift = 1;         // block sweeps: odd launches group the tiles half a block up and left (0: the same grouping in every launch)
-        int detect_defer = -1;      // imgfd_detect_dev: 1 = FAST-9 and the Harris chain are QUEUED only after the whole Canny chain (their release point on the device stays where canny_gate / harris_gate put it); 0 = queued where they are released; -1: 1 below 8 frames
-        int gauss_march = 1;        // u8 frames whose width is a multiple of 16: the marching Gaussian + gradient kernel (0: the tile kernel)
-        int gauss_march_seg = 0;    // rows per segment of that kernel (0: from the batch)
-        int harris_gate = -1;       // imgfd_detect_dev: the Harris chain is released behind Canny's gradient/NMS kernel (1), behind its blur (2), or together with FAST-9 (0); -1: 2 below 8 frames, else 1
-        int canny_gate = -1;        // imgfd_detect_dev: where Canny releases FAST-9 on the other stream (0 before the blur, 1 after it, 2 after gradient/NMS; -1: 2 for a single frame, else 0)
-        int xcd_remap = 1;          // marching FIR kernels: workers of one XCD own neighbouring tiles
-        int fused_response = 1;     // Harris: corner response in the structure-tensor kernel's epilogue
-        int nms_tiled = 0;          // Harris batch path: 1 = the tiled NMS kernel instead of the sparse one
-        int tensor_per_cu = 0, tensor_workers = 0, tensor_tw = 0;  // fir_tensor launch geometry (0: chosen)
-        int max_chunk_frames = 0;   // frames per sub-batch of the *_dev entry points (0: from the 12 GiB / 1 GiB budgets)
-        int tile_run = 0;           // tiles per workgroup of the u8 tile kernels (0: from the batch size)
-        int detect_graph = 0;       // imgfd_detect_dev: batches of fewer frames than this replay a recorded hipGraph when the call repeats
-                                    // (0 = never, the default: replay measured no faster than eager launches, profiles/r03)
-        int surf_lanes = 2;      // imgfd_surf_dev: the fronts (integral image + pyramid) of a group's tiles go round-robin over this many HIP streams (1..4)
-        int surf_group = 8;      // imgfd_surf_dev: tiles per group (1..16): a buffer set per tile, the latency-bound back stages (maximum test, ranking, K19) as ONE launch each per group
-        int surf_rec_cap = 1 << 18;  // imgfd_surf_dev: candidate records a tile's buffer holds before the tile is redone (tests lower it)
-        int surf_sort_cap = 2048;    // imgfd_surf_dev: selected records ranked by the LDS sort; more are ranked all-pairs (tests lower it)
-        int surf_split = 1;      // SURF: 1 = a tile that has the device to itself (one lane) runs octaves 1-3 on the companion's stream beside octave 0
+        // (the measured-and-lost alternatives these replaced -- tile widths and block shapes of the sweeps, release points of imgfd_detect_dev,
+        // hipGraph replay, tiled Harris NMS, 512-thread fHOG workgroups, plain-table SURF gathers ... -- left the library in round 6:
+        // LOG.md, scripts/experiments/r06_pruned_switches.patch)
+        int fhog_fused = 1;         // 1: cell_size 8 through fhog_hist8; 0: the three stage kernels (which serve every other cell size / width)
+        int fhog_bands = 0;         // bands a workgroup of fhog_hist8 marches through (0: chosen from the batch size; tests: 1..3)
+        int hyst_sweeps = 0;        // Canny hysteresis: sweeps queued before the union-find step (0: chosen; tests lower it to reach the union-find part)
+        int gauss_march = 1;        // u8 frames whose width is a multiple of 16: the marching Gaussian + gradient kernel (0: the tile kernel, which serves every other shape)
+        int gauss_march_seg = 0;    // rows per segment of that kernel (0: from the batch; tests: every length class)
+        int tensor_workers = 0;     // workgroups of fir_tensor (0: one per compute unit; tests: few workers, several segments each)
+        int max_chunk_frames = 0;   // frames per sub-batch of the *_dev entry points (0: from the 12 GiB / 1 GiB budgets; tests: small batches cross sub-batch boundaries)
+        int surf_lanes = 2;         // imgfd_surf_dev: the fronts (integral image + pyramid) of a group's tiles go round-robin over this many HIP streams (1..4)
+        int surf_group = 8;         // imgfd_surf_dev: tiles per group (1..16): a buffer set per tile, the latency-bound back stages (maximum test, ranking, K19) as ONE launch each per group
+        int surf_rec_cap = 1 << 18; // imgfd_surf_dev: candidate records a tile's buffer holds before the tile reports -needed (tests lower it)
+        int surf_sort_cap = 2048;   // imgfd_surf_dev: selected records ranked by the LDS sort; more are ranked all-pairs (tests lower it)
     } tune;
     // imgfd_surf_dev: events between the front streams and the back stream of a batch (created on first use)
     std::vector<hipEvent_t> surf_ev;
@@ -235,8 +215,6 @@ imgfd_status pin_reserve(imgfd_ctx *ctx, size_t bytes);
 imgfd_status aux_reserve(imgfd_ctx *ctx, size_t bytes);
 // the context's companion (created on first use): same device, own non-blocking stream, own workspace
 imgfd_status ctx_side(imgfd_ctx *ctx, imgfd_ctx **side);
-// detect.hip: forget the recorded launch sequence (context destruction)
-void detect_graph_drop(imgfd_ctx *ctx);
 // records a profiling event on the stream when K3 profiling is on (no-op otherwise)
 imgfd_status prof_mark(imgfd_ctx *ctx);
 

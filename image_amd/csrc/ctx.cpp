@@ -10,34 +10,16 @@ struct TuneKey { const char *name, *env; int imgfd_ctx::Tune::*field; };
 const std::vector<TuneKey> &tune_keys()
 {
     static const std::vector<TuneKey> keys = {
+        {"fir_mode", "IMGFD_FIR_MODE", nullptr},
         {"fhog_fused", "IMGFD_FHOG_FUSED", &imgfd_ctx::Tune::fhog_fused},
         {"fhog_bands", "IMGFD_FHOG_BANDS", &imgfd_ctx::Tune::fhog_bands},
-        {"fhog_threads", "IMGFD_FHOG_THREADS", &imgfd_ctx::Tune::fhog_threads},
-        {"fhog_arith", "IMGFD_FHOG_ARITH", &imgfd_ctx::Tune::fhog_arith},
         {"hyst_sweeps", "IMGFD_HYST_SWEEPS", &imgfd_ctx::Tune::hyst_sweeps},
-        {"hyst_words", "IMGFD_HYST_WORDS", &imgfd_ctx::Tune::hyst_words},
-        {"hyst_block", "IMGFD_HYST_BLOCK", &imgfd_ctx::Tune::hyst_block},
-        {"hyst_shift", "IMGFD_HYST_SHIFT", &imgfd_ctx::Tune::hyst_shift},
-        {"hyst_prio", "IMGFD_HYST_PRIO", &imgfd_ctx::Tune::hyst_prio},
-        {"detect_defer", "IMGFD_DETECT_DEFER", &imgfd_ctx::Tune::detect_defer},
-        {"detect_swap", "IMGFD_DETECT_SWAP", &imgfd_ctx::Tune::detect_swap},
-        {"canny_gate", "IMGFD_CANNY_GATE", &imgfd_ctx::Tune::canny_gate},
-        {"harris_gate", "IMGFD_HARRIS_GATE", &imgfd_ctx::Tune::harris_gate},
         {"gauss_march", "IMGFD_GAUSS_MARCH", &imgfd_ctx::Tune::gauss_march},
         {"gauss_march_seg", "IMGFD_GAUSS_MARCH_SEG", &imgfd_ctx::Tune::gauss_march_seg},
-        {"xcd_remap", "IMGFD_XCD_REMAP", &imgfd_ctx::Tune::xcd_remap},
-        {"fused_response", "IMGFD_FUSED_RESPONSE", &imgfd_ctx::Tune::fused_response},
-        {"nms_tiled", "IMGFD_NMS_TILED", &imgfd_ctx::Tune::nms_tiled},
-        {"tensor_per_cu", "IMGFD_TENSOR_PER_CU", &imgfd_ctx::Tune::tensor_per_cu},
         {"tensor_workers", "IMGFD_TENSOR_WORKERS", &imgfd_ctx::Tune::tensor_workers},
-        {"tensor_tw", "IMGFD_TENSOR_TW", &imgfd_ctx::Tune::tensor_tw},
         {"max_chunk_frames", "IMGFD_MAX_CHUNK_FRAMES", &imgfd_ctx::Tune::max_chunk_frames},
-        {"tile_run", "IMGFD_TILE_RUN", &imgfd_ctx::Tune::tile_run},
-        {"fir_mode", "IMGFD_FIR_MODE", nullptr},
-        {"detect_graph", "IMGFD_DETECT_GRAPH", &imgfd_ctx::Tune::detect_graph},
         {"surf_lanes", "IMGFD_SURF_LANES", &imgfd_ctx::Tune::surf_lanes},
         {"surf_group", "IMGFD_SURF_GROUP", &imgfd_ctx::Tune::surf_group},
-        {"surf_split", "IMGFD_SURF_SPLIT", &imgfd_ctx::Tune::surf_split},
         {"surf_sort_cap", "IMGFD_SURF_SORT_CAP", &imgfd_ctx::Tune::surf_sort_cap},
         {"surf_rec_cap", "IMGFD_SURF_REC_CAP", &imgfd_ctx::Tune::surf_rec_cap},
     };
@@ -109,7 +91,6 @@ void imgfd_ctx_destroy(imgfd_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);  // nothing of this context is in flight when its graph, events and buffers go
-    detect_graph_drop(ctx);
     if (ctx->side) imgfd_ctx_destroy(ctx->side);
     for (hipEvent_t e : {ctx->ev_fork, ctx->ev_gate, ctx->ev_gate2, ctx->ev_join})
         if (e) (void)hipEventDestroy(e);
@@ -168,8 +149,6 @@ imgfd_status imgfd_set_tuning(imgfd_ctx *ctx, const char *name, int value)
 imgfd_status imgfd_get_counter(imgfd_ctx *ctx, const char *name, int64_t *value)
 {
     if (!ctx || !name || !value) return IMGFD_ERR_INVALID;
-    if (!strcmp(name, "detect_graph_replays")) { *value = ctx->detect_replays; return IMGFD_OK; }
-    if (!strcmp(name, "detect_graph_records")) { *value = ctx->detect_records; return IMGFD_OK; }
     if (!strcmp(name, "gauss_march_launches")) { *value = ctx->gauss_march_launches; return IMGFD_OK; }
     if (!strcmp(name, "canny_sweeps_queued")) {  // sweep launches the last Canny call on this context (its companion's, for imgfd_detect_dev) queued
         *value = ctx->canny_sweeps ? ctx->canny_sweeps : (ctx->side ? ctx->side->canny_sweeps : 0);
@@ -247,7 +226,6 @@ imgfd_status prof_mark(imgfd_ctx *ctx)
 int tile_run_length(const imgfd_ctx *ctx, int tiles_x, int bands, int frames)
 {
     const int num_cu = ctx->num_cu;
-    if (ctx->tune.tile_run > 0) return ctx->tune.tile_run;
     // Measured on 32 x 4K frames (scripts/gpu_u8.sh, profiles/r02/u8_runs.txt): runs of 4 cut the fetched bytes by a third
     // at the same or a slightly better duration; longer runs fetch less still but serialise too much of a workgroup's
     // latency (staging -> phases -> barriers) and run slower, as does a grid of resident workgroups walking the runs

@@ -14,32 +14,6 @@
 
 namespace {
 
-// Everything a recorded launch sequence depends on -- the arguments (pointers included: they are baked into the kernel
-// nodes), the two workspace arenas the kernels were pointed at, the switches -- serialised MEMBER BY MEMBER: the argument
-// structs have padding (imgfd_frames after ny, imgfd_stream_params after accGrad and keep_edges), and padding copied from a
-// caller's struct is indeterminate: a key that compared it would never match, or match by accident.
-std::string make_key(const imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_stream_params *p, const void *c, const void *pt, const void *e,
-                     const void *n)
-{
-    // a member added to either struct must be added below: the sizes pin the layouts this list was written for
-    static_assert(sizeof(imgfd_frames) == 40 && sizeof(imgfd_stream_params) == 104, "imgfd_frames / imgfd_stream_params changed: extend make_key");
-    std::string k;
-    auto put = [&k](const auto &v) { k.append(reinterpret_cast<const char *>(&v), sizeof v); };
-    put(fr->d_frames); put(fr->n_frames); put(fr->nx); put(fr->ny); put(fr->frame_stride_bytes); put(fr->row_stride_bytes); put(fr->dtype);
-    put(p->harris); put(p->fast9); put(p->canny); put(p->k); put(p->sigma_d); put(p->sigma_i); put(p->threshold);
-    put(p->gaussian); put(p->gradient); put(p->measure); put(p->fast9_threshold); put(p->suppress_non_max);
-    put(p->s); put(p->low_thr); put(p->high_thr); put(p->accGrad); put(p->corner_cap); put(p->point_cap); put(p->keep_edges);
-    put(c); put(pt); put(e); put(n);
-    put(ctx->ws); put(ctx->ws_size);
-    const void *side_ws = ctx->side ? ctx->side->ws : nullptr;
-    const size_t side_size = ctx->side ? ctx->side->ws_size : 0;
-    put(side_ws); put(side_size);
-    put(ctx->fir_mode);
-    static_assert(sizeof(imgfd_ctx::Tune) % sizeof(int) == 0, "the switches are plain ints: no padding between them");
-    put(ctx->tune);
-    return k;
-}
-
 imgfd_status detect_body(imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_stream_params *p, imgfd_corner *d_corners,
                          imgfd_point *d_points, uint8_t *d_edges, int64_t *d_counts)
 {
@@ -52,10 +26,10 @@ imgfd_status detect_body(imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_str
     if (!p->harris && !p->fast9) return imgfd_canny_dev(ctx, fr, p->s, p->low_thr, p->high_thr, p->accGrad, d_edges, d_counts + 2 * B);
     imgfd_ctx *side = nullptr;
     IMGFD_TRY(ctx_side(ctx, &side));
-    // Two streams: `cs` runs Canny's chain, `os` FAST-9 and the Harris chain.  By default Canny takes the companion's stream;
-    // "detect_swap" 1 gives it the context's own: then nothing stands between the caller's previous work on that stream and the blur
-    // -- no fork event to cross -- and the join at the end is a wait that has usually been satisfied already.
-    const bool swap = ctx->tune.detect_swap < 0 ? B < 8 : ctx->tune.detect_swap == 1;
+    // Two streams: one runs Canny's chain, the other FAST-9 and the Harris chain.  For batches Canny takes the companion's stream; below
+    // eight frames the context's own: then nothing stands between the caller's previous work on that stream and the blur -- no
+    // fork event to cross -- and the join at the end is a wait that has usually been satisfied already (round 5, LOG.md).
+    const bool swap = B < 8;
     imgfd_ctx *cc = swap ? ctx : side, *oc = swap ? side : ctx;   // Canny's context / the other detectors'
     auto fail_from = [&](imgfd_ctx *c, imgfd_status st) -> imgfd_status {
         if (c != ctx && !c->err.empty()) ctx->err = c->err;
@@ -81,19 +55,18 @@ imgfd_status detect_body(imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_str
     // (Round 2 got this order by accident: the 16-wave rows_scan workgroup of FAST-9's compaction found no CU with 16 free
     // wave slots until the gradient/NMS kernel had drained.  Released together with FAST-9: 43.5 instead of 40.3 ms per
     // 10 passes of 32 4K frames, profiles/r03/experiments_log.txt.)
-    const int cg = ctx->tune.canny_gate < 0 ? 0 : ctx->tune.canny_gate;
-    const int fast_at = cg == 1 ? 1 : (cg == 0 ? 0 : 2);
+    const int fast_at = 0;
     // (small batches: behind the blur already -- the chain then ends before Canny's does, and the join below is a wait that has been
-    // satisfied by the time the stream reaches it: 182 against 190 us for a single 4K frame, profiles/r05/single_frame_variants.txt)
-    const int hg = ctx->tune.harris_gate < 0 ? (B < 8 ? 2 : 1) : ctx->tune.harris_gate;
-    const int harris_at = hg == 0 ? fast_at : (hg == 2 ? 1 : 2);
+    // satisfied by the time the stream reaches it: 182 against 190 us for a single 4K frame, profiles/r05/single_frame_variants.txt;
+    // the other release points measured: profiles/r06/single_frame_gates.txt)
+    const int harris_at = B < 8 ? 1 : 2;
     // Small batches are bound by Canny's chain of dependent kernels, and the HOST queues launches at 3-8 us each: with the other
     // detectors queued from inside the hook, a single 4K frame's first hysteresis sweep reached its queue 39 us after
     // gradient/NMS had finished (profiles/r04/f_single_frame_timeline.txt: the ten launches of FAST-9 and the Harris chain sat in
-    // between).  "detect_defer": the hook only RECORDS the release events where they belong in Canny's stream; the waits and the
-    // other detectors' launches are queued after the last Canny launch.  Same dependencies on the device, the critical chain
-    // first on the host.
-    const bool defer = ctx->tune.detect_defer < 0 ? B < 8 : ctx->tune.detect_defer != 0;
+    // between).  Below eight frames the hook therefore only RECORDS the release events where they belong in Canny's stream; the waits
+    // and the other detectors' launches are queued after the last Canny launch.  Same dependencies on the device, the critical
+    // chain first on the host.
+    const bool defer = B < 8;
     bool fast_due = false, harris_due = false;
     const std::function<imgfd_status(int)> hook = [&](int pos) -> imgfd_status {  // pos: 0 before Canny's blur, 1 behind it, 2 behind gradient/NMS
         if (pos == fast_at) {
@@ -132,15 +105,6 @@ imgfd_status detect_body(imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_str
 
 }  // namespace
 
-void detect_graph_drop(imgfd_ctx *ctx)
-{
-    if (ctx->detect_exec) (void)hipGraphExecDestroy((hipGraphExec_t)ctx->detect_exec);
-    ctx->detect_exec = nullptr;
-    ctx->detect_key.clear();
-    ctx->detect_seen.clear();
-    ctx->detect_unrecordable.clear();
-}
-
 extern "C" {
 
 imgfd_status imgfd_detect_dev(imgfd_ctx *ctx, const imgfd_frames *fr, const imgfd_stream_params *p, imgfd_corner *d_corners,
@@ -151,58 +115,10 @@ try {
         (p->fast9 && p->point_cap < 0) || (p->canny && !d_edges) || p->fast9_threshold < 0 || p->fast9_threshold > 255)
         return imgfd_fail(ctx, IMGFD_ERR_INVALID, "imgfd_detect_dev: bad argument");
     IMGFD_HIP(ctx, hipSetDevice(ctx->device));
-    // Lab switch "detect_graph" (off by default).  A small batch issues ~45 launches at 3-4 us of host time each; the launch
-    // sequence of a call that repeats -- same frames buffer, same outputs, same parameters: a camera loop -- can be recorded
-    // into a hipGraph the second time it is seen and replayed from the third (one submission).  The first sight runs
-    // eagerly: it sizes the workspaces, which a capture must not do.  Measured on single 4K frames: 0.2597 ms replayed
-    // against 0.2586 ms eager -- the frame is bound by Canny's chain of dependent kernels on the device, not by the host.
-    const int limit = ctx->tune.detect_graph;  // batches of fewer frames than this use the graph (0: never)
-    if (fr->n_frames < 1 || fr->n_frames >= limit || ctx->prof_on || !ctx->stream)  // (the default stream cannot be captured)
-        return detect_body(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
-    const std::string kb = make_key(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
-    if (ctx->detect_exec && kb == ctx->detect_key) {
-        IMGFD_HIP(ctx, hipGraphLaunch((hipGraphExec_t)ctx->detect_exec, ctx->stream));
-        ctx->detect_replays++;
-        return IMGFD_OK;
-    }
-    if (kb == ctx->detect_unrecordable) return detect_body(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
-    if (kb != ctx->detect_seen) {  // first sight
-        const imgfd_status st = detect_body(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
-        // the run may have grown a workspace: remember the state the NEXT call will see
-        ctx->detect_seen = make_key(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
-        return st;
-    }
-    detect_graph_drop(ctx);
-    hipGraph_t graph = nullptr;
-    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {  // no capture here: eager from now on
-        (void)hipGetLastError();
-        ctx->detect_unrecordable = kb;
-        return detect_body(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
-    }
-    const imgfd_status st = detect_body(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
-    const hipError_t ec = hipStreamEndCapture(ctx->stream, &graph);
-    if (st != IMGFD_OK || ec != hipSuccess || !graph) {
-        // Not recordable: a call that is illegal under capture (a workspace that grows, taps uploaded for a very large sigma, the
-        // pageable copy of Canny's long-kernel path) fails HERE although it succeeds eagerly.  Drop the capture and its error,
-        // remember the key, and run the call once more the ordinary way: only what that run says is reported.
-        if (graph) (void)hipGraphDestroy(graph);
-        (void)hipGetLastError();
-        ctx->err.clear();
-        ctx->detect_unrecordable = kb;
-        return detect_body(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
-    }
-    hipGraphExec_t exec = nullptr;
-    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (ei != hipSuccess || !exec) {
-        (void)hipGetLastError();
-        return detect_body(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
-    }
-    ctx->detect_exec = exec;
-    ctx->detect_key = kb;
-    ctx->detect_records++;
-    IMGFD_HIP(ctx, hipGraphLaunch(exec, ctx->stream));
-    return IMGFD_OK;
+    // (A recorded hipGraph of the launch sequence of a repeating small-batch call replayed in the same time as the eager launches,
+    // rounds 3 and 5: a single frame is bound by the device's chain of dependent kernels, not by the host.  The capture path left the
+    // library in round 6: scripts/experiments/r06_pruned_switches.patch.)
+    return detect_body(ctx, fr, p, d_corners, d_points, d_edges, d_counts);
 } catch (const std::bad_alloc &) {
     return imgfd_fail(ctx, IMGFD_ERR_OOM, "imgfd_detect_dev: out of host memory");
 } catch (...) {

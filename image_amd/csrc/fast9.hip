@@ -250,10 +250,10 @@ imgfd_status launch_fast9(imgfd_ctx *ctx, const uint8_t *d_img, int w, int h, in
     const int aligned16 = ((size_t)d_img % 16 == 0) && stride % 16 == 0 && frame_stride % 16 == 0;
     if (!nonmax)
         hipLaunchKernelGGL(fast9_tile<0>, grid, dim3(256), 0, ctx->stream, d_img, w, h, stride, frame_stride, threshold,
-                           aligned4, aligned16, cb.mask, cb.rowcount, cb.words_per_row, runs, ctx->tune.xcd_remap);
+                           aligned4, aligned16, cb.mask, cb.rowcount, cb.words_per_row, runs, 1);
     else
         hipLaunchKernelGGL(fast9_tile<1>, grid, dim3(256), 0, ctx->stream, d_img, w, h, stride, frame_stride, threshold,
-                           aligned4, aligned16, cb.mask, cb.rowcount, cb.words_per_row, runs, ctx->tune.xcd_remap);
+                           aligned4, aligned16, cb.mask, cb.rowcount, cb.words_per_row, runs, 1);
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }

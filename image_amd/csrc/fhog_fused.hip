@@ -400,10 +400,9 @@ imgfd_status fhog_fused_hist(imgfd_ctx *ctx, const uint8_t *d_rgb, size_t frame_
     }
     bpw = std::min(bpw, n_bands);
     const dim3 grid((unsigned)tiles_x * (unsigned)ceil_div(n_bands, bpw), nf);
-    if (ctx->tune.fhog_threads == 512)
-        hipLaunchKernelGGL(fhog_hist8<512>, grid, dim3(512), FH_LDS, ctx->stream, d_rgb, frame_stride, ctx->fhog_lut, hist, norm, g, bpw, tiles_x, ctx->tune.xcd_remap, ctx->tune.fhog_arith);
-    else
-        hipLaunchKernelGGL(fhog_hist8<256>, grid, dim3(256), FH_LDS, ctx->stream, d_rgb, frame_stride, ctx->fhog_lut, hist, norm, g, bpw, tiles_x, ctx->tune.xcd_remap, ctx->tune.fhog_arith);
+    // (512-thread workgroups: 83.8 against 77.6 us per tile, round 4; a wave with at least 32 lanes outside the table's LDS centre computes
+    // its words instead of gathering them: thresholds 16-64 measure the same, profiles/r04/fhog_arith.txt)
+    hipLaunchKernelGGL(fhog_hist8<256>, grid, dim3(256), FH_LDS, ctx->stream, d_rgb, frame_stride, ctx->fhog_lut, hist, norm, g, bpw, tiles_x, 1, 32);
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }

@@ -416,7 +416,7 @@ static imgfd_status launch_march(imgfd_ctx *ctx, FirParams &p, int n_frames)
     }
     p.seg_rows = seg;
     dim3 grid(strips, ceil_div(p.ny, seg), n_frames);
-    p.xcd_remap = ctx->tune.xcd_remap;
+    p.xcd_remap = 1;
     // float4 tile loads need 16-byte aligned planes, pitch and frame stride, and whole quads per row
     p.vec4 = MODE != 1 && ((size_t)p.in0 % 16 == 0) && ((size_t)p.in1 % 16 == 0) && p.in_pitch % 4 == 0 &&
              p.in_frame_stride % 4 == 0 && p.nx % 4 == 0 && p.nx >= 4;
@@ -513,7 +513,6 @@ imgfd_status launch_gaussian(imgfd_ctx *ctx, const void *d_in, int in_is_u8, int
 // 16-byte aligned planes whose rows are whole quads
 bool tensor_response_supported(const imgfd_ctx *ctx, int nx, int ny, float sigma, int gauss, int measure, const float *d_Ix, const float *d_Iy, const float *d_R)
 {
-    if (!ctx->tune.fused_response) return false;
     if (gauss != IMGFD_STD_GAUSSIAN || measure != IMGFD_HARRIS_MEASURE || !(sigma > 0)) return false;
     const int size = fir_size(sigma, 3);
     if (size > nx || !tensor_fast_path(size - 1)) return false;

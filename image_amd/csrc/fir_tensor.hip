@@ -489,8 +489,7 @@ static imgfd_status launch_tensor_r(imgfd_ctx *ctx, TensorParams &p, int n_frame
     // kernel).  One persistent workgroup per CU: 12 waves at 168 registers fill a CU's register file, and the hardware
     // admitted one workgroup even where LDS (68 KB for the 128-column instance) and the occupancy API promised two
     // (profiles/r02/k3_log.txt).
-    int per_cu = 1;
-    if (ctx->tune.tensor_per_cu > 0) per_cu = ctx->tune.tensor_per_cu;
+    const int per_cu = 1;
     const long slots = (long)per_cu * ctx->num_cu;
     p.nstrips = strips;
     p.n_frames = n_frames;
@@ -501,7 +500,7 @@ static imgfd_status launch_tensor_r(imgfd_ctx *ctx, TensorParams &p, int n_frame
     p.units_per_worker = (p.total_units + workers - 1) / workers;
     workers = (p.total_units + p.units_per_worker - 1) / p.units_per_worker;
     dim3 grid((unsigned)workers);
-    p.xcd_remap = ctx->tune.xcd_remap;
+    p.xcd_remap = 1;
     auto go = [&](auto kern) -> imgfd_status {
         IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, grid, dim3(G::NT), lds, ctx->stream, p);
@@ -541,7 +540,7 @@ imgfd_status launch_tensor_march(imgfd_ctx *ctx, const float *d_Ix, const float 
     if (out_mode != 0 && out_mode != 2) return IMGFD_ERR_UNSUPPORTED;
     if (out_mode != 0 && !vec) return IMGFD_ERR_UNSUPPORTED;
     // 256-column strips (12 waves: every SIMD carries three) unless the image is narrow
-    const int tw = ctx->tune.tensor_tw == 128 ? 128 : ctx->tune.tensor_tw == 256 ? 256 : (nx > 384 ? 256 : 128);
+    const int tw = nx > 384 ? 256 : 128;
 #define FT_GO(RR)                                                                                          \
     case RR:                                                                                               \
         if (tw == 256) {                                                                                   \

@@ -308,7 +308,7 @@ imgfd_status launch_gauss_grad_march(imgfd_ctx *ctx, const void *d_in, int in_pi
     while (seg < ny && ny - (ceil_div(ny, seg) - 1) * seg < 2) seg++;
     p.seg_rows = seg;
     p.nseg = ceil_div(ny, seg);
-    p.xcd_order = ctx->tune.xcd_remap;
+    p.xcd_order = 1;
     const dim3 grid((unsigned)((long)p.nstrips * p.nseg * n_frames));
     const bool sobel = grad_type == IMGFD_SOBEL_OPERATOR;
 #define GM_LAUNCH(G, F) hipLaunchKernelGGL((gauss_grad_march<R, G, F>), grid, dim3(GM_NT), 0, ctx->stream, p)

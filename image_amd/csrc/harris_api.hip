@@ -169,13 +169,11 @@ imgfd_status harris_device_stages(imgfd_ctx *ctx, const void *d_in, int in_is_u8
         // the default path: the structure tensor never leaves the CU -- its kernel's epilogue evaluates the corner
         // response (harris.cpp:78-133) and only R is stored; NMS then reads 4 B/px instead of 12
         IMGFD_TRY(prof_mark(ctx));
-        const bool sparse = !ctx->tune.nms_tiled;  // experiment switch: the round-2a kernel that streams R through LDS
         unsigned char *tq = reinterpret_cast<unsigned char *>(hp.A);  // the A plane is idle on this path: it holds the threshold quads
-        IMGFD_TRY(launch_tensor_response(ctx, hp.Ix, hp.Iy, hp.R, nx, ny, n_frames, a.sigma_i, a.k, sparse ? tq : nullptr, a.Th));
+        IMGFD_TRY(launch_tensor_response(ctx, hp.Ix, hp.Iy, hp.R, nx, ny, n_frames, a.sigma_i, a.k, tq, a.Th));
         IMGFD_TRY(prof_mark(ctx));
         if (!rc_cleared) IMGFD_TRY(compact_clear(ctx, hp.cb, ny, n_frames));
-        if (sparse) IMGFD_TRY(launch_harris_nms_sparse(ctx, hp.R, tq, nx, ny, n_frames, a.Th, radius, hp.cb));
-        else IMGFD_TRY(launch_harris_nms_tiled(ctx, hp.R, nx, ny, n_frames, a.Th, radius, hp.cb));
+        IMGFD_TRY(launch_harris_nms_sparse(ctx, hp.R, tq, nx, ny, n_frames, a.Th, radius, hp.cb));
         IMGFD_TRY(compact_emit(ctx, hp.cb, nx, ny, n_frames, 0, hp.R, d_corners, cap, d_counts));
         return IMGFD_OK;
     }
@@ -459,7 +457,8 @@ imgfd_status imgfd_k_tensor_response(imgfd_ctx *ctx, const float *d_Ix, const fl
 
 const char *imgfd_tensor_kernel_name(imgfd_ctx *ctx)
 {
-    return ctx && !ctx->tune.fused_response ? "fir_tensor<7, fma, vec, A/B/C> (20 B/px)" : "fir_tensor<7, fma, vec, response> (structure tensor + Harris response, 12 B/px)";
+    (void)ctx;
+    return "fir_tensor<7, fma, vec, response> (structure tensor + Harris response, 12 B/px)";
 }
 
 imgfd_status imgfd_time_structure_tensor(imgfd_ctx *ctx, const float *d_Ix, const float *d_Iy,

@@ -607,7 +607,7 @@ static imgfd_status launch_surf_pyramid_lds(imgfd_ctx *ctx, const SurfTable &T, 
     const size_t lds = sizeof(unsigned) * (size_t)G::H * G::P;
     IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)surf_pyramid_lds<O>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int bx = ceil_div(g.nc[O], G::LX), by = ceil_div(g.nr[O], G::LY);
-    hipLaunchKernelGGL(surf_pyramid_lds<O>, dim3((unsigned)bx * (unsigned)by), dim3(G::NT), lds, ctx->stream, T, d_pyr, g, d_mask, thr, bx, ctx->tune.xcd_remap);
+    hipLaunchKernelGGL(surf_pyramid_lds<O>, dim3((unsigned)bx * (unsigned)by), dim3(G::NT), lds, ctx->stream, T, d_pyr, g, d_mask, thr, bx, 1);
     return IMGFD_OK;
 }
 
@@ -1574,7 +1574,7 @@ imgfd_status surf_points_host(imgfd_ctx *ctx, const void *rgb, int kind, int row
         if (!d_rgb || !d.integral || !d.mask || !d.pyr || !d.rec || !d.surv || !d.cands || !d.count) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
         IMGFD_TRY(upload_image(ctx, rgb, kind, 3 * n, d_rgb));
         imgfd_ctx *fork = nullptr;
-        if (ctx->tune.surf_split) IMGFD_TRY(ctx_side(ctx, &fork));
+        IMGFD_TRY(ctx_side(ctx, &fork));
         SurfTable T;
         IMGFD_TRY(surf_device_stages(ctx, d_rgb, g, thr, d, &T, fork));
         unsigned long long cnt = 0;
@@ -1761,7 +1761,7 @@ imgfd_status imgfd_surf_points_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_f
     if (!d.integral || !d.mask || !d.pyr || !d.surv || !d.cands || !d.count) return imgfd_fail(ctx, IMGFD_ERR_OOM, "workspace reservation too small");
     d.cap = (unsigned long long)cap;
     imgfd_ctx *fork = nullptr;
-    if (ctx->tune.surf_split) IMGFD_TRY(ctx_side(ctx, &fork));
+    IMGFD_TRY(ctx_side(ctx, &fork));
     for (int f = 0; f < n_frames; f++) {  // tiles are processed back to back on the context's stream, no host sync
         d.rec = reinterpret_cast<SurfRecord *>(d_points) + (size_t)f * cap;
         IMGFD_TRY(surf_device_stages(ctx, d_rgb + (size_t)f * frame_stride_bytes, g, detection_threshold, d, nullptr, fork));
@@ -1803,7 +1803,7 @@ static imgfd_status surf_dev_run(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_fra
         if (st != IMGFD_OK) { ctx->err = lane[l - 1]->err; return st; }
     }
     imgfd_ctx *fork = nullptr;  // one tile: its two pyramid kernels side by side (surf_front, "surf_split")
-    if (G == 1 && ctx->tune.surf_split) IMGFD_TRY(ctx_side(ctx, &fork));
+    if (G == 1) IMGFD_TRY(ctx_side(ctx, &fork));
     // More than one group: two BANKS of buffer sets, and the back of group k on a stream of its own beside the fronts of group k + 1
     const int banks = !only && n_run > G ? 2 : 1;
     imgfd_ctx *back = ctx;

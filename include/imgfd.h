@@ -83,53 +83,37 @@ IMGFD_API imgfd_status imgfd_device_count(int *count);
  *       f32 stages (products, response) never contract.  Results differ from strict only when the
  *       f64 sum sits within ~1e-16 relative of a float rounding boundary. */
 IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
-/* Lab switches.  None changes a result; the defaults are the measured best.  Each can also be given through the
- * environment variable in brackets, which is read ONCE, when the context is created.
- *   "fhog_fused" [IMGFD_FHOG_FUSED]  1 (default): cell_size 8 runs the fused gradient + histogram kernel; 0: stage kernels
- *   "fhog_bands" [IMGFD_FHOG_BANDS]  bands of 8 cell rows one workgroup of that kernel marches through (0: from the batch)
- *   "fhog_threads" [IMGFD_FHOG_THREADS]  workgroup size of that kernel, 256 (default) or 512
- *   "fhog_arith" [IMGFD_FHOG_ARITH]  a wave of that kernel with at least this many lanes whose gradients lie outside the
- *                  table's LDS centre computes their (magnitude, bin) words instead of gathering them (default 32; 0: always
- *                  gathers; same bits either way)
- *   "fir_mode" [IMGFD_FIR_MODE]  as imgfd_set_fir_mode
- *   "hyst_sweeps" [IMGFD_HYST_SWEEPS]  Canny hysteresis: sweep launches queued before the union-find step (0: 8 up to 12 frames, 9 for batches)
- *   "hyst_words" [IMGFD_HYST_WORDS]  words per tile of a sweep: 1, 2 or 4 (0: 1 up to 12 frames, else 4)
- *   "hyst_block" [IMGFD_HYST_BLOCK]  tiles per workgroup of a sweep, 10 * across + down: 22, 42, 24 or 44 (0: 24 up to 12 frames, else 22)
- *   "hyst_shift" [IMGFD_HYST_SHIFT]  1 (default): odd sweep launches group the tiles half a block up and left; 0: one grouping
- *   "hyst_prio" [IMGFD_HYST_PRIO]  1 (default): the sweeps run at wave priority 3
- *   "canny_gate" [IMGFD_CANNY_GATE]  imgfd_detect_dev: where Canny releases FAST-9 on the other stream (0 before the blur,
- *                  1 behind it, 2 behind gradient/NMS; -1, default: 0)
- *   "detect_defer" [IMGFD_DETECT_DEFER]  imgfd_detect_dev: 1: FAST-9 and the Harris chain are QUEUED after Canny's last launch
- *                  (released on the device where the gates say); 0: queued where they are released; -1 (default): 1 below 8 frames
- *   "harris_gate" [IMGFD_HARRIS_GATE]  imgfd_detect_dev: 1: the Harris chain starts behind Canny's gradient/NMS kernel
- *                                      (FAST-9 starts with the blur); 2: behind the blur; 0: together with FAST-9; -1 (default): 2 below 8 frames, else 1
- *   "detect_swap" [IMGFD_DETECT_SWAP]  imgfd_detect_dev: 1: Canny's chain runs on the context's own stream, the other detectors on the
- *                                      companion's; 0: the other way round; -1 (default): 1 below 8 frames
- *   "gauss_march" [IMGFD_GAUSS_MARCH]  1 (default): u8 frames whose width is a multiple of 16 (>= 256) take the marching
- *                                      Gaussian + gradient kernel; 0: the tile kernel.  "gauss_march_seg": its rows per segment
- *   "xcd_remap" [IMGFD_XCD_REMAP]  1 (default): workers of one XCD own neighbouring tiles in the marching FIR kernels
- *   "fused_response" [IMGFD_FUSED_RESPONSE]  1 (default): corner response in the structure-tensor kernel's epilogue
- *   "nms_tiled" [IMGFD_NMS_TILED]  1: the tiled Harris NMS kernel instead of the sparse one
- *   "tensor_per_cu", "tensor_workers", "tensor_tw" [IMGFD_TENSOR_*]  launch geometry of fir_tensor: workgroups per CU, workers
- *                  (each takes an equal share of the batch's line of 16-row chunk units), strip width 128 | 256 (0: chosen)
- *   "max_chunk_frames" [IMGFD_MAX_CHUNK_FRAMES]  frames per sub-batch of the *_dev entry points (0: from the memory budgets)
- *   "tile_run" [IMGFD_TILE_RUN]  tiles per workgroup of the u8 tile kernels (0: from the batch size)
- *   "detect_graph" [IMGFD_DETECT_GRAPH]  imgfd_detect_dev replays a recorded hipGraph for repeating calls on fewer frames than this
- *                                        (0 = never, the default: a single 4K frame takes the same time either way, 0.20 ms in round 5)
+/* Switches: twelve, none changes a result.  Each selects a required fallback or is a knob the tests turn to reach a code path on small
+ * inputs; the defaults are the measured best.  Each can also be given through the environment variable in brackets, which is read ONCE,
+ * when the context is created.  (The measured-and-lost alternatives earlier rounds kept selectable -- sweep tile shapes, release points
+ * and stream assignment of imgfd_detect_dev, hipGraph replay, tiled Harris NMS, plain-table SURF gathers, ... -- left the library in round 6:
+ * LOG.md, scripts/experiments/r06_pruned_switches.patch.)  In brackets behind each: the GPU test that exercises it.
+ *   "fir_mode" [IMGFD_FIR_MODE]  as imgfd_set_fir_mode  (tests/test_full_size.py::test_harris_4k, every strict-mode stage test)
+ *   "fhog_fused" [IMGFD_FHOG_FUSED]  1 (default): cell_size 8 runs the fused gradient + histogram kernel; 0: the stage kernels that serve every
+ *                  other cell size and width  (tests/test_fhog.py::test_fused_kernel_shapes)
+ *   "fhog_bands" [IMGFD_FHOG_BANDS]  bands of 8 cell rows one workgroup of that kernel marches through (0: from the batch)  (same test)
+ *   "hyst_sweeps" [IMGFD_HYST_SWEEPS]  Canny hysteresis: sweep launches queued before the union-find step (0: 9 for batches; up to 12 frames as
+ *                  many as the recent calls on the context needed + 1, 8 at first)  (tests/test_canny.py::test_many_unconverged_frames_in_one_batch)
+ *   "gauss_march" [IMGFD_GAUSS_MARCH]  1 (default): u8 frames whose width is a multiple of 16 (>= 256) take the marching Gaussian + gradient
+ *                  kernel; 0: the tile kernel that serves every other shape  (tests/test_harris_stages.py::test_marching_gauss_grad_random_shapes)
+ *   "gauss_march_seg" [IMGFD_GAUSS_MARCH_SEG]  rows per segment of the marching kernel (0: from the batch)  (same test)
+ *   "tensor_workers" [IMGFD_TENSOR_WORKERS]  workgroups of fir_tensor, each with an equal share of the batch's line of 16-row chunk units
+ *                  (0: one per compute unit)  (tests/test_harris_stages.py: the structure-tensor tests with few workers)
+ *   "max_chunk_frames" [IMGFD_MAX_CHUNK_FRAMES]  frames per sub-batch of the *_dev entry points (0: from the memory budgets)  (tests/test_sub_batches.py)
  *   "surf_group" [IMGFD_SURF_GROUP]  8 (default): imgfd_surf_dev handles the tiles in groups of this many (1..16): a buffer set per tile,
- *                                    the latency-bound back stages (maximum test, ranking, orientation, descriptor) as one launch each per group
+ *                  the latency-bound back stages (maximum test, ranking, orientation, descriptor) as one launch each per group
  *   "surf_lanes" [IMGFD_SURF_LANES]  2 (default): the front stages (integral image, Hessian pyramid) of a group's tiles go round-robin
- *                                    over this many HIP streams (1..4)
- *   "surf_split" [IMGFD_SURF_SPLIT]  1 (default): a tile that has the device to itself (imgfd_surf, imgfd_surf_dev with one tile, the interest-point
- *                                  doorways) runs the Hessian pyramid of octaves 1-3 on the companion context's stream beside octave 0; 0: one stream
+ *                  over this many HIP streams (1..4)  (both: tests/test_surf.py::test_surf_dev_groups_of_tiles)
  *   "surf_sort_cap" [IMGFD_SURF_SORT_CAP]  selected records imgfd_surf_dev ranks with its LDS sort (2048); more: all-pairs ranking
- *   "surf_rec_cap" [IMGFD_SURF_REC_CAP]  candidate records per tile imgfd_surf_dev buffers before it redoes the tile (262144)
+ *                  (tests/test_surf.py::test_surf_dev_ranks_and_cuts_on_the_device)
+ *   "surf_rec_cap" [IMGFD_SURF_REC_CAP]  candidate records per tile imgfd_surf_dev buffers before the tile reports -needed (262144)
+ *                  (tests/test_surf.py::test_surf_dev_redoes_tiles_whose_candidates_overflow)
  * Unknown names give IMGFD_ERR_INVALID. */
 IMGFD_API imgfd_status imgfd_set_tuning(imgfd_ctx *ctx, const char *name, int value);
-/* reads a switch back, or a statistic: "detect_graph_records" / "detect_graph_replays" (launch sequences imgfd_detect_dev
- * recorded into a hipGraph / replayed from one on this context), "gauss_march_launches" (launches of the marching
- * Gaussian + gradient kernel), "canny_sweeps_working" / "canny_frames_unconverged" (last Canny call on this context: the last
- * sweep launch that changed a frame; frames the queued launches did not finish -- these two wait for the stream) */
+/* reads a switch back, or a statistic: "gauss_march_launches" (launches of the marching Gaussian + gradient kernel),
+ * "canny_sweeps_queued" (sweep launches the last Canny call on this context queued), "canny_sweeps_working" /
+ * "canny_frames_unconverged" (last Canny call on this context: the last sweep launch that changed a frame; frames the queued
+ * launches did not finish -- these two wait for the stream) */
 IMGFD_API imgfd_status imgfd_get_counter(imgfd_ctx *ctx, const char *name, int64_t *value);
 
 /* ------------------------------------------------------------------ Harris */

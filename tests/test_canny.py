@@ -222,48 +222,31 @@ def test_union_find_on_noise(be, seed):
         be.set_tuning("hyst_sweeps", 0)
 
 
-@pytest.mark.parametrize("words", [1, 2, 4])
-def test_hysteresis_tile_widths(be, words):
-    """the sweeps walk tiles of 1 word (up to a dozen frames) or 4 words (batches; 2: lab): same fixpoint, with few sweeps queued
-    the union-find step completes either"""
-    nx, ny = (384, 200) if be.name != "emu" else (264, 136)
-    img = _serpentine(nx, ny)
-    frames = np.stack([img, synth.frame(44, nx, ny), img[:, ::-1].copy()])
-    try:
-        be.set_tuning("hyst_words", words)
-        for sweeps in ((0, 2) if be.name != "emu" else (2,)):
-            be.set_tuning("hyst_sweeps", sweeps)
-            edges, n = be.canny(img, **SERP_KW)
-            ref, rn = oracle.canny(img, **SERP_KW)
-            assert n == rn and mismatch(edges, ref) == 0, (words, sweeps)
-            e, c = be.canny_dev(frames, **SERP_KW)
-            for f in range(3):
-                r, k = oracle.canny(frames[f], **SERP_KW)
-                assert c[f] == k and mismatch(e[f], r) <= (0 if f != 1 else 3), (words, sweeps, f)
-    finally:
-        be.set_tuning("hyst_words", 0); be.set_tuning("hyst_sweeps", 0)
-
-
-@pytest.mark.parametrize("shape,words", [(22, 2), (42, 4), (24, 1), (44, 4), (44, 2), (22, 1)])
-def test_hysteresis_block_shapes(be, shape, words):
-    """block sweeps: BX x BY tiles per workgroup exchange their outlines through LDS inside one launch (hyst_block = 10 BX + BY),
-    odd launches group the tiles half a block up and left.  The fixpoint is unique, so every shape, tile width and number
-    of queued sweeps gives the oracle's edge map -- on the serpentine (one chain through every tile, both directions, block
-    outlines included: 1000 x 260 spans several blocks of 2 x 2 two-word tiles) and on a synthetic frame."""
-    if be.name == "emu" and shape == 44:
-        pytest.skip("512 / 1024 fibers per workgroup: minutes on the emulator; the GPU run covers these shapes")
+@pytest.mark.parametrize("n_frames", [3, 14])
+def test_hysteresis_both_sweep_kernels(be, n_frames):
+    """up to a dozen frames the sweeps walk one-word tiles in blocks of 2 x 4 per workgroup, larger batches four-word tiles in blocks
+    of 2 x 2; the tiles of a block exchange their outlines through LDS inside one launch, odd launches group the tiles half a block
+    up and left.  The fixpoint is unique, so either kernel and any number of queued sweeps (the union-find part completes what they
+    leave) gives the oracle's edge map -- on the serpentine (one chain through every tile, both directions, block outlines
+    included: 1000 x 260 spans several blocks) and on a synthetic frame."""
+    if be.name == "emu" and n_frames > 3:
+        pytest.skip("14 frames of 512-fiber workgroups: minutes on the emulator; the GPU run covers the batch kernel")
     img = _serpentine(1000, 260) if be.name != "emu" else _serpentine(520, 200)
-    frames = np.stack([img, synth.frame(45, img.shape[1], img.shape[0]), img[::-1, ::-1].copy()])
+    kinds = [img, synth.frame(45, img.shape[1], img.shape[0]), img[::-1, ::-1].copy()]
+    frames = np.stack([kinds[f % 3] for f in range(n_frames)])
+    refs = [oracle.canny(k, **SERP_KW) for k in kinds]
     try:
-        be.set_tuning("hyst_block", shape); be.set_tuning("hyst_words", words)
         for sweeps in ((0, 1, 3) if be.name != "emu" else (2,)):
             be.set_tuning("hyst_sweeps", sweeps)
             e, c = be.canny_dev(frames, **SERP_KW)
-            for f in range(3):
-                r, k = oracle.canny(frames[f], **SERP_KW)
-                assert c[f] == k and mismatch(e[f], r) <= (0 if f != 1 else 3), (shape, words, sweeps, f)
+            for f in range(n_frames):
+                r, k = refs[f % 3]
+                assert c[f] == k and mismatch(e[f], r) <= (0 if f % 3 != 1 else 3), (n_frames, sweeps, f)
+            if n_frames == 3:
+                edges, n = be.canny(img, **SERP_KW)
+                assert n == refs[0][1] and mismatch(edges, refs[0][0]) == 0, sweeps
     finally:
-        be.set_tuning("hyst_block", 0); be.set_tuning("hyst_words", 0); be.set_tuning("hyst_sweeps", 0)
+        be.set_tuning("hyst_sweeps", 0)
 
 
 def test_batch_dev(be):

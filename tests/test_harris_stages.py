@@ -299,7 +299,7 @@ def test_nms_quads_plateaus(be):
     """The quad byte drops a pixel that a neighbour inside its quad beats; plateaus (ties inside a quad and across two) and
     peaks on every column residue must come out as the scan line has them.  (Plateaus that tie a plateau in the row above
     are left out: the scan line's skip marks of earlier rows, which then reach into the start-of-row rule, are not modelled
-    by either NMS kernel -- DESIGN.md section 4.)"""
+    by either NMS kernel -- LOG.md, round-5 section 4.)"""
     rng = np.random.default_rng(11)
     R = (rng.random((64, 132)) * 90).astype(np.float32)
     for i, c in enumerate(range(8, 120, 7)):          # isolated peaks on columns of every residue mod 4

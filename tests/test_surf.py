@@ -139,26 +139,21 @@ def test_threshold_zero_lists_every_level_pixel(be, w, h):
     assert len(ref) > 50 and got.shape == ref.shape and np.array_equal(got.view(np.uint64), ref.view(np.uint64))
 
 
-def test_single_tile_pyramid_on_one_stream_or_two(be):
-    """"surf_split" 1 (default): a call with one tile runs octaves 1-3 on the companion context's stream beside octave 0 and the
-    maximum test waits for both; 0: everything on the context's stream.  Same points, same features; repeated calls reuse
-    the buffers (the second tile's integral image must not overtake the first tile's gather kernel)"""
+def test_single_tile_calls_reuse_their_buffers(be):
+    """a call with one tile runs octaves 1-3 on the companion context's stream beside octave 0 and the maximum test waits for
+    both; repeated calls reuse the buffers (the second tile's integral image must not overtake the first tile's gather kernel)"""
     frames = np.stack([blobs(230 + f, 320, 240) for f in range(2)])
     ref = [oracle.surf(frames[f], 300, 4.0) for f in range(2)]
     pts = [oracle.surf_interest_points(frames[f], 4.0) for f in range(2)]
-    try:
-        for split in (1, 0):
-            be.set_tuning("surf_split", split)
-            for f in (0, 1):
-                got = be.surf_dev(frames[f:f + 1], max_points=300, threshold=4.0)[0]
-                assert len(ref[f]["x"]) > 20
-                assert np.array_equal(got["score"], ref[f]["score"]), (split, f)
-                key = lambda d: sorted(zip(d["score"], d["x"], d["y"], d["pyramid_scale"], d["laplacian"]))  # (equal scores may swap places)
-                assert key(got) == key(ref[f]), (split, f)
-                p = be.surf_interest_points(frames[f], 4.0)
-                assert p.shape == pts[f].shape and np.array_equal(p.view(np.uint64), pts[f].view(np.uint64)), (split, f)
-    finally:
-        be.set_tuning("surf_split", 1)
+    for rep in range(2):
+        for f in (0, 1):
+            got = be.surf_dev(frames[f:f + 1], max_points=300, threshold=4.0)[0]
+            assert len(ref[f]["x"]) > 20
+            assert np.array_equal(got["score"], ref[f]["score"]), (rep, f)
+            key = lambda d: sorted(zip(d["score"], d["x"], d["y"], d["pyramid_scale"], d["laplacian"]))  # (equal scores may swap places)
+            assert key(got) == key(ref[f]), (rep, f)
+            p = be.surf_interest_points(frames[f], 4.0)
+            assert p.shape == pts[f].shape and np.array_equal(p.view(np.uint64), pts[f].view(np.uint64)), (rep, f)
 
 
 @pytest.mark.parametrize("max_points", [1, 9, 25])
