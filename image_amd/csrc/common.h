@@ -78,6 +78,9 @@ struct imgfd_ctx {
         int surf_rec_cap = 1 << 18; // imgfd_surf_dev: candidate records a tile's buffer holds before the tile reports -needed (tests lower it)
         int surf_sort_cap = 2048;   // imgfd_surf_dev: selected records ranked by the LDS sort; more are ranked all-pairs (tests lower it)
     } tune;
+    // imgfd_surf: helper threads for the host half of K19 (surf.hip owns the object and its destructor)
+    void *surf_pool = nullptr;
+    void (*surf_pool_free)(void *) = nullptr;
     // imgfd_surf_dev: events between the front streams and the back stream of a batch (created on first use)
     std::vector<hipEvent_t> surf_ev;
     // imgfd_clock_probe (clock.hip): a stream of its own, a ring of (shader cycles, wall ticks) samples

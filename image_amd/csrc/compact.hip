@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(256) scatter_rows(const unsigned long long *__
         if (lane == 0) part[threadIdx.x >> 6] = sum;
         __syncthreads();
         running = part[0] + part[1] + part[2] + part[3];
-        for (int r = y0; r < y; r++) running += rc[r];  // the rows of the waves before this one (at most three, wave-uniform)
+        for (int r = y0; r < min(y, ny); r++) running += rc[r];  // the rows of the waves before this one (at most three, wave-uniform; never past the frame's last row)
         if (y == ny - 1 && lane == 0) counts[frame] = (long long)(running + rc[y]);
     } else {
         running = row_ok ? rowoff[(size_t)frame * ny + yy] : 0u;

@@ -99,6 +99,7 @@ void imgfd_ctx_destroy(imgfd_ctx *ctx)
     if (ctx->aux) (void)hipFree(ctx->aux);
     if (ctx->fhog_lut) (void)hipFree(ctx->fhog_lut);
     if (ctx->taps_dev) (void)hipFree(ctx->taps_dev);
+    if (ctx->surf_pool && ctx->surf_pool_free) ctx->surf_pool_free(ctx->surf_pool);
     for (hipEvent_t e : ctx->surf_ev) (void)hipEventDestroy(e);
     if (ctx->clk_stream) { (void)hipStreamSynchronize(ctx->clk_stream); (void)hipStreamDestroy(ctx->clk_stream); }
     if (ctx->clk_ring) (void)hipFree(ctx->clk_ring);

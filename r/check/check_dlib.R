@@ -5,7 +5,7 @@ p <- read_pnm(gold("cruise_boat.ppm"))
 x <- array(p$bytes, dim = c(3L, p$w, p$h))        # what image_fhog() / image_surf() take: integer RGB, (3, width, height)
 f <- image_fhog(x, cell_size = 8L, filter_rows_padding = 1L, filter_cols_padding = 1L)
 d <- scan(gold("fhog_cruise_boat_c8_dim.txt"), quiet = TRUE)
-ref <- read.csv(gold("fhog_cruise_boat_c8.csv"))$fhog
+ref <- readBin(gold("fhog_cruise_boat_c8.f32"), "numeric", n = prod(d), size = 4, endian = "little")   # dlib's floats, first index fastest
 ok(sprintf("image_fhog(cruise_boat): [%d, %d, 31], max |diff| %.3g", f$hog_height, f$hog_width, max(abs(as.vector(f$fhog) - ref))),
    identical(dim(f$fhog), as.integer(d)) && max(abs(as.vector(f$fhog) - ref)) <= 1e-6)          # dlib's own tolerance (test/fhog.cpp)
 s <- image_surf(x, max_points = 1000, detection_threshold = 30)

@@ -54,7 +54,8 @@ for acc in (0, 1):
 g = np.load(os.path.join(G, "fhog_cruise_boat.npz"))
 pnm("cruise_boat.ppm", g["image"])
 h = g["hog_c8"]            # [rows, cols, 31]; R's as.vector() runs the first index fastest
-csv("fhog_cruise_boat_c8.csv", ["fhog"], [h.transpose(2, 1, 0).ravel()])
+# 119 040 floats: as little-endian float32 (what dlib computes; readBin(..., size = 4) in R), 476 KB instead of a 3.5 MB text column
+h.transpose(2, 1, 0).ravel().astype("<f4").tofile(os.path.join(O, "fhog_cruise_boat_c8.f32"))
 with open(os.path.join(O, "fhog_cruise_boat_c8_dim.txt"), "w") as f:
     f.write("%d %d %d\n" % h.shape)
 

@@ -63,7 +63,7 @@ def test_r_check_kit_is_complete_and_current():
     named = set()
     for f in glob.glob(os.path.join(ROOT, "r", "check", "check_*.R")):
         txt = open(f).read()
-        named |= set(re.findall(r'"([A-Za-z0-9_]+\.(?:csv|pgm|ppm|txt))"', txt))   # file names without a sprintf pattern
+        named |= set(re.findall(r'"([A-Za-z0-9_]+\.(?:csv|pgm|ppm|txt|f32))"', txt))   # file names without a sprintf pattern
     assert len(named) >= 12
     for n in named:
         assert os.path.exists(os.path.join(gdir, n)), n
