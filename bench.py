@@ -348,8 +348,9 @@ class Detect4K(Workload):
         iy = torch.empty_like(ix)
         for f in range(B):
             det.gradients_of(self.frames[f], ix[f], iy[f])
-        det.clock_probe(20000)   # 20 ms of the doorway's ~100 ms of back-to-back launches: the clock this kernel alone runs at
-        us = det.time_structure_tensor_batch(ix, iy, warmup=12, iters=max(20, min(60, steps)))   # warm-up covers the first touch of the freshly allocated A, B, C
+        # warm-up covers the first touch of the freshly allocated A, B, C; a 40 ms clock probe (one wavefront of 6 registers: it fits
+        # beside the kernel's 3 x 168 per SIMD) spans the warm-up and the first timed launches: the clock this kernel alone runs at
+        us = det.time_structure_tensor_batch(ix, iy, warmup=12, iters=max(20, min(60, steps)), probe_us=40000)
         k3_clock = det.clock_probe_read()
         del ix, iy
         k3_bytes = TENSOR_BYTES_PER_PX * NX * NY * B

@@ -313,10 +313,13 @@ __global__ void __launch_bounds__(256) surf_int_sums(const unsigned char *__rest
 // the strips to the LEFT (the apply kernel summed them itself, lane by lane: up to 15 dependent round trips in front of its tile)
 constexpr int SC_RUN = 32;  // bands of a run held in registers
 __global__ void __launch_bounds__(256) surf_int_carry(unsigned *__restrict__ colsum, unsigned *__restrict__ bandstrip, unsigned *__restrict__ rowsum,
-                                                      int nbands, int rows, int cols, int nstrips)
+                                                      int nbands, int rows, int cols, int nstrips, unsigned long long *__restrict__ zero32)
 {
     __shared__ unsigned tot[SI_MAX_STRIPS][256 + 1];
     const int tid = threadIdx.x;
+    // on its way: the tile's 256-byte counter slot (records, survivors, candidates of K18) starts from zero -- a fill of its own
+    // was one more launch in a single tile's chain
+    if (zero32 && blockIdx.x == 0 && tid < 32) zero32[tid] = 0ull;
     const int col_blocks = (cols + 63) / 64;
     if ((int)blockIdx.x > col_blocks) {
         const int r = 256 * ((int)blockIdx.x - col_blocks - 1) + tid;
@@ -1406,8 +1409,9 @@ size_t surf_ws_bytes(const SurfGeom &g, size_t pyr_total, unsigned long long cap
 // K16 on the context's stream.  allow_residue: the band / strip form may write the table in the residue layout (SurfTable; the
 // return value's `per` says whether it did): images whose width is a multiple of 16 and whose table stays below 2 GiB (the gather
 // kernel of octaves 1-3 addresses it with 32-bit byte offsets).
+// zero32 (optional): a 256-byte counter slot to clear on the way
 SurfTable launch_surf_integral(imgfd_ctx *ctx, const uint8_t *d_rgb, unsigned *d_I, int rows, int cols, void *scratch, size_t scratch_bytes,
-                               bool allow_residue)
+                               bool allow_residue, unsigned long long *zero32 = nullptr)
 {
     SurfTable T{d_I, rows, cols, 0};
     const bool vec = cols % 4 == 0 && (size_t)d_rgb % 4 == 0 && (size_t)d_I % 16 == 0;
@@ -1420,7 +1424,7 @@ SurfTable launch_surf_integral(imgfd_ctx *ctx, const uint8_t *d_rgb, unsigned *d
         const dim3 grid(ceil_div(ns, 4), nb);
         hipLaunchKernelGGL(surf_int_sums, grid, dim3(256), 0, ctx->stream, d_rgb, colsum, rowsum, bandstrip, rows, cols, ns);
         hipLaunchKernelGGL(surf_int_carry, dim3(ceil_div(cols, 64) + 1 + ceil_div(rows, 256)), dim3(256), 0, ctx->stream, colsum, bandstrip, rowsum, nb, rows,
-                           cols, ns);
+                           cols, ns, zero32);
         const bool res = allow_residue && cols % 16 == 0 && (size_t)rows * cols * 4 < ((size_t)1 << 31);
         if (res)
             hipLaunchKernelGGL(surf_int_apply<true>, grid, dim3(256), 0, ctx->stream, d_rgb, (const unsigned *)colsum, (const unsigned *)bandstrip,
@@ -1431,6 +1435,7 @@ SurfTable launch_surf_integral(imgfd_ctx *ctx, const uint8_t *d_rgb, unsigned *d
         T.per = res ? cols >> 2 : 0;
         return T;
     }
+    if (zero32 && hipMemsetAsync(zero32, 0, 256, ctx->stream) != hipSuccess) T.p = nullptr;  // (the caller checks hipGetLastError)
     if (vec)
         hipLaunchKernelGGL(surf_gray_rowscan4, dim3(rows), dim3(256), 0, ctx->stream, d_rgb, d_I, cols);
     else
@@ -1465,7 +1470,8 @@ struct SurfStreamScope {
 imgfd_status surf_front(imgfd_ctx *ctx, const uint8_t *d_rgb, const SurfGeom &g, double thr, const SurfDevice &d, SurfTable *table,
                         imgfd_ctx *fork = nullptr)
 {
-    const SurfTable T = launch_surf_integral(ctx, d_rgb, d.integral, g.rows, g.cols, d.pyr, d.pyr_bytes, true);
+    const SurfTable T = launch_surf_integral(ctx, d_rgb, d.integral, g.rows, g.cols, d.pyr, d.pyr_bytes, true, d.count);
+    if (!T.p) return imgfd_fail(ctx, IMGFD_ERR_HIP, "hipMemsetAsync failed (SURF counters)");
     if (table) *table = T;
     static_assert(SURF_INT == 6 && SURF_OCT == 4, "dlib's build_pyramid(img, 4, 6, 2): the kernels unroll its geometry");
     const SurfBands bands = surf_bands(g);
@@ -1511,10 +1517,8 @@ imgfd_status surf_back_nms(imgfd_ctx *ctx, const SurfGeom &g, double thr, const 
         q.tile_pyr = (size_t)(d_next->pyr - d.pyr); q.tile_mask = (size_t)(d_next->mask - d.mask); q.tile_rec = (size_t)(d_next->rec - d.rec);
         q.tile_count = (size_t)(d_next->count - d.count); q.tile_table = (size_t)(d_next->integral - d.integral);
         q.tile_surv = (size_t)(d_next->surv - d.surv); q.tile_cand = (size_t)(d_next->cands - d.cands);
-        // the counter slots of a group lie side by side (256 bytes per tile, imgfd_surf_dev): one memset
-        if (q.tile_count * sizeof(unsigned long long) != 256) return imgfd_fail(ctx, IMGFD_ERR_INVALID, "surf_back_nms: the counters of a group must be 256 bytes apart");
     }
-    IMGFD_HIP(ctx, hipMemsetAsync(d.count, 0, 256 * (size_t)tiles, ctx->stream));
+    // (the counters -- [0] records, [1] survivors, [2] candidates, a 256-byte slot per tile -- were cleared by the tile's front)
     for (int i = 0; i < SURF_INT; i++) q.border_next[i] = (int)surf_border_of(std::min(i + 1, SURF_INT - 1));
     unsigned nb = 0;
     for (int o = 0; o < SURF_OCT; o++) {

@@ -2,7 +2,7 @@
 # One GPU call that collects what profiles/r03/ holds: pytest -m gpu, smoke, the default bench line (all BASELINE configs and
 # the CPU legs inside it), rocprofv3 kernel stats of the default command (two-stream and one-stream) and of configs 3 / 4,
 # the structure-tensor PMC passes, the all-kernel counter tables of the default step and of config 4, the single-frame timeline.
-# Usage on the box: bash scripts/gpu_profiles_r3.sh [tag]   -> gpurun_out/prof_<tag>/
+# Usage on the box: bash scripts/rounds/gpu_profiles_r3.sh [tag]   -> gpurun_out/prof_<tag>/
 set -u
 cd "$GRAFT_REPO_ROOT"; R="$GRAFT_REPO_ROOT"; TAG="${1:-r3}"; O="$R/gpurun_out/prof_$TAG"; mkdir -p "$O"
 export TMPDIR=/tmp

@@ -1,10 +1,10 @@
 #!/bin/bash
-# One GPU call that collects what profiles/r04/<tag>_* holds: pytest -m gpu, smoke, the default bench line (all BASELINE configs and
+# Round 5. One GPU call that collects what profiles/r05/<tag>_* holds: pytest -m gpu, smoke, the default bench line (all BASELINE configs and
 # the CPU legs inside it), rocprofv3 kernel stats of the default command (two-stream and one-stream) and of configs 3 / 4,
 # the structure-tensor PMC passes, the all-kernel counter tables of the default step and of config 4, the single-frame timeline.
-# Usage on the box: bash scripts/gpu_profiles_r4.sh [tag]   -> gpurun_out/prof_<tag>/
+# Usage on the box: bash scripts/rounds/gpu_profiles_r5.sh [tag]   -> gpurun_out/prof_<tag>/
 set -u
-cd "$GRAFT_REPO_ROOT"; R="$GRAFT_REPO_ROOT"; TAG="${1:-r4}"; O="$R/gpurun_out/prof_$TAG"; mkdir -p "$O"
+cd "$GRAFT_REPO_ROOT"; R="$GRAFT_REPO_ROOT"; TAG="${1:-r5}"; O="$R/gpurun_out/prof_$TAG"; mkdir -p "$O"
 export TMPDIR=/tmp
 ( timeout 1800 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 ) > "$O/pytest_gpu.txt" 2>&1
 ( timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ) > "$O/smoke.txt" 2>&1
@@ -29,7 +29,7 @@ cp gpurun_out/k3/k3_pmc.txt "$O/k3_pmc_summary.txt"; cp gpurun_out/k3/k3_traffic
 BATCHES=1,8,32 python scripts/k3_variants.py 2>/dev/null | grep kernel > "$O/k3_doorway.txt"
 bash scripts/gpu_pmc_all.sh "$O" > /dev/null 2>&1
 bash scripts/gpu_pmc_c4.sh "$O" > /dev/null 2>&1
-bash scripts/gpu_b1_timeline.sh > "$O/single_frame_timeline.txt" 2>&1
+bash scripts/rounds/gpu_r5_tl.sh > /dev/null 2>&1; cp gpurun_out/r5_tl/timeline.txt "$O/single_frame_timeline.txt"
 bash scripts/gpu_b32_timeline.sh > "$O/two_stream_timeline.txt" 2>&1
 IMGFD_SURF_LANES=1 python scripts/surf_dev_time.py > "$O/surf_one_lane.txt" 2>/dev/null
 python scripts/surf_dev_time.py > "$O/surf_two_lanes.txt" 2>/dev/null
@@ -41,5 +41,6 @@ NOISE=1 TILES=16 python scripts/fhog_variants.py >> "$O/fhog_variants.txt" 2>/de
 bash scripts/gpu_canny_trace.sh > "$O/canny_timeline.txt" 2>&1
 ./scripts/ubench/ubench7.bin > "$O/ubench7_f64_instruction_rates.txt" 2>&1
 ./scripts/ubench/ubench8.bin > "$O/ubench8_integer_dpp_instruction_rates.txt" 2>&1
-IMGFD_TENSOR_WAVE=1 BATCHES=1,32 python scripts/k3_variants.py 2>/dev/null | grep kernel > "$O/k3_doorway_wave_kernel.txt"
+python scripts/canny_shapes_probe.py 2>/dev/null | grep "^{" > "$O/canny_shapes.txt"
+python scripts/b1_host_probe.py 2>/dev/null | grep "^{" > "$O/single_frame_host_probe.txt"
 exit 0

@@ -27,4 +27,4 @@ BATCH=2 run "b2                                   "
 BATCH=4 run "b4                                   "
 BATCH=32 run "b32                                  "
 BATCH=32 run "b32 hyst 11                          " IMGFD_HYST_BLOCK=11
-bash scripts/gpu_r5_tl.sh > /dev/null 2>&1; cp $R/gpurun_out/r5_tl/timeline.txt $O/timeline_default.txt; cat $O/timeline_default.txt
+bash scripts/rounds/gpu_r5_tl.sh > /dev/null 2>&1; cp $R/gpurun_out/r5_tl/timeline.txt $O/timeline_default.txt; cat $O/timeline_default.txt

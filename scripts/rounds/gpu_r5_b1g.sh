@@ -22,4 +22,4 @@ BATCH=8 INNER=20 run "b8 swap                 " IMGFD_DETECT_SWAP=1
 BATCH=32 INNER=10 run "b32 default             "
 BATCH=32 INNER=10 run "b32 swap                " IMGFD_DETECT_SWAP=1
 IMGFD_DETECT_SWAP=1 python scripts/b1_host_probe.py 2>&1 | grep -v amdgpu.ids | head -1 | tee $O/host_probe.txt
-IMGFD_DETECT_SWAP=1 bash scripts/gpu_r5_tl.sh > /dev/null 2>&1; cp $R/gpurun_out/r5_tl/timeline.txt $O/timeline_swap.txt; cat $O/timeline_swap.txt
+IMGFD_DETECT_SWAP=1 bash scripts/rounds/gpu_r5_tl.sh > /dev/null 2>&1; cp $R/gpurun_out/r5_tl/timeline.txt $O/timeline_swap.txt; cat $O/timeline_swap.txt

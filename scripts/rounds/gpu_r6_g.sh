@@ -7,5 +7,5 @@ for cfg in "16 2" "8 2"; do set -- $cfg
 done
 echo -n "single tile " | tee -a $O/surf.txt
 TILES1=1 timeout 200 python scripts/surf_dev_time.py 2>&1 | grep "^{" | tee -a $O/surf.txt
-TILES1=1 TAG=one LAST=14 bash scripts/gpu_r6_tl.sh > /dev/null 2>&1; cp gpurun_out/r6tl/timeline_one.txt $O/
-TILES=32 TAG=g16 LAST=80 bash scripts/gpu_r6_tl.sh > /dev/null 2>&1; cp gpurun_out/r6tl/timeline_g16.txt $O/
+TILES1=1 TAG=one LAST=14 bash scripts/rounds/gpu_r6_tl.sh > /dev/null 2>&1; cp gpurun_out/r6tl/timeline_one.txt $O/
+TILES=32 TAG=g16 LAST=80 bash scripts/rounds/gpu_r6_tl.sh > /dev/null 2>&1; cp gpurun_out/r6tl/timeline_g16.txt $O/
