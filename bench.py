@@ -350,9 +350,19 @@ class Detect4K(Workload):
             det.gradients_of(self.frames[f], ix[f], iy[f])
         # warm-up covers the first touch of the freshly allocated A, B, C; a 40 ms clock probe (one wavefront of 6 registers: it fits
         # beside the kernel's 3 x 168 per SIMD) spans the warm-up and the first timed launches: the clock this kernel alone runs at
-        us = det.time_structure_tensor_batch(ix, iy, warmup=12, iters=max(20, min(60, steps)), probe_us=40000)
+        planes = tuple(torch.empty_like(ix) for _ in range(3))
+        us = det.time_structure_tensor_batch(ix, iy, warmup=12, iters=max(20, min(60, steps)), probe_us=40000, out=planes)
         k3_clock = det.clock_probe_read()
-        del ix, iy
+        # The same launch, one at a time with the device idle for 5 ms in front of each: what the kernel takes when the chip is not
+        # at the power limit its own back-to-back launches drive it to (an f64 FMA stream clocks an MI355X down by a fifth).  Reported
+        # BESIDE the sustained number, never instead of it.
+        spaced = []
+        for _ in range(8):
+            torch.cuda.synchronize(); time.sleep(0.005)
+            spaced.append(det.time_structure_tensor_batch(ix, iy, warmup=0, iters=1, probe_us=1000, out=planes))
+        spaced_clock = det.clock_probe_read()
+        spaced.sort()
+        del ix, iy, planes
         k3_bytes = TENSOR_BYTES_PER_PX * NX * NY * B
         achieved = k3_bytes / (us * 1e-6) / 1e9
         f64_floor_us = TENSOR_F64_OPS_PER_PX * NX * NY * B / F64_LANE_OPS_PER_S * 1e6
@@ -371,7 +381,11 @@ class Detect4K(Workload):
                                    "part, measured (scripts/ubench/ubench7.hip); the phase split and the barrier-free experiment behind this number: profiles/r04/k3_phase_split.txt, "
                                    "k3_wave_experiment.txt; DESIGN.md section 4, LOG.md"},
              "avg_launch_us": round(us, 2), "frames_per_launch": B, "algorithmic_bytes_per_launch": k3_bytes,
-             "shader_clock_GHz": k3_clock["mean_GHz"],   # while these launches ran (imgfd_clock_probe, 20 ms): tells a slow box from a slow kernel
+             "shader_clock_GHz": k3_clock["mean_GHz"],   # while these launches ran (imgfd_clock_probe, 40 ms): tells a slow box from a slow kernel
+             "single_launches_from_idle": {"median_us": round(spaced[len(spaced) // 2], 2), "min_us": round(spaced[0], 2), "launches": len(spaced),
+                                           "frac": round(k3_bytes / (spaced[len(spaced) // 2] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "shader_clock_GHz": spaced_clock["mean_GHz"],
+                                           "what": "one launch at a time, 5 ms of idle device in front of each: the kernel below the power limit its own back-to-back launches "
+                                                   "reach -- NOT the roofline number (that is the sustained one above)"},
              "timed": "HIP events on the context's stream around back-to-back launches of the stage doorway on this batch's gradients, after the timed region"}
         tr = traffic_for("fir_tensor", B)
         r["traffic"], r["traffic_unit"] = tr, "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/k3_traffic.json; refreshed by scripts/gpu_pmc_k3.sh)"
@@ -1105,7 +1119,8 @@ def line_summary(res):
     out = {"default": {"Mpx_s": res.get("value"), "ms_step": res.get("ms_per_step"), "clock_GHz": g(res, "config", "shader_clock", "mean_GHz")}}
     if "frac" in rf and "avg_launch_us" in rf:
         out["k3"] = {"frac": rf.get("frac"), "us": rf.get("avg_launch_us"), "clock_GHz": rf.get("shader_clock_GHz"), "traffic": rf.get("traffic"),
-                     "pipe_us": g(rf, "in_pipeline", "avg_launch_us")}
+                     "pipe_us": g(rf, "in_pipeline", "avg_launch_us"), "from_idle_us": g(rf, "single_launches_from_idle", "median_us"),
+                     "from_idle_clock_GHz": g(rf, "single_launches_from_idle", "shader_clock_GHz")}
     cb = res.get("cpu_baseline") or res.get("parity") or {}
     par = {}
     p0 = [cb.get("parity_frame0")] + list((cb.get("parity_frames") or {}).values())

@@ -135,12 +135,12 @@ class DeviceDetector:
         self.ctx.check(self.lib.imgfd_k_gradient(self.ctx.handle, sm.data_ptr(), ix.data_ptr(), iy.data_ptr(), nx, ny, 0), "imgfd_k_gradient")
         self.ctx.sync()  # f, sm die here
 
-    def time_structure_tensor_batch(self, ix: torch.Tensor, iy: torch.Tensor, sigma=2.5, gauss=0, warmup=3, iters=20, probe_us=0):
+    def time_structure_tensor_batch(self, ix: torch.Tensor, iy: torch.Tensor, sigma=2.5, gauss=0, warmup=3, iters=20, probe_us=0, out=None):
         """Mean microseconds per launch of the 20 B/px structure-tensor kernel over a batch [n, ny, nx] (HIP events on
         the context's stream, back-to-back launches).  probe_us > 0: one shader-clock probe of that span is queued right before the
         launches (after the output planes exist: allocating them takes milliseconds), so that it samples the clock while they run."""
         n, ny, nx = ix.shape
-        A, B, Cc = (torch.empty_like(ix) for _ in range(3))
+        A, B, Cc = out if out is not None else tuple(torch.empty_like(ix) for _ in range(3))   # out: planes of an earlier call (already touched)
         torch.cuda.synchronize()
         if probe_us:
             self.clock_probe(probe_us)
