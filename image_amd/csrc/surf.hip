@@ -5,16 +5,18 @@
 //   K16 integral image   integral_image_generic<int32>::load, dlib/image_transforms/integral_image.h:33-62, with
 //                        gray = (r+g+b)/3 (dlib/pixel.h:775-783).  int32 sums wrap (4096^2 bright tiles overflow);
 //                        wrap-around addition is associative, so a parallel scan gives the reference's bits:
-//                        surf_gray_rowscan4 (one workgroup per row, 16-byte stores) + surf_colscan_sums/_apply (columns
-//                        cut into row segments); surf_gray_rowscan / surf_colscan serve unaligned or small images.
+//                        surf_int_sums / surf_int_carry / surf_int_apply (bands of rows cut into strips; the table is written ONCE, by
+//                        column residue mod 4: SurfTable); surf_gray_rowscan / surf_colscan serve unaligned or small images.
 //   K17 Hessian pyramid  hessian_pyramid::build_pyramid(img, 4, 6, 2), dlib/image_keypoint/hessian_pyramid.h:87-178:
-//                        24 levels of box-filter determinants in f64, 32 integral-image look-ups per level pixel:
-//                        surf_pyramid_lds<0> (first octave: the table window of a block of level pixels in LDS, all six
-//                        intervals from it), surf_pyramid<LM> (octaves 1-3 in one launch, gathering from a copy of the
-//                        table re-laid by column residue, surf_residue_layout).  Both publish one threshold bit per
-//                        level pixel (|det| >= threshold).
-//   K18 interest points  get_interest_points :453-506: surf_nms_masked turns the threshold bits into dense lists and runs
-//                        the 3x3x3 maximum test (:324-356) + quadratic interpolation with
+//                        box-filter determinants in f64, 32 integral-image look-ups per level pixel, intervals 1-4 of every octave
+//                        (0 and 5 only exist as neighbours in the maximum test, which computes what it needs of them):
+//                        surf_pyramid_lds<0> (the table window of a block of first-octave level pixels in LDS; intervals 1 and 2 of
+//                        octave 1 come out of the same window), surf_pyramid_taps (the rest of octaves 1-3 in one launch ordered by
+//                        image band, a buffer load per look-up; surf_pyramid_plain for tables that are not laid out by residue).
+//                        All publish one threshold bit per level pixel (|det| >= threshold).
+//   K18 interest points  get_interest_points :453-506: surf_nms_list turns the threshold bits into a dense list, surf_nms_screen
+//                        runs the 3x3x3 maximum test (:324-356) against the stored intervals, surf_nms_finish against the
+//                        unbuilt ones + the quadratic interpolation with
 //                        the closed-form 3x3 inverse (:411-446, dlib/matrix/matrix_la.h:922-962), in f64 with the
 //                        reference's operation order (no contraction).  Survivors are appended with a sort key
 //                        (octave, interval, row, column); the host orders them by that key = the order in which the
@@ -481,7 +483,11 @@ struct SurfPyrLds {
     static constexpr int STEP = 2 << O;
     static constexpr int LX = O == 0 ? 64 : 32, LY = O == 0 ? SURF_LDS_LY : 8;  // level pixels per workgroup
     static constexpr int LOBE_MAX = STEP * SURF_INT + 1;               // hessian_pyramid.h:119-128: lobe = step*(i+1) + 1
+#ifdef SURF_LDS_EXPERIMENT_REACH  // timing experiment: a window wide enough for the filters of the next octave
+    static constexpr int REACH = SURF_LDS_EXPERIMENT_REACH;
+#else
     static constexpr int REACH = (3 * LOBE_MAX) / 2;                   // half of the widest box; "+1" for the l-1 / t-1 corner
+#endif
     static constexpr int HL = (REACH + 1 + 3) / 4 * 4;                 // left / top margin: a multiple of 4 (16-byte loads) and of STEP
     static constexpr int HR = REACH;
     static constexpr int W = STEP * (LX - 1) + 1 + HL + HR, H = STEP * (LY - 1) + 1 + HL + HR;
@@ -504,11 +510,10 @@ struct SurfPyrLds {
 // from this centre, as an index the optimiser cannot see through: every look-up then has a NON-NEGATIVE constant offset,
 // i.e. an immediate of its ds_read.  (Addressed from the centre, half of the look-ups sit at negative offsets, which the
 // 16-bit unsigned offset field cannot hold: one v_add_u32 each, 17 of the kernel's 98 vector instructions per value.)
-template <int O, int IT>
-__device__ __forceinline__ double surf_lds_interval(const unsigned *__restrict__ win, unsigned top, double area_inv)
+template <class G, int lobe>
+__device__ __forceinline__ double surf_lds_filter(const unsigned *__restrict__ win, unsigned top, double area_inv)
 {
-    using G = SurfPyrLds<O>;
-    constexpr int lobe = G::STEP * (IT + 1) + 1, off = lobe / 2 + 1;
+    constexpr int off = lobe / 2 + 1;
     auto at = [&](int dy, int dx) __attribute__((always_inline)) -> unsigned {
         const int m = ((dx % G::STEP) + G::STEP) % G::STEP;  // residue of a possibly negative offset
         return win[top + (unsigned)(G::BIAS + dy * G::P + m * (G::P / G::STEP) + (dx - m) / G::STEP)];
@@ -531,88 +536,188 @@ __device__ __forceinline__ double surf_lds_interval(const unsigned *__restrict__
     return sign * det;
 }
 
+// interval IT of the window's own octave O (hessian_pyramid.h:119-128: lobe = step * (i + 1) + 1)
+template <int O, int IT>
+__device__ __forceinline__ double surf_lds_interval(const unsigned *__restrict__ win, unsigned top, double area_inv)
+{
+    return surf_lds_filter<SurfPyrLds<O>, SurfPyrLds<O>::STEP * (IT + 1) + 1>(win, top, area_inv);
+}
+
+#ifndef SURF_LDS_RUN
+#define SURF_LDS_RUN 1  // consecutive blocks of level pixels per workgroup of the first octave's kernel
+#endif
+// A workgroup handles SURF_LDS_RUN consecutive blocks and requests the table window of block b + 1 (into registers) before it evaluates
+// block b out of the LDS: the window loads (memory round trips) and the filters (vector ALUs + LDS) of a CU overlap by construction.
+// (Round 6 measured the phases of the one-block-per-workgroup kernel alone: 37 us of window loads + 22 us of filters = the kernel's
+// 59-62 us -- the three resident workgroups of a CU start together and stay in step, `profiles/r06/surf_first_octave_phases.txt`.)
+#ifndef SURF_LDS_WAVES
+#define SURF_LDS_WAVES 6  // waves per SIMD the first octave's kernel is compiled for (registers: 512 / this)
+#endif
 template <int O>
-__global__ void __launch_bounds__(SURF_LDS_NT) surf_pyramid_lds(SurfTable T, double *__restrict__ pyr, SurfGeom g,
-                                                                unsigned long long *__restrict__ mask, double thr, int blocks_x, int xcd_order)
+__global__ void __launch_bounds__(SURF_LDS_NT) IMGFD_WAVES_PER_EU(SURF_LDS_WAVES, SURF_LDS_WAVES) surf_pyramid_lds(SurfTable T, double *__restrict__ pyr, SurfGeom g,
+                                                                unsigned long long *__restrict__ mask, double thr, int blocks_x, int n_blocks, int next_too)
 {
     using G = SurfPyrLds<O>;
     HIP_DYNAMIC_SHARED(unsigned, win)  // [G::H][G::P]
     const int tid = threadIdx.x;
-    // 1-D grid, XCD-aware order of the blocks (imgfd_xcd_tile): the windows of neighbouring blocks overlap by their halo
-    const int blk = (int)(xcd_order ? imgfd_xcd_tile(blockIdx.x, gridDim.x) : blockIdx.x);
-    const int blk_y = blk / blocks_x, blk_x = blk - blk_y * blocks_x;
-    const int lc0 = blk_x * G::LX, lr0 = blk_y * G::LY;
-    const int x0 = G::STEP * lc0 - G::HL, y0 = G::STEP * lr0 - G::HL;
+    // 1-D grid, XCD-aware order of the runs (imgfd_xcd_tile): the windows of neighbouring blocks overlap by their halo
+    const int first = (int)imgfd_xcd_tile(blockIdx.x, gridDim.x) * SURF_LDS_RUN;
     const int cols = g.cols, rows = g.rows;
     const unsigned *__restrict__ I = T.p;
-    const bool interior = x0 >= 0 && y0 >= 0 && x0 + G::P <= cols && y0 + G::H <= rows && (cols & 3) == 0;  // workgroup-uniform; x0 % 4 == 0
-    if (interior && T.per) {
-        // residue layout: window column dx = 4 k + m of a row is word k of plane m, from (x0 / 4) on: a thread keeps one
-        // (m, k) and walks down the rows, NT / P rows per trip -- runs of P / 4 consecutive words, no division in the loop
-        static_assert(G::P % 4 == 0, "whole quads per window row");
-        constexpr int RPT = G::NT / G::P;                     // rows per trip
-        const int slot = tid % G::P, rr = tid / G::P;         // (tid < RPT * P take part)
-        const int m = slot / (G::P / 4), k = slot - m * (G::P / 4);
-        const unsigned *src = I + (size_t)y0 * cols + (size_t)m * T.per + (x0 >> 2) + k;
-        unsigned *dst = win + G::col(4 * k + m);
-        if (rr < RPT) {
-#pragma unroll 4
-            for (int ry = rr; ry < G::H; ry += RPT) dst[ry * G::P] = src[(size_t)ry * cols];
-        }
-    } else if (interior) {
-        for (int i = tid; i < G::H * (G::P / 4); i += G::NT) {
-            const int ry = i / (G::P / 4), q = i - ry * (G::P / 4);
-            const uint4 v = *reinterpret_cast<const uint4 *>(I + (size_t)(y0 + ry) * cols + x0 + 4 * q);
-            unsigned *row = win + ry * G::P;
-            row[G::col(4 * q)] = v.x; row[G::col(4 * q + 1)] = v.y; row[G::col(4 * q + 2)] = v.z; row[G::col(4 * q + 3)] = v.w;
-        }
-    } else {  // at the image border: clamped coordinates (entries outside the image are never used by a valid centre)
-        for (int i = tid; i < G::H * G::P; i += G::NT) {
-            const int ry = i / G::P, rx = i - ry * G::P;
-            const int gy = min(max(y0 + ry, 0), rows - 1), gx = min(max(x0 + rx, 0), cols - 1);
-            win[ry * G::P + G::col(rx)] = T.at(gy, gx);
-        }
-    }
-    __syncthreads();
+    // residue layout: window column dx = 4 j + m of a row is word j of plane m, from word s = x0 / 4 of the plane's row on.  A task =
+    // one aligned quad of one plane of one window row (16-byte loads; s is rarely a multiple of 4, so a row of a plane takes NQ
+    // quads from s rounded down).  Rows and quads are clamped into the table: what lies outside the image is never looked up by a
+    // valid centre.
+    static_assert(G::P % 4 == 0, "whole quads per window row");
+    constexpr int PW = G::P / 4, NQ = (PW + 3 + 3) / 4, TASKS = G::H * 4 * NQ, TRIPS = (TASKS + G::NT - 1) / G::NT;
+    uint4 v[TRIPS];
+    auto request = [&](int blk) __attribute__((always_inline)) {
+        const int blk_y = blk / blocks_x, blk_x = blk - blk_y * blocks_x;
+        const int x0 = G::STEP * blk_x * G::LX - G::HL, y0 = G::STEP * blk_y * G::LY - G::HL;
+        const int a4 = (x0 >> 2) >> 2, quads = T.per >> 2;
 #pragma unroll
-    for (int k = 0; k < G::PX_PER_THREAD; k++) {
-        const int e = tid + G::NT * k;  // level pixel of the block: row-major, LX per row
-        const int lr = lr0 + e / G::LX, lc = lc0 + e % G::LX;
-        const int r = lr * G::STEP, c = lc * G::STEP;
-        // a wave = 64 consecutive level pixels of one row (LX = 64, lc0 a multiple of 64): its ballot is one word of the
-        // level's threshold mask (|det| >= thr: the only pixels surf_nms_masked has to look at); every lane votes
-        const bool inside = lr < g.nr[O] && lc < g.nc[O];
-        unsigned top = (unsigned)((r - y0) * G::P + (c - x0) / G::STEP - G::BIAS);  // (c - x0) is a multiple of STEP: residue plane 0
-        IMGFD_OPAQUE(top);
-        double *dst = pyr + (size_t)lr * g.nc[O] + lc;
-#define SPL_DO(IT)                                                                                        \
-        {                                                                                                  \
-            const SurfLevel &L = g.lev[O * SURF_INT + IT];                                                 \
-            const int bp = L.border_px;                                                                    \
-            bool hot = false;                                                                              \
-            if (inside && !(r < bp || r >= rows - bp || c < bp || c >= cols - bp)) {                       \
-                const double v = surf_lds_interval<O, IT>(win, top, L.area_inv);                           \
-                IMGFD_OUT_STORE(v, &dst[L.plane]);                                                         \
-                hot = fabs(v) >= thr;                                                                      \
-            }                                                                                              \
-            const unsigned long long word = __ballot(hot);                                                 \
-            if ((tid & 63) == 0 && lr < g.nr[O] && lc < g.nc[O]) mask[L.mask + (size_t)lr * ((g.nc[O] + 63) / 64) + (lc >> 6)] = word; \
+        for (int j = 0; j < TRIPS; j++) {
+            const int q = min(tid + G::NT * j, TASKS - 1);
+            const int ry = q / (4 * NQ), rem = q - ry * (4 * NQ), m = rem / NQ, k4 = rem - m * NQ;
+            const int gy = min(max(y0 + ry, 0), rows - 1), gq = min(max(a4 + k4, 0), quads - 1);
+            v[j] = *reinterpret_cast<const uint4 *>(I + (size_t)gy * cols + (size_t)m * T.per + 4 * gq);
         }
-        SPL_DO(1) SPL_DO(2) SPL_DO(3) SPL_DO(4)  // intervals 0 and 5 are not built (surf_geometry)
+    };
+    auto commit = [&](int blk) __attribute__((always_inline)) {
+        const int blk_x = blk % blocks_x;
+        const int lead = ((G::STEP * blk_x * G::LX - G::HL) >> 2) & 3;
+#pragma unroll
+        for (int j = 0; j < TRIPS; j++) {
+            const int q = tid + G::NT * j;
+            const int ry = q / (4 * NQ), rem = q - ry * (4 * NQ), m = rem / NQ, k4 = rem - m * NQ;
+            const unsigned e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+            unsigned *row = win + ry * G::P + G::col(m);   // col(4 w + m) = col(m) + 4 w / STEP
+            if (q < TASKS) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int w = 4 * k4 + i - lead;
+                    if (w >= 0 && w < PW) row[w * (4 / G::STEP)] = e[i];
+                }
+            }
+        }
+    };
+    if (T.per && first < n_blocks) request(first);
+#pragma unroll 1
+    for (int run = 0; run < SURF_LDS_RUN; run++) {
+        const int blk = first + run;
+        if (blk >= n_blocks) break;  // workgroup-uniform
+        const int blk_y = blk / blocks_x, blk_x = blk - blk_y * blocks_x;
+        const int lc0 = blk_x * G::LX, lr0 = blk_y * G::LY;
+        const int x0 = G::STEP * lc0 - G::HL, y0 = G::STEP * lr0 - G::HL;
+#ifdef SURF_LDS_EXPERIMENT_NO_LOAD  // timing experiment: no window load (results are garbage)
+        if (thr == -12345.0)
+#endif
+        if (T.per) {
+            commit(blk);
+        } else if (x0 >= 0 && y0 >= 0 && x0 + G::P <= cols && y0 + G::H <= rows && (cols & 3) == 0) {  // plain table, interior
+            for (int i = tid; i < G::H * (G::P / 4); i += G::NT) {
+                const int ry = i / (G::P / 4), q = i - ry * (G::P / 4);
+                const uint4 u = *reinterpret_cast<const uint4 *>(I + (size_t)(y0 + ry) * cols + x0 + 4 * q);
+                unsigned *row = win + ry * G::P;
+                row[G::col(4 * q)] = u.x; row[G::col(4 * q + 1)] = u.y; row[G::col(4 * q + 2)] = u.z; row[G::col(4 * q + 3)] = u.w;
+            }
+        } else {  // plain table at the image border: clamped coordinates
+            for (int i = tid; i < G::H * G::P; i += G::NT) {
+                const int ry = i / G::P, rx = i - ry * G::P;
+                const int gy = min(max(y0 + ry, 0), rows - 1), gx = min(max(x0 + rx, 0), cols - 1);
+                win[ry * G::P + G::col(rx)] = T.at(gy, gx);
+            }
+        }
+        __syncthreads();
+        if (T.per && run + 1 < SURF_LDS_RUN && blk + 1 < n_blocks) request(blk + 1);  // in flight while this block is evaluated
+#pragma unroll
+        for (int k = 0; k < G::PX_PER_THREAD; k++) {
+            const int e = tid + G::NT * k;  // level pixel of the block: row-major, LX per row
+            const int lr = lr0 + e / G::LX, lc = lc0 + e % G::LX;
+            const int r = lr * G::STEP, c = lc * G::STEP;
+            // a wave = 64 consecutive level pixels of one row (LX = 64, lc0 a multiple of 64): its ballot is one word of the
+            // level's threshold mask (|det| >= thr: the only pixels surf_nms_list has to look at); every lane votes
+            const bool inside = lr < g.nr[O] && lc < g.nc[O];
+            unsigned top = (unsigned)((r - y0) * G::P + (c - x0) / G::STEP - G::BIAS);  // (c - x0) is a multiple of STEP: residue plane 0
+            IMGFD_OPAQUE(top);
+            double *dst = pyr + (size_t)lr * g.nc[O] + lc;
+#ifdef SURF_LDS_EXPERIMENT_NO_STORE  // timing experiment: the values are not written (the threshold mask is)
+#define SURF_LDS_STORE(v, p) if (v == -12345.678) IMGFD_OUT_STORE(v, p)
+#else
+#define SURF_LDS_STORE(v, p) IMGFD_OUT_STORE(v, p)
+#endif
+#ifdef SURF_LDS_EXPERIMENT_NO_MATH  // timing experiment: window load + stores alone (results are garbage)
+#define SURF_LDS_VALUE(IT) ((double)win[top + G::BIAS + IT] * L.area_inv)
+#else
+#define SURF_LDS_VALUE(IT) surf_lds_interval<O, IT>(win, top, L.area_inv)
+#endif
+#define SPL_DO(IT)                                                                                        \
+            {                                                                                              \
+                const SurfLevel &L = g.lev[O * SURF_INT + IT];                                             \
+                const int bp = L.border_px;                                                                \
+                bool hot = false;                                                                          \
+                if (inside && !(r < bp || r >= rows - bp || c < bp || c >= cols - bp)) {                   \
+                    const double val = SURF_LDS_VALUE(IT);                                                 \
+                    SURF_LDS_STORE(val, &dst[L.plane]);                                                    \
+                    hot = fabs(val) >= thr;                                                                \
+                }                                                                                          \
+                const unsigned long long word = __ballot(hot);                                             \
+                if ((tid & 63) == 0 && lr < g.nr[O] && lc < g.nc[O]) mask[L.mask + (size_t)lr * ((g.nc[O] + 63) / 64) + (lc >> 6)] = word; \
+            }
+            SPL_DO(1) SPL_DO(2) SPL_DO(3) SPL_DO(4)  // intervals 0 and 5 are not built (surf_geometry)
 #undef SPL_DO
+#undef SURF_LDS_VALUE
+#undef SURF_LDS_STORE
+        }
+        // The first two built intervals of the NEXT octave (lobes 2 STEP * 2 + 1 and 2 STEP * 3 + 1: the second reaches exactly as far as this
+        // octave's widest filter, for which the window is cut) from the same window: a quarter as many level pixels, one value per
+        // thread.  In the gather kernel these two intervals of octave 1 cost the batch 15 us per 4096^2 tile, here 4.
+        // A wave = two rows of LX / 2 level pixels: its ballot is the low or high half of a mask word for each of them.
+        if (next_too) {
+            static_assert(G::NT == 2 * (G::LX / 2) * (G::LY / 2) && G::LX == 64, "a value per thread; half a mask word per block and row");
+            constexpr int N = O + 1, NSTEP = 2 * G::STEP;
+            const int e = tid & (G::NT / 2 - 1);
+            const int lr = blk_y * (G::LY / 2) + e / (G::LX / 2), lc = blk_x * (G::LX / 2) + e % (G::LX / 2);
+            const int r = lr * NSTEP, c = lc * NSTEP;
+            const bool inside = lr < g.nr[N] && lc < g.nc[N];
+            unsigned top = (unsigned)((r - y0) * G::P + (c - x0) / G::STEP - G::BIAS);
+            IMGFD_OPAQUE(top);
+            const int words = (g.nc[N] + 63) / 64;
+#define SPL_NEXT(IT)                                                                                      \
+            {                                                                                              \
+                const SurfLevel &L = g.lev[N * SURF_INT + IT];                                             \
+                const int bp = L.border_px;                                                                \
+                bool hot = false;                                                                          \
+                if (inside && !(r < bp || r >= rows - bp || c < bp || c >= cols - bp)) {                   \
+                    const double val = surf_lds_filter<G, NSTEP * (IT + 1) + 1>(win, top, L.area_inv);     \
+                    IMGFD_OUT_STORE(val, &pyr[L.plane + (size_t)lr * g.nc[N] + lc]);                       \
+                    hot = fabs(val) >= thr;                                                                \
+                }                                                                                          \
+                const unsigned long long word = __ballot(hot);                                             \
+                if ((tid & 31) == 0 && lr < g.nr[N] && (lc >> 6) < words) {                                \
+                    unsigned *half = reinterpret_cast<unsigned *>(mask + L.mask + (size_t)lr * words + (lc >> 6)) + ((lc >> 5) & 1); \
+                    half[0] = (unsigned)(word >> (tid & 32));                                              \
+                    if (blk_x == blocks_x - 1 && ((lc >> 5) & 1) == 0) half[1] = 0u;  /* no block to the right writes it */ \
+                }                                                                                          \
+            }
+            if (tid < G::NT / 2) SPL_NEXT(1) else SPL_NEXT(2)
+#undef SPL_NEXT
+        }
+        __syncthreads();  // the window is overwritten by the next block of the run
     }
 }
 
 template <int O>
 static imgfd_status launch_surf_pyramid_lds(imgfd_ctx *ctx, const SurfTable &T, double *d_pyr, const SurfGeom &g,
-                                            unsigned long long *d_mask, double thr)
+                                            unsigned long long *d_mask, double thr, bool next_too)
 {
     static_assert(SurfPyrLds<O>::LX == 64, "a wave's ballot is one mask word");
     using G = SurfPyrLds<O>;
     const size_t lds = sizeof(unsigned) * (size_t)G::H * G::P;
     IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)surf_pyramid_lds<O>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int bx = ceil_div(g.nc[O], G::LX), by = ceil_div(g.nr[O], G::LY);
-    hipLaunchKernelGGL(surf_pyramid_lds<O>, dim3((unsigned)bx * (unsigned)by), dim3(G::NT), lds, ctx->stream, T, d_pyr, g, d_mask, thr, bx, 1);
+    hipLaunchKernelGGL(surf_pyramid_lds<O>, dim3((unsigned)ceil_div(bx * by, SURF_LDS_RUN)), dim3(G::NT), lds, ctx->stream, T, d_pyr, g, d_mask,
+                       thr, bx, bx * by, next_too ? 1 : 0);
     return IMGFD_OK;
 }
 
@@ -630,6 +735,7 @@ static imgfd_status launch_surf_pyramid_lds(imgfd_ctx *ctx, const SurfTable &T, 
 // tile pixel fetched for a 4 B table.)
 struct SurfBands {
     int gx[SURF_OCT], gy[SURF_OCT];  // workgroups across / down per octave (0: the octave is not in this launch)
+    int it0[SURF_OCT];               // first interval this launch builds of the octave (1; 3 where the first octave's kernel built 1 and 2)
     int per_band;                    // 4 gx[1] + 2 gx[2] + gx[3]
     int nbands;
     unsigned total;                  // nbands * per_band, rounded up to a multiple of 8
@@ -638,8 +744,12 @@ static SurfBands surf_bands(const SurfGeom &g)
 {
     SurfBands b;
     memset(&b, 0, sizeof b);
+    for (int o = 0; o < SURF_OCT; o++) b.it0[o] = 1;
     for (int o = 1; o < SURF_OCT; o++)
         if (g.nr[o] >= 1 && g.nc[o] >= 1) { b.gx[o] = (g.nc[o] + 63) / 64; b.gy[o] = (g.nr[o] + 3) / 4; }
+#ifdef SURF_EXPERIMENT_TAPS_WITHOUT_OCTAVE1  // timing experiment (results are wrong)
+    b.gx[1] = b.gy[1] = 0;
+#endif
     b.per_band = 4 * b.gx[1] + 2 * b.gx[2] + b.gx[3];
     b.nbands = std::max(std::max((b.gy[1] + 3) / 4, (b.gy[2] + 1) / 2), b.gy[3]);
     b.total = (unsigned)align_up((size_t)b.nbands * b.per_band, (size_t)8);
@@ -671,7 +781,7 @@ __global__ void __launch_bounds__(256) surf_pyramid_plain(const unsigned *__rest
     const bool in_level = lr < g.nr[o] && lc < g.nc[o];
     const unsigned *ctr = I + (size_t)r * cols + c;
 #pragma unroll 1
-    for (int it = 1; it < SURF_INT - 1; it++) {
+    for (int it = bands.it0[o]; it < SURF_INT - 1; it++) {
         const SurfLevel &L = g.lev[o * SURF_INT + it];
         const bool inside = in_level && !(r < L.border_px || r >= g.rows - L.border_px || c < L.border_px || c >= cols - L.border_px);
         bool hot = false;
@@ -753,7 +863,7 @@ __global__ void __launch_bounds__(256) surf_pyramid_taps(const unsigned *__restr
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned *>(J), 0, (int)((unsigned)g.rows * (unsigned)cols * 4u), 0x00027000);
     const int base = r * cols + (c >> 2);  // word of (r, c) in J: c is a multiple of 4
 #pragma unroll 1
-    for (int it = 1; it < SURF_INT - 1; it++) {
+    for (int it = bands.it0[o]; it < SURF_INT - 1; it++) {
         const SurfLevel &L = g.lev[o * SURF_INT + it];
         const int e = (o - 1) * (SURF_INT - 2) + it - 1;
         const bool inside = in_level && !(r < L.border_px || r >= g.rows - L.border_px || c < L.border_px || c >= cols - L.border_px);
@@ -1474,7 +1584,12 @@ imgfd_status surf_front(imgfd_ctx *ctx, const uint8_t *d_rgb, const SurfGeom &g,
     if (!T.p) return imgfd_fail(ctx, IMGFD_ERR_HIP, "hipMemsetAsync failed (SURF counters)");
     if (table) *table = T;
     static_assert(SURF_INT == 6 && SURF_OCT == 4, "dlib's build_pyramid(img, 4, 6, 2): the kernels unroll its geometry");
-    const SurfBands bands = surf_bands(g);
+    SurfBands bands = surf_bands(g);
+    // intervals 1 and 2 of octave 1 come out of the first octave's windows where its blocks cover the octave (always, for dlib's geometry)
+    using G0 = SurfPyrLds<0>;
+    const bool next_too = g.nr[0] >= 1 && g.nc[0] >= 1 && bands.gx[1] > 0 && ceil_div(g.nr[1], G0::LY / 2) <= ceil_div(g.nr[0], G0::LY) &&
+                          ceil_div(g.nc[1], G0::LX / 2) <= ceil_div(g.nc[0], G0::LX);
+    if (next_too) bands.it0[1] = 3;
     hipStream_t upper = ctx->stream;  // the stream of the gather kernel (octaves 1-3)
     if (fork && bands.total) {
         IMGFD_HIP(ctx, hipEventRecord(ctx->ev_gate, ctx->stream));
@@ -1482,9 +1597,10 @@ imgfd_status surf_front(imgfd_ctx *ctx, const uint8_t *d_rgb, const SurfGeom &g,
         upper = fork->stream;
     }
     // octave 0 (three quarters of all level pixels): the table window of a block of level pixels in LDS
-    if (g.nr[0] >= 1 && g.nc[0] >= 1) IMGFD_TRY(launch_surf_pyramid_lds<0>(ctx, T, d.pyr, g, d.mask, thr));
-    // (octave 1 through the same kernel -- an 86 KB window, one workgroup per CU -- measured 219 us against 164 us for
-    // the gather kernel on a 4096^2 tile: not used)
+    if (g.nr[0] >= 1 && g.nc[0] >= 1) IMGFD_TRY(launch_surf_pyramid_lds<0>(ctx, T, d.pyr, g, d.mask, thr, next_too));
+    // (ALL of octave 1 from LDS needs a window that reaches 32 pixels instead of 20: +25 KB per block, two workgroups per CU -- 0.204 ->
+    // 0.217 ms per tile before the extra arithmetic, `profiles/r06/surf_first_octave_phases.txt`; a window kernel of its own for
+    // octave 1 measured 219 us against 164 us for the gather kernel in round 3)
     if (bands.total) {
         if (T.per) {
             SurfTaps taps;

@@ -1,11 +1,14 @@
-"""fHOG and SURF of the same tiles one after the other on one context (what bench.py --config 4 times) against fHOG on a second
-context while SURF runs on the first: per tile, whole-call timings (wall clock around a device-wide wait)."""
-import ctypes as C, json, os, sys, time
+"""fHOG beside SURF: config 4's two functions on the same tiles, one after the other on one stream (the bench's step) against fHOG on a
+second context / stream beside imgfd_surf_dev -- whole batch at once, or chunk by chunk."""
+import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from image_amd.device import DeviceDetector
-T, S = int(os.environ.get("TILES", 32)), 4096
-det, det2 = DeviceDetector(0), DeviceDetector(0)
+T, S = int(os.environ.get("TILES", "64")), 4096
+det = DeviceDetector(0)
+s2 = torch.cuda.Stream()
+with torch.cuda.stream(s2):
+    det2 = DeviceDetector(0)
 tiles = torch.empty((T, S, S, 3), dtype=torch.uint8, device="cuda")
 for t in range(T):
     tiles[t] = det.synth_frames(3, S, S, seed0=3 * (3 + t)).permute(1, 2, 0)
@@ -16,32 +19,35 @@ feat = torch.zeros((T, 1000, 70), dtype=torch.float64, device="cuda")
 counts = torch.zeros((T,), dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
 
+def serial():
+    det.fhog(tiles, hog); det.surf(tiles, feat, counts, redo=False)
 
-def one_after_the_other():
-    det.fhog(tiles, hog)
-    det.surf(tiles, feat, counts, max_points=1000, threshold=30.0)
+def beside(chunk):
+    def run():
+        main = torch.cuda.current_stream()
+        s2.wait_stream(main)
+        for a in range(0, T, chunk):
+            b = min(T, a + chunk)
+            with torch.cuda.stream(s2):
+                det2.fhog(tiles[a:b], hog[a:b])
+            det.surf(tiles[a:b], feat[a:b], counts[a:b], redo=False)
+        main.wait_stream(s2)
+    return run
 
-
-def side_by_side():
-    det2.fhog(tiles, hog)
-    det.surf(tiles, feat, counts, max_points=1000, threshold=30.0)
-
-
-def only_surf():
-    det.surf(tiles, feat, counts, max_points=1000, threshold=30.0)
-
-
-def only_fhog():
-    det.fhog(tiles, hog)
-
-
-out = {}
-for name, fn in (("one_after_the_other", one_after_the_other), ("side_by_side", side_by_side), ("only_surf", only_surf), ("only_fhog", only_fhog),
-                 ("side_by_side_again", side_by_side), ("one_after_the_other_again", one_after_the_other)):
-    fn(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3): fn()
+def timed(fn, reps=3):
+    for _ in range(2): fn()
     torch.cuda.synchronize()
-    out[name + "_ms_per_tile"] = round((time.perf_counter() - t0) * 1e3 / 3 / T, 4)
-out["surf_points"] = int(counts.sum())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); e1.synchronize()
+    return round(e0.elapsed_time(e1) / reps / T, 4)
+
+out = {"tiles": T, "serial_ms_per_tile": timed(serial)}
+ref_hog, ref_feat, ref_counts = hog.clone(), feat.clone(), counts.clone()
+for chunk in (T, 16, 8):
+    hog.zero_(); feat.zero_(); counts.zero_()
+    out[f"beside_chunk{chunk}_ms_per_tile"] = timed(beside(chunk))
+    out[f"beside_chunk{chunk}_same_bits"] = bool(torch.equal(hog, ref_hog) and torch.equal(counts, ref_counts) and torch.equal(feat, ref_feat))
+out["gpixel_per_s"] = {k: round(S * S / v / 1e6, 1) for k, v in out.items() if k.endswith("ms_per_tile")}
 print(json.dumps(out))
