@@ -1,6 +1,9 @@
 """Time imgfd_fhog_dev on 4096x4096 RGB tiles (BASELINE config 4) with HIP events; prints one JSON line."""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from image_amd import _lib
+if os.environ.get("VARIANT_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["VARIANT_LIB"])
 import numpy as np, torch
 from image_amd import synth
 from image_amd.device import DeviceDetector
