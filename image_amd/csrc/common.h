@@ -73,8 +73,8 @@ struct imgfd_ctx {
         int gauss_march_seg = 0;    // rows per segment of that kernel (0: from the batch; tests: every length class)
         int tensor_workers = 0;     // workgroups of fir_tensor (0: one per compute unit; tests: few workers, several segments each)
         int max_chunk_frames = 0;   // frames per sub-batch of the *_dev entry points (0: from the 12 GiB / 1 GiB budgets; tests: small batches cross sub-batch boundaries)
-        int surf_lanes = 2;         // imgfd_surf_dev: the fronts (integral image + pyramid) of a group's tiles go round-robin over this many HIP streams (1..4)
-        int surf_group = 8;         // imgfd_surf_dev: tiles per group (1..16): a buffer set per tile, the latency-bound back stages (maximum test, ranking, K19) as ONE launch each per group
+        int surf_lanes = 3;         // imgfd_surf_dev: the fronts (integral image + pyramid) of a group's tiles go round-robin over this many HIP streams (1..4)
+        int surf_group = 4;         // imgfd_surf_dev: tiles per group (1..16): a buffer set per tile, the latency-bound back stages (maximum test, ranking, K19) as ONE launch each per group
         int surf_rec_cap = 1 << 18; // imgfd_surf_dev: candidate records a tile's buffer holds before the tile reports -needed (tests lower it)
         int surf_sort_cap = 2048;   // imgfd_surf_dev: selected records ranked by the LDS sort; more are ranked all-pairs (tests lower it)
     } tune;

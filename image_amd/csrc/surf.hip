@@ -2022,11 +2022,13 @@ imgfd_status imgfd_surf_points_dev(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_f
 // reads).  Rounds 3-5 ran whole chains on up to four streams ("lanes"): the small kernels of one tile were to fill the gaps of the
 // other tiles' big ones -- but lanes that start together stay in step, beside another tile's gathers every streaming kernel ran
 // at a quarter of its own rate (surf_int_sums 48-94 us instead of 13), and 0.222 ms per tile came out where the fronts alone take
-// 0.144 (profiles/r06/surf_leave_one_out.txt, surf_timeline_two_lanes.txt).  Round 6: tiles go in GROUPS ("surf_group", 8).  The
-// fronts of a group run one after the other on two streams ("surf_lanes", 2: the first octave's kernel beside the next tile's
+// 0.144 (profiles/r06/surf_leave_one_out.txt, surf_timeline_two_lanes.txt).  Round 6: tiles go in GROUPS ("surf_group").  The
+// fronts of a group run one after the other on a few streams ("surf_lanes": the first octave's kernel beside the next tile's
 // scans), every tile into a buffer set of its own; then the back of the WHOLE group is four launches -- maximum test, ranking
 // (a workgroup per tile: eight in flight instead of one), orientation, descriptor, blockIdx.y = tile -- so that the
-// latency-bound kernels fill the chip with eight tiles' worth of independent chains and never sit beside a streaming kernel.
+// latency-bound kernels fill the chip with a group's worth of independent chains.  Groups of 4 on three streams are the default: over
+// seconds of back-to-back calls (the power limit) 0.196 ms per tile against 0.2145 for groups of 8 on two streams, which win a 100 ms
+// probe (profiles/r06/surf_groups_sustained.txt).
 static imgfd_status surf_dev_run(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_frames, int rows, int cols, size_t frame_stride_bytes,
                                  long max_points, double detection_threshold, double *d_features, int64_t cap, int64_t *d_counts,
                                  const std::vector<std::pair<int, unsigned long long>> *only)

@@ -100,9 +100,9 @@ IMGFD_API imgfd_status imgfd_set_fir_mode(imgfd_ctx *ctx, int mode);
  *   "tensor_workers" [IMGFD_TENSOR_WORKERS]  workgroups of fir_tensor, each with an equal share of the batch's line of 16-row chunk units
  *                  (0: one per compute unit)  (tests/test_harris_stages.py: the structure-tensor tests with few workers)
  *   "max_chunk_frames" [IMGFD_MAX_CHUNK_FRAMES]  frames per sub-batch of the *_dev entry points (0: from the memory budgets)  (tests/test_sub_batches.py)
- *   "surf_group" [IMGFD_SURF_GROUP]  8 (default): imgfd_surf_dev handles the tiles in groups of this many (1..16): a buffer set per tile,
+ *   "surf_group" [IMGFD_SURF_GROUP]  4 (default): imgfd_surf_dev handles the tiles in groups of this many (1..16): a buffer set per tile,
  *                  the latency-bound back stages (maximum test, ranking, orientation, descriptor) as one launch each per group
- *   "surf_lanes" [IMGFD_SURF_LANES]  2 (default): the front stages (integral image, Hessian pyramid) of a group's tiles go round-robin
+ *   "surf_lanes" [IMGFD_SURF_LANES]  3 (default): the front stages (integral image, Hessian pyramid) of a group's tiles go round-robin
  *                  over this many HIP streams (1..4)  (both: tests/test_surf.py::test_surf_dev_groups_of_tiles)
  *   "surf_sort_cap" [IMGFD_SURF_SORT_CAP]  selected records imgfd_surf_dev ranks with its LDS sort (2048); more: all-pairs ranking
  *                  (tests/test_surf.py::test_surf_dev_ranks_and_cuts_on_the_device)

@@ -228,7 +228,7 @@ def test_surf_dev_groups_of_tiles(be, group, lanes):
                     assert np.array_equal(got[f][k], ref[f][k]), (group, lanes, f, k)
                 assert np.abs(got[f]["surf"] - ref[f]["surf"]).max() <= 1e-9
     finally:
-        be.set_tuning("surf_group", 8); be.set_tuning("surf_lanes", 2)
+        be.set_tuning("surf_group", 4); be.set_tuning("surf_lanes", 3)
 
 
 def test_surf_dev_exact_score_ties_keep_emission_order(be):
