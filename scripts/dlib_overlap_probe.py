@@ -34,7 +34,7 @@ def beside(chunk):
         main.wait_stream(s2)
     return run
 
-def timed(fn, reps=3):
+def timed(fn, reps=int(os.environ.get("REPS", "3"))):
     for _ in range(2): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -45,7 +45,7 @@ def timed(fn, reps=3):
 
 out = {"tiles": T, "serial_ms_per_tile": timed(serial)}
 ref_hog, ref_feat, ref_counts = hog.clone(), feat.clone(), counts.clone()
-for chunk in (T, 16, 8):
+for chunk in (T, 64, 16):
     hog.zero_(); feat.zero_(); counts.zero_()
     out[f"beside_chunk{chunk}_ms_per_tile"] = timed(beside(chunk))
     out[f"beside_chunk{chunk}_same_bits"] = bool(torch.equal(hog, ref_hog) and torch.equal(counts, ref_counts) and torch.equal(feat, ref_feat))
