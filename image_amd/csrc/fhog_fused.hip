@@ -273,9 +273,6 @@ __global__ void __launch_bounds__(NT) fhog_hist8(const unsigned char *__restrict
         const int wr_main = FH_NEW * i + FH_CS;
         const int y_first = Y0 + (i ? wr_main : 0), y_end = Y0 + FH_NEW * i + FH_RING;
         const bool edge = !(cols_inside && y_first >= 1 && y_end <= g.visible_nr);
-#ifdef FH_EXPERIMENT_NO_PHASE1  // timing experiment: the window is not filled (results are garbage)
-        if (arith_lanes == -12345)
-#endif
         {
             FhRows it;
             it.live = true;
@@ -301,9 +298,6 @@ __global__ void __launch_bounds__(NT) fhog_hist8(const unsigned char *__restrict
         // bit 2 -> column bit 3; bits 4.. -> cell row.  The four 16-lane groups of a ds_read_b128 ({0-3,12-15,20-27}, ...:
         // the lanes whose bits 2,3,4 have even / odd parity) then hold 8 distinct columns mod 8 x 2 cell rows of different
         // parity: 16 distinct 16-byte slots of V (column step 2 slots, cell-row step an odd number of slots) and of O.
-#ifdef FH_EXPERIMENT_NO_PHASE2  // timing experiment: no histograms (results are garbage)
-        if (arith_lanes == -12345)
-#endif
         if ((tid >> 7) == role) {
             const int t = tid & 127;
             const int cc = (t & 3) | (((t >> 3) & 1) << 2) | (((t >> 2) & 1) << 3);

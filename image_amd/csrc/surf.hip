@@ -483,11 +483,7 @@ struct SurfPyrLds {
     static constexpr int STEP = 2 << O;
     static constexpr int LX = O == 0 ? 64 : 32, LY = O == 0 ? SURF_LDS_LY : 8;  // level pixels per workgroup
     static constexpr int LOBE_MAX = STEP * SURF_INT + 1;               // hessian_pyramid.h:119-128: lobe = step*(i+1) + 1
-#ifdef SURF_LDS_EXPERIMENT_REACH  // timing experiment: a window wide enough for the filters of the next octave
-    static constexpr int REACH = SURF_LDS_EXPERIMENT_REACH;
-#else
     static constexpr int REACH = (3 * LOBE_MAX) / 2;                   // half of the widest box; "+1" for the l-1 / t-1 corner
-#endif
     static constexpr int HL = (REACH + 1 + 3) / 4 * 4;                 // left / top margin: a multiple of 4 (16-byte loads) and of STEP
     static constexpr int HR = REACH;
     static constexpr int W = STEP * (LX - 1) + 1 + HL + HR, H = STEP * (LY - 1) + 1 + HL + HR;
@@ -543,38 +539,36 @@ __device__ __forceinline__ double surf_lds_interval(const unsigned *__restrict__
     return surf_lds_filter<SurfPyrLds<O>, SurfPyrLds<O>::STEP * (IT + 1) + 1>(win, top, area_inv);
 }
 
-#ifndef SURF_LDS_RUN
-#define SURF_LDS_RUN 1  // consecutive blocks of level pixels per workgroup of the first octave's kernel
-#endif
-// A workgroup handles SURF_LDS_RUN consecutive blocks and requests the table window of block b + 1 (into registers) before it evaluates
-// block b out of the LDS: the window loads (memory round trips) and the filters (vector ALUs + LDS) of a CU overlap by construction.
-// (Round 6 measured the phases of the one-block-per-workgroup kernel alone: 37 us of window loads + 22 us of filters = the kernel's
-// 59-62 us -- the three resident workgroups of a CU start together and stay in step, `profiles/r06/surf_first_octave_phases.txt`.)
 #ifndef SURF_LDS_WAVES
-#define SURF_LDS_WAVES 6  // waves per SIMD the first octave's kernel is compiled for (registers: 512 / this)
+#define SURF_LDS_WAVES 6  // waves per SIMD the first octave's kernel is compiled for (three workgroups of 8 waves per CU)
 #endif
+// One block of 64 x 16 level pixels per workgroup, three workgroups per CU.  Measured and not kept (profiles/r06/surf_first_octave_phases.txt,
+// surf_sparse_first_octave_not_kept.txt): a run of blocks per workgroup with the next window prefetched during the filters (compile-time
+// hooks in `git show 30adde6:image_amd/csrc/surf.hip`), and storing only the rows of values the maximum test can read
+// (scripts/experiments/r06_surf_sparse_first_octave.patch: 8.9 -> 3.7 B/px written, the kernel 66 -> 75 us, the batch unchanged).
 template <int O>
 __global__ void __launch_bounds__(SURF_LDS_NT) IMGFD_WAVES_PER_EU(SURF_LDS_WAVES, SURF_LDS_WAVES) surf_pyramid_lds(SurfTable T, double *__restrict__ pyr, SurfGeom g,
-                                                                unsigned long long *__restrict__ mask, double thr, int blocks_x, int n_blocks, int next_too)
+                                                                unsigned long long *__restrict__ mask, double thr, int blocks_x, int next_too)
 {
     using G = SurfPyrLds<O>;
     HIP_DYNAMIC_SHARED(unsigned, win)  // [G::H][G::P]
     const int tid = threadIdx.x;
-    // 1-D grid, XCD-aware order of the runs (imgfd_xcd_tile): the windows of neighbouring blocks overlap by their halo
-    const int first = (int)imgfd_xcd_tile(blockIdx.x, gridDim.x) * SURF_LDS_RUN;
+    // 1-D grid, XCD-aware order of the blocks (imgfd_xcd_tile): the windows of neighbouring blocks overlap by their halo
+    const int blk = (int)imgfd_xcd_tile(blockIdx.x, gridDim.x);
+    const int blk_y = blk / blocks_x, blk_x = blk - blk_y * blocks_x;
+    const int lc0 = blk_x * G::LX, lr0 = blk_y * G::LY;
+    const int x0 = G::STEP * lc0 - G::HL, y0 = G::STEP * lr0 - G::HL;
     const int cols = g.cols, rows = g.rows;
     const unsigned *__restrict__ I = T.p;
-    // residue layout: window column dx = 4 j + m of a row is word j of plane m, from word s = x0 / 4 of the plane's row on.  A task =
-    // one aligned quad of one plane of one window row (16-byte loads; s is rarely a multiple of 4, so a row of a plane takes NQ
-    // quads from s rounded down).  Rows and quads are clamped into the table: what lies outside the image is never looked up by a
-    // valid centre.
-    static_assert(G::P % 4 == 0, "whole quads per window row");
-    constexpr int PW = G::P / 4, NQ = (PW + 3 + 3) / 4, TASKS = G::H * 4 * NQ, TRIPS = (TASKS + G::NT - 1) / G::NT;
-    uint4 v[TRIPS];
-    auto request = [&](int blk) __attribute__((always_inline)) {
-        const int blk_y = blk / blocks_x, blk_x = blk - blk_y * blocks_x;
-        const int x0 = G::STEP * blk_x * G::LX - G::HL, y0 = G::STEP * blk_y * G::LY - G::HL;
-        const int a4 = (x0 >> 2) >> 2, quads = T.per >> 2;
+    if (T.per) {
+        // residue layout: window column dx = 4 j + m of a row is word j of plane m, from word s = x0 / 4 of the plane's row on.  A task =
+        // one aligned quad of one plane of one window row (16-byte loads; s is rarely a multiple of 4, so a row of a plane takes NQ
+        // quads from s rounded down); ALL of a thread's quads are requested before the first is written to the window.  Rows and
+        // quads are clamped into the table: what lies outside the image is never looked up by a valid centre.
+        static_assert(G::P % 4 == 0, "whole quads per window row");
+        constexpr int PW = G::P / 4, NQ = (PW + 3 + 3) / 4, TASKS = G::H * 4 * NQ, TRIPS = (TASKS + G::NT - 1) / G::NT;
+        const int s = x0 >> 2, a4 = s >> 2, lead = s & 3, quads = T.per >> 2;
+        uint4 v[TRIPS];
 #pragma unroll
         for (int j = 0; j < TRIPS; j++) {
             const int q = min(tid + G::NT * j, TASKS - 1);
@@ -582,10 +576,6 @@ __global__ void __launch_bounds__(SURF_LDS_NT) IMGFD_WAVES_PER_EU(SURF_LDS_WAVES
             const int gy = min(max(y0 + ry, 0), rows - 1), gq = min(max(a4 + k4, 0), quads - 1);
             v[j] = *reinterpret_cast<const uint4 *>(I + (size_t)gy * cols + (size_t)m * T.per + 4 * gq);
         }
-    };
-    auto commit = [&](int blk) __attribute__((always_inline)) {
-        const int blk_x = blk % blocks_x;
-        const int lead = ((G::STEP * blk_x * G::LX - G::HL) >> 2) & 3;
 #pragma unroll
         for (int j = 0; j < TRIPS; j++) {
             const int q = tid + G::NT * j;
@@ -600,110 +590,81 @@ __global__ void __launch_bounds__(SURF_LDS_NT) IMGFD_WAVES_PER_EU(SURF_LDS_WAVES
                 }
             }
         }
-    };
-    if (T.per && first < n_blocks) request(first);
-#pragma unroll 1
-    for (int run = 0; run < SURF_LDS_RUN; run++) {
-        const int blk = first + run;
-        if (blk >= n_blocks) break;  // workgroup-uniform
-        const int blk_y = blk / blocks_x, blk_x = blk - blk_y * blocks_x;
-        const int lc0 = blk_x * G::LX, lr0 = blk_y * G::LY;
-        const int x0 = G::STEP * lc0 - G::HL, y0 = G::STEP * lr0 - G::HL;
-#ifdef SURF_LDS_EXPERIMENT_NO_LOAD  // timing experiment: no window load (results are garbage)
-        if (thr == -12345.0)
-#endif
-        if (T.per) {
-            commit(blk);
-        } else if (x0 >= 0 && y0 >= 0 && x0 + G::P <= cols && y0 + G::H <= rows && (cols & 3) == 0) {  // plain table, interior
-            for (int i = tid; i < G::H * (G::P / 4); i += G::NT) {
-                const int ry = i / (G::P / 4), q = i - ry * (G::P / 4);
-                const uint4 u = *reinterpret_cast<const uint4 *>(I + (size_t)(y0 + ry) * cols + x0 + 4 * q);
-                unsigned *row = win + ry * G::P;
-                row[G::col(4 * q)] = u.x; row[G::col(4 * q + 1)] = u.y; row[G::col(4 * q + 2)] = u.z; row[G::col(4 * q + 3)] = u.w;
-            }
-        } else {  // plain table at the image border: clamped coordinates
-            for (int i = tid; i < G::H * G::P; i += G::NT) {
-                const int ry = i / G::P, rx = i - ry * G::P;
-                const int gy = min(max(y0 + ry, 0), rows - 1), gx = min(max(x0 + rx, 0), cols - 1);
-                win[ry * G::P + G::col(rx)] = T.at(gy, gx);
-            }
+    } else if (x0 >= 0 && y0 >= 0 && x0 + G::P <= cols && y0 + G::H <= rows && (cols & 3) == 0) {  // plain table, interior
+        for (int i = tid; i < G::H * (G::P / 4); i += G::NT) {
+            const int ry = i / (G::P / 4), q = i - ry * (G::P / 4);
+            const uint4 u = *reinterpret_cast<const uint4 *>(I + (size_t)(y0 + ry) * cols + x0 + 4 * q);
+            unsigned *row = win + ry * G::P;
+            row[G::col(4 * q)] = u.x; row[G::col(4 * q + 1)] = u.y; row[G::col(4 * q + 2)] = u.z; row[G::col(4 * q + 3)] = u.w;
         }
-        __syncthreads();
-        if (T.per && run + 1 < SURF_LDS_RUN && blk + 1 < n_blocks) request(blk + 1);  // in flight while this block is evaluated
+    } else {  // plain table at the image border: clamped coordinates
+        for (int i = tid; i < G::H * G::P; i += G::NT) {
+            const int ry = i / G::P, rx = i - ry * G::P;
+            const int gy = min(max(y0 + ry, 0), rows - 1), gx = min(max(x0 + rx, 0), cols - 1);
+            win[ry * G::P + G::col(rx)] = T.at(gy, gx);
+        }
+    }
+    __syncthreads();
 #pragma unroll
-        for (int k = 0; k < G::PX_PER_THREAD; k++) {
-            const int e = tid + G::NT * k;  // level pixel of the block: row-major, LX per row
-            const int lr = lr0 + e / G::LX, lc = lc0 + e % G::LX;
-            const int r = lr * G::STEP, c = lc * G::STEP;
-            // a wave = 64 consecutive level pixels of one row (LX = 64, lc0 a multiple of 64): its ballot is one word of the
-            // level's threshold mask (|det| >= thr: the only pixels surf_nms_list has to look at); every lane votes
-            const bool inside = lr < g.nr[O] && lc < g.nc[O];
-            unsigned top = (unsigned)((r - y0) * G::P + (c - x0) / G::STEP - G::BIAS);  // (c - x0) is a multiple of STEP: residue plane 0
-            IMGFD_OPAQUE(top);
-            double *dst = pyr + (size_t)lr * g.nc[O] + lc;
-#ifdef SURF_LDS_EXPERIMENT_NO_STORE  // timing experiment: the values are not written (the threshold mask is)
-#define SURF_LDS_STORE(v, p) if (v == -12345.678) IMGFD_OUT_STORE(v, p)
-#else
-#define SURF_LDS_STORE(v, p) IMGFD_OUT_STORE(v, p)
-#endif
-#ifdef SURF_LDS_EXPERIMENT_NO_MATH  // timing experiment: window load + stores alone (results are garbage)
-#define SURF_LDS_VALUE(IT) ((double)win[top + G::BIAS + IT] * L.area_inv)
-#else
-#define SURF_LDS_VALUE(IT) surf_lds_interval<O, IT>(win, top, L.area_inv)
-#endif
+    for (int k = 0; k < G::PX_PER_THREAD; k++) {
+        const int e = tid + G::NT * k;  // level pixel of the block: row-major, LX per row
+        const int lr = lr0 + e / G::LX, lc = lc0 + e % G::LX;
+        const int r = lr * G::STEP, c = lc * G::STEP;
+        // a wave = 64 consecutive level pixels of one row (LX = 64, lc0 a multiple of 64): its ballot is one word of the
+        // level's threshold mask (|det| >= thr: the only pixels surf_nms_list has to look at); every lane votes
+        const bool inside = lr < g.nr[O] && lc < g.nc[O];
+        unsigned top = (unsigned)((r - y0) * G::P + (c - x0) / G::STEP - G::BIAS);  // (c - x0) is a multiple of STEP: residue plane 0
+        IMGFD_OPAQUE(top);
+        double *dst = pyr + (size_t)lr * g.nc[O] + lc;
 #define SPL_DO(IT)                                                                                        \
-            {                                                                                              \
-                const SurfLevel &L = g.lev[O * SURF_INT + IT];                                             \
-                const int bp = L.border_px;                                                                \
-                bool hot = false;                                                                          \
-                if (inside && !(r < bp || r >= rows - bp || c < bp || c >= cols - bp)) {                   \
-                    const double val = SURF_LDS_VALUE(IT);                                                 \
-                    SURF_LDS_STORE(val, &dst[L.plane]);                                                    \
-                    hot = fabs(val) >= thr;                                                                \
-                }                                                                                          \
-                const unsigned long long word = __ballot(hot);                                             \
-                if ((tid & 63) == 0 && lr < g.nr[O] && lc < g.nc[O]) mask[L.mask + (size_t)lr * ((g.nc[O] + 63) / 64) + (lc >> 6)] = word; \
-            }
-            SPL_DO(1) SPL_DO(2) SPL_DO(3) SPL_DO(4)  // intervals 0 and 5 are not built (surf_geometry)
+        {                                                                                                  \
+            const SurfLevel &L = g.lev[O * SURF_INT + IT];                                                 \
+            const int bp = L.border_px;                                                                    \
+            bool hot = false;                                                                              \
+            if (inside && !(r < bp || r >= rows - bp || c < bp || c >= cols - bp)) {                       \
+                const double val = surf_lds_interval<O, IT>(win, top, L.area_inv);                         \
+                IMGFD_OUT_STORE(val, &dst[L.plane]);                                                       \
+                hot = fabs(val) >= thr;                                                                    \
+            }                                                                                              \
+            const unsigned long long word = __ballot(hot);                                                 \
+            if ((tid & 63) == 0 && lr < g.nr[O] && lc < g.nc[O]) mask[L.mask + (size_t)lr * ((g.nc[O] + 63) / 64) + (lc >> 6)] = word; \
+        }
+        SPL_DO(1) SPL_DO(2) SPL_DO(3) SPL_DO(4)  // intervals 0 and 5 are not built (surf_geometry)
 #undef SPL_DO
-#undef SURF_LDS_VALUE
-#undef SURF_LDS_STORE
-        }
-        // The first two built intervals of the NEXT octave (lobes 2 STEP * 2 + 1 and 2 STEP * 3 + 1: the second reaches exactly as far as this
-        // octave's widest filter, for which the window is cut) from the same window: a quarter as many level pixels, one value per
-        // thread.  In the gather kernel these two intervals of octave 1 cost the batch 15 us per 4096^2 tile, here 4.
-        // A wave = two rows of LX / 2 level pixels: its ballot is the low or high half of a mask word for each of them.
-        if (next_too) {
-            static_assert(G::NT == 2 * (G::LX / 2) * (G::LY / 2) && G::LX == 64, "a value per thread; half a mask word per block and row");
-            constexpr int N = O + 1, NSTEP = 2 * G::STEP;
-            const int e = tid & (G::NT / 2 - 1);
-            const int lr = blk_y * (G::LY / 2) + e / (G::LX / 2), lc = blk_x * (G::LX / 2) + e % (G::LX / 2);
-            const int r = lr * NSTEP, c = lc * NSTEP;
-            const bool inside = lr < g.nr[N] && lc < g.nc[N];
-            unsigned top = (unsigned)((r - y0) * G::P + (c - x0) / G::STEP - G::BIAS);
-            IMGFD_OPAQUE(top);
-            const int words = (g.nc[N] + 63) / 64;
+    }
+    // ---- The first two built intervals of the NEXT octave (lobes 2 STEP * 2 + 1 and 2 STEP * 3 + 1: the second reaches exactly as far as this
+    // octave's widest filter, for which the window is cut) from the same window: a quarter as many level pixels, one value per
+    // thread, all stored.  In the gather kernel these two intervals of octave 1 cost the batch 15 us per 4096^2 tile, here 4.
+    // A wave = two rows of LX / 2 level pixels: its ballot is the low or high half of a mask word for each of them.
+    if (next_too) {
+        static_assert(G::NT == 2 * (G::LX / 2) * (G::LY / 2) && G::LX == 64, "a value per thread; half a mask word per block and row");
+        constexpr int N = O + 1, NSTEP = 2 * G::STEP;
+        const int e = tid & (G::NT / 2 - 1);
+        const int lr = blk_y * (G::LY / 2) + e / (G::LX / 2), lc = blk_x * (G::LX / 2) + e % (G::LX / 2);
+        const int r = lr * NSTEP, c = lc * NSTEP;
+        const bool inside = lr < g.nr[N] && lc < g.nc[N];
+        unsigned top = (unsigned)((r - y0) * G::P + (c - x0) / G::STEP - G::BIAS);
+        IMGFD_OPAQUE(top);
+        const int words = (g.nc[N] + 63) / 64;
 #define SPL_NEXT(IT)                                                                                      \
-            {                                                                                              \
-                const SurfLevel &L = g.lev[N * SURF_INT + IT];                                             \
-                const int bp = L.border_px;                                                                \
-                bool hot = false;                                                                          \
-                if (inside && !(r < bp || r >= rows - bp || c < bp || c >= cols - bp)) {                   \
-                    const double val = surf_lds_filter<G, NSTEP * (IT + 1) + 1>(win, top, L.area_inv);     \
-                    IMGFD_OUT_STORE(val, &pyr[L.plane + (size_t)lr * g.nc[N] + lc]);                       \
-                    hot = fabs(val) >= thr;                                                                \
-                }                                                                                          \
-                const unsigned long long word = __ballot(hot);                                             \
-                if ((tid & 31) == 0 && lr < g.nr[N] && (lc >> 6) < words) {                                \
-                    unsigned *half = reinterpret_cast<unsigned *>(mask + L.mask + (size_t)lr * words + (lc >> 6)) + ((lc >> 5) & 1); \
-                    half[0] = (unsigned)(word >> (tid & 32));                                              \
-                    if (blk_x == blocks_x - 1 && ((lc >> 5) & 1) == 0) half[1] = 0u;  /* no block to the right writes it */ \
-                }                                                                                          \
-            }
-            if (tid < G::NT / 2) SPL_NEXT(1) else SPL_NEXT(2)
-#undef SPL_NEXT
+        {                                                                                                  \
+            const SurfLevel &L = g.lev[N * SURF_INT + IT];                                                 \
+            const int bp = L.border_px;                                                                    \
+            bool hot = false;                                                                              \
+            if (inside && !(r < bp || r >= rows - bp || c < bp || c >= cols - bp)) {                       \
+                const double nv = surf_lds_filter<G, NSTEP * (IT + 1) + 1>(win, top, L.area_inv);          \
+                IMGFD_OUT_STORE(nv, &pyr[L.plane + (size_t)lr * g.nc[N] + lc]);                            \
+                hot = fabs(nv) >= thr;                                                                     \
+            }                                                                                              \
+            const unsigned long long word = __ballot(hot);                                                 \
+            if ((tid & 31) == 0 && lr < g.nr[N] && (lc >> 6) < words) {                                    \
+                unsigned *half = reinterpret_cast<unsigned *>(mask + L.mask + (size_t)lr * words + (lc >> 6)) + ((lc >> 5) & 1); \
+                half[0] = (unsigned)(word >> (tid & 32));                                                  \
+                if (blk_x == blocks_x - 1 && ((lc >> 5) & 1) == 0) half[1] = 0u;  /* no block to the right writes it */ \
+            }                                                                                              \
         }
-        __syncthreads();  // the window is overwritten by the next block of the run
+        if (tid < G::NT / 2) SPL_NEXT(1) else SPL_NEXT(2)
+#undef SPL_NEXT
     }
 }
 
@@ -716,8 +677,7 @@ static imgfd_status launch_surf_pyramid_lds(imgfd_ctx *ctx, const SurfTable &T, 
     const size_t lds = sizeof(unsigned) * (size_t)G::H * G::P;
     IMGFD_HIP(ctx, hipFuncSetAttribute((const void *)surf_pyramid_lds<O>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int bx = ceil_div(g.nc[O], G::LX), by = ceil_div(g.nr[O], G::LY);
-    hipLaunchKernelGGL(surf_pyramid_lds<O>, dim3((unsigned)ceil_div(bx * by, SURF_LDS_RUN)), dim3(G::NT), lds, ctx->stream, T, d_pyr, g, d_mask,
-                       thr, bx, bx * by, next_too ? 1 : 0);
+    hipLaunchKernelGGL(surf_pyramid_lds<O>, dim3((unsigned)(bx * by)), dim3(G::NT), lds, ctx->stream, T, d_pyr, g, d_mask, thr, bx, next_too ? 1 : 0);
     return IMGFD_OK;
 }
 
@@ -747,9 +707,6 @@ static SurfBands surf_bands(const SurfGeom &g)
     for (int o = 0; o < SURF_OCT; o++) b.it0[o] = 1;
     for (int o = 1; o < SURF_OCT; o++)
         if (g.nr[o] >= 1 && g.nc[o] >= 1) { b.gx[o] = (g.nc[o] + 63) / 64; b.gy[o] = (g.nr[o] + 3) / 4; }
-#ifdef SURF_EXPERIMENT_TAPS_WITHOUT_OCTAVE1  // timing experiment (results are wrong)
-    b.gx[1] = b.gy[1] = 0;
-#endif
     b.per_band = 4 * b.gx[1] + 2 * b.gx[2] + b.gx[3];
     b.nbands = std::max(std::max((b.gy[1] + 3) / 4, (b.gy[2] + 1) / 2), b.gy[3]);
     b.total = (unsigned)align_up((size_t)b.nbands * b.per_band, (size_t)8);
