@@ -168,7 +168,10 @@ __global__ void __launch_bounds__(128) surf_orient(SurfTable I,
 
 // trig: m x 5 (angle, sin, cos, sin(-angle), cos(-angle)); point p's descriptor goes to des[p*des_stride .. +64) and, if
 // angle_out, its angle to angle_out[p*des_stride]
-__global__ void __launch_bounds__(64) surf_desc(SurfTable I,
+#ifndef SURF_DESC_NT
+#define SURF_DESC_NT 64  // threads per point of surf_desc
+#endif
+__global__ void __launch_bounds__(SURF_DESC_NT) surf_desc(SurfTable I,
                                                 const double *__restrict__ pts, const double *__restrict__ trig,
                                                 double *__restrict__ des, int des_stride, double *__restrict__ angle_out,
                                                 const unsigned *__restrict__ m_dev, SurfGroup grp)
@@ -191,7 +194,7 @@ __global__ void __launch_bounds__(64) surf_desc(SurfTable I,
     const long sc = (long)(scale + 0.5);
     const Haar H{I, I.rows, I.cols};
     // the 20 x 20 sample grid (:176-186)
-    for (int s = lane; s < 400; s += 64) {
+    for (int s = lane; s < 400; s += SURF_DESC_NT) {
         const long yy = s / 20 - 10, xx = s % 20 - 10;
         const double qx = xx * scale, qy = yy * scale;
         const long px = surf_to_long((cs * qx - sn * qy) + x), py = surf_to_long((sn * qx + cs * qy) + y);
@@ -199,7 +202,7 @@ __global__ void __launch_bounds__(64) surf_desc(SurfTable I,
     }
     __syncthreads();
     // weighted, rotated back (:188-199), per bucket slot j = (yy - (r-1))*7 + (xx - (c-1))
-    for (int slot = lane; slot < 16 * 49; slot += 64) {
+    for (int slot = lane; slot < 16 * 49; slot += SURF_DESC_NT) {
         const int bucket = slot / 49, j = slot % 49;
         const long r = -10 + 5 * (bucket >> 2), c = -10 + 5 * (bucket & 3);
         const long yy = r - 1 + j / 7, xx = c - 1 + j % 7;
@@ -215,7 +218,7 @@ __global__ void __launch_bounds__(64) surf_desc(SurfTable I,
         ry[slot] = vy;
     }
     __syncthreads();
-    {   // lane = bucket*4 + {vx, vy, |vx|, |vy|} (:201-212), samples in the reference's order
+    if (lane < 64) {   // lane = bucket*4 + {vx, vy, |vx|, |vy|} (:201-212), samples in the reference's order
         const int bucket = lane >> 2, comp = lane & 3;
         const long r = -10 + 5 * (bucket >> 2), c = -10 + 5 * (bucket & 3);
         const double *src = (comp & 1) ? ry + bucket * 49 : rx + bucket * 49;
@@ -237,7 +240,7 @@ __global__ void __launch_bounds__(64) surf_desc(SurfTable I,
         inv_len_s = 1.0 / (sqrt(ss) + 1e-7);
     }
     __syncthreads();
-    des[p * des_stride + lane] = d[lane] * inv_len_s;
+    if (lane < 64) des[p * des_stride + lane] = d[lane] * inv_len_s;
     if (angle_out && lane == 0) angle_out[p * des_stride] = trig[5 * p];
 }
 
@@ -275,7 +278,7 @@ imgfd_status launch_surf_desc(imgfd_ctx *ctx, const SurfTable &I, const double *
     if (m < 1) return IMGFD_OK;
     const SurfGroup one{1, 0, 0, 0, 0};
     const SurfGroup &G = grp ? *grp : one;
-    hipLaunchKernelGGL(surf_desc, dim3(m, G.tiles), dim3(64), 0, ctx->stream, I, d_pts, d_trig, d_des, des_stride, d_angle, m_dev, G);
+    hipLaunchKernelGGL(surf_desc, dim3(m, G.tiles), dim3(SURF_DESC_NT), 0, ctx->stream, I, d_pts, d_trig, d_des, des_stride, d_angle, m_dev, G);
     IMGFD_HIP(ctx, hipGetLastError());
     return IMGFD_OK;
 }
