@@ -561,33 +561,37 @@ __global__ void __launch_bounds__(SURF_LDS_NT) IMGFD_WAVES_PER_EU(SURF_LDS_WAVES
     const int cols = g.cols, rows = g.rows;
     const unsigned *__restrict__ I = T.p;
     if (T.per) {
-        // residue layout: window column dx = 4 j + m of a row is word j of plane m, from word s = x0 / 4 of the plane's row on.  A task =
-        // one aligned quad of one plane of one window row (16-byte loads; s is rarely a multiple of 4, so a row of a plane takes NQ
-        // quads from s rounded down); ALL of a thread's quads are requested before the first is written to the window.  Rows and
-        // quads are clamped into the table: what lies outside the image is never looked up by a valid centre.
+        // residue layout: window column dx = 4 w + m of a row is word w of plane m, from word s = x0 / 4 of the plane's row on (s is
+        // rarely a multiple of 4: a row of a plane takes NQ aligned quads from s rounded down).  A thread keeps ONE (plane, quad) and
+        // walks down the window rows, RPT rows per trip: its table offset grows by a multiple of the row pitch, its window address by a
+        // constant (the ds_write's immediate), which of its four words fall inside the window row is decided once -- 16-byte loads,
+        // ALL of a thread's quads requested before the first is written.  (A task list cut into (row, plane, quad) by divisions, with
+        // 64-bit addresses, was 333 of the kernel's 870 vector instructions per thread: round 6.)  Rows and quads are clamped into
+        // the table: what lies outside the image is never looked up by a valid centre.
         static_assert(G::P % 4 == 0, "whole quads per window row");
-        constexpr int PW = G::P / 4, NQ = (PW + 3 + 3) / 4, TASKS = G::H * 4 * NQ, TRIPS = (TASKS + G::NT - 1) / G::NT;
-        const int s = x0 >> 2, a4 = s >> 2, lead = s & 3, quads = T.per >> 2;
+        constexpr int PW = G::P / 4, NQ = (PW + 3 + 3) / 4, RPT = G::NT / (4 * NQ), TRIPS = (G::H + RPT - 1) / RPT;
+        static_assert(RPT >= 1, "a window row's quads fit the workgroup");
+        const int slot = tid % (4 * NQ), rw = tid / (4 * NQ);  // rw >= RPT: the workgroup's last threads have no quad
+        const int m = slot / NQ, k4 = slot - m * NQ;
+        const int s = x0 >> 2, lead = s & 3, quads = T.per >> 2;
+        const unsigned in_row = (unsigned)m * (unsigned)T.per + 4u * (unsigned)min(max((s >> 2) + k4, 0), quads - 1);
         uint4 v[TRIPS];
 #pragma unroll
         for (int j = 0; j < TRIPS; j++) {
-            const int q = min(tid + G::NT * j, TASKS - 1);
-            const int ry = q / (4 * NQ), rem = q - ry * (4 * NQ), m = rem / NQ, k4 = rem - m * NQ;
-            const int gy = min(max(y0 + ry, 0), rows - 1), gq = min(max(a4 + k4, 0), quads - 1);
-            v[j] = *reinterpret_cast<const uint4 *>(I + (size_t)gy * cols + (size_t)m * T.per + 4 * gq);
+            const int gy = min(max(y0 + min(rw + RPT * j, G::H - 1), 0), rows - 1);
+            v[j] = *reinterpret_cast<const uint4 *>(I + (__umul24((unsigned)gy, (unsigned)cols) + in_row));  // the table has < 2^29 words (launch_surf_integral)
         }
+        unsigned *dst = win + rw * G::P + G::col(m) + (4 * k4 - lead) * (4 / G::STEP);  // col(4 w + m) = col(m) + 4 w / STEP
+        bool ok[4];
 #pragma unroll
-        for (int j = 0; j < TRIPS; j++) {
-            const int q = tid + G::NT * j;
-            const int ry = q / (4 * NQ), rem = q - ry * (4 * NQ), m = rem / NQ, k4 = rem - m * NQ;
+        for (int i = 0; i < 4; i++) ok[i] = rw < RPT && 4 * k4 + i - lead >= 0 && 4 * k4 + i - lead < PW;
+#pragma unroll
+        for (int j = 0; j < TRIPS; j++) {  // trip by trip: the first quads are written while the last are still on their way
             const unsigned e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
-            unsigned *row = win + ry * G::P + G::col(m);   // col(4 w + m) = col(m) + 4 w / STEP
-            if (q < TASKS) {
+            if (RPT * j + RPT <= G::H || rw + RPT * j < G::H) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int w = 4 * k4 + i - lead;
-                    if (w >= 0 && w < PW) row[w * (4 / G::STEP)] = e[i];
-                }
+                for (int i = 0; i < 4; i++)
+                    if (ok[i]) dst[RPT * j * G::P + i * (4 / G::STEP)] = e[i];
             }
         }
     } else if (x0 >= 0 && y0 >= 0 && x0 + G::P <= cols && y0 + G::H <= rows && (cols & 3) == 0) {  // plain table, interior

@@ -273,6 +273,7 @@ template <typename T> static inline T __shfl_xor(T v, int m, int width = 64) {
     int src = lane ^ m;
     return hipemu_shfl_idx(v, src >= base + width ? lane : src);
 }
+static inline unsigned __umul24(unsigned a, unsigned b) { return (unsigned)((unsigned long long)(a & 0xffffffu) * (unsigned long long)(b & 0xffffffu)); }  // v_mul_u32_u24: low 32 bits of the product of the low 24 bits
 static inline int __mul24(int a, int b) { return (int)((long long)((a << 8) >> 8) * (long long)((b << 8) >> 8)); }  // v_mul_i32_i24: the low 24 bits of each operand, sign-extended
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
