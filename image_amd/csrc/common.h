@@ -315,6 +315,6 @@ imgfd_status launch_fast9(imgfd_ctx *ctx, const uint8_t *d_img, int w, int h, in
                           size_t frame_stride, int n_frames, int threshold, int nonmax, const CompactBuffers &cb);
 // canny.hip: imgfd_canny_dev with a hook that runs on the host while the (first chunk of the) batch is being queued --
 // called with the position reached (0 before the blur, 1 behind it, 2 behind gradient/NMS; canny_device); imgfd_detect_dev
-// queues the other detectors from it (lab switches "canny_gate" / "harris_gate" choose the position)
+// queues the other detectors from it (detect.hip: FAST-9 at position 0, Harris at 1 for small batches and 2 otherwise)
 imgfd_status canny_dev_hooked(imgfd_ctx *ctx, const imgfd_frames *fr, double s, double low_thr, double high_thr, int accGrad,
                               uint8_t *d_edges, int64_t *d_counts, const std::function<imgfd_status(int)> *hook);

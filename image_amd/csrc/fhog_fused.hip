@@ -149,7 +149,7 @@ __device__ __forceinline__ void fh_phase1(const unsigned *__restrict__ img, cons
         for (int p = 0; p < 4; p++)
             nw[p] = lut_c[((unsigned)tys[p] & (2u * FH_CEN - 1u)) * (2 * FH_CEN) + ((unsigned)txs[p] & (2u * FH_CEN - 1u))];
         const bool far = span >= 2u * FH_CEN && it.live;
-        // A wave with at least arith_lanes such lanes (switch "fhog_arith", 32) computes their words: the arithmetic (~40 VALU
+        // A wave with at least arith_lanes such lanes (32) computes their words: the arithmetic (~40 VALU
         // instructions per pixel) costs the same for one lane or 64, a gather's cost in the texture unit follows its lanes.
         // Uniform noise, where every lane is outside: 112 -> 86.5 us per 4096^2 tile; the synthetic tile (75 us) takes the gathers.
         if (arith_lanes > 0 && (int)__popcll(__ballot(far)) >= arith_lanes) {

@@ -1537,7 +1537,7 @@ struct SurfStreamScope {
 // fork (optional): the context's companion.  Octave 0 and octaves 1-3 are two kernels that both read the finished table and
 // write different planes: with a companion at hand (a call with ONE tile has no other tile to fill the chip with) the second
 // runs on its stream beside the first -- a VALU / LDS bound kernel next to one that waits for its gathers -- and whatever is
-// queued on the context's stream next waits for both ("surf_split").
+// queued on the context's stream next waits for both.
 imgfd_status surf_front(imgfd_ctx *ctx, const uint8_t *d_rgb, const SurfGeom &g, double thr, const SurfDevice &d, SurfTable *table,
                         imgfd_ctx *fork = nullptr)
 {
@@ -2009,7 +2009,7 @@ static imgfd_status surf_dev_run(imgfd_ctx *ctx, const uint8_t *d_rgb, int n_fra
         const imgfd_status st = ctx_side(lane[l - 1], &lane[l]);
         if (st != IMGFD_OK) { ctx->err = lane[l - 1]->err; return st; }
     }
-    imgfd_ctx *fork = nullptr;  // one tile: its two pyramid kernels side by side (surf_front, "surf_split")
+    imgfd_ctx *fork = nullptr;  // one tile: its two pyramid kernels side by side (surf_front)
     if (G == 1) IMGFD_TRY(ctx_side(ctx, &fork));
     // More than one group: two BANKS of buffer sets, and the back of group k on a stream of its own beside the fronts of group k + 1
     const int banks = !only && n_run > G ? 2 : 1;

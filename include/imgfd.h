@@ -328,7 +328,7 @@ IMGFD_API imgfd_status imgfd_k_gauss_grad_u8(imgfd_ctx *ctx, const uint8_t *d_u8
  * orientation bin (fhog.h:846-859) */
 IMGFD_API imgfd_status imgfd_k_fhog_lut(imgfd_ctx *ctx, uint32_t *d_out);
 /* the same table computed without the float chain (integer orientation rule of fhog_fused.hip's fh_word_arith, what the
- * fused kernel evaluates for waves with many large gradients, switch "fhog_arith"): equal to imgfd_k_fhog_lut's bit for bit */
+ * fused kernel evaluates for waves with many large gradients): equal to imgfd_k_fhog_lut's bit for bit */
 IMGFD_API imgfd_status imgfd_k_fhog_lut_arith(imgfd_ctx *ctx, uint32_t *d_out);
 /* K3: the structure-tensor pass, compute_autocorrelation_matrix harris.cpp:44-70:
  * reads Ix,Iy (8 B/px), writes the smoothed A,B,C (12 B/px) */
