@@ -290,18 +290,22 @@ imgfd_status launch_gauss_grad_march(imgfd_ctx *ctx, const void *d_in, int in_pi
     p.nstrips = ceil_div(nx, GM_TW);
     // Segment length: a segment of sr rows takes m = ceil((sr + 2R - 13) / 16) + 1 steps, so sr = 16 m - 2 - 2R fills them; the
     // launch takes ceil(workgroups / slots) rounds of m steps with three workgroups resident per CU: the segment count that
-    // minimises the product (ties: fewer, longer segments = fewer halo rows)
+    // minimises the product -- and of the counts within 3 % of that minimum the one with the SHORTEST segments: the kernel runs beside
+    // the other detectors' kernels, and many short workgroups interleave with them better than few long ones (32 4K frames, sustained:
+    // segments of 1080 rows, the model's minimum, 71.2 Gpixel/s; 135-540 rows 72.5-72.8; profiles/r06/gauss_march_segments.txt)
     const long slots = 4L * ctx->num_cu;
     long best = -1;
     int seg = ny;
-    for (int m = 2; m <= ceil_div(ny + 2 * R + 2, GM_CH) + 1; m++) {
-        const int sr = std::min(ny, GM_CH * m - 2 - 2 * R);
-        if (sr < 1) continue;
-        const long wgs = (long)p.nstrips * ceil_div(ny, sr) * n_frames;
-        const long cost = ((wgs + slots - 1) / slots) * m;
-        if (best < 0 || cost < best) { best = cost; seg = sr; }
-        if (sr >= ny) break;
-    }
+    for (int pass = 0; pass < 2; pass++)
+        for (int m = 2; m <= ceil_div(ny + 2 * R + 2, GM_CH) + 1; m++) {
+            const int sr = std::min(ny, GM_CH * m - 2 - 2 * R);
+            if (sr < 1) continue;
+            const long wgs = (long)p.nstrips * ceil_div(ny, sr) * n_frames;
+            const long cost = ((wgs + slots - 1) / slots) * m;
+            if (pass == 0) { if (best < 0 || cost < best) best = cost; }
+            else if (100 * cost <= 103 * best) { seg = sr; break; }  // m ascending: the first hit is the shortest
+            if (sr >= ny) break;
+        }
     if (ctx->tune.gauss_march_seg > 0) seg = std::min(ny, std::max(2, ctx->tune.gauss_march_seg));
     // the last segment holds two rows at least: its last row is evaluated one row up (gradient.cpp:40-55) and the smoothed row
     // above that must be one the segment computes
