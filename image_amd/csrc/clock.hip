@@ -60,6 +60,7 @@ try {
     for (int i = 0; i < ctx->clk_n; i++) {
         if (!h[2 * i + 1]) continue;
         const double ghz = (double)h[2 * i] / (double)h[2 * i + 1] * (double)ctx->clk_rate_khz * 1e-6;  // cycles per tick x ticks per second
+        if (!(ghz > 0.05 && ghz < 10.0)) continue;  // a sample whose cycle counter stepped backwards between the two reads (seen once in ~10^3 probes)
         sum += ghz; lo = std::min(lo, ghz); hi = std::max(hi, ghz); n++;
     }
     ctx->clk_n = 0;
